@@ -1,0 +1,132 @@
+"""Seeded synthetic checkpoints with the exact MetaVoice-1B tensor names and shapes.
+
+No model weights are reachable offline, so every measurement and parity test runs on synthetic
+parameters laid out exactly like the real `first_stage.pt` / `second_stage.pt`
+(`fam/llm/finetune.py:300-313`: {"model", "model_args", "config", "meta"}; tensor names as listed
+in SURVEY.md section 8a).  Values follow `GPT._init_weights` (`fam/llm/model.py:145-176`): N(0, 0.02) for
+Linear/Embedding weights, N(0, 0.02/sqrt(2*n_layer)) for the residual projections `c_proj`; norm
+weights are 1 + 0.1*N(0,1) instead of the reference's constant 1 so that the norm-scale multiply is
+actually exercised.  Everything is rounded to bf16, so a bf16 engine and an fp32 oracle see the
+same parameters.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+
+def _normal(gen: torch.Generator, shape, std: float) -> torch.Tensor:
+    return (torch.randn(shape, generator=gen, dtype=torch.float32) * std).to(torch.bfloat16)
+
+
+def _norm_weight(gen: torch.Generator, n: int) -> torch.Tensor:
+    return (1.0 + 0.1 * torch.randn(n, generator=gen, dtype=torch.float32)).to(torch.bfloat16)
+
+
+def stage1_state_dict(*, n_layer: int = 24, n_head: int = 16, dim: int = 2048, vocab_size: int = 2562,
+                      block_size: int = 2048, intermediate_size: Optional[int] = None, speaker_emb_dim: int = 256,
+                      seed: int = 0, orig_mod_prefix: bool = False) -> Dict[str, torch.Tensor]:
+    """`first_stage.pt["model"]` with nanoGPT names (before the gpt-fast remap).  bf16 tensors."""
+    if intermediate_size is None:
+        n_hidden = int(2 * (4 * dim) / 3)
+        intermediate_size = n_hidden if n_hidden % 256 == 0 else n_hidden + 256 - n_hidden % 256
+    g = torch.Generator().manual_seed(seed)
+    proj_std = 0.02 / math.sqrt(2 * n_layer)
+    sd: Dict[str, torch.Tensor] = {}
+    sd["transformer.wtes.0.weight"] = _normal(g, (vocab_size, dim), 0.02)
+    sd["transformer.wpe.weight"] = _normal(g, (block_size, dim), 0.02)
+    sd["speaker_cond_pos.weight"] = _normal(g, (dim, speaker_emb_dim), 0.02)
+    for i in range(n_layer):
+        p = f"transformer.h.{i}."
+        sd[p + "ln_1.weight"] = _norm_weight(g, dim)
+        sd[p + "attn.c_attn.weight"] = _normal(g, (3 * dim, dim), 0.02)
+        sd[p + "attn.c_proj.weight"] = _normal(g, (dim, dim), proj_std)
+        sd[p + "ln_2.weight"] = _norm_weight(g, dim)
+        sd[p + "mlp.swiglu.w1.weight"] = _normal(g, (intermediate_size, dim), 0.02)
+        sd[p + "mlp.swiglu.w3.weight"] = _normal(g, (intermediate_size, dim), 0.02)
+        sd[p + "mlp.c_proj.weight"] = _normal(g, (dim, intermediate_size), proj_std)
+    sd["transformer.ln_f.weight"] = _norm_weight(g, dim)
+    # tied to wtes.0 inside GPT (model.py:139-143) but stored under its own key
+    sd["lm_heads.0.weight"] = sd["transformer.wtes.0.weight"]
+    if orig_mod_prefix:
+        sd = {"_orig_mod." + k: v for k, v in sd.items()}
+    return sd
+
+
+def stage2_model_args(*, block_size: int = 1024, n_layer: int = 6, n_head: int = 6, n_embd: int = 384,
+                      bias: bool = False, norm_type: str = "rmsnorm", nonlinearity_type: str = "swiglu") -> dict:
+    """A `GPTConfig` kwargs dict of the second-stage kind (non-causal, 2 input hierarchies = text+cb0 / cb1,
+    6 target hierarchies cb2..cb7).  The real `second_stage.pt["model_args"]` is not available offline;
+    the engine is shape-generic and reads whatever the checkpoint says."""
+    return dict(
+        block_size=block_size, vocab_sizes=[1538, 1025], target_vocab_sizes=[1025] * 6, n_layer=n_layer,
+        n_head=n_head, n_embd=n_embd, dropout=0.0, spkemb_dropout=0.0, bias=bias, causal=False,
+        spk_emb_on_text=True, norm_type=norm_type, rmsnorm_eps=1e-5 if norm_type == "rmsnorm" else None,
+        nonlinearity_type=nonlinearity_type, swiglu_multiple_of=256 if nonlinearity_type == "swiglu" else None,
+        attn_kernel_type="torch_attn", kv_cache_enabled=False,
+    )
+
+
+def stage2_state_dict(model_args: dict, speaker_emb_dim: Optional[int] = 256, seed: int = 1) -> Dict[str, torch.Tensor]:
+    """`second_stage.pt["model"]` for `model_args` (names of `fam/llm/model.py:121-143`).  fp32 tensors holding
+    bf16-representable values (the real checkpoint is fp32 and runs under bf16 autocast)."""
+    a = model_args
+    C, L = a["n_embd"], a["n_layer"]
+    g = torch.Generator().manual_seed(seed)
+    proj_std = 0.02 / math.sqrt(2 * L)
+    if a["nonlinearity_type"] == "swiglu":
+        hidden = int(2 * 4 * C / 3)
+        hidden = a["swiglu_multiple_of"] * math.ceil(hidden / a["swiglu_multiple_of"])
+    else:
+        hidden = 4 * C
+    sd: Dict[str, torch.Tensor] = {}
+
+    def lin(name, out_f, in_f, std):
+        sd[name + ".weight"] = _normal(g, (out_f, in_f), std).float()
+        if a["bias"]:
+            sd[name + ".bias"] = _normal(g, (out_f,), 0.02).float()
+
+    def norm(name):
+        sd[name + ".weight"] = _norm_weight(g, C).float()
+        if a["norm_type"] == "layernorm" and a["bias"]:
+            sd[name + ".bias"] = _normal(g, (C,), 0.02).float()
+
+    for i, v in enumerate(a["vocab_sizes"]):
+        sd[f"transformer.wtes.{i}.weight"] = _normal(g, (v, C), 0.02).float()
+    sd["transformer.wpe.weight"] = _normal(g, (a["block_size"], C), 0.02).float()
+    for i in range(L):
+        p = f"transformer.h.{i}."
+        norm(p + "ln_1")
+        lin(p + "attn.c_attn", 3 * C, C, 0.02)
+        lin(p + "attn.c_proj", C, C, proj_std)
+        norm(p + "ln_2")
+        if a["nonlinearity_type"] == "swiglu":
+            lin(p + "mlp.swiglu.w1", hidden, C, 0.02)
+            lin(p + "mlp.swiglu.w3", hidden, C, 0.02)
+        else:
+            lin(p + "mlp.c_fc", hidden, C, 0.02)
+        lin(p + "mlp.c_proj", C, hidden, proj_std)
+    norm("transformer.ln_f")
+    if speaker_emb_dim is not None:
+        sd["speaker_cond_pos.weight"] = _normal(g, (C, speaker_emb_dim), 0.02).float()
+    for i, v in enumerate(a["target_vocab_sizes"]):
+        sd[f"lm_heads.{i}.weight"] = _normal(g, (v, C), 0.02).float()
+    return sd
+
+
+def speaker_embedding(seed: int = 0, dim: int = 256) -> torch.Tensor:
+    """A stand-in for the LSTM speaker encoder's output (`speaker_encoder/model.py:57-58`: ReLU then
+    L2-normalise), shape (1, dim), fp32 holding bf16-representable values."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    e = torch.relu(torch.randn(1, dim, generator=g))
+    e = e / e.norm(dim=-1, keepdim=True)
+    return e.to(torch.bfloat16).float()
+
+
+def prompt_tokens(n: int = 128, seed: int = 0, text_offset: int = 2049, n_text: int = 512) -> torch.Tensor:
+    """BASELINE config prompt: n-1 uniform text ids in [2049, 2560] followed by EOT 2561 (int32)."""
+    g = torch.Generator().manual_seed(2000 + seed)
+    body = torch.randint(text_offset, text_offset + n_text, (n - 1,), generator=g)
+    return torch.cat([body, torch.tensor([text_offset + n_text])]).to(torch.int32)

@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in this directory by running the REFERENCE code itself.
+
+Run in the build container only (needs /root/reference, which does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+The reference (`fam.llm.fast_model`, `fam.llm.fast_inference_utils`, `fam.llm.model`,
+`fam.llm.fast_quantize`, `fam.llm.adapters`, `fam.llm.utils`) is imported straight from
+/root/reference with `librosa` / `tiktoken` stubbed in `sys.modules` (they are imported at module top
+but unused by the model code) and executed on CPU with this repo's seeded synthetic checkpoints
+(`metavoice-src_amd/synthetic.py`).  Nothing from the reference is copied: only its OUTPUTS are stored.
+`tests/test_oracle_golden.py` then checks `oracle/` against these files on any machine.
+"""
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = os.environ.get("MV_REFERENCE", "/root/reference")
+
+for m in ("librosa", "tiktoken"):
+    sys.modules.setdefault(m, types.ModuleType(m))
+sys.path.insert(0, REFERENCE)
+sys.path.insert(0, ROOT)
+
+from fam.llm import fast_inference_utils as ref_fiu  # noqa: E402
+from fam.llm import fast_quantize as ref_fq  # noqa: E402
+from fam.llm.adapters import FlattenedInterleavedEncodec2Codebook, TiltedEncodec  # noqa: E402
+from fam.llm.fast_model import ModelArgs, Transformer  # noqa: E402
+from fam.llm.model import GPT, GPTConfig  # noqa: E402
+from fam.llm.utils import normalize_text as ref_normalize_text  # noqa: E402
+
+synthetic = importlib.import_module("metavoice-src_amd.synthetic")
+from oracle import adapters as o_adapters  # noqa: E402
+from oracle import quantize as o_quant  # noqa: E402
+from oracle import stage1 as o_s1  # noqa: E402
+from oracle import stage2 as o_s2  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def build_ref_stage1(cfg_kwargs, seed, dtype):
+    """Reference `Transformer` holding the synthetic checkpoint (after the reference-style key remap)."""
+    args = ModelArgs(n_layer=cfg_kwargs["n_layer"], n_head=cfg_kwargs["n_head"], dim=cfg_kwargs["dim"],
+                     vocab_size=cfg_kwargs["vocab_size"], block_size=cfg_kwargs["block_size"])
+    model = Transformer(args)
+    sd = synthetic.stage1_state_dict(seed=seed, **cfg_kwargs)
+    sd = o_s1.remap_checkpoint_keys(sd)
+    missing = model.load_state_dict({k: v.to(dtype) for k, v in sd.items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model = model.to(dtype).eval()
+    model.config.dtype = dtype  # ModelArgs picks fp16 when no GPU is present (utils.py:83-84)
+    model.setup_spk_cond_mask()
+    model.setup_caches(max_batch_size=2, max_seq_length=args.block_size)
+    return model, sd
+
+
+def stage1_case(name, cfg_kwargs, seed, T, n_new, with_bf16):
+    model, sd = build_ref_stage1(cfg_kwargs, seed, torch.float32)
+    prompt = synthetic.prompt_tokens(T, seed=seed)
+    spk = synthetic.speaker_embedding(seed)
+    # (1) the reference's own generate(), greedy expressed as top_k=1
+    torch.manual_seed(0)
+    seq = ref_fiu.generate(model, prompt, spk, max_new_tokens=n_new, temperature=torch.tensor(1.0), top_k=1,
+                           top_p=None, guidance_scale=torch.tensor(3.0), end_of_audio_token=9999)
+    seq = seq.tolist()
+    # (2) teacher-forced logits along that stream, fp32
+    def forced_logits(m, dtype):
+        m.setup_caches(2, cfg_kwargs["block_size"])
+        for b in m.layers:  # fresh caches
+            b.attention.kv_cache.k_cache.zero_()
+            b.attention.kv_cache.v_cache.zero_()
+        out = []
+        x = prompt.view(1, -1).repeat(2, 1)
+        lg = m(x, spk.to(dtype), torch.arange(T))
+        out.append(lg[:, -1].float())
+        for i in range(n_new - 1):
+            tok = seq[T + i]
+            lg = m(torch.full((2, 1), tok, dtype=torch.int32), spk.to(dtype), torch.tensor([T + i]))
+            out.append(lg[:, -1].float())
+        return torch.stack(out)
+    logits32 = forced_logits(model, torch.float32)
+    out = dict(cfg=json.dumps(cfg_kwargs), seed=seed, T=T, n_new=n_new, seq=np.array(seq, dtype=np.int32),
+               logits_fp32=logits32.numpy())
+    # cross-check the oracle right away
+    cfg = o_s1.Stage1Config(**cfg_kwargs)
+    orc = o_s1.Stage1Oracle({k: v.float() for k, v in sd.items()}, cfg, rounding="fp32", max_seq_length=cfg.block_size)
+    oseq, ologits = o_s1.generate(orc, prompt, spk, max_new_tokens=n_new, end_of_audio_token=9999, top_k=1,
+                                  noise=False, return_logits=True)
+    print(f"[{name}] fp32: seq equal={oseq == seq}  max|dlogit|={float((ologits - logits32).abs().max()):.3e}")
+    if with_bf16:
+        mb, _ = build_ref_stage1(cfg_kwargs, seed, torch.bfloat16)
+        logits16 = forced_logits(mb, torch.bfloat16)
+        out["logits_bf16"] = logits16.numpy()
+        ob = o_s1.Stage1Oracle({k: v.float() for k, v in sd.items()}, cfg, rounding="bf16", max_seq_length=cfg.block_size)
+        ol = []
+        x = prompt.view(1, -1).repeat(2, 1)
+        ol.append(ob.forward(x, spk, torch.arange(T))[:, -1])
+        for i in range(n_new - 1):
+            ol.append(ob.forward(torch.full((2, 1), seq[T + i]), spk, torch.tensor([T + i]))[:, -1])
+        ol = torch.stack(ol)
+        print(f"[{name}] bf16-points oracle vs reference bf16 eager: max|d|={float((ol - logits16).abs().max()):.3e} "
+              f"(vs fp32 ref: oracle {float((ol - logits32).abs().max()):.3e}, ref-bf16 {float((logits16 - logits32).abs().max()):.3e})")
+    np.savez_compressed(os.path.join(HERE, f"stage1_{name}.npz"), **out)
+
+
+def slow_vs_fast_selftest(cfg_kwargs, seed):
+    """the nanoGPT-style `GPT` and the gpt-fast `Transformer` are two independent reference
+    implementations of stage 1; they must agree on the same checkpoint."""
+    model, _ = build_ref_stage1(cfg_kwargs, seed, torch.float32)
+    gconf = GPTConfig(block_size=cfg_kwargs["block_size"], vocab_sizes=[cfg_kwargs["vocab_size"]], n_layer=cfg_kwargs["n_layer"],
+                      n_head=cfg_kwargs["n_head"], n_embd=cfg_kwargs["dim"], bias=False, causal=True, norm_type="rmsnorm",
+                      rmsnorm_eps=1e-5, nonlinearity_type="swiglu", swiglu_multiple_of=256)
+    slow = GPT(gconf, speaker_emb_dim=256).eval()
+    sd = synthetic.stage1_state_dict(seed=seed, **cfg_kwargs)
+    slow.load_state_dict({k: v.float() for k, v in sd.items()})
+    prompt = synthetic.prompt_tokens(10, seed=seed)
+    spk = synthetic.speaker_embedding(seed)
+    fast = model(prompt.view(1, -1).repeat(2, 1), spk, torch.arange(10))[:, -1]
+    lg, _ = slow(prompt.long().view(1, 1, -1).repeat(2, 1, 1), speaker_embs=[spk[0], None])
+    d = float((lg[0][:, -1] - fast).abs().max())
+    print(f"[selftest] slow GPT vs fast Transformer max|d|={d:.3e}")
+    assert d < 1e-4
+
+
+def sampling_case():
+    g = torch.Generator().manual_seed(7)
+    V = 2562
+    logits = torch.randn(6, V, generator=g) * 3.0
+    logits[1, 100] = logits[1].max()  # an exact tie at the top
+    combos = [dict(temperature=1.0, top_p=0.95, top_k=None), dict(temperature=0.7, top_p=0.9, top_k=None),
+              dict(temperature=1.0, top_p=None, top_k=50), dict(temperature=1.3, top_p=0.95, top_k=200),
+              dict(temperature=0.0, top_p=None, top_k=None), dict(temperature=1.0, top_p=None, top_k=1),
+              # the GPU path passes bf16 scalars: 0.95 -> 0.94921875 (SURVEY 8c gotcha 9)
+              dict(temperature=1.0, top_p=float(torch.tensor(0.95).bfloat16()), top_k=None)]
+    probs = np.zeros((len(combos), logits.shape[0], V), dtype=np.float32)
+    worst = 0.0
+    for ci, c in enumerate(combos):
+        for li in range(logits.shape[0]):
+            p = ref_fiu.logits_to_probs(logits[li].clone(), temperature=torch.tensor(c["temperature"]),
+                                        top_p=None if c["top_p"] is None else torch.tensor(c["top_p"]), top_k=c["top_k"])
+            probs[ci, li] = p.numpy()
+            o = o_s1.logits_to_probs(logits[li].clone(), c["temperature"], top_p=c["top_p"], top_k=c["top_k"])
+            worst = max(worst, float((o - p).abs().max()))
+    # CFG mix through the reference's sample(): (2,1,V) logits
+    pair = torch.randn(2, 1, V, generator=g) * 3.0
+    torch.manual_seed(0)
+    _, pmix = ref_fiu.sample(pair, guidance_scale=torch.tensor(3.0), temperature=torch.tensor(1.0), top_p=torch.tensor(0.95))
+    _, omix = o_s1.sample(pair, 3.0, 1.0, top_p=0.95)
+    worst = max(worst, float((omix - pmix).abs().max()))
+    print(f"[sampling] oracle vs reference max|dprob|={worst:.3e}")
+    np.savez_compressed(os.path.join(HERE, "sampling.npz"), logits=logits.numpy(), combos=json.dumps(combos), probs=probs,
+                        cfg_pair=pair.numpy(), cfg_probs=pmix.numpy())
+
+
+def quant_case():
+    g = torch.Generator().manual_seed(11)
+    w = (torch.randn(64, 512, generator=g) * 0.02).to(torch.bfloat16)
+    w[3, :128] = 0.0  # a constant group: exercises the 1e-6 clamp
+    q, sz = ref_fq.group_quantize_tensor(w, n_bit=4, groupsize=128)
+    scales, zeros = ref_fq.get_group_qparams(w, 4, 128)
+    deq = ref_fq.group_dequantize_tensor_from_qparams(q, scales, zeros, 4, 128)
+    q8, s8, _ = ref_fq.dynamically_quantize_per_channel(w.float(), -128, 127, torch.int8)
+    oq, osz = o_quant.group_quantize_tensor(w)
+    od = o_quant.group_dequantize(oq, osz, out_dtype=torch.bfloat16)
+    oq8, os8 = o_quant.quantize_per_channel_int8(w.float())
+    print(f"[quant] int4 codes equal={bool((oq == q).all())} sz equal={bool((osz == sz).all())} "
+          f"deq equal={bool((od == deq).all())} int8 equal={bool((oq8 == q8).all())} scales equal={bool((os8 == s8).all())}")
+    np.savez_compressed(os.path.join(HERE, "quant.npz"), w=w.float().numpy(), q4=q.numpy().astype(np.int8),
+                        scales_and_zeros=sz.float().numpy(), deq=deq.float().numpy(), q8=q8.numpy(), s8=s8.numpy())
+
+
+def adapters_case():
+    rng = np.random.default_rng(3)
+    cases = []
+    for n in (0, 1, 7, 40, 41):
+        toks = [int(t) for t in rng.integers(2049, 2562, size=5)] + [int(t) for t in rng.integers(0, 2049, size=n)]
+        toks += [2048] if n % 2 else []
+        t_text, t_audio = FlattenedInterleavedEncodec2Codebook(end_of_audio_token=1024).decode([toks])
+        cases.append(dict(kind="flattened", tokens=toks, text=t_text, audio=t_audio))
+        assert o_adapters.flattened_interleaved_decode(toks) == (t_text, t_audio)
+    for t in (3, 16):
+        grid = [[int(x) for x in rng.integers(1025, 1538, size=4)] + [int(x) for x in rng.integers(0, 1025, size=t)]]
+        for r in range(7):
+            grid.append([1024] * 4 + [int(x) for x in rng.integers(0, 1026, size=t)])
+        t_text, t_audio = TiltedEncodec(end_of_audio_token=1024).decode(grid)
+        cases.append(dict(kind="tilted", tokens=grid, text=t_text, audio=t_audio))
+        assert o_adapters.tilted_decode(grid) == (t_text, t_audio)
+    texts = ["Hello  “world” — it’s 12…", "a\tb\nc  *d*  ", "plain ascii", "café naïve"]
+    norm = []
+    for s in texts:
+        norm.append(dict(text=s, out=ref_normalize_text(s)))
+        assert o_adapters.normalize_text(s) == norm[-1]["out"]
+    try:
+        ref_normalize_text("你好")
+        raised = False
+    except ValueError:
+        raised = True
+    norm.append(dict(text="你好", raises=raised))
+    with open(os.path.join(HERE, "adapters.json"), "w") as f:
+        json.dump(dict(cases=cases, normalize=norm), f)
+    print(f"[adapters] {len(cases)} adapter cases + {len(norm)} normalize_text cases pinned")
+
+
+def stage2_case(name, **kw):
+    args = synthetic.stage2_model_args(block_size=32, n_layer=2, n_head=2, n_embd=128, **kw)
+    sd = synthetic.stage2_state_dict(args, speaker_emb_dim=256, seed=5)
+    model = GPT(GPTConfig(**args), speaker_emb_dim=256).eval()
+    model.load_state_dict(sd)
+    g = torch.Generator().manual_seed(9)
+    t = args["block_size"]
+    row0 = torch.cat([torch.randint(1025, 1538, (6,), generator=g), torch.randint(0, 1024, (t - 8,), generator=g), torch.tensor([1024, 1024])])
+    row1 = torch.cat([torch.full((6,), 1024), torch.randint(0, 1024, (t - 8,), generator=g), torch.tensor([1024, 1024])])
+    idx = torch.stack([row0, row1])[None].long()
+    spk = synthetic.speaker_embedding(2)
+    logits, _ = model(idx, speaker_embs=spk)
+    torch.manual_seed(0)
+    toks = model.generate(idx, None, temperature=1.0, top_k=1, speaker_embs=spk, batch_size=1)
+    cfg = o_s2.Stage2Config(**{k: v for k, v in args.items() if k in o_s2.Stage2Config.__dataclass_fields__})
+    orc = o_s2.Stage2Oracle(sd, cfg, rounding="fp32")
+    ol = orc.forward(idx, spk)
+    d = max(float((a - b).abs().max()) for a, b in zip(ol, logits))
+    ot = orc.non_causal_sample(idx, spk, temperature=1.0, top_k=1)
+    print(f"[stage2 {name}] max|dlogit|={d:.3e} greedy tokens equal={bool((ot == toks).all())}")
+    np.savez_compressed(os.path.join(HERE, f"stage2_{name}.npz"), model_args=json.dumps(args), seed=5, idx=idx.numpy(),
+                        logits_sub=torch.stack(logits)[:, :, ::4].numpy(), tokens=toks.numpy())
+
+
+if __name__ == "__main__":
+    small = dict(n_layer=2, n_head=2, dim=256, vocab_size=2562, block_size=64)
+    wide = dict(n_layer=2, n_head=16, dim=2048, vocab_size=2562, block_size=2048)
+    slow_vs_fast_selftest(small, 0)
+    stage1_case("small", small, seed=0, T=12, n_new=20, with_bf16=True)
+    stage1_case("wide2", wide, seed=1, T=16, n_new=6, with_bf16=False)
+    sampling_case()
+    quant_case()
+    adapters_case()
+    stage2_case("rms_swiglu")
+    stage2_case("ln_gelu_bias", bias=True, norm_type="layernorm", nonlinearity_type="gelu")
+    print("golden vectors written to", HERE)
