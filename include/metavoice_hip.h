@@ -1,0 +1,125 @@
+/*
+ * metavoice_hip.h -- C ABI of the MI355X-native MetaVoice-1B synthesis engine (libmetavoice_hip.so).
+ *
+ * The reference (metavoiceio/metavoice-src) has NO FFI / plugin interface: its boundary for this path is a
+ * Python call surface.  This header is the C-ABI a binding for that surface binds to;
+ * each entry point names the reference interface it replaces (paths relative to the reference repo).
+ * Plain pointers and sizes only -- no torch types.  Every function returns 0 on success or a negative
+ * mv_status; mv_last_error() gives the message.  All device work of one engine runs on the engine's
+ * own HIP stream; an engine is NOT re-entrant (same as the reference: one global TTS, serving.py:46-51).
+ *
+ * Host-side mirror of the reference API built on this ABI: metavoice-src_amd/ (Python, ctypes).
+ */
+#ifndef METAVOICE_HIP_H
+#define METAVOICE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mv_engine mv_engine;
+
+enum mv_status {
+    MV_OK = 0,
+    MV_ERR_INVALID = -1,      /* bad argument / unsupported shape            (Python: ValueError)  */
+    MV_ERR_HIP = -2,          /* a HIP runtime call failed                   (Python: RuntimeError) */
+    MV_ERR_STATE = -3,        /* call order violated (e.g. run before begin) (Python: RuntimeError) */
+    MV_ERR_MISSING_WEIGHT = -4,
+    MV_ERR_PROMPT_TOO_LONG = -5 /* fam/llm/fast_inference_utils.py:203-204 -> ValueError           */
+};
+
+enum mv_dtype { MV_BF16 = 0, MV_F32 = 1, MV_I32 = 2, MV_I8 = 3 };
+enum mv_weight_format { MV_W_BF16 = 0, MV_W_INT4_G128 = 1, MV_W_INT8 = 2 };
+
+/* Mirrors ModelArgs (fam/llm/fast_model.py:52-84) plus engine sizing. */
+typedef struct mv_config {
+    int32_t n_layer;          /* 24   */
+    int32_t n_head;           /* 16   (head_dim = dim / n_head must be 128) */
+    int32_t dim;              /* 2048 */
+    int32_t intermediate;     /* 5632 */
+    int32_t vocab;            /* 2562 (<= 4096) */
+    int32_t block_size;       /* 2048 */
+    int32_t spk_dim;          /* 256  */
+    float norm_eps;           /* 1e-5 */
+    int32_t max_utterances;   /* utterances decoded together; each takes 2 CFG rows (fast_model.py:132-134) */
+    int32_t weight_format;    /* mv_weight_format: quantisation_mode of TTS.__init__ (fast_inference.py:41-50) */
+} mv_config;
+
+/* Per-utterance sampling controls == **sampling_kwargs of generate() (fast_inference_utils.py:85-120).
+ * The reference passes guidance/temperature/top_p as 0-d tensors in the model dtype, i.e. already rounded
+ * to bf16 on the GPU path; the host shim does that rounding and passes plain floats here. */
+typedef struct mv_sampling {
+    float guidance_scale;     /* g          */
+    float one_minus_guidance; /* (1 - g) as the reference computes it in the model dtype */
+    float temperature;        /* clamped to >= 1e-5 by the engine (fast_inference_utils.py:92) */
+    float top_p;              /* <= 0 : disabled (None) */
+    int32_t top_k;            /* <= 0 : disabled (None) */
+    uint64_t seed;            /* Philox key for the Exp(1) race noise (fast_inference_utils.py:61-65) */
+} mv_sampling;
+
+/* ---- lifecycle: replaces _load_model/build_model (fam/llm/fast_inference_utils.py:236-392) ------------- */
+int mv_engine_create(const mv_config* cfg, mv_engine** out);
+int mv_engine_destroy(mv_engine* e);
+/* `name` is the gpt-fast tensor name AFTER the key remap of fast_inference_utils.py:250-278
+ * ("tok_embeddings.weight", "layers.3.attention.wqkv.weight", ...).  `data` may be a host or a device
+ * pointer (row-major [rows][cols], dtype MV_BF16 or MV_F32); the engine copies it into its own arena. */
+int mv_load_weight(mv_engine* e, const char* name, const void* data, int32_t dtype, int64_t rows, int64_t cols);
+/* Checks every tensor is present, quantises if cfg.weight_format asks for it (numerics of
+ * fam/llm/fast_quantize.py:70-132 / :38-67), allocates the static KV caches
+ * (Transformer.setup_caches, fast_model.py:136-148) and captures the decode-step hipGraph
+ * (the role torch.compile(mode="max-autotune") + CUDA graphs play at fast_inference_utils.py:357-361). */
+int mv_finalize(mv_engine* e);
+int64_t mv_model_bytes(const mv_engine* e);   /* == model_size of build_model (:348) for the stored format */
+
+/* ---- generation: replaces generate()/prefill()/decode_n_tokens() (fast_inference_utils.py:123-228) ----- */
+/* prompts: host int32 [n_utt][max_len] (row u valid for prompt_lens[u] entries); spk_emb: host bf16 bits
+ * [n_utt][spk_dim]; max_new_tokens < 0 means "up to block_size" (generate(): :197-204).
+ * prefill_mode 0 = teacher-forced decode steps, 1 = batched MFMA prefill. */
+int mv_begin(mv_engine* e, int32_t n_utt, const int32_t* prompts, const int32_t* prompt_lens, int32_t max_len,
+             const uint16_t* spk_emb, const mv_sampling* sampling, int32_t max_new_tokens, int32_t eoa_token,
+             int32_t prefill_mode);
+/* Runs decode steps (one hipGraph replay each) until every utterance has drawn its end-of-audio token or hit
+ * its length cap, or max_steps (<0: no limit) have run.  `poll_every` steps the host reads the device-side
+ * "all done" word -- the reference synchronises every token (fast_inference_utils.py:161). */
+int mv_run(mv_engine* e, int32_t max_steps, int32_t poll_every, int32_t* steps_run);
+float mv_last_run_ms(const mv_engine* e);      /* HIP-event time of the last mv_run on the engine stream */
+/* Full sequence prompt ++ generated (generate() return value, :226-228), EOA included when drawn. */
+int mv_get_tokens(mv_engine* e, int32_t utt, int32_t* out, int32_t cap, int32_t* n_out);
+
+/* ---- parity hooks (no reference equivalent; SURVEY.md 8b "mv_logits_debug") --------------------------- */
+/* When enabled before mv_begin, every step stores the raw logits of all rows (fp32 [step][rows][vocab]). */
+int mv_set_logits_capture(mv_engine* e, int32_t enable, int32_t max_steps);
+int mv_get_captured_logits(mv_engine* e, float* out, int32_t first_step, int32_t n_steps);
+
+/* ---- single-kernel entry points on caller-owned DEVICE buffers (used by tests and the roofline probe) -- */
+/* out[r][n] = bf16( sum_k bf16_x[r][k] * W[n][k] ), optional fused RMSNorm prologue (norm_w != NULL) and
+ * residual epilogue (residual != NULL): the building block of K2+K3, K6, K7, K8. */
+int mv_op_gemv(void* stream, int32_t rows, int32_t N, int32_t K, const void* x, const void* w, const void* norm_w,
+               float eps, const void* residual, void* out);
+int mv_op_swiglu_gemv(void* stream, int32_t rows, int32_t N, int32_t K, const void* x, const void* w1, const void* w3,
+                      const void* norm_w, float eps, void* out);
+/* Split-KV decode attention over keys [0, n_keys) of a [rows][n_head][cache_len][128] bf16 cache. */
+int mv_op_attention_decode(void* stream, int32_t rows, int32_t n_head, int32_t cache_len, const int32_t* n_keys_dev,
+                           const void* q, const void* kcache, const void* vcache, void* scratch, void* out);
+int64_t mv_op_attention_scratch_bytes(int32_t rows, int32_t n_head);
+/* CFG mix + temperature + top-k/top-p + Exp(1) race on one (2, vocab) bf16 logits pair; writes token and the
+ * kept-probabilities vector (fp32 [vocab], original token order). */
+int mv_op_sample(void* stream, int32_t vocab, const void* logits_pair, const mv_sampling* s, uint32_t step,
+                 int32_t* token_out, float* probs_out);
+
+/* Roofline probe: launches one kernel kind of the decode step `iters` times back to back on the engine stream, cycling
+ * through the layers' weights (so the stream is HBM-cold: 24 x 46 MB >> the 256 MB Infinity Cache), bracketed by HIP
+ * events on that stream.  Returns the average launch duration and the ALGORITHMIC bytes one launch must move
+ * (SURVEY.md 8d).  kind: 0 norm+wqkv+kv-write, 1 attention (at the utterances' current positions), 2 wo+residual,
+ * 3 norm+w1|w3+silu-gate, 4 w2+residual, 5 norm+LM head. */
+int mv_probe_kernel(mv_engine* e, int32_t kind, int32_t iters, float* avg_ms, double* bytes_per_launch);
+
+const char* mv_last_error(void);
+const char* mv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* METAVOICE_HIP_H */

@@ -1,0 +1,75 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of the MetaVoice engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+#define MV_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xFFFF0000u); }
+
+// fp32 -> bf16, round to nearest even (the rounding torch's .to(bfloat16) applies).
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (bf16_t)((u >> 16) | 0x40u);  // quiet NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float round_bf(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+// acc += w.lo*x.lo + w.hi*x.hi  (v_dot2c_f32_bf16; products of two bf16 are exact in fp32)
+__device__ __forceinline__ float dot2_bf16(uint32_t w, uint32_t x, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w), __builtin_bit_cast(bf16x2_t, x), acc, false);
+}
+__device__ __forceinline__ float dot8_bf16(const u32x4& w, const u32x4& x, float acc) {
+    acc = dot2_bf16(w.x, x.x, acc);
+    acc = dot2_bf16(w.y, x.y, acc);
+    acc = dot2_bf16(w.z, x.z, acc);
+    acc = dot2_bf16(w.w, x.w, acc);
+    return acc;
+}
+
+// Streaming (read-once) 16-byte load: global_load_dwordx4 ... nt  (MI355X_MICROARCH "nt-weights").
+__device__ __forceinline__ u32x4 load_stream16(const void* p) { return __builtin_nontemporal_load((const u32x4*)p); }
+__device__ __forceinline__ u32x4 load16(const void* p) { return *(const u32x4*)p; }
+
+// ---- cross-lane sums over a 64-lane wave; every lane ends up with the total -------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float sum_across16(float v) {
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]  (lane ^ 1)
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]  (lane ^ 2)
+    v += dpp_f<0x141>(v);  // row_half_mirror      (8-lane halves)
+    v += dpp_f<0x140>(v);  // row_mirror           (16-lane rows)
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = sum_across16(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float max_across16(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = max_across16(v);
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }

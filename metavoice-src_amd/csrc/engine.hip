@@ -1,0 +1,581 @@
+// Host side of libmetavoice_hip.so: weight arena, static KV caches, decode-step hipGraph, the C ABI of
+// include/metavoice_hip.h.  See DESIGN.md for the memory layout and the kernel list.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess) return fail(MV_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                          __FILE__, __LINE__);                                             \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+__global__ void f32_to_bf16_kernel(const float* in, bf16_t* out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        uint32_t u = __float_as_uint(in[i]);
+        if ((u & 0x7FFFFFFFu) > 0x7F800000u) { out[i] = (bf16_t)((u >> 16) | 0x40u); return; }
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        out[i] = (bf16_t)(u >> 16);
+    }
+}
+
+struct LayerW {
+    bf16_t *attn_norm = nullptr, *wqkv = nullptr, *wo = nullptr, *ffn_norm = nullptr, *w1 = nullptr, *w3 = nullptr,
+           *w2 = nullptr;
+};
+
+struct Slot {
+    std::string name;
+    bf16_t** ptr;
+    int64_t rows, cols;
+    bool loaded = false;
+};
+
+}  // namespace
+
+struct mv_engine {
+    mv_config cfg{};
+    int R = 0;  // CFG rows = 2 * max_utterances
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // weights (bf16, one arena, laid out in streaming order: per layer norm|wqkv|wo|norm|w1|w3|w2)
+    unsigned char* arena = nullptr;
+    size_t arena_bytes = 0;
+    bf16_t *tok_emb = nullptr, *pos_emb = nullptr, *spk_w = nullptr, *final_norm = nullptr, *head = nullptr;
+    std::vector<LayerW> layers;
+    std::vector<Slot> slots;
+    bool finalized = false;
+
+    // activations / state
+    bf16_t *x = nullptr, *h = nullptr, *q = nullptr, *attn = nullptr, *act = nullptr, *logits = nullptr;
+    bf16_t *kcache = nullptr, *vcache = nullptr;  // [n_layer][R][n_head][block_size][128]
+    size_t kv_layer_elems = 0;
+    float* partial = nullptr;
+    uint32_t* counters = nullptr;
+    UttState* utt = nullptr;
+    int32_t* pos_arr = nullptr;
+    int32_t* seq = nullptr;
+    bf16_t *spk_emb = nullptr, *spk_proj = nullptr;
+    int32_t* n_active = nullptr;
+    int32_t* host_flag = nullptr;  // pinned
+    float* capture = nullptr;
+    int capture_max = 0;
+    bool capture_on = false;
+
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    bool use_graph = true;
+
+    int n_utt = 0;
+    bool begun = false;
+    int steps_budget = 0;
+    float last_ms = 0.f;
+};
+
+namespace {
+
+int enqueue_step(mv_engine* e) {
+    const mv_config& c = e->cfg;
+    const int R = e->R;
+    hipStream_t s = e->stream;
+    for (int l = 0; l < c.n_layer; ++l) {
+        const LayerW& w = e->layers[l];
+        bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
+        bf16_t* vc = e->vcache + (size_t)l * e->kv_layer_elems;
+        {   // RMSNorm + wqkv + KV-cache write            (fast_model.py:179,209,218)
+            GemvArgs a;
+            a.x = e->x; a.w = w.wqkv; a.norm_w = w.attn_norm; a.out = e->q; a.kcache = kc; a.vcache = vc;
+            a.pos = e->pos_arr; a.cache_len = c.block_size; a.n_head = c.n_head; a.dim = c.dim;
+            a.N = 3 * c.dim; a.K = c.dim; a.eps = c.norm_eps;
+            HIP_TRY(launch_gemv(s, R, a, GEMV_QKV));
+        }
+        {   // attention over keys [0, pos]                (fast_model.py:222)
+            AttnArgs a;
+            a.q = e->q; a.kcache = kc; a.vcache = vc; a.pos = e->pos_arr; a.partial = e->partial;
+            a.counters = e->counters; a.out = e->attn; a.n_head = c.n_head; a.cache_len = c.block_size;
+            HIP_TRY(launch_attention_decode(s, R, a));
+        }
+        {   // h = x + wo(attn)                            (fast_model.py:226,179)
+            GemvArgs a;
+            a.x = e->attn; a.w = w.wo; a.residual = e->x; a.out = e->h; a.N = c.dim; a.K = c.dim;
+            HIP_TRY(launch_gemv(s, R, a, GEMV_RESID));
+        }
+        {   // act = silu(w1 n(h)) * w3 n(h)               (fast_model.py:180,237)
+            GemvArgs a;
+            a.x = e->h; a.w = w.w1; a.w2 = w.w3; a.norm_w = w.ffn_norm; a.out = e->act; a.N = c.intermediate;
+            a.K = c.dim; a.eps = c.norm_eps;
+            HIP_TRY(launch_gemv(s, R, a, GEMV_SWIGLU));
+        }
+        {   // x = h + w2(act)                             (fast_model.py:247,180)
+            GemvArgs a;
+            a.x = e->act; a.w = w.w2; a.residual = e->h; a.out = e->x; a.N = c.dim; a.K = c.intermediate;
+            HIP_TRY(launch_gemv(s, R, a, GEMV_RESID));
+        }
+    }
+    {   // logits = head(norm(x))                          (fast_model.py:161-162)
+        GemvArgs a;
+        a.x = e->x; a.w = e->head; a.norm_w = e->final_norm; a.out = e->logits; a.N = c.vocab; a.K = c.dim;
+        a.eps = c.norm_eps;
+        HIP_TRY(launch_gemv(s, R, a, GEMV_PLAIN));
+    }
+    {   // sample, bookkeeping, next input embedding        (fast_inference_utils.py:107-120,148-174)
+        SampleArgs a;
+        a.logits = e->logits; a.utt = e->utt; a.pos_arr = e->pos_arr; a.seq = e->seq; a.tok_emb = e->tok_emb;
+        a.pos_emb = e->pos_emb; a.spk_proj = e->spk_proj; a.x_next = e->x; a.n_active = e->n_active;
+        a.capture = e->capture_on ? e->capture : nullptr; a.capture_max = e->capture_max;
+        a.vocab = c.vocab; a.dim = c.dim; a.block_size = c.block_size; a.n_utt = c.max_utterances;
+        HIP_TRY(launch_sample(s, a, false));
+    }
+    return MV_OK;
+}
+
+int build_graph(mv_engine* e) {
+    if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+    if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
+    if (!e->use_graph) return MV_OK;
+    HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeRelaxed));
+    const int rc = enqueue_step(e);
+    hipGraph_t g = nullptr;
+    hipError_t ce = hipStreamEndCapture(e->stream, &g);
+    if (rc != MV_OK) { if (g) hipGraphDestroy(g); return rc; }
+    if (ce != hipSuccess) return fail(MV_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+    e->graph = g;
+    HIP_TRY(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+    return MV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mv_last_error(void) { return g_err.c_str(); }
+const char* mv_version(void) { return "metavoice_hip 0.1 (gfx950)"; }
+
+int mv_engine_create(const mv_config* cfg, mv_engine** out) {
+    if (!cfg || !out) return fail(MV_ERR_INVALID, "null argument");
+    const mv_config& c = *cfg;
+    if (c.n_layer < 1 || c.n_head < 1 || c.dim < 128 || c.dim % c.n_head != 0 || c.dim / c.n_head != 128)
+        return fail(MV_ERR_INVALID, "head_dim must be 128 (dim=%d n_head=%d)", c.dim, c.n_head);
+    if (c.vocab < 2 || c.vocab > 4096) return fail(MV_ERR_INVALID, "vocab %d out of range [2,4096]", c.vocab);
+    if (c.max_utterances < 1 || c.max_utterances > 4) return fail(MV_ERR_INVALID, "max_utterances must be 1..4");
+    if (!gemv_supported(2 * c.max_utterances, c.dim) || !gemv_supported(2 * c.max_utterances, c.intermediate))
+        return fail(MV_ERR_INVALID, "unsupported dim/intermediate %d/%d (K must be a multiple of 8 with ceil(K/512) in {1,2,4,11})",
+                    c.dim, c.intermediate);
+    if (c.weight_format != MV_W_BF16) return fail(MV_ERR_INVALID, "weight_format %d not supported by this build", c.weight_format);
+    if (c.block_size < 8 || c.spk_dim < 1) return fail(MV_ERR_INVALID, "bad block_size/spk_dim");
+
+    mv_engine* e = new mv_engine();
+    e->cfg = c;
+    e->R = 2 * c.max_utterances;
+    e->use_graph = getenv("MV_NO_GRAPH") == nullptr;
+    e->layers.resize(c.n_layer);
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
+        hipEventCreate(&e->ev1) != hipSuccess) {
+        delete e;
+        return fail(MV_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+
+    // ---- weight arena, in the order the decode step streams it ------------------------------------------
+    auto add = [&](const std::string& name, bf16_t** p, int64_t rows, int64_t cols) {
+        e->slots.push_back(Slot{name, p, rows, cols});
+    };
+    add("tok_embeddings.weight", &e->tok_emb, c.vocab, c.dim);
+    add("pos_embeddings.weight", &e->pos_emb, c.block_size, c.dim);
+    add("speaker_cond_pos.weight", &e->spk_w, c.dim, c.spk_dim);
+    for (int l = 0; l < c.n_layer; ++l) {
+        const std::string p = "layers." + std::to_string(l) + ".";
+        LayerW& w = e->layers[l];
+        add(p + "attention_norm.weight", &w.attn_norm, 1, c.dim);
+        add(p + "attention.wqkv.weight", &w.wqkv, 3 * (int64_t)c.dim, c.dim);
+        add(p + "attention.wo.weight", &w.wo, c.dim, c.dim);
+        add(p + "ffn_norm.weight", &w.ffn_norm, 1, c.dim);
+        add(p + "feed_forward.swiglu.w1.weight", &w.w1, c.intermediate, c.dim);
+        add(p + "feed_forward.swiglu.w3.weight", &w.w3, c.intermediate, c.dim);
+        add(p + "feed_forward.w2.weight", &w.w2, c.dim, c.intermediate);
+    }
+    add("norm.weight", &e->final_norm, 1, c.dim);
+    add("output.weight", &e->head, c.vocab, c.dim);
+    size_t off = 0;
+    std::vector<size_t> offs;
+    for (auto& s : e->slots) {
+        offs.push_back(off);
+        off += align_up((size_t)s.rows * s.cols * 2, 256);
+    }
+    e->arena_bytes = off;
+    if (hipMalloc((void**)&e->arena, e->arena_bytes) != hipSuccess) {
+        mv_engine_destroy(e);
+        return fail(MV_ERR_HIP, "hipMalloc of %zu weight bytes failed", e->arena_bytes);
+    }
+    for (size_t i = 0; i < e->slots.size(); ++i) *e->slots[i].ptr = (bf16_t*)(e->arena + offs[i]);
+    *out = e;
+    return MV_OK;
+}
+
+int mv_engine_destroy(mv_engine* e) {
+    if (!e) return MV_OK;
+    if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
+    if (e->graph) hipGraphDestroy(e->graph);
+    void* bufs[] = {e->arena, e->x, e->h, e->q, e->attn, e->act, e->logits, e->kcache, e->vcache, e->partial, e->counters,
+                    e->utt, e->pos_arr, e->seq, e->spk_emb, e->spk_proj, e->n_active, e->capture};
+    for (void* b : bufs)
+        if (b) hipFree(b);
+    if (e->host_flag) hipHostFree(e->host_flag);
+    if (e->ev0) hipEventDestroy(e->ev0);
+    if (e->ev1) hipEventDestroy(e->ev1);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+    return MV_OK;
+}
+
+int mv_load_weight(mv_engine* e, const char* name, const void* data, int32_t dtype, int64_t rows, int64_t cols) {
+    if (!e || !name || !data) return fail(MV_ERR_INVALID, "null argument");
+    if (e->finalized) return fail(MV_ERR_STATE, "engine already finalized");
+    for (auto& s : e->slots) {
+        if (s.name != name) continue;
+        if ((int64_t)rows * cols != s.rows * s.cols || (s.rows != 1 && (rows != s.rows || cols != s.cols)))
+            return fail(MV_ERR_INVALID, "%s: shape (%lld,%lld) != expected (%lld,%lld)", name, (long long)rows,
+                        (long long)cols, (long long)s.rows, (long long)s.cols);
+        const size_t n = (size_t)rows * cols;
+        if (dtype == MV_BF16) {
+            HIP_TRY(hipMemcpy(*s.ptr, data, n * 2, hipMemcpyDefault));
+        } else if (dtype == MV_F32) {
+            float* tmp = nullptr;
+            HIP_TRY(hipMalloc((void**)&tmp, n * 4));
+            hipError_t ce = hipMemcpy(tmp, data, n * 4, hipMemcpyDefault);
+            if (ce == hipSuccess) {
+                hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, tmp, *s.ptr, n);
+                ce = hipStreamSynchronize(e->stream);
+            }
+            hipFree(tmp);
+            if (ce != hipSuccess) return fail(MV_ERR_HIP, "%s: upload failed: %s", name, hipGetErrorString(ce));
+        } else {
+            return fail(MV_ERR_INVALID, "%s: dtype %d not accepted (bf16 or f32)", name, dtype);
+        }
+        s.loaded = true;
+        return MV_OK;
+    }
+    return fail(MV_ERR_INVALID, "unknown tensor name '%s'", name);
+}
+
+int mv_finalize(mv_engine* e) {
+    if (!e) return fail(MV_ERR_INVALID, "null engine");
+    if (e->finalized) return MV_OK;
+    for (auto& s : e->slots)
+        if (!s.loaded) return fail(MV_ERR_MISSING_WEIGHT, "tensor '%s' was never loaded", s.name.c_str());
+    const mv_config& c = e->cfg;
+    const int R = e->R, U = c.max_utterances;
+    e->kv_layer_elems = (size_t)R * c.n_head * c.block_size * 128;
+    HIP_TRY(hipMalloc((void**)&e->x, (size_t)R * c.dim * 2));
+    HIP_TRY(hipMalloc((void**)&e->h, (size_t)R * c.dim * 2));
+    HIP_TRY(hipMalloc((void**)&e->q, (size_t)R * c.dim * 2));
+    HIP_TRY(hipMalloc((void**)&e->attn, (size_t)R * c.dim * 2));
+    HIP_TRY(hipMalloc((void**)&e->act, (size_t)R * c.intermediate * 2));
+    HIP_TRY(hipMalloc((void**)&e->logits, (size_t)R * c.vocab * 2));
+    HIP_TRY(hipMalloc((void**)&e->kcache, e->kv_layer_elems * c.n_layer * 2));
+    HIP_TRY(hipMalloc((void**)&e->vcache, e->kv_layer_elems * c.n_layer * 2));
+    HIP_TRY(hipMemset(e->kcache, 0, e->kv_layer_elems * c.n_layer * 2));
+    HIP_TRY(hipMemset(e->vcache, 0, e->kv_layer_elems * c.n_layer * 2));
+    HIP_TRY(hipMalloc((void**)&e->partial, (size_t)R * c.n_head * ATTN_NSPLIT * ATTN_PART_STRIDE * 4));
+    HIP_TRY(hipMalloc((void**)&e->counters, (size_t)R * c.n_head * 4));
+    HIP_TRY(hipMemset(e->counters, 0, (size_t)R * c.n_head * 4));
+    HIP_TRY(hipMalloc((void**)&e->utt, (size_t)U * sizeof(UttState)));
+    HIP_TRY(hipMalloc((void**)&e->pos_arr, (size_t)U * 4));
+    HIP_TRY(hipMalloc((void**)&e->seq, (size_t)U * c.block_size * 4));
+    HIP_TRY(hipMalloc((void**)&e->spk_emb, (size_t)U * c.spk_dim * 2));
+    HIP_TRY(hipMalloc((void**)&e->spk_proj, (size_t)U * c.dim * 2));
+    HIP_TRY(hipMalloc((void**)&e->n_active, 4));
+    HIP_TRY(hipHostMalloc((void**)&e->host_flag, 4, hipHostMallocDefault));
+    HIP_TRY(hipMemset(e->x, 0, (size_t)R * c.dim * 2));
+    HIP_TRY(hipDeviceSynchronize());
+    e->finalized = true;
+    return build_graph(e);
+}
+
+int64_t mv_model_bytes(const mv_engine* e) {
+    if (!e) return 0;
+    int64_t b = 0;
+    for (auto& s : e->slots) b += s.rows * s.cols * 2;
+    return b;
+}
+
+int mv_set_logits_capture(mv_engine* e, int32_t enable, int32_t max_steps) {
+    if (!e || !e->finalized) return fail(MV_ERR_STATE, "engine not finalized");
+    const bool want = enable != 0;
+    if (want) {
+        if (max_steps < 1 || max_steps > e->cfg.block_size) max_steps = e->cfg.block_size;
+        if (!e->capture || e->capture_max < max_steps) {
+            if (e->capture) hipFree(e->capture);
+            e->capture = nullptr;
+            HIP_TRY(hipMalloc((void**)&e->capture, (size_t)max_steps * e->R * e->cfg.vocab * 4));
+            e->capture_max = max_steps;
+        }
+    }
+    if (want != e->capture_on) {
+        e->capture_on = want;
+        return build_graph(e);  // the capture pointer is a kernel argument frozen in the graph
+    }
+    return MV_OK;
+}
+
+int mv_get_captured_logits(mv_engine* e, float* out, int32_t first_step, int32_t n_steps) {
+    if (!e || !e->capture) return fail(MV_ERR_STATE, "logits capture is not enabled");
+    if (first_step < 0 || n_steps < 0 || first_step + n_steps > e->capture_max) return fail(MV_ERR_INVALID, "range out of capture");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const size_t per = (size_t)e->R * e->cfg.vocab;
+    HIP_TRY(hipMemcpy(out, e->capture + (size_t)first_step * per, (size_t)n_steps * per * 4, hipMemcpyDeviceToHost));
+    return MV_OK;
+}
+
+int mv_begin(mv_engine* e, int32_t n_utt, const int32_t* prompts, const int32_t* prompt_lens, int32_t max_len,
+             const uint16_t* spk_emb, const mv_sampling* sampling, int32_t max_new_tokens, int32_t eoa_token,
+             int32_t prefill_mode) {
+    (void)prefill_mode;
+    if (!e || !e->finalized) return fail(MV_ERR_STATE, "engine not finalized");
+    if (!prompts || !prompt_lens || !spk_emb || !sampling) return fail(MV_ERR_INVALID, "null argument");
+    const mv_config& c = e->cfg;
+    const int U = c.max_utterances;
+    if (n_utt < 1 || n_utt > U) return fail(MV_ERR_INVALID, "n_utt %d not in [1,%d]", n_utt, U);
+    std::vector<UttState> st(U);
+    std::vector<int32_t> seq((size_t)U * c.block_size, 0), pos(U, 0);
+    int budget = 0;
+    for (int u = 0; u < U; ++u) {
+        UttState& s = st[u];
+        memset(&s, 0, sizeof(s));
+        if (u >= n_utt) { s.done = 1; s.prompt_len = 1; s.max_len = 1; continue; }
+        const int T = prompt_lens[u];
+        if (T < 1 || T > max_len) return fail(MV_ERR_INVALID, "prompt %d has length %d (max_len %d)", u, T, max_len);
+        // generate(): fast_inference_utils.py:195-204
+        int cap = max_new_tokens < 0 ? c.block_size : (T + max_new_tokens < c.block_size ? T + max_new_tokens : c.block_size);
+        if (cap - T <= 0) return fail(MV_ERR_PROMPT_TOO_LONG, "Prompt is too long to generate more tokens");
+        for (int i = 0; i < T; ++i) {
+            const int t = prompts[(size_t)u * max_len + i];
+            if (t < 0 || t >= c.vocab) return fail(MV_ERR_INVALID, "token %d out of vocabulary", t);
+            seq[(size_t)u * c.block_size + i] = t;
+        }
+        s.pos = 0; s.prompt_len = T; s.max_len = cap; s.done = 0; s.eoa_token = eoa_token; s.n_tokens = T; s.s = sampling[u];
+        if (cap - 1 > budget) budget = cap - 1;
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->utt, st.data(), st.size() * sizeof(UttState), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->seq, seq.data(), seq.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->pos_arr, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->n_active, &n_utt, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(e->spk_emb, 0, (size_t)U * c.spk_dim * 2));
+    HIP_TRY(hipMemcpy(e->spk_emb, spk_emb, (size_t)n_utt * c.spk_dim * 2, hipMemcpyHostToDevice));
+    HIP_TRY(launch_spk_proj(e->stream, U, c.dim, c.spk_dim, e->spk_emb, e->spk_w, e->spk_proj));
+    SampleArgs a;
+    a.seq = e->seq; a.tok_emb = e->tok_emb; a.pos_emb = e->pos_emb; a.spk_proj = e->spk_proj; a.x_next = e->x;
+    a.dim = c.dim; a.block_size = c.block_size; a.n_utt = U;
+    HIP_TRY(launch_embed_first(e->stream, a));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->n_utt = n_utt;
+    e->begun = true;
+    e->steps_budget = budget;
+    return MV_OK;
+}
+
+int mv_run(mv_engine* e, int32_t max_steps, int32_t poll_every, int32_t* steps_run) {
+    if (!e || !e->begun) return fail(MV_ERR_STATE, "mv_begin has not been called");
+    if (poll_every < 1) poll_every = 16;
+    int limit = e->steps_budget;
+    if (max_steps >= 0 && max_steps < limit) limit = max_steps;
+    int done_steps = 0;
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    while (done_steps < limit) {
+        const int chunk = (limit - done_steps) < poll_every ? (limit - done_steps) : poll_every;
+        for (int i = 0; i < chunk; ++i) {
+            if (e->graph_exec) {
+                HIP_TRY(hipGraphLaunch(e->graph_exec, e->stream));
+            } else {
+                const int rc = enqueue_step(e);
+                if (rc != MV_OK) return rc;
+            }
+        }
+        done_steps += chunk;
+        if (done_steps >= limit) break;
+        HIP_TRY(hipMemcpyAsync(e->host_flag, e->n_active, 4, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (*e->host_flag <= 0) break;
+    }
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1));
+    e->steps_budget -= done_steps;
+    if (steps_run) *steps_run = done_steps;
+    return MV_OK;
+}
+
+float mv_last_run_ms(const mv_engine* e) { return e ? e->last_ms : 0.f; }
+
+int mv_get_tokens(mv_engine* e, int32_t utt, int32_t* out, int32_t cap, int32_t* n_out) {
+    if (!e || !e->begun) return fail(MV_ERR_STATE, "mv_begin has not been called");
+    if (utt < 0 || utt >= e->n_utt || !out || !n_out) return fail(MV_ERR_INVALID, "bad argument");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    UttState s;
+    HIP_TRY(hipMemcpy(&s, e->utt + utt, sizeof(s), hipMemcpyDeviceToHost));
+    int n = s.n_tokens;
+    // while the prompt is still being teacher-forced n_tokens trails prompt_len; report at least the prompt
+    if (n < s.prompt_len) n = s.prompt_len;
+    if (n > cap) return fail(MV_ERR_INVALID, "output buffer too small (%d < %d)", cap, n);
+    HIP_TRY(hipMemcpy(out, e->seq + (size_t)utt * e->cfg.block_size, (size_t)n * 4, hipMemcpyDeviceToHost));
+    *n_out = n;
+    return MV_OK;
+}
+
+int mv_probe_kernel(mv_engine* e, int32_t kind, int32_t iters, float* avg_ms, double* bytes_per_launch) {
+    if (!e || !e->finalized || !avg_ms || !bytes_per_launch) return fail(MV_ERR_STATE, "engine not finalized / null argument");
+    if (iters < 1 || kind < 0 || kind > 5) return fail(MV_ERR_INVALID, "bad probe arguments");
+    const mv_config& c = e->cfg;
+    const int R = e->R;
+    hipStream_t s = e->stream;
+    double bytes = 0;
+    if (kind == 1) {
+        std::vector<int32_t> pos(c.max_utterances);
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(pos.data(), e->pos_arr, pos.size() * 4, hipMemcpyDeviceToHost));
+        for (int u = 0; u < c.max_utterances; ++u) bytes += 2.0 /*rows*/ * c.n_head * (pos[u] + 1.0) * 128 * 2 /*B*/ * 2 /*K,V*/;
+    } else if (kind == 0) bytes = 3.0 * c.dim * c.dim * 2 + c.dim * 2;
+    else if (kind == 2) bytes = (double)c.dim * c.dim * 2;
+    else if (kind == 3) bytes = 2.0 * c.intermediate * c.dim * 2 + c.dim * 2;
+    else if (kind == 4) bytes = (double)c.dim * c.intermediate * 2;
+    else bytes = (double)c.vocab * c.dim * 2 + c.dim * 2;
+    auto launch = [&](int l) -> int {
+        const LayerW& w = e->layers[l];
+        bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
+        bf16_t* vc = e->vcache + (size_t)l * e->kv_layer_elems;
+        GemvArgs a;
+        switch (kind) {
+            case 0:
+                a.x = e->x; a.w = w.wqkv; a.norm_w = w.attn_norm; a.out = e->q; a.kcache = kc; a.vcache = vc; a.pos = e->pos_arr;
+                a.cache_len = c.block_size; a.n_head = c.n_head; a.dim = c.dim; a.N = 3 * c.dim; a.K = c.dim; a.eps = c.norm_eps;
+                HIP_TRY(launch_gemv(s, R, a, GEMV_QKV));
+                break;
+            case 1: {
+                AttnArgs t;
+                t.q = e->q; t.kcache = kc; t.vcache = vc; t.pos = e->pos_arr; t.partial = e->partial; t.counters = e->counters;
+                t.out = e->attn; t.n_head = c.n_head; t.cache_len = c.block_size;
+                HIP_TRY(launch_attention_decode(s, R, t));
+                break;
+            }
+            case 2:
+                a.x = e->attn; a.w = w.wo; a.residual = e->x; a.out = e->h; a.N = c.dim; a.K = c.dim;
+                HIP_TRY(launch_gemv(s, R, a, GEMV_RESID));
+                break;
+            case 3:
+                a.x = e->h; a.w = w.w1; a.w2 = w.w3; a.norm_w = w.ffn_norm; a.out = e->act; a.N = c.intermediate; a.K = c.dim;
+                a.eps = c.norm_eps;
+                HIP_TRY(launch_gemv(s, R, a, GEMV_SWIGLU));
+                break;
+            case 4:
+                a.x = e->act; a.w = w.w2; a.residual = e->h; a.out = e->attn /* scratch: keep x intact */; a.N = c.dim; a.K = c.intermediate;
+                HIP_TRY(launch_gemv(s, R, a, GEMV_RESID));
+                break;
+            default:
+                a.x = e->x; a.w = e->head; a.norm_w = e->final_norm; a.out = e->logits; a.N = c.vocab; a.K = c.dim; a.eps = c.norm_eps;
+                HIP_TRY(launch_gemv(s, R, a, GEMV_PLAIN));
+        }
+        return MV_OK;
+    };
+    for (int i = 0; i < c.n_layer && i < 4; ++i) { const int rc = launch(i % c.n_layer); if (rc != MV_OK) return rc; }  // warm-up
+    HIP_TRY(hipEventRecord(e->ev0, s));
+    for (int i = 0; i < iters; ++i) { const int rc = launch(i % c.n_layer); if (rc != MV_OK) return rc; }
+    HIP_TRY(hipEventRecord(e->ev1, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    *avg_ms = ms / iters;
+    *bytes_per_launch = bytes;
+    return MV_OK;
+}
+
+// ---- single-kernel entry points -----------------------------------------------------------------------------------
+
+int mv_op_gemv(void* stream, int32_t rows, int32_t N, int32_t K, const void* x, const void* w, const void* norm_w,
+               float eps, const void* residual, void* out) {
+    if (!gemv_supported(rows, K)) return fail(MV_ERR_INVALID, "gemv: unsupported rows=%d K=%d", rows, K);
+    GemvArgs a;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.norm_w = (const bf16_t*)norm_w; a.residual = (const bf16_t*)residual;
+    a.out = (bf16_t*)out; a.N = N; a.K = K; a.eps = eps;
+    HIP_TRY(launch_gemv((hipStream_t)stream, rows, a, residual ? GEMV_RESID : GEMV_PLAIN));
+    return MV_OK;
+}
+
+int mv_op_swiglu_gemv(void* stream, int32_t rows, int32_t N, int32_t K, const void* x, const void* w1, const void* w3,
+                      const void* norm_w, float eps, void* out) {
+    if (!gemv_supported(rows, K)) return fail(MV_ERR_INVALID, "gemv: unsupported rows=%d K=%d", rows, K);
+    GemvArgs a;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w1; a.w2 = (const bf16_t*)w3; a.norm_w = (const bf16_t*)norm_w;
+    a.out = (bf16_t*)out; a.N = N; a.K = K; a.eps = eps;
+    HIP_TRY(launch_gemv((hipStream_t)stream, rows, a, GEMV_SWIGLU));
+    return MV_OK;
+}
+
+int64_t mv_op_attention_scratch_bytes(int32_t rows, int32_t n_head) {
+    return (int64_t)rows * n_head * ATTN_NSPLIT * ATTN_PART_STRIDE * 4 + (int64_t)rows * n_head * 4;
+}
+
+int mv_op_attention_decode(void* stream, int32_t rows, int32_t n_head, int32_t cache_len, const int32_t* n_keys_dev,
+                           const void* q, const void* kcache, const void* vcache, void* scratch, void* out) {
+    if (rows < 2 || rows % 2) return fail(MV_ERR_INVALID, "rows must be even");
+    AttnArgs a;
+    a.q = (const bf16_t*)q; a.kcache = (const bf16_t*)kcache; a.vcache = (const bf16_t*)vcache; a.pos = n_keys_dev;
+    a.pos_is_count = 1; a.partial = (float*)scratch;
+    a.counters = (uint32_t*)((char*)scratch + (size_t)rows * n_head * ATTN_NSPLIT * ATTN_PART_STRIDE * 4);
+    a.out = (bf16_t*)out; a.n_head = n_head; a.cache_len = cache_len;
+    HIP_TRY(hipMemsetAsync(a.counters, 0, (size_t)rows * n_head * 4, (hipStream_t)stream));
+    HIP_TRY(launch_attention_decode((hipStream_t)stream, rows, a));
+    return MV_OK;
+}
+
+int mv_op_sample(void* stream, int32_t vocab, const void* logits_pair, const mv_sampling* s, uint32_t step,
+                 int32_t* token_out, float* probs_out) {
+    if (!s || !logits_pair || !token_out) return fail(MV_ERR_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    UttState h;
+    memset(&h, 0, sizeof(h));
+    h.pos = (int32_t)step - 1;  // the sampler draws noise for sequence index pos + 1
+    h.prompt_len = 0; h.max_len = 1 << 30; h.eoa_token = -1; h.s = *s;
+    UttState* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, sizeof(UttState)));
+    hipError_t ce = hipMemcpy(d, &h, sizeof(h), hipMemcpyHostToDevice);
+    if (ce == hipSuccess && probs_out) ce = hipMemsetAsync(probs_out, 0, (size_t)vocab * 4, st);
+    if (ce == hipSuccess) {
+        SampleArgs a;
+        a.logits = (const bf16_t*)logits_pair; a.utt = d; a.token_out = token_out; a.probs_out = probs_out;
+        a.vocab = vocab; a.n_utt = 1;
+        ce = launch_sample(st, a, true);
+    }
+    if (ce == hipSuccess) ce = hipStreamSynchronize(st);
+    hipFree(d);
+    if (ce != hipSuccess) return fail(MV_ERR_HIP, "mv_op_sample: %s", hipGetErrorString(ce));
+    return MV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// Internal kernel-launch interface shared by the engine and the mv_op_* test entry points.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/metavoice_hip.h"
+
+typedef uint16_t bf16_t;
+
+// ---- gemv.hip ------------------------------------------------------------------------------------------------
+enum { GEMV_PLAIN = 0, GEMV_RESID = 1, GEMV_SWIGLU = 2, GEMV_QKV = 3 };
+struct GemvArgs {
+    const bf16_t* x = nullptr;         // [rows][K]
+    const bf16_t* w = nullptr;         // [N][K]
+    const bf16_t* w2 = nullptr;        // [N][K], SWIGLU only (w3)
+    const bf16_t* norm_w = nullptr;    // [K] or null: fused RMSNorm prologue
+    const bf16_t* residual = nullptr;  // [rows][N], RESID only
+    bf16_t* out = nullptr;             // [rows][N]  (QKV: q [rows][dim])
+    bf16_t* kcache = nullptr;          // QKV only: [rows][n_head][cache_len][128]
+    bf16_t* vcache = nullptr;
+    const int32_t* pos = nullptr;      // QKV only: [rows/2] current input position per utterance
+    int32_t cache_len = 0, n_head = 0, dim = 0;
+    int32_t N = 0, K = 0;
+    float eps = 1e-5f;
+};
+hipError_t launch_gemv(hipStream_t s, int rows, const GemvArgs& a, int epi);
+bool gemv_supported(int rows, int K);
+
+// ---- attention.hip -------------------------------------------------------------------------------------------
+constexpr int ATTN_NSPLIT = 8;          // max KV splits per (row, head)
+constexpr int ATTN_PART_STRIDE = 132;   // floats per partial: m, l, pad, pad, o[128]
+struct AttnArgs {
+    const bf16_t* q = nullptr;        // [rows][n_head*128]
+    const bf16_t* kcache = nullptr;   // [rows][n_head][cache_len][128]
+    const bf16_t* vcache = nullptr;
+    const int32_t* pos = nullptr;     // [rows/2]: keys [0, pos+1) are attended (pos = input position), or
+    int32_t pos_is_count = 0;         //   when set, pos[] already holds the key count
+    float* partial = nullptr;         // [rows][n_head][ATTN_NSPLIT][ATTN_PART_STRIDE]
+    uint32_t* counters = nullptr;     // [rows][n_head], zero between launches
+    bf16_t* out = nullptr;            // [rows][n_head*128]
+    int32_t n_head = 0, cache_len = 0;
+};
+hipError_t launch_attention_decode(hipStream_t s, int rows, const AttnArgs& a);
+
+// ---- sampling.hip --------------------------------------------------------------------------------------------
+struct UttState {            // one per utterance, device resident
+    int32_t pos;             // input position of the token currently in x (= index of the last token in seq)
+    int32_t prompt_len;
+    int32_t max_len;         // sequence length cap (prompt + new tokens, <= block_size)
+    int32_t done;
+    int32_t eoa_token;
+    int32_t n_tokens;        // tokens in seq so far (prompt prefix consumed + generated)
+    int32_t pad0, pad1;
+    mv_sampling s;
+};
+struct SampleArgs {
+    const bf16_t* logits = nullptr;       // [rows][vocab]
+    UttState* utt = nullptr;              // [n_utt]
+    int32_t* pos_arr = nullptr;           // [n_utt] mirror of utt[].pos read by the QKV / attention kernels
+    int32_t* seq = nullptr;               // [n_utt][block_size]: prompt then generated tokens
+    const bf16_t* tok_emb = nullptr;      // [vocab][dim]
+    const bf16_t* pos_emb = nullptr;      // [block_size][dim]
+    const bf16_t* spk_proj = nullptr;     // [n_utt][dim] (bf16 of speaker_cond_pos(spk_emb))
+    bf16_t* x_next = nullptr;             // [rows][dim]
+    int32_t* n_active = nullptr;          // device word: utterances still running
+    float* capture = nullptr;             // optional [max_steps][rows][vocab] fp32
+    int32_t* capture_step = nullptr;      // device step counter for capture
+    int32_t capture_max = 0;
+    float* probs_out = nullptr;           // optional [vocab] (mv_op_sample only)
+    int32_t* token_out = nullptr;         // optional (mv_op_sample only)
+    uint32_t fixed_step = 0;              // mv_op_sample only
+    int32_t vocab = 0, dim = 0, block_size = 0, n_utt = 0;
+};
+hipError_t launch_sample(hipStream_t s, const SampleArgs& a, bool standalone);
+hipError_t launch_embed_first(hipStream_t s, const SampleArgs& a);
+hipError_t launch_spk_proj(hipStream_t s, int n_utt, int dim, int spk_dim, const bf16_t* spk_emb, const bf16_t* w,
+                           bf16_t* out);

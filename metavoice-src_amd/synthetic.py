@@ -18,21 +18,23 @@ import torch
 
 
 def _normal(gen: torch.Generator, shape, std: float) -> torch.Tensor:
-    return (torch.randn(shape, generator=gen, dtype=torch.float32) * std).to(torch.bfloat16)
+    return (torch.randn(shape, generator=gen, dtype=torch.float32, device=gen.device) * std).to(torch.bfloat16)
 
 
 def _norm_weight(gen: torch.Generator, n: int) -> torch.Tensor:
-    return (1.0 + 0.1 * torch.randn(n, generator=gen, dtype=torch.float32)).to(torch.bfloat16)
+    return (1.0 + 0.1 * torch.randn(n, generator=gen, dtype=torch.float32, device=gen.device)).to(torch.bfloat16)
 
 
 def stage1_state_dict(*, n_layer: int = 24, n_head: int = 16, dim: int = 2048, vocab_size: int = 2562,
                       block_size: int = 2048, intermediate_size: Optional[int] = None, speaker_emb_dim: int = 256,
-                      seed: int = 0, orig_mod_prefix: bool = False) -> Dict[str, torch.Tensor]:
-    """`first_stage.pt["model"]` with nanoGPT names (before the gpt-fast remap).  bf16 tensors."""
+                      seed: int = 0, orig_mod_prefix: bool = False, device: str = "cpu") -> Dict[str, torch.Tensor]:
+    """`first_stage.pt["model"]` with nanoGPT names (before the gpt-fast remap).  bf16 tensors.
+    `device="cuda"` draws from the GPU generator instead (different values, same distribution): used by bench.py,
+    where 1.2 B parameters would take ~10 s to draw on the host."""
     if intermediate_size is None:
         n_hidden = int(2 * (4 * dim) / 3)
         intermediate_size = n_hidden if n_hidden % 256 == 0 else n_hidden + 256 - n_hidden % 256
-    g = torch.Generator().manual_seed(seed)
+    g = torch.Generator(device=device).manual_seed(seed)
     proj_std = 0.02 / math.sqrt(2 * n_layer)
     sd: Dict[str, torch.Tensor] = {}
     sd["transformer.wtes.0.weight"] = _normal(g, (vocab_size, dim), 0.02)

@@ -195,12 +195,14 @@ def logits_to_probs(logits: torch.Tensor, temperature: float, top_p: Optional[fl
 
 
 def cfg_mix(logits: torch.Tensor, guidance_scale: float, rnd=_identity) -> torch.Tensor:
-    """fast_inference_utils.py:113-117: `g * cond + (1 - g) * uncond` on the last position."""
+    """fast_inference_utils.py:113-117: `g * cond + (1 - g) * uncond` on the last position.  `(1 - g)` is itself a
+    tensor op in the model dtype there, hence the rounding of the scalar."""
     last = logits[:, -1]
     half = last.size(0) // 2
     cond, uncond = last[:half], last[half:]
     g = float(guidance_scale)
-    return rnd(rnd(g * cond) + rnd((1.0 - g) * uncond))
+    one_minus_g = float(rnd(torch.tensor(1.0 - g)))
+    return rnd(rnd(g * cond) + rnd(one_minus_g * uncond))
 
 
 def sample(logits: torch.Tensor, guidance_scale: float, temperature: float, top_p: Optional[float] = None,

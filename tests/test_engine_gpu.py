@@ -1,0 +1,176 @@
+"""First-stage engine (hipGraph decode loop in libmetavoice_hip.so) against the oracle, on the GPU.
+
+Parity criteria: the engine computes in bf16 with fp32 accumulation; the oracle runs the reference
+algorithm in fp32 with bf16 rounding at the same tensor boundaries (rounding="bf16"), on identical bf16 weights.  The two
+differ only by fp32 summation order, so
+  (i)  logits at every position agree to a few bf16 ulps of the logit scale, and
+  (ii) the free-running token stream is identical unless the oracle's own top-1/top-2 gap at the first mismatch is inside
+       that noise (then the streams legitimately fork and the test stops comparing there).
+The fp32-arithmetic oracle (what the reference computes on CPU, golden-pinned) is compared too, with the bf16 noise floor
+measured on the reference itself (tests/golden: |bf16 - fp32| ~ 1e-2 on logits of std ~0.3 for the small model).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_pkg
+from oracle import stage1 as o_s1
+
+pytestmark = pytest.mark.gpu
+
+mv = load_pkg()
+synthetic = load_pkg("synthetic")
+
+SMALL = dict(n_layer=2, n_head=2, dim=256, vocab_size=2562, block_size=64)
+WIDE2 = dict(n_layer=2, n_head=16, dim=2048, vocab_size=2562, block_size=2048)
+
+
+def build(cfg_kwargs, seed, max_utterances=1):
+    sd = o_s1.remap_checkpoint_keys(synthetic.stage1_state_dict(seed=seed, **cfg_kwargs))
+    args = mv.ModelArgs(**cfg_kwargs)
+    engine = mv.Stage1Engine(args, max_utterances=max_utterances)
+    engine.load_state_dict(sd)
+    engine.finalize()
+    cfg = o_s1.Stage1Config(**cfg_kwargs)
+    return engine, sd, cfg
+
+
+def oracle_for(sd, cfg, rounding):
+    return o_s1.Stage1Oracle({k: v.float() for k, v in sd.items()}, cfg, rounding=rounding, max_seq_length=cfg.block_size)
+
+
+def first_fork(a, b):
+    for i, (x, y) in enumerate(zip(a, b)):
+        if x != y:
+            return i
+    return None if len(a) == len(b) else min(len(a), len(b))
+
+
+def check_stream(engine_seq, oracle_seq, oracle_logits, T, gap_tol):
+    """Identical, or forked at a position where the oracle's CFG-mixed top-2 gap is below `gap_tol`."""
+    fork = first_fork(engine_seq, oracle_seq)
+    if fork is None:
+        return len(oracle_seq) - T
+    assert fork >= T, "prompt was altered"
+    lg = oracle_logits[fork - T]  # logits that decided sequence index `fork`
+    mixed = o_s1.cfg_mix(lg[:, None, :], 3.0, o_s1._round_bf16)[0]
+    top2 = torch.topk(mixed, 2).values
+    gap = float(top2[0] - top2[1])
+    assert gap <= gap_tol, f"streams fork at index {fork} although the oracle's top-2 gap is {gap:.4f} > {gap_tol}"
+    return fork - T
+
+
+@pytest.mark.parametrize("name,cfgk,seed,T,n_new", [("small", SMALL, 0, 12, 20), ("wide2", WIDE2, 1, 16, 6)])
+def test_greedy_against_oracle_and_golden(name, cfgk, seed, T, n_new):
+    engine, sd, cfg = build(cfgk, seed)
+    prompt = synthetic.prompt_tokens(T, seed=seed)
+    spk = synthetic.speaker_embedding(seed)
+    engine.capture_logits(True)
+    engine.begin([prompt], spk, mv.SamplingParams(top_k=1, seed=5), max_new_tokens=n_new, end_of_audio_token=9999)
+    steps = engine.run()
+    assert steps == T + n_new - 1
+    seq = engine.tokens(0)
+    assert len(seq) == T + n_new and seq[:T] == prompt.tolist()
+    got = engine.captured_logits(0, T + n_new - 1)  # (pos, rows, V)
+
+    # (a) oracle with the engine's rounding points, free-running with the same Philox noise
+    ob = oracle_for(sd, cfg, "bf16")
+    oseq, ologits = o_s1.generate(ob, prompt, spk, max_new_tokens=n_new, end_of_audio_token=9999, top_k=1, seed=5,
+                                  return_logits=True)
+    scale = float(ologits.std())
+    agree = check_stream(seq, oseq, ologits, T, gap_tol=0.05 * scale)
+    # logits of every position up to the fork (the prefill positions are teacher-forced in both)
+    ob2 = oracle_for(sd, cfg, "bf16")
+    pre = ob2.forward(prompt.view(1, -1).repeat(2, 1), spk, torch.arange(T))  # (2, T, V)
+    d_pre = float((got[:T].transpose(0, 1) - pre).abs().max())
+    d_dec = float((got[T - 1:T - 1 + max(agree, 1)] - ologits[:max(agree, 1)]).abs().max())
+    print(f"[{name}] stream agreement {agree}/{n_new} tokens; max|dlogit| prefill {d_pre:.4f} decode {d_dec:.4f} (logit std {scale:.3f})")
+    assert d_pre <= 0.06 * scale and d_dec <= 0.06 * scale
+
+    # (b) the fp32 reference numbers (golden, minted from the reference itself)
+    g = np.load(os.path.join(GOLDEN, f"stage1_{name}.npz"))
+    assert json.loads(str(g["cfg"])) == cfgk
+    gold = torch.from_numpy(g["logits_fp32"])  # (n_new, 2, V): prefill-last then teacher-forced decode steps
+    gseq = g["seq"].tolist()
+    fork = first_fork(seq, gseq)
+    n_cmp = n_new if fork is None else fork - T + 1
+    d32 = float((got[T - 1:T - 1 + n_cmp] - gold[:n_cmp]).abs().max())
+    print(f"[{name}] vs reference fp32 golden: first fork {fork}, max|dlogit| {d32:.4f}")
+    assert d32 <= 0.12 * scale
+    engine.close()
+
+
+@pytest.mark.parametrize("combo", [dict(top_p=0.95), dict(top_p=0.9, temperature=0.8), dict(top_k=50), dict()])
+def test_stochastic_stream_matches_oracle(combo):
+    engine, sd, cfg = build(SMALL, 3)
+    T, n_new = 10, 40
+    prompt = synthetic.prompt_tokens(T, seed=3)
+    spk = synthetic.speaker_embedding(3)
+    sp = mv.SamplingParams(guidance_scale=3.0, seed=99, **combo)
+    nat = sp.to_native(torch.bfloat16)
+    engine.begin([prompt], spk, sp, max_new_tokens=n_new, end_of_audio_token=9999)
+    engine.run()
+    seq = engine.tokens(0)
+    ob = oracle_for(sd, cfg, "bf16")
+    oseq = o_s1.generate(ob, prompt, spk, max_new_tokens=n_new, end_of_audio_token=9999, guidance_scale=nat.guidance_scale,
+                         temperature=nat.temperature, top_p=(nat.top_p if sp.top_p is not None else None), top_k=sp.top_k, seed=99)
+    fork = first_fork(seq, oseq)
+    agree = n_new if fork is None else fork - T
+    print(f"[stochastic {combo}] identical for {agree}/{n_new} sampled tokens")
+    assert agree >= n_new // 2, f"sampled streams fork after only {agree} tokens"
+    assert len(set(seq[T:])) > 3  # it really is sampling
+    engine.close()
+
+
+def test_end_of_audio_stops_and_is_included():
+    engine, sd, cfg = build(SMALL, 0)
+    T = 12
+    prompt = synthetic.prompt_tokens(T, seed=0)
+    spk = synthetic.speaker_embedding(0)
+    engine.begin([prompt], spk, mv.SamplingParams(top_k=1), max_new_tokens=20, end_of_audio_token=9999)
+    engine.run()
+    full = engine.tokens(0)
+    eoa = full[T + 5]  # declare the 6th generated token to be end-of-audio
+    first = full[T:].index(eoa)
+    engine.begin([prompt], spk, mv.SamplingParams(top_k=1), max_new_tokens=20, end_of_audio_token=eoa)
+    steps = engine.run(poll_every=4)
+    seq = engine.tokens(0)
+    assert seq == full[: T + first + 1] and seq[-1] == eoa  # EOA itself is part of the result (fast_inference_utils.py:161)
+    assert steps <= T + first + 4
+    engine.close()
+
+
+def test_prompt_too_long_and_length_cap():
+    engine, sd, cfg = build(SMALL, 0)
+    spk = synthetic.speaker_embedding(0)
+    with pytest.raises(ValueError, match="Prompt is too long"):
+        engine.begin([synthetic.prompt_tokens(64, seed=0)], spk, mv.SamplingParams(top_k=1))
+    # max_new_tokens=None -> run to block_size (fast_inference_utils.py:195-201)
+    engine.begin([synthetic.prompt_tokens(60, seed=0)], spk, mv.SamplingParams(top_k=1), end_of_audio_token=9999)
+    engine.run()
+    assert len(engine.tokens(0)) == 64
+    engine.close()
+
+
+def test_two_utterances_with_ragged_prompts_match_single_runs():
+    """Rows of different utterances never interact: a batch of 2 (different prompt lengths, speakers, seeds) must give
+    exactly the streams each utterance gives alone."""
+    engine2, sd, cfg = build(SMALL, 4, max_utterances=2)
+    prompts = [synthetic.prompt_tokens(9, seed=10), synthetic.prompt_tokens(17, seed=11)]
+    spks = torch.cat([synthetic.speaker_embedding(10), synthetic.speaker_embedding(11)])
+    sps = [mv.SamplingParams(top_p=0.95, seed=1), mv.SamplingParams(top_k=1, seed=2)]
+    engine2.begin(prompts, spks, sps, max_new_tokens=24, end_of_audio_token=9999)
+    engine2.run()
+    both = [engine2.tokens(0), engine2.tokens(1)]
+    engine2.close()
+    engine1, _, _ = build(SMALL, 4, max_utterances=1)
+    for u in range(2):
+        engine1.begin([prompts[u]], spks[u:u + 1], sps[u], max_new_tokens=24, end_of_audio_token=9999)
+        engine1.run()
+        single = engine1.tokens(0)
+        assert single == both[u]  # the noise stream is keyed by (seed, token id, sequence index), not by the slot
+        assert len(both[u]) == len(prompts[u]) + 24
+    engine1.close()
