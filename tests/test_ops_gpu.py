@@ -81,8 +81,10 @@ def test_swiglu_gemv(rows, N_, K):
     gate, up = rb(xin @ w1.double().T), rb(xin @ w3.double().T)
     y = rb(rb(torch.nn.functional.silu(gate)) * up)
     out = torch.empty(rows, N_, dtype=torch.bfloat16, device="cuda")
-    N.check(N.lib().mv_op_swiglu_gemv(stream(), rows, N_, K, ptr(dev(x.bfloat16())), ptr(dev(w1.bfloat16())),
-                                      ptr(dev(w3.bfloat16())), ptr(dev(nw.bfloat16())), 1e-5, ptr(out)))
+    # keep every device tensor referenced until the kernel has run: a temporary would be freed (and its block reused by
+    # the next temporary) before the asynchronous launch reads it
+    dx, d1, d3, dn = dev(x.bfloat16()), dev(w1.bfloat16()), dev(w3.bfloat16()), dev(nw.bfloat16())
+    N.check(N.lib().mv_op_swiglu_gemv(stream(), rows, N_, K, ptr(dx), ptr(d1), ptr(d3), ptr(dn), 1e-5, ptr(out)))
     torch.cuda.synchronize()
     nbad, worst = bf16_close(out.cpu(), y, ulps=4.0, atol=3e-3)
     assert nbad == 0, f"{nbad} outputs off, worst {worst:.2f}"
@@ -104,10 +106,10 @@ def test_attention_decode(n_keys):
         ref[r] = torch.einsum("hs,hsd->hd", torch.softmax(s, -1), v[r, :, :P].double()).reshape(-1).float()
     scratch = torch.zeros(int(N.lib().mv_op_attention_scratch_bytes(rows, H)), dtype=torch.uint8, device="cuda")
     out = torch.empty(rows, H * 128, dtype=torch.bfloat16, device="cuda")
+    dnk, dq, dk, dv = dev(nk), dev(q.bfloat16()), dev(k.bfloat16()), dev(v.bfloat16())
     for _ in range(2):  # twice: the in-launch arrival counters must re-arm themselves
         out.zero_()
-        N.check(N.lib().mv_op_attention_decode(stream(), rows, H, S, ptr(dev(nk)), ptr(dev(q.bfloat16())), ptr(dev(k.bfloat16())),
-                                               ptr(dev(v.bfloat16())), ptr(scratch), ptr(out)))
+        N.check(N.lib().mv_op_attention_decode(stream(), rows, H, S, ptr(dnk), ptr(dq), ptr(dk), ptr(dv), ptr(scratch), ptr(out)))
         torch.cuda.synchronize()
         err = (out.cpu().float() - ref).abs().max().item()
         assert err < 2e-2, f"max abs err {err}"
@@ -132,7 +134,8 @@ def test_sampler_matches_oracle(combo, V):
         sp = eng.SamplingParams(guidance_scale=3.0, seed=1234 + trial, **combo)
         nat = sp.to_native(torch.bfloat16)
         step = 100 + trial
-        N.check(N.lib().mv_op_sample(stream(), V, ptr(dev(pair.view(2, V).bfloat16())), C.byref(nat), step, ptr(token), ptr(probs)))
+        dpair = dev(pair.view(2, V).bfloat16())
+        N.check(N.lib().mv_op_sample(stream(), V, ptr(dpair), C.byref(nat), step, ptr(token), ptr(probs)))
         torch.cuda.synchronize()
         qn = torch.from_numpy(o_rng.exp1_noise(sp.seed, step, V))
         top_p = None if combo["top_p"] is None else nat.top_p
