@@ -116,6 +116,11 @@ int mv_op_sample(void* stream, int32_t vocab, const void* logits_pair, const mv_
  * 3 norm+w1|w3+silu-gate, 4 w2+residual, 5 norm+LM head. */
 int mv_probe_kernel(mv_engine* e, int32_t kind, int32_t iters, float* avg_ms, double* bytes_per_launch);
 
+/* Tuning hook (no reference equivalent): process-wide launch knobs of the decode kernels and the side-stream prefetcher,
+ * used by tools/sweep.py; keys are listed in DESIGN.md "Tuning".  A finalized engine passed as `e` (may be NULL)
+ * re-captures its decode graph at the next mv_begin. */
+int mv_tune(mv_engine* e, const char* key, int32_t value);
+
 const char* mv_last_error(void);
 const char* mv_version(void);
 

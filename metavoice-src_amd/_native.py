@@ -59,6 +59,7 @@ SYMBOLS = [
     ("mv_op_attention_scratch_bytes", C.c_int64, [C.c_int32, C.c_int32]),
     ("mv_op_sample", C.c_int, [_P, C.c_int32, _P, C.POINTER(mv_sampling), C.c_uint32, _P, _P]),
     ("mv_probe_kernel", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
+    ("mv_tune", C.c_int, [_P, C.c_char_p, C.c_int32]),
     ("mv_last_error", C.c_char_p, []),
     ("mv_version", C.c_char_p, []),
 ]

@@ -52,11 +52,19 @@ __device__ __forceinline__ float sum_across16(float v) {
     v += dpp_f<0x140>(v);  // row_mirror           (16-lane rows)
     return v;
 }
+// Whole-wave sum, result wave-uniform.  After the 4 intra-row steps every lane holds its 16-lane row total; two DPP
+// row broadcasts (row_bcast15 into rows 1,3; row_bcast31 into rows 2,3) leave the wave total in lane 63, read back
+// through an SGPR.  6 DPP adds + 1 v_readlane (~60 cycles) instead of two ds_bpermute round trips through the LDS
+// crossbar (~200 cycles): this sits on the serial tail of every decode kernel.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_bcast_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
     v = sum_across16(v);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    v += dpp_bcast_f<0x142, 0xA>(v);  // row_bcast15
+    v += dpp_bcast_f<0x143, 0xC>(v);  // row_bcast31
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float max_across16(float v) {
     v = fmaxf(v, dpp_f<0xB1>(v));
@@ -67,9 +75,10 @@ __device__ __forceinline__ float max_across16(float v) {
 }
 __device__ __forceinline__ float wave_max(float v) {
     v = max_across16(v);
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
-    return v;
+    // lanes outside the row mask receive `old`; -inf is the identity of max
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0xFF800000, __float_as_int(v), 0x142, 0xA, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0xFF800000, __float_as_int(v), 0x143, 0xC, 0xF, false)));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }

@@ -91,6 +91,8 @@ struct mv_engine {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     bool use_graph = true;
+    bool graph_dirty = false;   // a tuning knob changed after capture
+
 
     int n_utt = 0;
     bool begun = false;
@@ -119,6 +121,7 @@ int enqueue_step(mv_engine* e) {
             AttnArgs a;
             a.q = e->q; a.kcache = kc; a.vcache = vc; a.pos = e->pos_arr; a.partial = e->partial;
             a.counters = e->counters; a.out = e->attn; a.n_head = c.n_head; a.cache_len = c.block_size;
+           
             HIP_TRY(launch_attention_decode(s, R, a));
         }
         {   // h = x + wo(attn)                            (fast_model.py:226,179)
@@ -150,6 +153,7 @@ int enqueue_step(mv_engine* e) {
         a.pos_emb = e->pos_emb; a.spk_proj = e->spk_proj; a.x_next = e->x; a.n_active = e->n_active;
         a.capture = e->capture_on ? e->capture : nullptr; a.capture_max = e->capture_max;
         a.vocab = c.vocab; a.dim = c.dim; a.block_size = c.block_size; a.n_utt = c.max_utterances;
+       
         HIP_TRY(launch_sample(s, a, false));
     }
     return MV_OK;
@@ -158,7 +162,8 @@ int enqueue_step(mv_engine* e) {
 int build_graph(mv_engine* e) {
     if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
     if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
-    if (!e->use_graph) return MV_OK;
+    e->graph_dirty = false;
+    if (!e->use_graph || !g_tune.use_graph) return MV_OK;
     HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeRelaxed));
     const int rc = enqueue_step(e);
     hipGraph_t g = nullptr;
@@ -175,6 +180,23 @@ int build_graph(mv_engine* e) {
 extern "C" {
 
 const char* mv_last_error(void) { return g_err.c_str(); }
+
+int mv_tune(mv_engine* e, const char* key, int32_t value) {
+    if (!key) return fail(MV_ERR_INVALID, "null key");
+    const std::string k = key;
+    static const char* epi_names[4] = {"plain", "resid", "swiglu", "qkv"};
+    bool found = false;
+    for (int i = 0; i < 4 && !found; ++i) {
+        if (k == std::string("gemv_threads_") + epi_names[i]) { g_tune.gemv_threads[i] = value; found = true; }
+        else if (k == std::string("gemv_nr_") + epi_names[i]) { g_tune.gemv_nr[i] = value; found = true; }
+    }
+    if (found) {}
+    else if (k == "gemv_nt") g_tune.gemv_nt = value;
+    else if (k == "use_graph") g_tune.use_graph = value;
+    else return fail(MV_ERR_INVALID, "unknown tuning key '%s'", key);
+    if (e && e->finalized) e->graph_dirty = true;  // launch geometry is frozen in the captured graph: re-capture at mv_begin
+    return MV_OK;
+}
 const char* mv_version(void) { return "metavoice_hip 0.1 (gfx950)"; }
 
 int mv_engine_create(const mv_config* cfg, mv_engine** out) {
@@ -189,6 +211,7 @@ int mv_engine_create(const mv_config* cfg, mv_engine** out) {
                     c.dim, c.intermediate);
     if (c.weight_format != MV_W_BF16) return fail(MV_ERR_INVALID, "weight_format %d not supported by this build", c.weight_format);
     if (c.block_size < 8 || c.spk_dim < 1) return fail(MV_ERR_INVALID, "bad block_size/spk_dim");
+    if (c.block_size > ATTN_NSPLIT * 128) return fail(MV_ERR_INVALID, "block_size %d > %d", c.block_size, ATTN_NSPLIT * 128);
 
     mv_engine* e = new mv_engine();
     e->cfg = c;
@@ -383,6 +406,10 @@ int mv_begin(mv_engine* e, int32_t n_utt, const int32_t* prompts, const int32_t*
         if (cap - 1 > budget) budget = cap - 1;
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->graph_dirty) {
+        const int rc = build_graph(e);
+        if (rc != MV_OK) return rc;
+    }
     HIP_TRY(hipMemcpy(e->utt, st.data(), st.size() * sizeof(UttState), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->seq, seq.data(), seq.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->pos_arr, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
@@ -451,6 +478,8 @@ int mv_get_tokens(mv_engine* e, int32_t utt, int32_t* out, int32_t cap, int32_t*
 
 int mv_probe_kernel(mv_engine* e, int32_t kind, int32_t iters, float* avg_ms, double* bytes_per_launch) {
     if (!e || !e->finalized || !avg_ms || !bytes_per_launch) return fail(MV_ERR_STATE, "engine not finalized / null argument");
+    const bool warm = (kind & 0x100) != 0;      // same layer every launch: operands stay on die (L2 / Infinity Cache)
+    kind &= 0xFF;
     if (iters < 1 || kind < 0 || kind > 5) return fail(MV_ERR_INVALID, "bad probe arguments");
     const mv_config& c = e->cfg;
     const int R = e->R;
@@ -503,9 +532,13 @@ int mv_probe_kernel(mv_engine* e, int32_t kind, int32_t iters, float* avg_ms, do
         }
         return MV_OK;
     };
-    for (int i = 0; i < c.n_layer && i < 4; ++i) { const int rc = launch(i % c.n_layer); if (rc != MV_OK) return rc; }  // warm-up
+    for (int i = 0; i < c.n_layer && i < 4; ++i) { const int rc = launch(warm ? 0 : i % c.n_layer); if (rc != MV_OK) return rc; }  // warm-up
+    HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipEventRecord(e->ev0, s));
-    for (int i = 0; i < iters; ++i) { const int rc = launch(i % c.n_layer); if (rc != MV_OK) return rc; }
+    for (int i = 0; i < iters; ++i) {
+        const int rc = launch(warm ? 0 : i % c.n_layer);
+        if (rc != MV_OK) return rc;
+    }
     HIP_TRY(hipEventRecord(e->ev1, s));
     HIP_TRY(hipStreamSynchronize(s));
     float ms = 0.f;

@@ -21,8 +21,8 @@
 
 enum { EPI_PLAIN = GEMV_PLAIN, EPI_RESID = GEMV_RESID, EPI_SWIGLU = GEMV_SWIGLU, EPI_QKV = GEMV_QKV };
 
-template <int R, int KCH, int NR, int EPI>
-__global__ void __launch_bounds__(768) gemv_kernel(const GemvArgs a) {
+template <int R, int KCH, int NR, int EPI, bool NT>
+__global__ void __launch_bounds__(1024) gemv_kernel(const GemvArgs a) {
     constexpr int NMAT = (EPI == EPI_SWIGLU) ? 2 : 1;
     constexpr int KP = KCH * 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -43,8 +43,8 @@ __global__ void __launch_bounds__(768) gemv_kernel(const GemvArgs a) {
 #pragma unroll
         for (int j = 0; j < KCH; ++j) {
             const int c = min(j * 512 + lane * 8, K - 8);
-            wv[0][i][j] = load_stream16(a.w + (size_t)n * K + c);
-            if (NMAT == 2) wv[NMAT - 1][i][j] = load_stream16(a.w2 + (size_t)n * K + c);
+            wv[0][i][j] = NT ? load_stream16(a.w + (size_t)n * K + c) : load16(a.w + (size_t)n * K + c);
+            if (NMAT == 2) wv[NMAT - 1][i][j] = NT ? load_stream16(a.w2 + (size_t)n * K + c) : load16(a.w2 + (size_t)n * K + c);
         }
     }
 
@@ -162,22 +162,41 @@ __global__ void __launch_bounds__(768) gemv_kernel(const GemvArgs a) {
     }
 }
 
+MvTune g_tune;
+
 template <int R, int KCH, int NR, int EPI>
 static hipError_t launch_one(hipStream_t s, const GemvArgs& a, int threads) {
     const int nwaves = threads / 64;
     const int blocks = (a.N + nwaves * NR - 1) / (nwaves * NR);
     const size_t lds = (size_t)R * KCH * 512 * 2 + (size_t)nwaves * R * 4;
-    hipLaunchKernelGGL((gemv_kernel<R, KCH, NR, EPI>), dim3(blocks), dim3(threads), lds, s, a);
+    if (g_tune.gemv_nt) hipLaunchKernelGGL((gemv_kernel<R, KCH, NR, EPI, true>), dim3(blocks), dim3(threads), lds, s, a);
+    else hipLaunchKernelGGL((gemv_kernel<R, KCH, NR, EPI, false>), dim3(blocks), dim3(threads), lds, s, a);
     return hipGetLastError();
+}
+
+// Weight rows per wave.  Built-in: 1 (2 for the two matrices of SwiGLU, 3 for the fused QKV).
+template <int R, int KCH, int EPI>
+static hipError_t launch_nr(hipStream_t s, const GemvArgs& a, int threads, int nr) {
+    if (R * nr > 64) nr = 64 / R;  // a lane per (row of W, row of x) in the epilogue
+    if (KCH * nr * (EPI == EPI_SWIGLU ? 2 : 1) > 24) nr = 1;  // keep the in-flight working set <= 96 VGPRs
+    switch (nr) {
+        case 1: return launch_one<R, KCH, 1, EPI>(s, a, threads);
+        case 2: return launch_one<R, KCH, 2, EPI>(s, a, threads);
+        case 3: return launch_one<R, KCH, 3, EPI>(s, a, threads);
+        case 4: return launch_one<R, KCH, 4, EPI>(s, a, threads);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <int R, int KCH>
 static hipError_t launch_epi(hipStream_t s, const GemvArgs& a, int epi, int threads) {
+    static const int builtin_nr[4] = {1, 1, 1, 3};  // tools/sweep.py, profiles/r01b_attn_sampler
+    const int nr = g_tune.gemv_nr[epi] > 0 ? g_tune.gemv_nr[epi] : builtin_nr[epi];
     switch (epi) {
-        case EPI_PLAIN: return launch_one<R, KCH, 1, EPI_PLAIN>(s, a, threads);
-        case EPI_RESID: return launch_one<R, KCH, 1, EPI_RESID>(s, a, threads);
-        case EPI_SWIGLU: return launch_one<R, KCH, 2, EPI_SWIGLU>(s, a, threads);
-        case EPI_QKV: return launch_one<R, KCH, 3, EPI_QKV>(s, a, threads);
+        case EPI_PLAIN: return launch_nr<R, KCH, EPI_PLAIN>(s, a, threads, nr);
+        case EPI_RESID: return launch_nr<R, KCH, EPI_RESID>(s, a, threads, nr);
+        case EPI_SWIGLU: return launch_nr<R, KCH, EPI_SWIGLU>(s, a, threads, nr);
+        case EPI_QKV: return launch_nr<R, KCH, EPI_QKV>(s, a, threads, nr);
     }
     return hipErrorInvalidValue;
 }
@@ -199,9 +218,12 @@ static hipError_t launch_kch(hipStream_t s, const GemvArgs& a, int epi, int thre
 int gemv_default_threads(int epi, int N, int K) {
     const int kp8 = ((K + 511) / 512) * 64;  // threads needed by the norm prologue
     int t;
-    if (epi == EPI_SWIGLU) t = (N % 22 == 0) ? 704 : 512;
+    if (g_tune.gemv_threads[epi] > 0) t = g_tune.gemv_threads[epi];
+    else if (epi == EPI_SWIGLU) t = (N % 22 == 0) ? 704 : 512;
     else if (epi == EPI_PLAIN) t = (N > 2048 && N < 3072) ? 768 : 512;
     else t = 512;
+    t = (t + 63) / 64 * 64;
+    if (t > 1024) t = 1024;
     return t < kp8 ? kp8 : t;
 }
 

@@ -6,6 +6,15 @@
 
 typedef uint16_t bf16_t;
 
+// ---- tuning knobs (mv_tune): defaults are the measured best for MetaVoice-1B on MI355X (DESIGN.md "Tuning") ------
+struct MvTune {
+    int gemv_threads[4] = {0, 0, 0, 0};  // per epilogue kind (GEMV_*): 0 = built-in choice
+    int gemv_nr[4] = {0, 0, 0, 0};       // weight rows per wave: 0 = built-in choice
+    int gemv_nt = 1;                     // 1: non-temporal weight loads, 0: default cache policy
+    int use_graph = 1;
+};
+extern MvTune g_tune;
+
 // ---- gemv.hip ------------------------------------------------------------------------------------------------
 enum { GEMV_PLAIN = 0, GEMV_RESID = 1, GEMV_SWIGLU = 2, GEMV_QKV = 3 };
 struct GemvArgs {
@@ -26,7 +35,7 @@ hipError_t launch_gemv(hipStream_t s, int rows, const GemvArgs& a, int epi);
 bool gemv_supported(int rows, int K);
 
 // ---- attention.hip -------------------------------------------------------------------------------------------
-constexpr int ATTN_NSPLIT = 8;          // max KV splits per (row, head)
+constexpr int ATTN_NSPLIT = 16;         // max KV splits per (row, head): 16 x 128 keys = block_size 2048
 constexpr int ATTN_PART_STRIDE = 132;   // floats per partial: m, l, pad, pad, o[128]
 struct AttnArgs {
     const bf16_t* q = nullptr;        // [rows][n_head*128]
@@ -74,3 +83,4 @@ hipError_t launch_sample(hipStream_t s, const SampleArgs& a, bool standalone);
 hipError_t launch_embed_first(hipStream_t s, const SampleArgs& a);
 hipError_t launch_spk_proj(hipStream_t s, int n_utt, int dim, int spk_dim, const bf16_t* spk_emb, const bf16_t* w,
                            bf16_t* out);
+

@@ -8,17 +8,24 @@
 // Bytes are negligible (2 x 2562 logits); this kernel is latency-bound and sits on the critical path of every step.
 //   1. CFG mix `g*cond + (1-g)*uncond` and the temperature divide, each rounded to bf16 exactly where the
 //      reference's bf16 tensors are; everything after that is fp32 (DESIGN.md "Sampling").
-//   2. top-k / top-p need the ascending order: 64-bit keys (order-preserving float bits << 32 | token id) are bitonic
-//      sorted in LDS -- total order, ties by ascending id, same as the oracle's stable sort.
-//   3. softmax over the sorted values, inclusive block scan for the ascending cumulative mass, removal of
-//      `cum <= 1 - top_p` (largest always kept), renormalise.
+//   2. top-k / top-p are defined on the ascending (value, id) order (stable sort, fast_inference_utils.py:68-82,95-97)
+//      but never need the sorted array: after step 1 every value is a bf16, i.e. a 16-bit order-preserving key.
+//      top-k: the k-th largest key by base-4 bisection on block-wide counts.  top-p: "remove while the ascending
+//      cumulative mass <= 1 - top_p" == remove every token with key < X, where X is the largest key whose
+//      strictly-below mass F(X) <= thr (base-4 bisection on block-wide sums, 8 rounds of 3 sums), plus the first m
+//      (by id) of the tokens AT key X while F(X) + m*e_X <= thr; the largest (value, id) is always kept.  All sums
+//      run in a fixed order (deterministic); ~13 block reductions instead of the 78 barrier-separated passes of a
+//      4096-key bitonic sort (40 us -> 6 us per step, profiles/).
+//   3. softmax over the survivors (exp against the global max, renormalise).
 //   4. Exp(1) race: argmax p_i / q_i with q from Philox4x32-10 keyed by the utterance's seed, counter
 //      (token id, sequence index) -- independent of the slot the utterance occupies; ties to the lowest id.
 #include "common.h"
 #include "kernels.h"
 
-#define SAMPLE_THREADS 1024
+#define SAMPLE_THREADS 512
+#define SAMPLE_WAVES (SAMPLE_THREADS / 64)
 #define SAMPLE_MAXV 4096
+#define SAMPLE_PER (SAMPLE_MAXV / SAMPLE_THREADS)
 
 __device__ __forceinline__ uint32_t philox4x32_10_word0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                         uint32_t k1) {
@@ -42,40 +49,60 @@ __device__ __forceinline__ float mv_exp1_noise(uint64_t seed, uint32_t step, uin
     return -logf(u);
 }
 
-__device__ __forceinline__ uint32_t float_order_bits(float f) {
+// bf16-valued float <-> 16-bit key with the same ordering
+__device__ __forceinline__ uint32_t bf_order_key(float f) {
     const uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((u & 0x80000000u) ? ~u : (u | 0x80000000u)) >> 16;
 }
-__device__ __forceinline__ float order_bits_float(uint32_t k) {
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+__device__ __forceinline__ float bf_key_value(uint32_t k) {
+    const uint32_t k32 = k << 16;
+    return (k32 & 0x80000000u) ? __uint_as_float(k32 & 0x7FFFFFFFu) : __uint_as_float(~(k32 | 0xFFFFu));
 }
 
-// Block-wide helpers (SAMPLE_THREADS threads, `red` has >= 2*16 floats of scratch).
-__device__ __forceinline__ float block_sum(float v, float* red) {
-    v = wave_sum(v);
+// Block-wide reductions over SAMPLE_THREADS threads.  `buf` alternates between two LDS regions from one call to the next
+// (the caller flips `par`), so one barrier per reduction is enough: a region is rewritten only after every thread has
+// passed the barrier that followed its last read.
+struct SampleScratch {
+    float f[2][3][SAMPLE_WAVES];
+    unsigned long long q[2][SAMPLE_WAVES];
+};
+template <int NV>
+__device__ __forceinline__ void block_sum_f(float (&v)[NV], SampleScratch& sc, int& par) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const float t = wave_sum(v[j]);
+        if (lane == 0) sc.f[par][j][wave] = t;
+    }
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = 0.f;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
-    return t;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < SAMPLE_WAVES; ++w) t += sc.f[par][j][w];
+        v[j] = t;
+    }
+    par ^= 1;
 }
-__device__ __forceinline__ float block_max(float v, float* red) {
-    v = wave_max(v);
+__device__ __forceinline__ unsigned long long block_max_q(unsigned long long v, SampleScratch& sc, int& par) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    if (lane == 0) sc.q[par][wave] = v;
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = -INFINITY;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t = fmaxf(t, red[w]);
+    unsigned long long t = 0ull;
+#pragma unroll
+    for (int w = 0; w < SAMPLE_WAVES; ++w) t = sc.q[par][w] > t ? sc.q[par][w] : t;
+    par ^= 1;
     return t;
 }
 
 __global__ void __launch_bounds__(SAMPLE_THREADS) sample_kernel(const SampleArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned long long keys[SAMPLE_MAXV];
-    __shared__ float val[SAMPLE_MAXV];   // mixed logits (token order), later e_j (sorted order)
-    __shared__ float red[64];
-    __shared__ unsigned long long best[16];
-    __shared__ int s_tok;
+    __shared__ SampleScratch sc;
+    int par = 0;
 
     const int u = blockIdx.x;
     const int tid = threadIdx.x;
@@ -105,148 +132,143 @@ __global__ void __launch_bounds__(SAMPLE_THREADS) sample_kernel(const SampleArgs
         const float temp = fmaxf(sp.temperature, 1e-5f);
         const bool use_k = sp.top_k > 0;
         const bool use_p = sp.top_p > 0.f;
-        int NP = 1;
-        while (NP < V) NP <<= 1;
+        const int npt = (V + SAMPLE_THREADS - 1) / SAMPLE_THREADS;  // thread t owns ids [t*npt, t*npt + npt)
+        const int i0 = tid * npt;
 
         // ---- 1. CFG mix + temperature (bf16 rounding points of fast_inference_utils.py:115-117,92)
-        for (int i = tid; i < NP; i += blockDim.x) {
-            if (i < V) {
+        float val[SAMPLE_PER], e[SAMPLE_PER];
+        uint32_t key[SAMPLE_PER];
+        bool valid[SAMPLE_PER];
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int k = 0; k < SAMPLE_PER; ++k) {
+            const int i = i0 + k;
+            valid[k] = (k < npt) && (i < V);
+            val[k] = 0.f;
+            key[k] = 0u;
+            if (valid[k]) {
                 const float c = bf2f(lc[i]), un = bf2f(lu[i]);
                 const float mixed = round_bf(round_bf(sp.guidance_scale * c) + round_bf(sp.one_minus_guidance * un));
-                const float t = round_bf(mixed / temp);
-                val[i] = t;
-                keys[i] = ((unsigned long long)float_order_bits(t) << 32) | (unsigned)i;
+                float t = round_bf(mixed / temp);
+                t = (t == 0.f) ? 0.f : t;  // -0 sorts with +0 (stable sort compares values)
+                val[k] = t;
+                key[k] = bf_order_key(t);
+                const unsigned long long cand = ((unsigned long long)key[k] << 32) | (unsigned)i;
+                best = cand > best ? cand : best;
+            }
+        }
+        best = block_max_q(best, sc, par);
+        const uint32_t kmax = (uint32_t)(best >> 32);
+        const int last_id = (int)(best & 0xFFFFFFFFu);  // last element of the ascending (value, id) order: always kept
+        const float vmax = bf_key_value(kmax);
+
+        // ---- 2. top-k pivot: the k-th largest key (tokens equal to the pivot all survive, `logits < pivot` is masked)
+        uint32_t pivot = 0u;
+        if (use_k) {
+            const int kk = min(sp.top_k, V);
+            if (kk == 1) {
+                pivot = kmax;
             } else {
-                keys[i] = ~0ull;
+                for (int lvl = 7; lvl >= 0; --lvl) {  // largest X with #{key >= X} >= kk
+                    const uint32_t step = 1u << (2 * lvl);
+                    float cnt[3] = {0.f, 0.f, 0.f};  // counts <= 4096 are exact in fp32
+#pragma unroll
+                    for (int k = 0; k < SAMPLE_PER; ++k)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) cnt[j] += (valid[k] && key[k] >= pivot + (j + 1) * step) ? 1.f : 0.f;
+                    block_sum_f(cnt, sc, par);
+                    uint32_t d = 0;
+                    if (cnt[0] >= (float)kk) d = 1;
+                    if (cnt[1] >= (float)kk) d = 2;
+                    if (cnt[2] >= (float)kk) d = 3;
+                    pivot += d * step;
+                }
             }
         }
-        __syncthreads();
 
-        float vmax, S2;
-        if (use_k || use_p) {
-            // ---- 2. ascending bitonic sort of (value, id)
-            for (int k = 2; k <= NP; k <<= 1) {
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int t = tid; t < (NP >> 1); t += blockDim.x) {
-                        const int i = 2 * t - (t & (j - 1));
-                        const unsigned long long x = keys[i], y = keys[i + j];
-                        const bool asc = ((i & k) == 0);
-                        if ((x > y) == asc) { keys[i] = y; keys[i + j] = x; }
-                    }
-                    __syncthreads();
-                }
-            }
-            vmax = order_bits_float((uint32_t)(keys[V - 1] >> 32));
-            float pivot = -INFINITY;
-            if (use_k) pivot = order_bits_float((uint32_t)(keys[V - min(sp.top_k, V)] >> 32));
+        // ---- 3. e_i = exp(v_i - max) (0 when masked by top-k), total mass
+        float S1[1] = {0.f};
+#pragma unroll
+        for (int k = 0; k < SAMPLE_PER; ++k) {
+            e[k] = (valid[k] && key[k] >= pivot) ? __expf(val[k] - vmax) : 0.f;
+            S1[0] += e[k];
+        }
+        block_sum_f(S1, sc, par);
+        const float S = S1[0];
+        bool keep[SAMPLE_PER];
+#pragma unroll
+        for (int k = 0; k < SAMPLE_PER; ++k) keep[k] = valid[k] && (e[k] > 0.f || !use_k);
 
-            // ---- 3. e_j = exp(v_j - max) in sorted order (0 for top-k-masked), total mass, cumulative mass
-            float loc[4];
-            const int j0 = tid * 4;  // NP <= 4096 = 4 * SAMPLE_THREADS
-            float lsum = 0.f;
+        // ---- 4. top-p on the ascending order, without sorting
+        if (use_p) {
+            const float thr = 1.0f - sp.top_p;
+            uint32_t X = 0u;
+            float FX = 0.f;
+            for (int lvl = 7; lvl >= 0; --lvl) {  // largest X with F(X) = mass{key < X} <= thr
+                const uint32_t step = 1u << (2 * lvl);
+                float f[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = j0 + q;
-                float e = 0.f;
-                if (j < V) {
-                    const float v = order_bits_float((uint32_t)(keys[j] >> 32));
-                    e = (v < pivot) ? 0.f : __expf(v - vmax);
-                }
-                loc[q] = e;
-                lsum += e;
+                for (int k = 0; k < SAMPLE_PER; ++k)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) f[j] += (key[k] < X + (j + 1) * step) ? e[k] : 0.f;
+                block_sum_f(f, sc, par);
+                uint32_t d = 0;
+                if (f[0] / S <= thr) { d = 1; FX = f[0]; }
+                if (f[1] / S <= thr) { d = 2; FX = f[1]; }
+                if (f[2] / S <= thr) { d = 3; FX = f[2]; }
+                X += d * step;
             }
-            const float S = block_sum(lsum, red);
-            bool keep[4];
+            // tokens AT key X, in id order: the m-th (1-based) has cumulative mass F(X) + m * e_X
+            float tcnt = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) keep[q] = (j0 + q < V) && (loc[q] > 0.f || !use_k);
-            if (use_p) {
-                // inclusive scan of per-thread sums: wave scan + wave offsets
-                float incl = lsum;
+            for (int k = 0; k < SAMPLE_PER; ++k) tcnt += (valid[k] && key[k] == X) ? 1.f : 0.f;
+            float incl = tcnt;  // inclusive scan over threads (= id order: thread t owns a contiguous id range)
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const float n = __shfl_up(incl, off, 64);
-                    if ((tid & 63) >= off) incl += n;
-                }
-                __syncthreads();
-                if ((tid & 63) == 63) red[32 + (tid >> 6)] = incl;
-                __syncthreads();
-                float woff = 0.f;
-                for (int w = 0; w < (tid >> 6); ++w) woff += red[32 + w];
-                float cum = woff + incl - lsum;  // exclusive prefix of this thread, in units of e
-                const float thr = 1.0f - sp.top_p;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    cum += loc[q];
-                    const int j = j0 + q;
-                    if (j < V && j != V - 1 && (cum / S) <= thr) keep[q] = false;
-                }
+            for (int off = 1; off < 64; off <<= 1) {
+                const float n = __shfl_up(incl, off, 64);
+                if ((tid & 63) >= off) incl += n;
             }
-            // ---- renormalise over the survivors
-            float ksum = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (!keep[q]) loc[q] = 0.f;
-                ksum += loc[q];
-            }
-            S2 = block_sum(ksum, red);
-            // ---- 4. race
-            unsigned long long bst = 0ull;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = j0 + q;
-                if (j < V) {
-                    const unsigned id = (unsigned)(keys[j] & 0xFFFFFFFFu);
-                    const float p = loc[q] / S2;
-                    if (a.probs_out) a.probs_out[id] = p;
-                    const float r = p / mv_exp1_noise(sp.seed, (uint32_t)next_index, 0u, id);
-                    const unsigned long long cand = ((unsigned long long)__float_as_uint(r) << 32) | (0xFFFFFFFFu - id);
-                    bst = cand > bst ? cand : bst;
-                }
-            }
-            // wave max of 64-bit candidates
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned long long o = __shfl_xor(bst, off, 64);
-                bst = o > bst ? o : bst;
-            }
-            if ((tid & 63) == 0) best[tid >> 6] = bst;
+            if ((tid & 63) == 63) sc.f[par][0][tid >> 6] = incl;
             __syncthreads();
-            if (tid == 0) {
-                unsigned long long b = 0ull;
-                for (int w = 0; w < (int)(blockDim.x >> 6); ++w) b = best[w] > b ? best[w] : b;
-                s_tok = (int)(0xFFFFFFFFu - (unsigned)(b & 0xFFFFFFFFu));
-            }
-        } else {
-            // no truncation: plain softmax over all tokens, no sort needed
-            float lm = -INFINITY;
-            for (int i = tid; i < V; i += blockDim.x) lm = fmaxf(lm, val[i]);
-            vmax = block_max(lm, red);
-            float ls = 0.f;
-            for (int i = tid; i < V; i += blockDim.x) ls += __expf(val[i] - vmax);
-            S2 = block_sum(ls, red);
-            unsigned long long bst = 0ull;
-            for (int i = tid; i < V; i += blockDim.x) {
-                const float p = __expf(val[i] - vmax) / S2;
-                if (a.probs_out) a.probs_out[i] = p;
-                const float r = p / mv_exp1_noise(sp.seed, (uint32_t)next_index, 0u, (unsigned)i);
-                const unsigned long long cand = ((unsigned long long)__float_as_uint(r) << 32) | (0xFFFFFFFFu - (unsigned)i);
-                bst = cand > bst ? cand : bst;
-            }
+            float before = incl - tcnt;
+            for (int w = 0; w < (tid >> 6); ++w) before += sc.f[par][0][w];
+            par ^= 1;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned long long o = __shfl_xor(bst, off, 64);
-                bst = o > bst ? o : bst;
-            }
-            if ((tid & 63) == 0) best[tid >> 6] = bst;
-            __syncthreads();
-            if (tid == 0) {
-                unsigned long long b = 0ull;
-                for (int w = 0; w < (int)(blockDim.x >> 6); ++w) b = best[w] > b ? best[w] : b;
-                s_tok = (int)(0xFFFFFFFFu - (unsigned)(b & 0xFFFFFFFFu));
+            for (int k = 0; k < SAMPLE_PER; ++k) {
+                if (!valid[k]) continue;
+                if (key[k] < X) keep[k] = false;
+                if (key[k] == X) {
+                    before += 1.f;
+                    if ((FX + before * e[k]) / S <= thr) keep[k] = false;
+                }
+                if (i0 + k == last_id) keep[k] = valid[k];  // "always keep the last" (fast_inference_utils.py:76)
             }
         }
-        __syncthreads();
-        tok = s_tok;
+
+        // ---- renormalise over the survivors
+        float S2a[1] = {0.f};
+#pragma unroll
+        for (int k = 0; k < SAMPLE_PER; ++k) {
+            if (!keep[k]) e[k] = 0.f;
+            S2a[0] += e[k];
+        }
+        block_sum_f(S2a, sc, par);
+        const float S2 = S2a[0];
+
+        // ---- 5. Exp(1) race: argmax p_i / q_i, ties to the lowest id
+        unsigned long long bst = 0ull;
+#pragma unroll
+        for (int k = 0; k < SAMPLE_PER; ++k) {
+            if (!valid[k]) continue;
+            const unsigned id = (unsigned)(i0 + k);
+            const float p = e[k] / S2;
+            if (a.probs_out) a.probs_out[id] = p;
+            const float r = (p > 0.f) ? p / mv_exp1_noise(sp.seed, (uint32_t)next_index, 0u, id) : 0.f;
+            const unsigned long long cand = ((unsigned long long)__float_as_uint(r) << 32) | (0xFFFFFFFFu - id);
+            bst = cand > bst ? cand : bst;
+        }
+        bst = block_max_q(bst, sc, par);
+        tok = (int)(0xFFFFFFFFu - (unsigned)(bst & 0xFFFFFFFFu));
     }
 
     if (standalone) {

@@ -131,6 +131,11 @@ class Stage1Engine:
         N.check(N.lib().mv_get_tokens(self._h, utt, out, cap, C.byref(n)))
         return list(out[: n.value])
 
+    def tune(self, **knobs: int):
+        """mv_tune: launch knobs of the decode kernels / prefetcher (DESIGN.md "Tuning"); takes effect at the next begin()."""
+        for k, v in knobs.items():
+            N.check(N.lib().mv_tune(self._h, k.encode(), int(v)))
+
     # ---- parity hooks --------------------------------------------------------------------------------------------
     def capture_logits(self, enable: bool = True, max_steps: int = -1):
         N.check(N.lib().mv_set_logits_capture(self._h, int(enable), max_steps))
