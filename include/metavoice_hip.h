@@ -109,12 +109,49 @@ int64_t mv_op_attention_scratch_bytes(int32_t rows, int32_t n_head);
 int mv_op_sample(void* stream, int32_t vocab, const void* logits_pair, const mv_sampling* s, uint32_t step,
                  int32_t* token_out, float* probs_out);
 
+/* Many-row blocks (first-stage prefill, second stage): out[M][N] = epilogue(a[M][K] . w[N][K]^T), bf16 in/out, fp32 MFMA
+ * accumulate; w2 != NULL: SwiGLU gate bf16(bf16(silu(a.w^T + bias)) * bf16(a.w2^T + bias2)); gelu: exact-erf GELU;
+ * residual [M][N] bf16 added after the bf16 rounding of the product (fam/llm/fast_model.py:179-180,237). */
+int mv_op_gemm(void* stream, int32_t M, int32_t N, int32_t K, const void* a, const void* w, const void* w2, const void* bias,
+               const void* bias2, const void* residual, int32_t gelu, void* out);
+/* softmax(q k^T / sqrt(head_dim)) v for every query position of a packed c_attn output [batch][T][3][n_head][head_dim]
+ * (fam/llm/layers/attn.py:132-159; causal = 0 is the second-stage case), head_dim 64 or 128. */
+int mv_op_attention_rows(void* stream, int32_t batch, int32_t T, int32_t n_head, int32_t head_dim, int32_t causal, const void* qkv,
+                         void* out);
+
 /* Roofline probe: launches one kernel kind of the decode step `iters` times back to back on the engine stream, cycling
  * through the layers' weights (so the stream is HBM-cold: 24 x 46 MB >> the 256 MB Infinity Cache), bracketed by HIP
  * events on that stream.  Returns the average launch duration and the ALGORITHMIC bytes one launch must move
  * (SURVEY.md 8d).  kind: 0 norm+wqkv+kv-write, 1 attention (at the utterances' current positions), 2 wo+residual,
  * 3 norm+w1|w3+silu-gate, 4 w2+residual, 5 norm+LM head. */
 int mv_probe_kernel(mv_engine* e, int32_t kind, int32_t iters, float* avg_ms, double* bytes_per_launch);
+
+/* ---- second stage: replaces Model(...)/GPT for the non-causal model (fam/llm/inference.py:53-156, fam/llm/model.py:79-156,
+ * 195-314) and _non_causal_sample (fam/llm/mixins/non_causal.py:15-67).  Sizes mirror GPTConfig (model.py:27-47) and come
+ * from second_stage.pt["model_args"]; tensor names are the checkpoint's own ("transformer.h.0.attn.c_attn.weight", ...). */
+typedef struct mv_stage2 mv_stage2;
+typedef struct mv_stage2_config {
+    int32_t n_layer, n_head, n_embd;
+    int32_t hidden;            /* MLP width (layers.py:45-58) */
+    int32_t block_size, spk_dim;
+    int32_t n_in, n_out;       /* input hierarchies (2), target hierarchies (6) */
+    int32_t vocab_in[4], vocab_out[8];
+    int32_t bias;              /* GPTConfig.bias */
+    int32_t norm_type;         /* 0 rmsnorm, 1 layernorm */
+    int32_t act;               /* 0 swiglu, 1 gelu */
+    int32_t causal;            /* 0 for the second stage */
+    float norm_eps;            /* rmsnorm_eps */
+    int32_t max_batch;
+} mv_stage2_config;
+int mv_stage2_create(const mv_stage2_config* cfg, mv_stage2** out);
+int mv_stage2_destroy(mv_stage2* s);
+int mv_stage2_load_weight(mv_stage2* s, const char* name, const void* data, int32_t dtype, int64_t rows, int64_t cols);
+int mv_stage2_finalize(mv_stage2* s);
+/* idx: host int32 [batch][n_in][T]; spk_emb: host bf16 bits [batch][spk_dim] or NULL.  Logits stay on the device. */
+int mv_stage2_forward(mv_stage2* s, int32_t batch, int32_t T, const int32_t* idx, const uint16_t* spk_emb);
+int mv_stage2_get_logits(mv_stage2* s, int32_t head, float* out);  /* parity hook: fp32 [batch*T][vocab_out[head]] */
+/* One draw per (position, target hierarchy): /temperature, top-k mask, softmax, multinomial; out: host [batch][n_out][T]. */
+int mv_stage2_sample(mv_stage2* s, float temperature, int32_t top_k, uint64_t seed, int32_t* out);
 
 /* Tuning hook (no reference equivalent): process-wide launch knobs of the decode kernels and the side-stream prefetcher,
  * used by tools/sweep.py; keys are listed in DESIGN.md "Tuning".  A finalized engine passed as `e` (may be NULL)

@@ -10,3 +10,4 @@ from . import synthetic  # noqa: F401
 from ._native import LIB_PATH, NativeLibraryMissing  # noqa: F401
 from .engine import SamplingParams, Stage1Engine  # noqa: F401
 from .fast_model import ModelArgs, Transformer, find_multiple, transformer_configs  # noqa: F401
+from .model import GPT, GPTConfig  # noqa: F401

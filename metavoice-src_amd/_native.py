@@ -31,6 +31,15 @@ class mv_config(C.Structure):
     ]
 
 
+class mv_stage2_config(C.Structure):
+    _fields_ = [
+        ("n_layer", C.c_int32), ("n_head", C.c_int32), ("n_embd", C.c_int32), ("hidden", C.c_int32), ("block_size", C.c_int32),
+        ("spk_dim", C.c_int32), ("n_in", C.c_int32), ("n_out", C.c_int32), ("vocab_in", C.c_int32 * 4), ("vocab_out", C.c_int32 * 8),
+        ("bias", C.c_int32), ("norm_type", C.c_int32), ("act", C.c_int32), ("causal", C.c_int32), ("norm_eps", C.c_float),
+        ("max_batch", C.c_int32),
+    ]
+
+
 class mv_sampling(C.Structure):
     _fields_ = [
         ("guidance_scale", C.c_float), ("one_minus_guidance", C.c_float), ("temperature", C.c_float),
@@ -58,6 +67,15 @@ SYMBOLS = [
     ("mv_op_attention_decode", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
     ("mv_op_attention_scratch_bytes", C.c_int64, [C.c_int32, C.c_int32]),
     ("mv_op_sample", C.c_int, [_P, C.c_int32, _P, C.POINTER(mv_sampling), C.c_uint32, _P, _P]),
+    ("mv_op_gemm", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
+    ("mv_op_attention_rows", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    ("mv_stage2_create", C.c_int, [C.POINTER(mv_stage2_config), C.POINTER(_P)]),
+    ("mv_stage2_destroy", C.c_int, [_P]),
+    ("mv_stage2_load_weight", C.c_int, [_P, C.c_char_p, _P, C.c_int32, C.c_int64, C.c_int64]),
+    ("mv_stage2_finalize", C.c_int, [_P]),
+    ("mv_stage2_forward", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint16)]),
+    ("mv_stage2_get_logits", C.c_int, [_P, C.c_int32, C.POINTER(C.c_float)]),
+    ("mv_stage2_sample", C.c_int, [_P, C.c_float, C.c_int32, C.c_uint64, C.POINTER(C.c_int32)]),
     ("mv_probe_kernel", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     ("mv_tune", C.c_int, [_P, C.c_char_p, C.c_int32]),
     ("mv_last_error", C.c_char_p, []),

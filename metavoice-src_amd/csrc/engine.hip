@@ -24,6 +24,7 @@ int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
+void set_error(const char* msg) { g_err = msg; }
 
 #define HIP_TRY(expr)                                                                                      \
     do {                                                                                                   \
@@ -58,6 +59,17 @@ struct Slot {
 
 }  // namespace
 
+// error reporting shared with stage2.hip
+int mv_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    set_error(buf);
+    return code;
+}
+
 struct mv_engine {
     mv_config cfg{};
     int R = 0;  // CFG rows = 2 * max_utterances
@@ -88,6 +100,9 @@ struct mv_engine {
     int capture_max = 0;
     bool capture_on = false;
 
+    // prefill workspace (M = 2 T rows of one utterance), allocated on the first batched prefill
+    bf16_t *px = nullptr, *ph = nullptr, *pn = nullptr, *pq = nullptr, *pattn = nullptr, *pact = nullptr;
+
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     bool use_graph = true;
@@ -101,6 +116,8 @@ struct mv_engine {
 };
 
 namespace {
+
+int enqueue_tail(mv_engine* e);
 
 int enqueue_step(mv_engine* e) {
     const mv_config& c = e->cfg;
@@ -141,6 +158,14 @@ int enqueue_step(mv_engine* e) {
             HIP_TRY(launch_gemv(s, R, a, GEMV_RESID));
         }
     }
+    return enqueue_tail(e);
+}
+
+// Final norm + LM head on the current rows of x, then the sampler: the tail of a decode step, and the end of a prefill.
+int enqueue_tail(mv_engine* e) {
+    const mv_config& c = e->cfg;
+    const int R = e->R;
+    hipStream_t s = e->stream;
     {   // logits = head(norm(x))                          (fast_model.py:161-162)
         GemvArgs a;
         a.x = e->x; a.w = e->head; a.norm_w = e->final_norm; a.out = e->logits; a.N = c.vocab; a.K = c.dim;
@@ -156,6 +181,62 @@ int enqueue_step(mv_engine* e) {
        
         HIP_TRY(launch_sample(s, a, false));
     }
+    return MV_OK;
+}
+
+// `prefill()` of the reference (fast_inference_utils.py:123-132): Transformer.forward over all T prompt positions of
+// utterance u (2 CFG rows -> M = 2T), as MFMA GEMMs + causal attention over the KV rows it writes.  Leaves the residual
+// stream of the LAST position in x[2u], x[2u+1]; the caller then runs enqueue_tail (the reference also evaluates the LM
+// head on all T positions, fast_model.py:162 -- only the last one is ever used, :115).
+int enqueue_prefill(mv_engine* e, int u, int T) {
+    const mv_config& c = e->cfg;
+    hipStream_t s = e->stream;
+    const int M = 2 * T;
+    if (!e->px) {
+        const size_t rows = (size_t)2 * c.block_size;
+        HIP_TRY(hipMalloc((void**)&e->px, rows * c.dim * 2));
+        HIP_TRY(hipMalloc((void**)&e->ph, rows * c.dim * 2));
+        HIP_TRY(hipMalloc((void**)&e->pn, rows * c.dim * 2));
+        HIP_TRY(hipMalloc((void**)&e->pq, rows * c.dim * 2));
+        HIP_TRY(hipMalloc((void**)&e->pattn, rows * c.dim * 2));
+        HIP_TRY(hipMalloc((void**)&e->pact, rows * c.intermediate * 2));
+    }
+    HIP_TRY(launch_embed_rows(s, e->seq + (size_t)u * c.block_size, T, c.dim, e->tok_emb, e->pos_emb,
+                              e->spk_proj + (size_t)u * c.dim, e->px));
+    const size_t row_off = (size_t)2 * u * c.n_head * c.block_size * 128;
+    for (int l = 0; l < c.n_layer; ++l) {
+        const LayerW& w = e->layers[l];
+        bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems + row_off;
+        bf16_t* vc = e->vcache + (size_t)l * e->kv_layer_elems + row_off;
+        NormArgs n;
+        n.x_bf16 = e->px; n.w_bf16 = w.attn_norm; n.out = e->pn; n.M = M; n.C = c.dim; n.mode = 0; n.eps = c.norm_eps;
+        HIP_TRY(launch_norm_rows(s, n));
+        GemmArgs g;
+        g.a = e->pn; g.w = w.wqkv; g.out_bf16 = e->pq; g.M = M; g.N = 3 * c.dim; g.K = c.dim; g.lda = c.dim; g.ldc = c.dim;
+        g.qkv_dim = c.dim; g.seq_len = T; g.n_head = c.n_head; g.cache_len = c.block_size; g.kcache = kc; g.vcache = vc;
+        HIP_TRY(launch_gemm(s, g));
+        AttnRowsArgs at;
+        at.q = e->pq; at.k = kc; at.v = vc; at.out = e->pattn; at.k_batch_stride = (int64_t)c.n_head * c.block_size * 128;
+        at.k_head_stride = (int64_t)c.block_size * 128; at.k_key_stride = 128; at.q_row_stride = c.dim; at.out_row_stride = c.dim;
+        at.T = T; at.n_head = c.n_head; at.batch = 2; at.head_dim = 128; at.causal = 1;
+        HIP_TRY(launch_attn_rows(s, at));
+        g = GemmArgs();
+        g.a = e->pattn; g.w = w.wo; g.res_bf16 = e->px; g.out_bf16 = e->ph; g.M = M; g.N = c.dim; g.K = c.dim; g.lda = c.dim; g.ldc = c.dim;
+        HIP_TRY(launch_gemm(s, g));
+        n.x_bf16 = e->ph; n.w_bf16 = w.ffn_norm;
+        HIP_TRY(launch_norm_rows(s, n));
+        g = GemmArgs();
+        g.a = e->pn; g.w = w.w1; g.w2 = w.w3; g.out_bf16 = e->pact; g.M = M; g.N = c.intermediate; g.K = c.dim; g.lda = c.dim;
+        g.ldc = c.intermediate;
+        HIP_TRY(launch_gemm(s, g));
+        g = GemmArgs();
+        g.a = e->pact; g.w = w.w2; g.res_bf16 = e->ph; g.out_bf16 = e->px; g.M = M; g.N = c.dim; g.K = c.intermediate;
+        g.lda = c.intermediate; g.ldc = c.dim;
+        HIP_TRY(launch_gemm(s, g));
+    }
+    for (int r = 0; r < 2; ++r)
+        HIP_TRY(hipMemcpyAsync(e->x + (size_t)(2 * u + r) * c.dim, e->px + ((size_t)r * T + T - 1) * c.dim, (size_t)c.dim * 2,
+                               hipMemcpyDeviceToDevice, s));
     return MV_OK;
 }
 
@@ -266,7 +347,8 @@ int mv_engine_destroy(mv_engine* e) {
     if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
     if (e->graph) hipGraphDestroy(e->graph);
     void* bufs[] = {e->arena, e->x, e->h, e->q, e->attn, e->act, e->logits, e->kcache, e->vcache, e->partial, e->counters,
-                    e->utt, e->pos_arr, e->seq, e->spk_emb, e->spk_proj, e->n_active, e->capture};
+                    e->utt, e->pos_arr, e->seq, e->spk_emb, e->spk_proj, e->n_active, e->capture, e->px, e->ph, e->pn, e->pq,
+                    e->pattn, e->pact};
     for (void* b : bufs)
         if (b) hipFree(b);
     if (e->host_flag) hipHostFree(e->host_flag);
@@ -379,7 +461,6 @@ int mv_get_captured_logits(mv_engine* e, float* out, int32_t first_step, int32_t
 int mv_begin(mv_engine* e, int32_t n_utt, const int32_t* prompts, const int32_t* prompt_lens, int32_t max_len,
              const uint16_t* spk_emb, const mv_sampling* sampling, int32_t max_new_tokens, int32_t eoa_token,
              int32_t prefill_mode) {
-    (void)prefill_mode;
     if (!e || !e->finalized) return fail(MV_ERR_STATE, "engine not finalized");
     if (!prompts || !prompt_lens || !spk_emb || !sampling) return fail(MV_ERR_INVALID, "null argument");
     const mv_config& c = e->cfg;
@@ -388,6 +469,10 @@ int mv_begin(mv_engine* e, int32_t n_utt, const int32_t* prompts, const int32_t*
     std::vector<UttState> st(U);
     std::vector<int32_t> seq((size_t)U * c.block_size, 0), pos(U, 0);
     int budget = 0;
+    // batched (MFMA) prefill needs every prompt to have >= 2 tokens and GEMM-tileable widths; otherwise the prompt is
+    // teacher-forced through the decode graph
+    bool use_prefill = prefill_mode == 1;
+    for (int u = 0; u < n_utt && u < U; ++u) use_prefill = use_prefill && prompt_lens[u] >= 2;
     for (int u = 0; u < U; ++u) {
         UttState& s = st[u];
         memset(&s, 0, sizeof(s));
@@ -402,8 +487,12 @@ int mv_begin(mv_engine* e, int32_t n_utt, const int32_t* prompts, const int32_t*
             if (t < 0 || t >= c.vocab) return fail(MV_ERR_INVALID, "token %d out of vocabulary", t);
             seq[(size_t)u * c.block_size + i] = t;
         }
-        s.pos = 0; s.prompt_len = T; s.max_len = cap; s.done = 0; s.eoa_token = eoa_token; s.n_tokens = T; s.s = sampling[u];
-        if (cap - 1 > budget) budget = cap - 1;
+        const bool batched = use_prefill;
+        s.pos = batched ? T - 1 : 0; s.prompt_len = T; s.max_len = cap; s.done = 0; s.eoa_token = eoa_token; s.n_tokens = T;
+        s.s = sampling[u];
+        pos[u] = s.pos;
+        const int steps = batched ? cap - T - 1 : cap - 1;  // the prefill tail already drew the first new token
+        if (steps > budget) budget = steps;
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (e->graph_dirty) {
@@ -420,7 +509,19 @@ int mv_begin(mv_engine* e, int32_t n_utt, const int32_t* prompts, const int32_t*
     SampleArgs a;
     a.seq = e->seq; a.tok_emb = e->tok_emb; a.pos_emb = e->pos_emb; a.spk_proj = e->spk_proj; a.x_next = e->x;
     a.dim = c.dim; a.block_size = c.block_size; a.n_utt = U;
-    HIP_TRY(launch_embed_first(e->stream, a));
+    HIP_TRY(launch_embed_first(e->stream, a));   // x rows of position 0 (teacher-forced utterances start here)
+    bool any_batched = false;
+    for (int u = 0; u < n_utt; ++u) {
+        if (st[u].pos > 0) {
+            const int rc = enqueue_prefill(e, u, st[u].prompt_len);
+            if (rc != MV_OK) return rc;
+            any_batched = true;
+        }
+    }
+    if (any_batched) {
+        const int rc = enqueue_tail(e);  // LM head + sampler of position T-1: the first generated token
+        if (rc != MV_OK) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->n_utt = n_utt;
     e->begun = true;
@@ -584,6 +685,28 @@ int mv_op_attention_decode(void* stream, int32_t rows, int32_t n_head, int32_t c
     a.out = (bf16_t*)out; a.n_head = n_head; a.cache_len = cache_len;
     HIP_TRY(hipMemsetAsync(a.counters, 0, (size_t)rows * n_head * 4, (hipStream_t)stream));
     HIP_TRY(launch_attention_decode((hipStream_t)stream, rows, a));
+    return MV_OK;
+}
+
+int mv_op_gemm(void* stream, int32_t M, int32_t N, int32_t K, const void* a, const void* w, const void* w2, const void* bias,
+               const void* bias2, const void* residual, int32_t gelu, void* out) {
+    GemmArgs g;
+    g.a = (const bf16_t*)a; g.w = (const bf16_t*)w; g.w2 = (const bf16_t*)w2; g.bias = (const bf16_t*)bias; g.bias2 = (const bf16_t*)bias2;
+    g.res_bf16 = (const bf16_t*)residual; g.out_bf16 = (bf16_t*)out; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N;
+    g.act = gelu ? GEMM_ACT_GELU : GEMM_ACT_NONE;
+    if (launch_gemm((hipStream_t)stream, g) != hipSuccess) return fail(MV_ERR_INVALID, "gemm: unsupported shape M=%d N=%d K=%d (K %% 8 == 0)", M, N, K);
+    return MV_OK;
+}
+
+int mv_op_attention_rows(void* stream, int32_t batch, int32_t T, int32_t n_head, int32_t head_dim, int32_t causal, const void* qkv,
+                         void* out) {
+    // qkv: [batch][T][3][n_head][head_dim] bf16 (the c_attn output layout, fam/llm/layers/attn.py:174); out [batch][T][C]
+    const int C = n_head * head_dim;
+    AttnRowsArgs a;
+    a.q = (const bf16_t*)qkv; a.k = a.q + C; a.v = a.q + 2 * C; a.out = (bf16_t*)out;
+    a.k_batch_stride = (int64_t)T * 3 * C; a.k_head_stride = head_dim; a.k_key_stride = 3 * C; a.q_row_stride = 3 * C; a.out_row_stride = C;
+    a.T = T; a.n_head = n_head; a.batch = batch; a.head_dim = head_dim; a.causal = causal;
+    if (launch_attn_rows((hipStream_t)stream, a) != hipSuccess) return fail(MV_ERR_INVALID, "attention_rows: head_dim %d not supported", head_dim);
     return MV_OK;
 }
 

@@ -1,0 +1,284 @@
+// Many-row (M >= 16) building blocks: MFMA bf16 GEMM with fused epilogues, row normalisation, multi-query attention.
+//
+// Used by (a) the first-stage PREFILL: `prefill()` runs `Transformer.forward` over all T prompt positions x 2 CFG rows
+// (fam/llm/fast_inference_utils.py:123-132, fam/llm/fast_model.py:150-163) -- M = 2T rows, MFMA-bound side of the ridge
+// (rows FLOP/B ~ 256), and (b) the second-stage non-causal GPT forward over (b, block_size) positions
+// (fam/llm/model.py:195-314, fam/llm/layers/*.py) under bf16 autocast (fam/llm/inference.py:80-82).
+//
+// GEMM: C[M][N] = A[M][K] . W[N][K]^T, both operands K-contiguous, which is exactly the per-lane fragment shape of
+// v_mfma_f32_16x16x32_bf16 (lane l: row l&15, 8 consecutive k at (l>>4)*8), so tiles go global -> registers -> LDS
+// (16 B per lane, XOR-swizzled 16-byte chunks: <= 2-way conflicts on ds_read_b128) -> fragments with no transposes.
+// 64x64x64 block tile, 4 waves (2x2), each wave 2x2 MFMA tiles; the next K-tile's global loads are issued before the
+// current tile's MFMAs (register double buffer).  M = 2T ~ 256 only gives 4 row-tiles, so N/64 column tiles x 4 keep
+// >= 128 blocks in flight and W is re-read 4x through L2, not HBM.
+#include "common.h"
+#include "kernels.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+#define GT 64  // block tile edge (M, N and K)
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) u32x4 lds[3][GT * 8];  // A, W, W2 tiles: [row][8 chunks of 16 B], chunk ^= row & 7
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile_m = blockIdx.y * GT, tile_n = blockIdx.x * GT;
+    const bool gated = a.w2 != nullptr;
+    const int M = a.M, N = a.N, K = a.K;
+
+    // staging: thread owns chunk (tid & 7) of rows (tid >> 3) and (tid >> 3) + 32 of each tile
+    const int sr = tid >> 3, sc = tid & 7;
+    const bf16_t* ga0 = a.a + (size_t)min(tile_m + sr, M - 1) * a.lda + sc * 8;
+    const bf16_t* ga1 = a.a + (size_t)min(tile_m + sr + 32, M - 1) * a.lda + sc * 8;
+    const bf16_t* gw0 = a.w + (size_t)min(tile_n + sr, N - 1) * K + sc * 8;
+    const bf16_t* gw1 = a.w + (size_t)min(tile_n + sr + 32, N - 1) * K + sc * 8;
+    const bf16_t* gv0 = gated ? a.w2 + (size_t)min(tile_n + sr, N - 1) * K + sc * 8 : nullptr;
+    const bf16_t* gv1 = gated ? a.w2 + (size_t)min(tile_n + sr + 32, N - 1) * K + sc * 8 : nullptr;
+    const int s0 = sr * 8 + (sc ^ (sr & 7)), s1 = (sr + 32) * 8 + (sc ^ ((sr + 32) & 7));
+
+    f32x4_t acc[2][2], acc2[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc[i][j] = f32x4_t{0, 0, 0, 0}; acc2[i][j] = f32x4_t{0, 0, 0, 0}; }
+
+    // K need only be a multiple of 8: 16-byte chunks past the end of a row are staged as zeros
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    const bool in0 = sc * 8 < K;
+    u32x4 ra0 = in0 ? load16(ga0) : zero, ra1 = in0 ? load16(ga1) : zero, rw0 = in0 ? load16(gw0) : zero,
+          rw1 = in0 ? load16(gw1) : zero, rv0 = zero, rv1 = zero;
+    if (gated && in0) { rv0 = load16(gv0); rv1 = load16(gv1); }
+    for (int k0 = 0; k0 < K; k0 += GT) {
+        __syncthreads();  // everyone is done reading the previous tile
+        lds[0][s0] = ra0; lds[0][s1] = ra1; lds[1][s0] = rw0; lds[1][s1] = rw1;
+        if (gated) { lds[2][s0] = rv0; lds[2][s1] = rv1; }
+        __syncthreads();
+        if (k0 + GT < K) {  // next tile's loads fly under this tile's MFMAs
+            const bool in = k0 + GT + sc * 8 < K;
+            ra0 = in ? load16(ga0 + k0 + GT) : zero; ra1 = in ? load16(ga1 + k0 + GT) : zero;
+            rw0 = in ? load16(gw0 + k0 + GT) : zero; rw1 = in ? load16(gw1 + k0 + GT) : zero;
+            if (gated) { rv0 = in ? load16(gv0 + k0 + GT) : zero; rv1 = in ? load16(gv1 + k0 + GT) : zero; }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t af[2], bf[2], cf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = wm * 32 + i * 16 + (lane & 15);
+                af[i] = __builtin_bit_cast(bf16x8_t, lds[0][r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = wn * 32 + j * 16 + (lane & 15);
+                bf[j] = __builtin_bit_cast(bf16x8_t, lds[1][r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
+                if (gated) cf[j] = __builtin_bit_cast(bf16x8_t, lds[2][r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    if (gated) acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], cf[j], acc2[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- epilogue: C fragment (i, j): column lane & 15, rows (lane >> 4) * 4 + reg ---------------------------------
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = tile_n + wn * 32 + j * 16 + (lane & 15);
+            if (n >= N) continue;
+            const float b1 = a.bias ? bf2f(a.bias[n]) : 0.f;
+            const float b2 = (gated && a.bias2) ? bf2f(a.bias2[n]) : 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int m = tile_m + wm * 32 + i * 16 + (lane >> 4) * 4 + reg;
+                if (m >= M) continue;
+                float y = round_bf(acc[i][j][reg] + b1);  // the bf16 Linear output
+                if (gated) {  // bf16(bf16(silu(w1 x)) * bf16(w3 x))   (fast_model.py:237, layers.py:62-72)
+                    const float u = round_bf(acc2[i][j][reg] + b2);
+                    y = round_bf(round_bf(y / (1.0f + __expf(-y))) * u);
+                } else if (a.act == GEMM_ACT_GELU) {
+                    y = round_bf(gelu_erf(y));
+                }
+                if (a.qkv_dim > 0) {  // first-stage prefill: q -> out, k/v -> cache[row][head][t][128]  (fast_model.py:209-218)
+                    const bf16_t v = f2bf(y);
+                    const int dim = a.qkv_dim;
+                    if (n < dim) {
+                        a.out_bf16[(size_t)m * dim + n] = v;
+                    } else {
+                        const int which = (n - dim) / dim, hd = (n - dim) % dim;
+                        const int row = m / a.seq_len, t = m % a.seq_len;
+                        bf16_t* cache = which ? a.vcache : a.kcache;
+                        cache[(((size_t)row * a.n_head + hd / 128) * a.cache_len + t) * 128 + hd % 128] = v;
+                    }
+                } else if (a.out_f32) {  // second stage: fp32 residual stream, x = x + bf16(linear)  (combined.py:37-52)
+                    a.out_f32[(size_t)m * a.ldc + n] = (a.res_f32 ? a.res_f32[(size_t)m * a.ldc + n] : 0.f) + y;
+                } else {  // first stage: bf16 residual stream (fast_model.py:179-180)
+                    a.out_bf16[(size_t)m * a.ldc + n] = a.res_bf16 ? f2bf(bf2f(a.res_bf16[(size_t)m * a.ldc + n]) + y) : f2bf(y);
+                }
+            }
+        }
+}
+
+hipError_t launch_gemm(hipStream_t s, const GemmArgs& a) {
+    if (a.M < 1 || a.N < 1 || a.K < 8 || a.K % 8 != 0 || a.lda % 8 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gemm_bf16_kernel, dim3((a.N + GT - 1) / GT, (a.M + GT - 1) / GT), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---- row normalisation: y[m][:] = norm(x[m][:]) -> bf16 ----------------------------------------------------------------
+// mode 0: first-stage RMSNorm on a bf16 stream: bf16(bf16(x * rstd) * w)              (fast_model.py:250-261)
+// mode 1: second-stage RMSNorm under autocast: fp32 x * rstd * w, rounded once at the Linear input (layers.py:20-30)
+// mode 2: second-stage LayerNorm (fp32, weight and optional bias), rounded once        (layers.py:8-17)
+__global__ void __launch_bounds__(256) norm_rows_kernel(const NormArgs a) {
+    __shared__ float red[2][4];
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = a.C;
+    float s = 0.f, s2 = 0.f;
+    for (int c = tid; c < C; c += 256) {
+        const float v = a.x_f32 ? a.x_f32[(size_t)m * C + c] : bf2f(a.x_bf16[(size_t)m * C + c]);
+        s += v;
+        s2 += v * v;
+    }
+    s = wave_sum(s);
+    s2 = wave_sum(s2);
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = s2; }
+    __syncthreads();
+    const float sum = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const float sq = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const float mean = (a.mode == 2) ? sum / C : 0.f;
+    const float var = (a.mode == 2) ? fmaxf(sq / C - mean * mean, 0.f) : sq / C;
+    const float rstd = rsqrtf(var + a.eps);
+    for (int c = tid; c < C; c += 256) {
+        const float v = a.x_f32 ? a.x_f32[(size_t)m * C + c] : bf2f(a.x_bf16[(size_t)m * C + c]);
+        const float w = a.w_f32 ? a.w_f32[c] : bf2f(a.w_bf16[c]);
+        float y;
+        if (a.mode == 0) y = round_bf(round_bf(v * rstd) * w);
+        else if (a.mode == 1) y = round_bf(v * rstd * w);
+        else y = round_bf((v - mean) * rstd * w + (a.b_f32 ? a.b_f32[c] : 0.f));
+        a.out[(size_t)m * C + c] = f2bf(y);
+    }
+}
+hipError_t launch_norm_rows(hipStream_t s, const NormArgs& a) {
+    hipLaunchKernelGGL(norm_rows_kernel, dim3(a.M), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---- multi-query attention: one block per (query, head, batch row), keys streamed from L2 ------------------------------
+// First-stage prefill: causal over the KV cache just written, `F.scaled_dot_product_attention(..., attn_mask=causal)`
+// (fast_model.py:218-222).  Second stage: `is_causal=False` over all block_size positions (layers/attn.py:132-159).
+// T <= 2048 and the K/V of one (row, head) is <= 512 KB: L2-resident, so a query re-streams it from L2; scores, softmax
+// and P.V are fp32 (online softmax across 4-instruction chunks), output bf16.  HD/8 lanes cover one key row (16 B each).
+template <int HD>
+__global__ void __launch_bounds__(256) attn_rows_kernel(const AttnRowsArgs a) {
+    constexpr int LPK = HD / 8;       // lanes per key
+    constexpr int KPI = 64 / LPK;     // keys per wave instruction
+    constexpr int UN = 4;
+    __shared__ __attribute__((aligned(16))) float sm[4][LPK][12];
+    const int t = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane / LPK, dl = lane % LPK;
+    const int nkeys = a.causal ? t + 1 : a.T;
+    const bf16_t* kb = a.k + (size_t)b * a.k_batch_stride + (size_t)h * a.k_head_stride + dl * 8;
+    const bf16_t* vb = a.v + (size_t)b * a.k_batch_stride + (size_t)h * a.k_head_stride + dl * 8;
+    const u32x4 qv = load16(a.q + ((size_t)b * a.T + t) * a.q_row_stride + h * HD + dl * 8);
+    const float scale = rsqrtf((float)HD);
+
+    float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) o[d] = 0.f;
+    for (int base = wave * KPI * UN; base < nkeys; base += 4 * KPI * UN) {
+        u32x4 kv[UN], vv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int kc = min(base + u * KPI + g, nkeys - 1);
+            kv[u] = load16(kb + (size_t)kc * a.k_key_stride);
+            vv[u] = load16(vb + (size_t)kc * a.k_key_stride);
+        }
+        float sc[UN], mc = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            float s = dot8_bf16(kv[u], qv, 0.f);
+            s += dpp_f<0xB1>(s);
+            s += dpp_f<0x4E>(s);
+            s += dpp_f<0x141>(s);
+            if (LPK == 16) s += dpp_f<0x140>(s);
+            s = (base + u * KPI + g < nkeys) ? s * scale : -INFINITY;
+            sc[u] = s;
+            mc = fmaxf(mc, s);
+        }
+        if (mc == -INFINITY) continue;
+        const float mn = fmaxf(m, mc);
+        const float corr = (m == -INFINITY) ? 0.f : fast_exp(m - mn);
+        l *= corr;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) o[d] *= corr;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const float p = (sc[u] == -INFINITY) ? 0.f : fast_exp(sc[u] - mn);
+            l += p;
+            o[0] += p * bf_lo(vv[u].x); o[1] += p * bf_hi(vv[u].x);
+            o[2] += p * bf_lo(vv[u].y); o[3] += p * bf_hi(vv[u].y);
+            o[4] += p * bf_lo(vv[u].z); o[5] += p * bf_hi(vv[u].z);
+            o[6] += p * bf_lo(vv[u].w); o[7] += p * bf_hi(vv[u].w);
+        }
+        m = mn;
+    }
+    // fold the KPI lane groups of the wave (xor over the group index bits), then the 4 waves through LDS
+#pragma unroll
+    for (int off = LPK; off < 64; off <<= 1) {
+        const float mo = fmaxf(m, __shfl_xor(m, off, 64));
+        const float w = (m == -INFINITY) ? 0.f : fast_exp(m - mo);
+        l *= w;
+        l += __shfl_xor(l, off, 64);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const float tt = o[d] * w;
+            o[d] = tt + __shfl_xor(tt, off, 64);
+        }
+        m = mo;
+    }
+    if (g == 0) {
+        sm[wave][dl][0] = m;
+        sm[wave][dl][1] = l;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) sm[wave][dl][2 + d] = o[d];
+    }
+    __syncthreads();
+    if (threadIdx.x < LPK) {
+        float mb = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) mb = fmaxf(mb, sm[w][dl][0]);
+        float lb = 0.f, ob[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) ob[d] = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = sm[w][dl][0];
+            const float f = (mw == -INFINITY) ? 0.f : fast_exp(mw - mb);
+            lb += sm[w][dl][1] * f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) ob[d] += sm[w][dl][2 + d] * f;
+        }
+        const float inv = 1.0f / lb;
+        u32x4 y;
+        y.x = pack_bf2(ob[0] * inv, ob[1] * inv);
+        y.y = pack_bf2(ob[2] * inv, ob[3] * inv);
+        y.z = pack_bf2(ob[4] * inv, ob[5] * inv);
+        y.w = pack_bf2(ob[6] * inv, ob[7] * inv);
+        *(u32x4*)(a.out + ((size_t)b * a.T + t) * a.out_row_stride + h * HD + dl * 8) = y;
+    }
+}
+hipError_t launch_attn_rows(hipStream_t s, const AttnRowsArgs& a) {
+    const dim3 grid(a.T, a.n_head, a.batch);
+    if (a.head_dim == 128) hipLaunchKernelGGL(attn_rows_kernel<128>, grid, dim3(256), 0, s, a);
+    else if (a.head_dim == 64) hipLaunchKernelGGL(attn_rows_kernel<64>, grid, dim3(256), 0, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}

@@ -81,6 +81,51 @@ struct SampleArgs {
 };
 hipError_t launch_sample(hipStream_t s, const SampleArgs& a, bool standalone);
 hipError_t launch_embed_first(hipStream_t s, const SampleArgs& a);
+hipError_t launch_embed_rows(hipStream_t s, const int32_t* seq, int T, int dim, const bf16_t* tok_emb, const bf16_t* pos_emb,
+                             const bf16_t* spk, bf16_t* out);
 hipError_t launch_spk_proj(hipStream_t s, int n_utt, int dim, int spk_dim, const bf16_t* spk_emb, const bf16_t* w,
                            bf16_t* out);
 
+
+// ---- gemm.hip: many-row blocks shared by the first-stage prefill and the second-stage forward ---------------------
+enum { GEMM_ACT_NONE = 0, GEMM_ACT_GELU = 1 };
+struct GemmArgs {
+    const bf16_t* a = nullptr;      // [M][lda] bf16 activations (K-contiguous)
+    const bf16_t* w = nullptr;      // [N][K]
+    const bf16_t* w2 = nullptr;     // [N][K]: gated (SwiGLU) second matrix, or null
+    const bf16_t* bias = nullptr;   // [N] or null
+    const bf16_t* bias2 = nullptr;
+    const bf16_t* res_bf16 = nullptr;  // [M][ldc] residual (bf16 stream) or null
+    const float* res_f32 = nullptr;    // [M][ldc] residual (fp32 stream) or null
+    bf16_t* out_bf16 = nullptr;     // [M][ldc]
+    float* out_f32 = nullptr;       // [M][ldc]: when set the output (and residual) is fp32
+    int32_t M = 0, N = 0, K = 0, lda = 0, ldc = 0, act = GEMM_ACT_NONE;
+    // first-stage QKV epilogue (qkv_dim > 0): columns [0,dim) -> out_bf16 [M][dim]; K and V -> cache at position m % seq_len
+    int32_t qkv_dim = 0, seq_len = 0, n_head = 0, cache_len = 0;
+    bf16_t* kcache = nullptr;
+    bf16_t* vcache = nullptr;
+};
+hipError_t launch_gemm(hipStream_t s, const GemmArgs& a);
+
+struct NormArgs {
+    const bf16_t* x_bf16 = nullptr;
+    const float* x_f32 = nullptr;   // exactly one of x_bf16 / x_f32
+    const bf16_t* w_bf16 = nullptr;
+    const float* w_f32 = nullptr;
+    const float* b_f32 = nullptr;   // LayerNorm bias or null
+    bf16_t* out = nullptr;          // [M][C]
+    int32_t M = 0, C = 0, mode = 0;
+    float eps = 1e-5f;
+};
+hipError_t launch_norm_rows(hipStream_t s, const NormArgs& a);
+
+struct AttnRowsArgs {
+    const bf16_t* q = nullptr;      // query (b, t, h) at q + (b*T + t)*q_row_stride + h*head_dim
+    const bf16_t* k = nullptr;      // key (b, h, j)   at k + b*k_batch_stride + h*k_head_stride + j*k_key_stride
+    const bf16_t* v = nullptr;
+    bf16_t* out = nullptr;          // (b, t, h) at out + (b*T + t)*out_row_stride + h*head_dim
+    int64_t k_batch_stride = 0, k_head_stride = 0, k_key_stride = 0;
+    int32_t q_row_stride = 0, out_row_stride = 0;
+    int32_t T = 0, n_head = 0, batch = 0, head_dim = 128, causal = 0;
+};
+hipError_t launch_attn_rows(hipStream_t s, const AttnRowsArgs& a);

@@ -336,6 +336,26 @@ __global__ void spk_proj_kernel(int dim, int spk_dim, const bf16_t* spk_emb, con
     if (lane == 0) out[(size_t)u * dim + wave] = f2bf(acc);
 }
 
+// Prefill input rows: x[(r*T + t)] for the conditioned (r=0) and unconditioned (r=1) copy of the prompt (fast_model.py:152-157).
+__global__ void embed_rows_kernel(const int32_t* seq, int T, int dim, const bf16_t* tok_emb, const bf16_t* pos_emb,
+                                  const bf16_t* spk, bf16_t* out) {
+    const int t = blockIdx.x;
+    const bf16_t* te = tok_emb + (size_t)seq[t] * dim;
+    const bf16_t* pe = pos_emb + (size_t)t * dim;
+    bf16_t* x0 = out + (size_t)t * dim;
+    bf16_t* x1 = out + ((size_t)T + t) * dim;
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) {
+        const float base = round_bf(bf2f(te[i]) + bf2f(pe[i]));
+        x0[i] = f2bf(base + bf2f(spk[i]));
+        x1[i] = f2bf(base);
+    }
+}
+hipError_t launch_embed_rows(hipStream_t s, const int32_t* seq, int T, int dim, const bf16_t* tok_emb, const bf16_t* pos_emb,
+                             const bf16_t* spk, bf16_t* out) {
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(T), dim3(256), 0, s, seq, T, dim, tok_emb, pos_emb, spk, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_sample(hipStream_t s, const SampleArgs& a, bool standalone) {
     if (a.vocab > SAMPLE_MAXV || a.vocab < 2) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sample_kernel, dim3(standalone ? 1 : a.n_utt), dim3(SAMPLE_THREADS), 0, s, a);

@@ -1,0 +1,81 @@
+"""Mirror of `fam/llm/decoders.py`: token grid -> waveform file.
+
+The reference builds `audiocraft.MultiBandDiffusion.get_mbd_24khz(bw=6)` at import time (`decoders.py:13`) and calls
+`mbd.tokens_to_wav` (`:84-85`).  audiocraft is third-party and absent here; the vocoder is injected as a callable
+`vocoder(tokens: LongTensor (1, 8, f)) -> FloatTensor (1, 1, samples)` at 24 kHz.  Until the HIP vocoder lands
+ `EncodecDecoder.decode(causal=False)` raises if no vocoder was given -- it never falls back to CPU.
+"""
+from __future__ import annotations
+
+import os
+import pathlib
+import struct
+import uuid
+from abc import ABC, abstractmethod
+from datetime import datetime
+from typing import Callable, List, Optional, Tuple, Union
+
+import torch
+
+
+class Decoder(ABC):
+    @abstractmethod
+    def decode(self, tokens: List[int], ref_audio_path: Optional[str] = None, causal: Optional[bool] = None):
+        raise NotImplementedError
+
+
+def write_wav_pcm16(path: str, wav: torch.Tensor, sample_rate: int) -> None:
+    """Mono 16-bit PCM RIFF writer (stands in for audiocraft's `audio_write`, `decoders.py:40-47`)."""
+    x = wav.detach().reshape(-1).float().cpu().clamp(-1.0, 1.0)
+    pcm = (x * 32767.0).round().to(torch.int16).numpy().tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE")
+        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, sample_rate, sample_rate * 2, 2, 16))
+        f.write(b"data" + struct.pack("<I", len(pcm)) + pcm)
+
+
+class EncodecDecoder(Decoder):
+    def __init__(self, tokeniser_decode_fn: Callable[[List[int]], str],
+                 data_adapter_fn: Callable[[List[List[int]]], Tuple[List[int], List[List[int]]]], output_dir: str,
+                 vocoder: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
+        self._mbd_sample_rate = 24_000
+        self._end_of_audio_token = 1024
+        self._num_codebooks = 8
+        self.vocoder = vocoder
+        self.tokeniser_decode_fn = tokeniser_decode_fn
+        self._data_adapter_fn = data_adapter_fn
+        self.output_dir = pathlib.Path(output_dir).resolve()
+        os.makedirs(self.output_dir, exist_ok=True)
+
+    def _save_audio(self, name, wav: torch.Tensor):
+        # the reference normalises loudness (strategy="loudness", compressor) inside audiocraft's audio_write; here: peak
+        # normalisation to -1 dBFS, documented difference (waveform parity is stated before this step)
+        peak = wav.abs().max().clamp(min=1e-8)
+        write_wav_pcm16(str(name) + ".wav", wav / peak * 0.891, self._mbd_sample_rate)
+
+    def decode(self, tokens: List[List[int]], causal: bool = True, ref_audio_path: Optional[str] = None) -> Union[str, torch.Tensor]:
+        """`decoders.py:66-102`: adapter -> (1, n, f) grid padded with 0 up to 8 codebooks; causal=True returns the grid,
+        causal=False vocodes and SAVES `<output_dir>/synth_<timestamp>_<text[:25]>_<uuid>.wav`, returning the path stem."""
+        text_ids, extracted_audio_ids = self._data_adapter_fn(tokens)
+        text = self.tokeniser_decode_fn(text_ids)
+        grid = torch.tensor(extracted_audio_ids, dtype=torch.long).unsqueeze(0)
+        if grid.shape[1] < self._num_codebooks:
+            pad = torch.zeros(1, self._num_codebooks - grid.shape[1], grid.shape[2], dtype=torch.long)
+            grid = torch.cat([grid, pad], dim=1)
+        if causal:
+            return grid
+        if self.vocoder is None:
+            raise NotImplementedError("no vocoder: the multiband-diffusion / EnCodec decode stage is not built yet (DESIGN.md section 7)")
+        wav = self.vocoder(grid)
+        if wav.shape[-1] < 9600:
+            raise Exception("wav predicted is shorter than 400ms!")
+        stamp = datetime.now().strftime("%y-%m-%d--%H-%M-%S")
+        try:
+            name = self.output_dir / f"synth_{stamp}_{text.replace(' ', '_')[:25]}_{uuid.uuid4()}"
+            self._save_audio(name, wav)
+            return name
+        except Exception as e:
+            print(f"Failed to save audio! Reason: {e}")
+            name = self.output_dir / f"synth_{stamp}_{uuid.uuid4()}"
+            self._save_audio(name, wav)
+            return name

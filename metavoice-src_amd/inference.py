@@ -1,0 +1,110 @@
+"""Mirror of the inference-side of `fam/llm/inference.py`: `InferenceConfig` and `Model` for the second (non-causal) stage.
+
+`Model(config, tokenizer_cls, decoder_cls, data_adapter_fn)` loads `second_stage.pt` ({"model", "model_args", "config",
+"meta"}, `fam/llm/finetune.py:300-313`) into the HIP second-stage engine and `Model(...)(texts=..., encodec_tokens=..., ...)`
+packs the (2, block_size) input grid, samples the 6 remaining codebooks and hands the (8, t) grid to the decoder -- the
+contract of `inference.py:53-156,248-377`.  The causal batched slow path (`causal_sample`, `:158-246`) is not part of the
+`TTS.synthesise` hot path and is not provided.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Callable, List, Optional, Type
+
+import torch
+
+from .decoders import Decoder
+from .model import GPT, GPTConfig
+from .tokenise import TrainedBPETokeniser
+
+
+@dataclasses.dataclass
+class InferenceConfig:
+    """`fam/llm/inference.py:28-50`."""
+
+    ckpt_path: str
+    output_dir: str
+    num_samples: int = 10
+    seed: int = 1337
+    device: str = "cuda"
+    dtype: str = "bfloat16"
+    compile: bool = False
+    init_from: str = "resume"
+
+    def __str__(self):
+        return "InferenceConfig:\n" + "\n".join(f"  {f.name}: {getattr(self, f.name)}" for f in dataclasses.fields(self))
+
+
+def pack_second_stage_input(text_tokens: List[int], codebooks: List[List[int]], ctx_window: int, pad_token: int = 1024) -> List[List[int]]:
+    """`inference.py:283-306`: row 0 = text ++ codebook 0 ++ [pad], row 1 = [pad]*len(text) ++ codebook 1 ++ [pad], each
+    right-padded with `pad_token` or TRUNCATED to `ctx_window`."""
+    rows = [list(text_tokens) + list(codebooks[0]) + [pad_token],
+            [pad_token] * len(text_tokens) + list(codebooks[1]) + [pad_token]]
+    assert len(rows[0]) == len(rows[1])
+    return [(r + [pad_token] * (ctx_window - len(r)))[:ctx_window] for r in rows]
+
+
+class Model:
+    def __init__(self, config: InferenceConfig, tokenizer_cls: Type[TrainedBPETokeniser], decoder_cls: Type[Decoder],
+                 data_adapter_fn: Callable, use_kv_cache=None, checkpoint: Optional[dict] = None, **decoder_kwargs):
+        self._encodec_codes_pad_token = 1024
+        self._num_encodec_codebooks = 8
+        self.config = config
+        if use_kv_cache is not None:
+            raise Exception("kv_cache not supported for non-causal models!")  # inference.py:147-149
+        if checkpoint is None:
+            checkpoint = torch.load(config.ckpt_path, map_location="cpu", weights_only=False)
+        self.checkpoint_config = checkpoint.get("config", {})
+        if self.checkpoint_config.get("causal", True):
+            raise NotImplementedError("Model wraps the non-causal second stage; the causal first stage runs through fast_inference_utils")
+        self.meta = checkpoint["meta"]
+        self.vocab_sizes = checkpoint["model_args"]["vocab_sizes"]
+        self.speaker_cond = bool(self.meta.get("speaker_cond"))
+        model_args = checkpoint["model_args"]
+        self._encodec_ctx_window = model_args["block_size"]
+        self.model = GPT(GPTConfig(**model_args), speaker_emb_dim=self.meta["speaker_emb_size"] if self.speaker_cond else None)
+        self.model.load_state_dict(checkpoint["model"])
+        self.tokenizer = tokenizer_cls(**self.meta["tokenizer"])
+        self.decoder = decoder_cls(tokeniser_decode_fn=self.tokenizer.decode, output_dir=config.output_dir,
+                                   data_adapter_fn=data_adapter_fn, **decoder_kwargs)
+        self._calls = 0
+
+    def non_causal_sample(self, *, texts: List[str], encodec_tokens: List[torch.Tensor], batch_size: int, top_k: Optional[int],
+                          temperature: Optional[float], speaker_embs: Optional[torch.Tensor] = None) -> list:
+        """`inference.py:248-338`: returns one decoder result (path of the saved audio) per text, `None` where decoding failed."""
+        if speaker_embs is not None:
+            assert len(texts) == len(speaker_embs)
+        grids = []
+        for text, enc in zip(texts, encodec_tokens):
+            assert enc.shape[0] == 1
+            codebooks = enc[0].tolist()
+            assert 1 <= len(codebooks) <= self._num_encodec_codebooks
+            grids.append(pack_second_stage_input(self.tokenizer.encode(text), codebooks, self._encodec_ctx_window,
+                                                 self._encodec_codes_pad_token))
+        in_x = torch.tensor(grids, dtype=torch.long)
+        if not self.speaker_cond:
+            speaker_embs = None
+        to_return = []
+        for _ in range(self.config.num_samples):
+            self._calls += 1
+            y = self.model.generate(in_x, None, temperature=temperature, top_k=top_k, top_p=None, speaker_embs=speaker_embs,
+                                    batch_size=batch_size, guidance_scale=None, seed=self.config.seed + 7919 * self._calls)
+            for tokens in torch.cat([in_x, y], dim=1):
+                try:
+                    to_return.append(self.decoder.decode(tokens=tokens.tolist(), causal=False))
+                except Exception as e:  # the reference swallows vocoder failures into a None entry (:331-336)
+                    print("failed to run MBD.")
+                    print(f"reason: {str(e)}")
+                    to_return.append(None)
+        return to_return
+
+    def __call__(self, *, texts: List[str], batch_size: int, max_new_tokens: Optional[int], top_k: Optional[int],
+                 top_p: Optional[float], temperature: Optional[float], encodec_tokens: Optional[List[torch.Tensor]] = None,
+                 speaker_embs: Optional[torch.Tensor] = None, guidance_scale: Optional[float] = None):
+        """`inference.py:340-377`, non-causal branch."""
+        assert encodec_tokens is not None
+        assert guidance_scale is None
+        assert max_new_tokens is None
+        assert top_p is None
+        return self.non_causal_sample(texts=texts, encodec_tokens=encodec_tokens, batch_size=batch_size, speaker_embs=speaker_embs,
+                                      top_k=top_k, temperature=temperature)

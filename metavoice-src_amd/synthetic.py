@@ -132,3 +132,33 @@ def prompt_tokens(n: int = 128, seed: int = 0, text_offset: int = 2049, n_text: 
     g = torch.Generator().manual_seed(2000 + seed)
     body = torch.randint(text_offset, text_offset + n_text, (n - 1,), generator=g)
     return torch.cat([body, torch.tensor([text_offset + n_text])]).to(torch.int32)
+
+
+def write_model_dir(path: str, *, stage1: Optional[dict] = None, stage2_args: Optional[dict] = None, seed: int = 0) -> str:
+    """Write `first_stage.pt` / `second_stage.pt` with the reference's checkpoint layout (`fam/llm/finetune.py:300-313`:
+    {"model", "model_args", "config", "meta"}) and synthetic weights + a synthetic 512-rank BPE table, so that the whole
+    `TTS` load path (key remap, tokenizer from `meta`, speaker conditioning flags) can be exercised offline."""
+    import os
+
+    from .tokenise import byte_level_tokenizer_info
+
+    os.makedirs(path, exist_ok=True)
+    s1 = dict(n_layer=2, n_head=2, dim=256, vocab_size=2562, block_size=256)
+    s1.update(stage1 or {})
+    sd1 = stage1_state_dict(seed=seed, orig_mod_prefix=True, **s1)
+    torch.save({
+        "model": sd1,
+        "model_args": dict(n_layer=s1["n_layer"], n_head=s1["n_head"], n_embd=s1["dim"], block_size=s1["block_size"],
+                           vocab_sizes=[s1["vocab_size"]], target_vocab_sizes=None, bias=False, causal=True,
+                           norm_type="rmsnorm", nonlinearity_type="swiglu"),
+        "config": {"causal": True},
+        "meta": {"tokenizer": byte_level_tokenizer_info(offset=2049), "speaker_cond": True, "speaker_emb_size": 256},
+    }, os.path.join(path, "first_stage.pt"))
+    a2 = stage2_args or stage2_model_args(block_size=256, n_layer=2, n_head=2, n_embd=128)
+    torch.save({
+        "model": stage2_state_dict(a2, speaker_emb_dim=256, seed=seed + 1),
+        "model_args": a2,
+        "config": {"causal": False},
+        "meta": {"tokenizer": byte_level_tokenizer_info(offset=1025), "speaker_cond": True, "speaker_emb_size": 256},
+    }, os.path.join(path, "second_stage.pt"))
+    return path

@@ -53,3 +53,14 @@ def exp1_noise(seed: int, step: int, n: int, stream: int = 0) -> np.ndarray:
                                 seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     u = uniform24(w0)
     return (-np.log(u.astype(np.float32))).astype(np.float32)
+
+
+def uniform_noise(seed: int, rows: int, head: int) -> np.ndarray:
+    """U(0,1) variate of the second-stage sampler for flat row index 0..rows-1 (= b*T + t) and codebook `head`.
+
+    counter = (row, head, 1, 0), key = (seed lo, seed hi), word 0.  Mirrors `s2_sample_kernel` in
+    metavoice-src_amd/csrc/stage2.hip.
+    """
+    i = np.arange(rows, dtype=np.uint32)
+    w0, _, _, _ = philox4x32_10(i, np.uint32(head), np.uint32(1), np.uint32(0), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    return uniform24(w0)

@@ -118,7 +118,7 @@ class Stage2Oracle:
         assert t == self.cfg.block_size
         outs = []
         for i, logits in enumerate(self.forward(idx, speaker_embs)):
-            logits = (logits / temperature).float()
+            logits = self.rnd(logits / temperature).float()  # bf16 tensor / float -> bf16 under autocast
             if top_k is not None:
                 v, _ = torch.topk(logits, min(top_k, logits.size(-1)))
                 logits = logits.masked_fill(logits < v[:, :, [-1]], float("-inf"))

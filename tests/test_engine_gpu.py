@@ -174,3 +174,49 @@ def test_two_utterances_with_ragged_prompts_match_single_runs():
         assert single == both[u]  # the noise stream is keyed by (seed, token id, sequence index), not by the slot
         assert len(both[u]) == len(prompts[u]) + 24
     engine1.close()
+
+
+@pytest.mark.parametrize("name,cfgk,seed,T,n_new", [("small", SMALL, 0, 12, 20), ("wide2", WIDE2, 1, 130, 8)])
+def test_batched_prefill_matches_teacher_forcing_and_oracle(name, cfgk, seed, T, n_new):
+    """`prefill()` (fast_inference_utils.py:123-132) as MFMA GEMMs + causal attention == the same prompt pushed token by
+    token through the decode graph: same first-token logits (to fp32 summation order) and the same greedy stream."""
+    engine, sd, cfg = build(cfgk, seed)
+    prompt = synthetic.prompt_tokens(T, seed=seed)
+    spk = synthetic.speaker_embedding(seed)
+    sp = mv.SamplingParams(top_k=1, seed=5)
+    engine.capture_logits(True)
+    runs = {}
+    for mode in (0, 1):
+        engine.begin([prompt], spk, sp, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=mode)
+        steps = engine.run()
+        assert steps == (T + n_new - 1 if mode == 0 else n_new - 1)
+        runs[mode] = (engine.tokens(0), engine.captured_logits(T - 1, n_new))
+    ob = oracle_for(sd, cfg, "bf16")
+    oseq, ologits = o_s1.generate(ob, prompt, spk, max_new_tokens=n_new, end_of_audio_token=9999, top_k=1, seed=5, return_logits=True)
+    scale = float(ologits.std())
+    d01 = float((runs[0][1][0] - runs[1][1][0]).abs().max())
+    d1o = float((runs[1][1][0] - ologits[0]).abs().max())
+    print(f"[{name}] first-token logits: prefill vs teacher-forced {d01:.4f}, prefill vs oracle {d1o:.4f} (logit std {scale:.3f})")
+    assert d01 <= 0.06 * scale and d1o <= 0.06 * scale
+    assert len(runs[1][0]) == T + n_new and runs[1][0][:T] == prompt.tolist()
+    agree = check_stream(runs[1][0], oseq, ologits, T, gap_tol=0.05 * scale)
+    print(f"[{name}] prefill-mode stream agreement with the oracle: {agree}/{n_new}")
+    engine.close()
+
+
+def test_batched_prefill_ragged_two_utterances():
+    engine2, sd, cfg = build(SMALL, 4, max_utterances=2)
+    prompts = [synthetic.prompt_tokens(9, seed=10), synthetic.prompt_tokens(17, seed=11)]
+    spks = torch.cat([synthetic.speaker_embedding(10), synthetic.speaker_embedding(11)])
+    sps = [mv.SamplingParams(top_k=1, seed=1), mv.SamplingParams(top_k=1, seed=2)]
+    out = {}
+    for mode in (0, 1):
+        engine2.begin(prompts, spks, sps, max_new_tokens=12, end_of_audio_token=9999, prefill_mode=mode)
+        engine2.run()
+        out[mode] = [engine2.tokens(0), engine2.tokens(1)]
+        assert [len(t) for t in out[mode]] == [9 + 12, 17 + 12]
+    # greedy streams agree unless a near-tie flips on fp32 summation order: require the first 4 generated tokens at least
+    for u in range(2):
+        T = len(prompts[u])
+        assert out[0][u][: T + 4] == out[1][u][: T + 4]
+    engine2.close()

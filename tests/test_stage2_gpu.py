@@ -1,0 +1,178 @@
+"""Many-row kernels (MFMA GEMM, multi-query attention) and the second-stage engine against torch restatements / the oracle,
+through the C ABI, on the GPU."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_pkg
+from oracle import rng as o_rng
+from oracle import stage2 as o_s2
+
+pytestmark = pytest.mark.gpu
+
+N = load_pkg("_native")
+mv = load_pkg()
+synthetic = load_pkg("synthetic")
+
+
+def rb(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def dev(t):
+    return t.to("cuda").contiguous()
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def close_bf16(got, ref, ulps, atol):
+    ref, got = ref.float(), got.float()
+    tol = ulps * torch.clamp(ref.abs(), min=1e-30) * 2.0 ** -7 + atol
+    bad = (got - ref).abs() > tol
+    return int(bad.sum()), float(((got - ref).abs() / tol).max())
+
+
+@pytest.mark.parametrize("M,N_,K", [(256, 6144, 2048), (220, 2048, 2048), (256, 2048, 5632), (64, 1025, 384), (37, 100, 72), (2048, 384, 1024)])
+@pytest.mark.parametrize("mode", ["plain", "bias_resid", "gated", "gelu"])
+def test_gemm(M, N_, K, mode):
+    g = torch.Generator().manual_seed(M + N_ + K)
+    a = rb(torch.randn(M, K, generator=g))
+    w = rb(torch.randn(N_, K, generator=g) * 0.05)
+    w2 = rb(torch.randn(N_, K, generator=g) * 0.05) if mode == "gated" else None
+    bias = rb(torch.randn(N_, generator=g) * 0.1) if mode in ("bias_resid", "gated") else None
+    bias2 = rb(torch.randn(N_, generator=g) * 0.1) if mode == "gated" else None
+    res = rb(torch.randn(M, N_, generator=g)) if mode == "bias_resid" else None
+    y = rb(a.double() @ w.double().T + (bias.double() if bias is not None else 0.0))
+    if mode == "gated":
+        u = rb(a.double() @ w2.double().T + bias2.double())
+        y = rb(rb(torch.nn.functional.silu(y)) * u)
+    elif mode == "gelu":
+        y = rb(torch.nn.functional.gelu(y))
+    elif mode == "bias_resid":
+        y = rb(res + y)
+    da, dw = dev(a.bfloat16()), dev(w.bfloat16())
+    dw2 = dev(w2.bfloat16()) if w2 is not None else None
+    db = dev(bias.bfloat16()) if bias is not None else None
+    db2 = dev(bias2.bfloat16()) if bias2 is not None else None
+    dr = dev(res.bfloat16()) if res is not None else None
+    out = torch.empty(M, N_, dtype=torch.bfloat16, device="cuda")
+    N.check(N.lib().mv_op_gemm(stream(), M, N_, K, ptr(da), ptr(dw), ptr(dw2), ptr(db), ptr(db2), ptr(dr), int(mode == "gelu"), ptr(out)))
+    torch.cuda.synchronize()
+    # residual mode: a 1-ulp flip of the (large) product survives into a possibly small sum -> absolute slack of one
+    # bf16 ulp at the product's magnitude
+    atol = 2e-3 if mode != "bias_resid" else float((a.double() @ w.double().T).abs().max()) * 2.0 ** -7
+    nbad, worst = close_bf16(out.cpu(), y, ulps=1.01 if mode in ("plain", "bias_resid") else 3.0, atol=atol)
+    assert nbad == 0, f"{nbad} outputs off, worst {worst:.2f} tolerance units"
+
+
+@pytest.mark.parametrize("batch,T,H,hd,causal", [(1, 64, 6, 64, 0), (2, 100, 2, 64, 0), (1, 257, 16, 128, 1), (2, 33, 2, 128, 0), (1, 96, 4, 64, 1)])
+def test_attention_rows(batch, T, H, hd, causal):
+    g = torch.Generator().manual_seed(T * H + hd)
+    Cdim = H * hd
+    qkv = rb(torch.randn(batch, T, 3, H, hd, generator=g))
+    qkv[0, 3, 1, 0] *= 8.0  # a dominant key (power of two: stays bf16-representable)
+    q, k, v = (qkv[:, :, j].transpose(1, 2).double() for j in range(3))  # (b, H, T, hd)
+    s = q @ k.transpose(-1, -2) / np.sqrt(hd)
+    if causal:
+        s = s.masked_fill(~torch.tril(torch.ones(T, T, dtype=torch.bool)), float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(batch, T, Cdim).float()
+    dq = dev(qkv.bfloat16())
+    out = torch.empty(batch, T, Cdim, dtype=torch.bfloat16, device="cuda")
+    N.check(N.lib().mv_op_attention_rows(stream(), batch, T, H, hd, causal, ptr(dq), ptr(out)))
+    torch.cuda.synchronize()
+    nbad, worst = close_bf16(out.cpu(), rb(ref), ulps=2.0, atol=2e-3)
+    assert nbad == 0, f"{nbad} off, worst {worst:.2f}"
+
+
+def build_stage2(name):
+    g = np.load(os.path.join(GOLDEN, f"stage2_{name}.npz"))
+    args = json.loads(str(g["model_args"]))
+    sd = synthetic.stage2_state_dict(args, speaker_emb_dim=256, seed=int(g["seed"]))
+    cfg = o_s2.Stage2Config(**{k: v for k, v in args.items() if k in o_s2.Stage2Config.__dataclass_fields__})
+    model = mv.GPT(mv.GPTConfig(**args), speaker_emb_dim=256)
+    model.load_state_dict(sd)
+    return g, args, sd, cfg, model
+
+
+@pytest.mark.parametrize("name", ["rms_swiglu", "ln_gelu_bias"])
+def test_stage2_logits_against_oracle_and_reference_golden(name):
+    g, args, sd, cfg, model = build_stage2(name)
+    idx = torch.from_numpy(g["idx"])  # (1, 2, t)
+    spk = synthetic.speaker_embedding(2)
+    got = torch.stack(model.logits(idx, spk))  # (6, b, t, V)
+    ob = o_s2.Stage2Oracle(sd, cfg, rounding="bf16")
+    ref = torch.stack(ob.forward(idx, spk))
+    scale = float(ref.std())
+    d = float((got - ref).abs().max())
+    print(f"[{name}] max|dlogit| vs bf16-rounding oracle {d:.4f} (logit std {scale:.3f})")
+    assert d <= 0.05 * scale
+    # fp32 numbers of the reference itself (golden): bf16 autocast noise floor
+    gold = torch.from_numpy(g["logits_sub"])
+    d32 = float((got[:, :, ::4] - gold).abs().max())
+    print(f"[{name}] vs reference fp32 golden {d32:.4f}")
+    assert d32 <= 0.1 * scale
+    model.close()
+
+
+@pytest.mark.parametrize("name", ["rms_swiglu", "ln_gelu_bias"])
+def test_stage2_sampling(name):
+    g, args, sd, cfg, model = build_stage2(name)
+    T = args["block_size"]
+    gen = torch.Generator().manual_seed(5)
+    b = 2
+    idx = torch.stack([torch.randint(0, args["vocab_sizes"][0], (b, T), generator=gen),
+                       torch.randint(0, args["vocab_sizes"][1], (b, T), generator=gen)], dim=1)
+    spk = torch.cat([synthetic.speaker_embedding(2), synthetic.speaker_embedding(3)])
+    ob = o_s2.Stage2Oracle(sd, cfg, rounding="bf16")
+    n_out = len(args["target_vocab_sizes"])
+    # greedy (top_k = 1): the argmax of the oracle's logits wherever its top-2 gap is above the bf16 noise
+    y = model.generate(idx, None, temperature=1.0, top_k=1, speaker_embs=spk, batch_size=2, seed=11)
+    assert y.shape == (b, n_out, T) and y.dtype == torch.int64
+    ol = torch.stack(ob.forward(idx, spk))  # (6, b, T, V)
+    top2 = torch.topk(ol, 2, dim=-1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 0.05 * float(ol.std())
+    agree = (y.permute(1, 0, 2) == ol.argmax(-1))
+    assert bool(agree[clear].all()) and float(clear.float().mean()) > 0.5
+    # stochastic (top_k = 200, T = 1.0, the TTS setting): same draws as the oracle given the same uniforms, except where a
+    # cumulative probability sits within the logit noise of u
+    seed = 77
+    y = model.generate(idx, None, temperature=1.0, top_k=200, speaker_embs=spk, batch_size=2, seed=seed)
+    u = torch.stack([torch.from_numpy(o_rng.uniform_noise(seed, b * T, h)).view(b, T) for h in range(n_out)])
+    oy = ob.non_causal_sample(idx, spk, 1.0, top_k=200, u=u)
+    match = float((y == oy).float().mean())
+    print(f"[{name}] stochastic second-stage draws identical to the oracle at {match * 100:.1f}% of positions")
+    assert match > 0.9
+    assert len(torch.unique(y)) > 50  # it really is sampling
+    # different seed -> different draws; same seed -> same draws
+    y2 = model.generate(idx, None, temperature=1.0, top_k=200, speaker_embs=spk, batch_size=2, seed=seed)
+    y3 = model.generate(idx, None, temperature=1.0, top_k=200, speaker_embs=spk, batch_size=2, seed=seed + 1)
+    assert torch.equal(y, y2) and not torch.equal(y, y3)
+    model.close()
+
+
+def test_stage2_batching_is_row_independent():
+    g, args, sd, cfg, model = build_stage2("rms_swiglu")
+    T = args["block_size"]
+    gen = torch.Generator().manual_seed(9)
+    idx = torch.stack([torch.randint(0, args["vocab_sizes"][0], (3, T), generator=gen),
+                       torch.randint(0, args["vocab_sizes"][1], (3, T), generator=gen)], dim=1)
+    spk = torch.cat([synthetic.speaker_embedding(i) for i in range(3)])
+    full = torch.stack(model.logits(idx, spk))
+    for i in range(3):
+        one = torch.stack(model.logits(idx[i:i + 1], spk[i:i + 1]))
+        assert torch.equal(one[:, 0], full[:, i])
+    with pytest.raises(ValueError):
+        bad = idx.clone()
+        bad[0, 1, 0] = 5000
+        model.logits(bad, spk)
+    model.close()
