@@ -153,6 +153,10 @@ int mv_stage2_get_logits(mv_stage2* s, int32_t head, float* out);  /* parity hoo
 /* One draw per (position, target hierarchy): /temperature, top-k mask, softmax, multinomial; out: host [batch][n_out][T]. */
 int mv_stage2_sample(mv_stage2* s, float temperature, int32_t top_k, uint64_t seed, int32_t* out);
 
+/* Debug hook (MV_DEBUG_VECTORS=1 in the environment at mv_finalize, MetaVoice-1B widths only): bf16 bits of every layer's
+ * q | attention output | h | SwiGLU activation | x of the LAST decode step, [n_layer][5][2 rows][5632]. */
+int mv_debug_vectors(mv_engine* e, uint16_t* out, int64_t cap_elems);
+
 /* Tuning hook (no reference equivalent): process-wide launch knobs of the decode kernels and the side-stream prefetcher,
  * used by tools/sweep.py; keys are listed in DESIGN.md "Tuning".  A finalized engine passed as `e` (may be NULL)
  * re-captures its decode graph at the next mv_begin. */

@@ -1,0 +1,390 @@
+// Persistent decode-step kernel: all 24 layers + the LM head of one token in ONE launch (MetaVoice-1B shape, one utterance
+// = 2 CFG rows).  Same arithmetic, in the same order, as the per-layer launches (gemv.hip / attention.hip share
+// gemv_core.h / attn_core.h with this file): the two paths produce identical bits (tests/test_engine_gpu.py).
+//
+// Why (profiles/r01b_attn_sampler/NOTES.md): with one launch per op a decode step is 122 dependent launches of 1.5-9 us
+// of streaming each; every launch pays ~2.8 us of boundary + ramp + tail during which HBM idles, ~34 % of the step.  The
+// weights do not depend on the activations, so here 256 resident workgroups (one per CU) each own a fixed slice of every
+// weight matrix and issue the NEXT phase's weight loads (into registers: the register file is the largest on-chip
+// memory, 512 KB per CU) BEFORE waiting for the current phase's input: the weight stream never stops, and the
+// all-to-all dependency between phases costs one hand-off instead of a kernel boundary plus a cold start.
+//
+// Hand-off (cdna_hip_programming.md Guideline 16, recipe R2): every activation vector is exchanged as 8-byte granules
+// {payload: 2 x bf16, tag: 32-bit epoch}, written with ONE agent-scope (sc1, write-through) store by the producing lane
+// and re-read with agent-scope loads by every consumer until all tags match -- the data is the flag: no fence, no
+// barrier object, no dependence on workgroup placement.  epoch = step counter (bumped by the sampler kernel, i.e. across
+// a kernel boundary) x 256 + layer x 8 + phase + 1: strictly increasing, so a stale granule can never match.
+// Every wait is bounded; a timeout raises a device flag that the host turns into an error (a plain launch gives no
+// residency guarantee: if another kernel occupies CUs the grid may not be co-resident).
+#include "attn_core.h"
+#include "gemv_core.h"
+
+#define MG_THREADS 512
+#define MG_WAVES 8
+#define MG_DIM 2048
+#define MG_INTER 5632
+#define MG_HEADS 16
+#define MG_SPIN_LIMIT (1 << 18)
+
+typedef u64 gran_t;
+
+__device__ __forceinline__ void gran_store(gran_t* g, uint32_t payload, uint32_t tag) {
+    __hip_atomic_store(g, ((u64)tag << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 gran_load(const gran_t* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct MegaCtx {
+    uint32_t* abort_flag;
+    int* s_abort;  // LDS word
+};
+
+// Block-wide wait until every granule this block needs carries `tag`.  `fetch(k, &value)` loads the k-th granule of the
+// calling thread (or returns false when the thread has no k-th granule); `sink(k, payload)` writes its payload to LDS.
+// The LDS writes of the successful round are ordered before the return by the voting barrier.
+template <int PER, typename Fetch, typename Sink>
+__device__ __forceinline__ bool mega_poll(uint32_t tag, const MegaCtx& cx, Fetch fetch, Sink sink) {
+    for (int tries = 0;; ++tries) {
+        u64 v[PER];
+        bool have[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) have[k] = fetch(k, v[k]);
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) ok = ok && (!have[k] || (uint32_t)(v[k] >> 32) == tag);
+        if (ok) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                if (have[k]) sink(k, (uint32_t)v[k]);
+        }
+        if (__syncthreads_and(ok)) return true;
+        if ((tries & 1023) == 1023) {  // rare slow path: peer missing (grid not co-resident?) or a peer already gave up
+            if (threadIdx.x == 0) {
+                int ab = __hip_atomic_load(cx.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                if (tries >= MG_SPIN_LIMIT) {
+                    __hip_atomic_store(cx.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ab = 1;
+                }
+                *cx.s_abort = ab;
+            }
+            __syncthreads();
+            if (*cx.s_abort) return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// Row-paired vector of NCOL columns (granule n = {row0[n], row1[n]}) -> raw[2][NCOL] bf16 in LDS.
+template <int NCOL>
+__device__ __forceinline__ bool poll_rowpair(const gran_t* g, uint32_t tag, bf16_t* raw, const MegaCtx& cx, int tid) {
+    constexpr int PER = (NCOL + MG_THREADS - 1) / MG_THREADS;
+    return mega_poll<PER>(
+        tag, cx,
+        [&](int k, u64& v) { const int n = tid + k * MG_THREADS; if (n >= NCOL) return false; v = gran_load(g + n); return true; },
+        [&](int k, uint32_t p) { const int n = tid + k * MG_THREADS; raw[n] = (bf16_t)p; raw[NCOL + n] = (bf16_t)(p >> 16); });
+}
+
+// RMSNorm of raw[2][2048] into xs[2][2048], bit-identical to gemv.hip's prologue (threads 0..255 own 8 columns each).
+__device__ __forceinline__ void mega_norm(const bf16_t* raw, const bf16_t* norm_w, bf16_t* xs, float* red, float eps) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = tid * 8;
+    const bool in_k = c < MG_DIM;
+    u32x4 xv[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        xv[r] = in_k ? *(const u32x4*)(raw + r * MG_DIM + c) : u32x4{0, 0, 0, 0};
+        const float s = wave_sum(sumsq8(xv[r]));
+        if (lane == 0) red[wave * 2 + r] = s;
+    }
+    const u32x4 nw = in_k ? load16(norm_w + c) : u32x4{0, 0, 0, 0};
+    __syncthreads();
+    if (in_k) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float tot = 0.f;
+            for (int w = 0; w < MG_WAVES; ++w) tot += red[w * 2 + r];
+            *(u32x4*)(xs + r * MG_DIM + c) = rms_apply8(xv[r], rms_rstd(tot, MG_DIM, eps), nw);
+        }
+    }
+    __syncthreads();
+}
+
+// acc[i][r] += W row i (registers) . x row r (LDS), lane l covering columns 512 j + 8 l .. + 7 of chunk j
+template <int KCH, int NR, int KP>
+__device__ __forceinline__ void mega_dots(const u32x4* wv, const bf16_t* xs, int lane, float (&acc)[NR][2]) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { acc[i][0] = 0.f; acc[i][1] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < KCH; ++j) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const u32x4 xv = *(const u32x4*)(xs + r * KP + j * 512 + lane * 8);
+#pragma unroll
+            for (int i = 0; i < NR; ++i) acc[i][r] = dot8_bf16(wv[i * KCH + j], xv, acc[i][r]);
+        }
+    }
+}
+template <int KCH>
+__device__ __forceinline__ void mega_issue_row(u32x4* wv, const bf16_t* w, int n, int K, int lane) {
+    const bf16_t* row = w + (size_t)n * K;
+#pragma unroll
+    for (int j = 0; j < KCH; ++j) wv[j] = load_stream16(row + min(j * 512 + lane * 8, K - 8));
+}
+
+__global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t raw_x[2 * MG_DIM];   // residual stream entering the layer (P0 in, P2 residual)
+    __shared__ __attribute__((aligned(16))) bf16_t raw_h[2 * MG_DIM];   // residual stream after attention (P3 in, P4 residual)
+    __shared__ __attribute__((aligned(16))) bf16_t xs[2 * MG_INTER];    // the GEMV operand of the current phase
+    __shared__ __attribute__((aligned(16))) bf16_t qkv_s[3 * 2 * 128];  // q, k_new, v_new of this block's head, both rows
+    __shared__ __attribute__((aligned(16))) float sm[2][ATTN_WAVES][16][12];
+    __shared__ float red[MG_WAVES * 2];
+    __shared__ int s_abort;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const MegaCtx cx{a.abort_flag, &s_abort};
+    const uint32_t epoch = a.step_counter[0] * 256u;
+    const int P = a.pos[0] + 1;  // keys [0, P): the cache holds [0, P-1), key P-1 is produced by this step's QKV phase
+
+    // attention geometry: block (h, s) = one of the 16 even key ranges of head h, both rows; 4 waves per row
+    const int at_h = b >> 4, at_s = b & 15, at_r = wave >> 2, at_w = wave & 3;
+    const int g = lane >> 4, dl = lane & 15;
+    const int cs = attn_keys_per_split(P);
+    const int nact = (P + cs - 1) / cs;
+    const int at_s0 = at_s * cs + at_w * ATTN_KEYS_PER_WAVE, at_s1 = min(P, at_s * cs + cs);
+
+    u32x4 wv[24];  // the weight working set of the current GEMV phase (next phase's rows are issued into it after the dots)
+    // phase 0 of layer 0: rows 24 b + 3 wave + i of wqkv
+    {
+        const bf16_t* w = a.layers[0].wqkv;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave + i, MG_DIM, lane);
+    }
+
+    for (int l = 0; l < a.n_layer; ++l) {
+        // Address arithmetic below is a function of (lane, wave): left alone, the compiler hoists ~60 loop-invariant 64-bit
+        // addresses out of the layer loop and spills them.  Making the two ids opaque once per layer keeps every address
+        // computation next to its load (a handful of VALU ops) and the kernel spill-free.
+        int lane_o = lane, wave_o = wave;
+        asm volatile("" : "+v"(lane_o), "+v"(wave_o));
+        const int tid_o = wave_o * 64 + lane_o;
+        const MegaLayer L = a.layers[l];
+        const uint32_t tag0 = epoch + (uint32_t)l * 8u + 1u;  // + phase index
+        bf16_t* kc = a.kcache + (size_t)l * a.kv_layer_elems;
+        bf16_t* vc = a.vcache + (size_t)l * a.kv_layer_elems;
+
+        // ================= P0: RMSNorm + wqkv (+ KV-cache write)        fast_model.py:179,209,218 ====================
+        __syncthreads();
+        if (l == 0) {
+            *(u32x4*)(raw_x + tid * 8) = load16(a.x_in + tid * 8);  // written by the sampler in the previous launch
+        } else if (!poll_rowpair<MG_DIM>(a.g_x, tag0 - 8u + 4u, raw_x, cx, tid_o)) return;
+        if (l == 0) __syncthreads();
+        mega_norm(raw_x, L.attn_norm, xs, red, a.eps);
+        {
+            float acc[3][2];
+            mega_dots<4, 3, MG_DIM>(wv, xs, lane, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float t0 = wave_sum(acc[i][0]), t1 = wave_sum(acc[i][1]);
+                if (lane == i) { v0 = t0; v1 = t1; }
+            }
+            if (lane < 3) {
+                const int n = 24 * b + 3 * wave + lane;
+                const bf16_t y0 = f2bf(v0), y1 = f2bf(v1);
+                gran_store(a.g_qkv + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 0u);
+                if (a.dbg && n < MG_DIM) { bf16_t* d = a.dbg + ((size_t)l * 5 + 0) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
+                if (n >= MG_DIM) {  // K / V rows also go to the cache for the FUTURE steps (this step reads them from the granules)
+                    const int which = (n - MG_DIM) / MG_DIM, hd = (n - MG_DIM) % MG_DIM;
+                    bf16_t* cache = which ? vc : kc;
+                    const size_t off = ((size_t)(hd / 128) * a.cache_len + (P - 1)) * 128 + hd % 128;
+                    cache[off] = y0;
+                    cache[(size_t)MG_HEADS * a.cache_len * 128 + off] = y1;
+                }
+            }
+        }
+        // next: the K/V stream of this block's attention slice (rows of EARLIER steps: independent of this step)
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 kv[ATTN_U], vv[ATTN_U];
+        {
+            const int at_ro = wave_o >> 2, go = lane_o >> 4, dlo = lane_o & 15, s0o = at_s * cs + (wave_o & 3) * ATTN_KEYS_PER_WAVE;
+            const size_t head_base = ((size_t)at_ro * MG_HEADS + at_h) * (size_t)a.cache_len * 128 + dlo * 8;
+            // Addresses are clamped to the newest row an EARLIER launch wrote (P-2): row P-1 is being written by this launch and
+            // is taken from the hand-off below -- it must not even be touched here (a line fetched before its producer's store
+            // could be served stale to the next launch).
+            const int last_old = max(P - 2, 0);
+#pragma unroll
+            for (int u = 0; u < ATTN_U; ++u) kv[u] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int u = 0; u < ATTN_U; ++u) vv[u] = u32x4{0u, 0u, 0u, 0u};
+            if (P > 1) {
+#pragma unroll
+                for (int u = 0; u < ATTN_U; ++u) kv[u] = load_stream16(kc + head_base + (size_t)min(s0o + u * 4 + go, last_old) * 128);
+#pragma unroll
+                for (int u = 0; u < ATTN_U; ++u) vv[u] = load_stream16(vc + head_base + (size_t)min(s0o + u * 4 + go, last_old) * 128);
+            }
+        }
+
+        // ================= P1: attention over keys [0, P)               fast_model.py:218-222 =========================
+        if (at_s < nact) {
+            __syncthreads();
+            {   // q, k_new, v_new of head at_h: 3 x 128 row-paired granules
+                const bool mine = tid_o < 384;
+                const int sec = tid_o >> 7, c = tid_o & 127;
+                const gran_t* gp = a.g_qkv + sec * MG_DIM + at_h * 128 + c;
+                if (!mega_poll<1>(tag0 + 0u, cx, [&](int, u64& v) { if (!mine) return false; v = gran_load(gp); return true; },
+                                  [&](int, uint32_t p) { qkv_s[(sec * 2 + 0) * 128 + c] = (bf16_t)p; qkv_s[(sec * 2 + 1) * 128 + c] = (bf16_t)(p >> 16); }))
+                    return;
+            }
+            const u32x4 qv = *(const u32x4*)(qkv_s + (0 * 2 + at_r) * 128 + dl * 8);
+#pragma unroll
+            for (int u = 0; u < ATTN_U; ++u) {
+                if (at_s0 + u * 4 + g == P - 1) {  // the key produced by this step: not in the cache yet for this launch
+                    kv[u] = *(const u32x4*)(qkv_s + (1 * 2 + at_r) * 128 + dl * 8);
+                    vv[u] = *(const u32x4*)(qkv_s + (2 * 2 + at_r) * 128 + dl * 8);
+                }
+            }
+            const AttnAcc w = attn_wave_partial(kv, vv, qv, at_s0, at_s1, g);
+            if (g == 0) {
+                sm[at_r][at_w][dl][0] = w.m;
+                sm[at_r][at_w][dl][1] = w.l;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) sm[at_r][at_w][dl][2 + d] = w.o[d];
+            }
+            __syncthreads();
+        }
+        // next: wo row 8 b + wave
+        __builtin_amdgcn_sched_barrier(0);
+        mega_issue_row<4>(wv, L.wo, 8 * b + wave_o, MG_DIM, lane_o);
+        __builtin_amdgcn_sched_barrier(0);
+        if (at_s < nact && at_w == 0) {  // waves 0 and 4: one per row
+            AttnAcc bb = attn_merge_waves(sm[at_r], g, dl);
+            bool last = true;
+            if (nact > 1) {
+                // One partial slab PER LAYER: inside a launch an address is then written once before it is read.  Reusing one slab
+                // across layers is wrong without tags: the combiner's one-shot agent-scope load can be served a line its XCD's
+                // L2 still holds from the previous layer's combine (remote write-through stores invalidate other L2s with a
+                // delay; a polled granule just retries, a one-shot load cannot) -- seen as 1-ulp drifts in one CFG row.
+                float* pbase = a.partial + (((size_t)l * 2 + at_r) * MG_HEADS + at_h) * ATTN_NSPLIT * ATTN_PART_STRIDE;
+                last = attn_publish_combine(bb, pbase, a.counters + at_r * MG_HEADS + at_h, at_s, nact, lane);
+            }
+            if (last && g == 0) {  // 8 dims per lane = 4 column-paired granules
+                const u32x4 y = attn_normalise(bb);
+                gran_t* gp = a.g_attn + at_r * (MG_DIM / 2) + (at_h * 128 + dl * 8) / 2;
+                gran_store(gp + 0, y.x, tag0 + 1u);
+                gran_store(gp + 1, y.y, tag0 + 1u);
+                gran_store(gp + 2, y.z, tag0 + 1u);
+                gran_store(gp + 3, y.w, tag0 + 1u);
+                if (a.dbg) *(u32x4*)(a.dbg + ((size_t)l * 5 + 1) * 2 * MG_INTER + at_r * MG_INTER + at_h * 128 + dl * 8) = y;
+            }
+        }
+
+        // ================= P2: h = x + wo(attn)                         fast_model.py:224-226,179 =====================
+        __syncthreads();
+        {
+            if (!mega_poll<4>(tag0 + 1u, cx, [&](int k, u64& v) { v = gran_load(a.g_attn + tid_o + k * MG_THREADS); return true; },
+                              [&](int k, uint32_t p) { ((uint32_t*)xs)[tid_o + k * MG_THREADS] = p; }))  // granule i = elements 2i, 2i+1 of [2][2048]
+                return;
+            float acc[1][2];
+            mega_dots<4, 1, MG_DIM>(wv, xs, lane, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            // next: w1 / w3 rows.  22 rows per block: waves 0..5 take 3, waves 6,7 take 2 (third slot clamped, masked)
+            const int rb = 22 * b + (wave_o < 6 ? 3 * wave_o : 18 + 2 * (wave_o - 6));
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int n = min(rb + i, MG_INTER - 1);
+                mega_issue_row<4>(wv + 4 * i, L.w1, n, MG_DIM, lane_o);
+                mega_issue_row<4>(wv + 12 + 4 * i, L.w3, n, MG_DIM, lane_o);
+            }
+            const float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
+            if (lane == 0) {
+                const int n = 8 * b + wave;
+                const bf16_t y0 = epi_resid(raw_x[n], t0), y1 = epi_resid(raw_x[MG_DIM + n], t1);
+                gran_store(a.g_h + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 2u);
+                if (a.dbg) { bf16_t* d = a.dbg + ((size_t)l * 5 + 2) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
+            }
+        }
+
+        // ================= P3: act = silu(w1 n(h)) * w3 n(h)            fast_model.py:180,237 =========================
+        __syncthreads();
+        {
+            if (!poll_rowpair<MG_DIM>(a.g_h, tag0 + 2u, raw_h, cx, tid_o)) return;
+            mega_norm(raw_h, L.ffn_norm, xs, red, a.eps);
+            float acc1[3][2], acc3[3][2];
+            mega_dots<4, 3, MG_DIM>(wv, xs, lane, acc1);
+            mega_dots<4, 3, MG_DIM>(wv + 12, xs, lane, acc3);
+            __builtin_amdgcn_sched_barrier(0);
+            // next: w2 row 8 b + wave (K = 5632: 11 chunks)
+            mega_issue_row<11>(wv, L.w2, 8 * b + wave_o, MG_INTER, lane_o);
+            const int nrows = wave < 6 ? 3 : 2;
+            const int rb = 22 * b + (wave < 6 ? 3 * wave : 18 + 2 * (wave - 6));
+            float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float a0 = wave_sum(acc1[i][0]), a1 = wave_sum(acc1[i][1]), c0 = wave_sum(acc3[i][0]), c1 = wave_sum(acc3[i][1]);
+                if (lane == i) { g0 = a0; g1 = a1; u0 = c0; u1 = c1; }
+            }
+            if (lane < nrows) {
+                const bf16_t y0 = epi_swiglu(g0, u0), y1 = epi_swiglu(g1, u1);
+                gran_store(a.g_act + rb + lane, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 3u);
+                if (a.dbg) { bf16_t* d = a.dbg + ((size_t)l * 5 + 3) * 2 * MG_INTER; d[rb + lane] = y0; d[MG_INTER + rb + lane] = y1; }
+            }
+        }
+
+        // ================= P4: x = h + w2(act)                          fast_model.py:247,180 =========================
+        __syncthreads();
+        {
+            if (!poll_rowpair<MG_INTER>(a.g_act, tag0 + 3u, xs, cx, tid_o)) return;
+            float acc[1][2];
+            mega_dots<11, 1, MG_INTER>(wv, xs, lane, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            // next: the following layer's wqkv rows, or the LM-head rows 11 b + wave + 8 i
+            if (l + 1 < a.n_layer) {
+                const bf16_t* w = a.layers[l + 1].wqkv;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave_o + i, MG_DIM, lane_o);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) mega_issue_row<4>(wv + 4 * i, a.head, min(11 * b + wave_o + 8 * i, a.vocab - 1), MG_DIM, lane_o);
+            }
+            const float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
+            if (lane == 0) {
+                const int n = 8 * b + wave;
+                const bf16_t y0 = epi_resid(raw_h[n], t0), y1 = epi_resid(raw_h[MG_DIM + n], t1);
+                gran_store(a.g_x + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 4u);
+                if (a.dbg) { bf16_t* d = a.dbg + ((size_t)l * 5 + 4) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
+            }
+        }
+    }
+
+    // ================= LM head on the last position: logits = head(norm(x))     fast_model.py:161-162 =================
+    __syncthreads();
+    if (!poll_rowpair<MG_DIM>(a.g_x, epoch + (uint32_t)(a.n_layer - 1) * 8u + 1u + 4u, raw_x, cx, tid)) return;
+    mega_norm(raw_x, a.final_norm, xs, red, a.eps);
+    {
+        float acc[2][2];
+        mega_dots<4, 2, MG_DIM>(wv, xs, lane, acc);
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float t0 = wave_sum(acc[i][0]), t1 = wave_sum(acc[i][1]);
+            if (lane == i) { v0 = t0; v1 = t1; }
+        }
+        if (lane < 2) {
+            const int slot = wave + 8 * lane, n = 11 * b + slot;
+            if (slot < 11 && n < a.vocab) {
+                a.logits[n] = f2bf(v0);
+                a.logits[a.vocab + n] = f2bf(v1);
+            }
+        }
+    }
+}
+
+bool mega_supported(const mv_config& c, int rows, int n_cus) {
+    return rows == 2 && c.dim == MG_DIM && c.intermediate == MG_INTER && c.n_head == MG_HEADS && c.vocab <= 256 * 11 && n_cus >= 256 &&
+           c.block_size <= ATTN_NSPLIT * 128;
+}
+
+hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a) {
+    hipLaunchKernelGGL(decode_mega_kernel, dim3(256), dim3(MG_THREADS), 0, s, a);
+    return hipGetLastError();
+}

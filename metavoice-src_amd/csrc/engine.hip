@@ -100,6 +100,14 @@ struct mv_engine {
     int capture_max = 0;
     bool capture_on = false;
 
+    // persistent decode-step kernel (decode_mega.hip)
+    bool mega_ok = false;
+    MegaLayer* mega_layers = nullptr;
+    unsigned long long* granules = nullptr;   // g_x | g_qkv | g_attn | g_h | g_act
+    uint32_t* step_counter = nullptr;
+    uint32_t* abort_flag = nullptr;
+    bf16_t* dbg = nullptr;   // MV_DEBUG_VECTORS=1: every layer's q|attn|h|act|x of the last step, both paths (mv_debug_vectors)
+
     // prefill workspace (M = 2 T rows of one utterance), allocated on the first batched prefill
     bf16_t *px = nullptr, *ph = nullptr, *pn = nullptr, *pq = nullptr, *pattn = nullptr, *pact = nullptr;
 
@@ -118,11 +126,22 @@ struct mv_engine {
 namespace {
 
 int enqueue_tail(mv_engine* e);
+int enqueue_sampler(mv_engine* e);
 
 int enqueue_step(mv_engine* e) {
     const mv_config& c = e->cfg;
     const int R = e->R;
     hipStream_t s = e->stream;
+    if (e->mega_ok && g_tune.mega) {  // one persistent launch for the 24 layers + LM head, then the sampler
+        MegaArgs m;
+        m.x_in = e->x; m.layers = e->mega_layers; m.n_layer = c.n_layer; m.vocab = c.vocab; m.cache_len = c.block_size;
+        m.final_norm = e->final_norm; m.head = e->head; m.logits = e->logits; m.kcache = e->kcache; m.vcache = e->vcache;
+        m.kv_layer_elems = e->kv_layer_elems; m.pos = e->pos_arr; m.step_counter = e->step_counter;
+        m.g_x = e->granules; m.g_qkv = m.g_x + c.dim; m.g_attn = m.g_qkv + 3 * c.dim; m.g_h = m.g_attn + c.dim; m.g_act = m.g_h + c.dim;
+        m.partial = e->partial; m.counters = e->counters; m.abort_flag = e->abort_flag; m.eps = c.norm_eps; m.dbg = e->dbg;
+        HIP_TRY(launch_decode_mega(s, m));
+        return enqueue_sampler(e);
+    }
     for (int l = 0; l < c.n_layer; ++l) {
         const LayerW& w = e->layers[l];
         bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
@@ -134,6 +153,16 @@ int enqueue_step(mv_engine* e) {
             a.N = 3 * c.dim; a.K = c.dim; a.eps = c.norm_eps;
             HIP_TRY(launch_gemv(s, R, a, GEMV_QKV));
         }
+        auto dbg_copy = [&](int which, const bf16_t* src, int cols) -> hipError_t {
+            if (!e->dbg || R != 2) return hipSuccess;
+            for (int r = 0; r < 2; ++r) {
+                hipError_t ce = hipMemcpyAsync(e->dbg + (((size_t)l * 5 + which) * 2 + r) * 5632, src + (size_t)r * cols, (size_t)cols * 2,
+                                               hipMemcpyDeviceToDevice, s);
+                if (ce != hipSuccess) return ce;
+            }
+            return hipSuccess;
+        };
+        HIP_TRY(dbg_copy(0, e->q, c.dim));
         {   // attention over keys [0, pos]                (fast_model.py:222)
             AttnArgs a;
             a.q = e->q; a.kcache = kc; a.vcache = vc; a.pos = e->pos_arr; a.partial = e->partial;
@@ -141,22 +170,26 @@ int enqueue_step(mv_engine* e) {
            
             HIP_TRY(launch_attention_decode(s, R, a));
         }
+        HIP_TRY(dbg_copy(1, e->attn, c.dim));
         {   // h = x + wo(attn)                            (fast_model.py:226,179)
             GemvArgs a;
             a.x = e->attn; a.w = w.wo; a.residual = e->x; a.out = e->h; a.N = c.dim; a.K = c.dim;
             HIP_TRY(launch_gemv(s, R, a, GEMV_RESID));
         }
+        HIP_TRY(dbg_copy(2, e->h, c.dim));
         {   // act = silu(w1 n(h)) * w3 n(h)               (fast_model.py:180,237)
             GemvArgs a;
             a.x = e->h; a.w = w.w1; a.w2 = w.w3; a.norm_w = w.ffn_norm; a.out = e->act; a.N = c.intermediate;
             a.K = c.dim; a.eps = c.norm_eps;
             HIP_TRY(launch_gemv(s, R, a, GEMV_SWIGLU));
         }
+        HIP_TRY(dbg_copy(3, e->act, c.intermediate));
         {   // x = h + w2(act)                             (fast_model.py:247,180)
             GemvArgs a;
             a.x = e->act; a.w = w.w2; a.residual = e->h; a.out = e->x; a.N = c.dim; a.K = c.intermediate;
             HIP_TRY(launch_gemv(s, R, a, GEMV_RESID));
         }
+        HIP_TRY(dbg_copy(4, e->x, c.dim));
     }
     return enqueue_tail(e);
 }
@@ -172,13 +205,19 @@ int enqueue_tail(mv_engine* e) {
         a.eps = c.norm_eps;
         HIP_TRY(launch_gemv(s, R, a, GEMV_PLAIN));
     }
+    return enqueue_sampler(e);
+}
+
+int enqueue_sampler(mv_engine* e) {
+    const mv_config& c = e->cfg;
+    hipStream_t s = e->stream;
     {   // sample, bookkeeping, next input embedding        (fast_inference_utils.py:107-120,148-174)
         SampleArgs a;
         a.logits = e->logits; a.utt = e->utt; a.pos_arr = e->pos_arr; a.seq = e->seq; a.tok_emb = e->tok_emb;
         a.pos_emb = e->pos_emb; a.spk_proj = e->spk_proj; a.x_next = e->x; a.n_active = e->n_active;
         a.capture = e->capture_on ? e->capture : nullptr; a.capture_max = e->capture_max;
         a.vocab = c.vocab; a.dim = c.dim; a.block_size = c.block_size; a.n_utt = c.max_utterances;
-       
+        a.step_counter = e->step_counter;
         HIP_TRY(launch_sample(s, a, false));
     }
     return MV_OK;
@@ -262,6 +301,15 @@ extern "C" {
 
 const char* mv_last_error(void) { return g_err.c_str(); }
 
+int mv_debug_vectors(mv_engine* e, uint16_t* out, int64_t cap_elems) {
+    if (!e || !e->dbg || !out) return fail(MV_ERR_STATE, "debug vectors are not enabled (MV_DEBUG_VECTORS=1 before mv_finalize)");
+    const size_t n = (size_t)e->cfg.n_layer * 5 * 2 * 5632;
+    if ((size_t)cap_elems < n) return fail(MV_ERR_INVALID, "buffer too small");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(out, e->dbg, n * 2, hipMemcpyDeviceToHost));
+    return MV_OK;
+}
+
 int mv_tune(mv_engine* e, const char* key, int32_t value) {
     if (!key) return fail(MV_ERR_INVALID, "null key");
     const std::string k = key;
@@ -274,6 +322,7 @@ int mv_tune(mv_engine* e, const char* key, int32_t value) {
     if (found) {}
     else if (k == "gemv_nt") g_tune.gemv_nt = value;
     else if (k == "use_graph") g_tune.use_graph = value;
+    else if (k == "mega") g_tune.mega = value;
     else return fail(MV_ERR_INVALID, "unknown tuning key '%s'", key);
     if (e && e->finalized) e->graph_dirty = true;  // launch geometry is frozen in the captured graph: re-capture at mv_begin
     return MV_OK;
@@ -348,7 +397,7 @@ int mv_engine_destroy(mv_engine* e) {
     if (e->graph) hipGraphDestroy(e->graph);
     void* bufs[] = {e->arena, e->x, e->h, e->q, e->attn, e->act, e->logits, e->kcache, e->vcache, e->partial, e->counters,
                     e->utt, e->pos_arr, e->seq, e->spk_emb, e->spk_proj, e->n_active, e->capture, e->px, e->ph, e->pn, e->pq,
-                    e->pattn, e->pact};
+                    e->pattn, e->pact, e->mega_layers, e->granules, e->step_counter, e->abort_flag, e->dbg};
     for (void* b : bufs)
         if (b) hipFree(b);
     if (e->host_flag) hipHostFree(e->host_flag);
@@ -407,7 +456,8 @@ int mv_finalize(mv_engine* e) {
     HIP_TRY(hipMalloc((void**)&e->vcache, e->kv_layer_elems * c.n_layer * 2));
     HIP_TRY(hipMemset(e->kcache, 0, e->kv_layer_elems * c.n_layer * 2));
     HIP_TRY(hipMemset(e->vcache, 0, e->kv_layer_elems * c.n_layer * 2));
-    HIP_TRY(hipMalloc((void**)&e->partial, (size_t)R * c.n_head * ATTN_NSPLIT * ATTN_PART_STRIDE * 4));
+    // one slab per layer: the persistent kernel must not reuse a partial's address inside a launch (decode_mega.hip)
+    HIP_TRY(hipMalloc((void**)&e->partial, (size_t)c.n_layer * R * c.n_head * ATTN_NSPLIT * ATTN_PART_STRIDE * 4));
     HIP_TRY(hipMalloc((void**)&e->counters, (size_t)R * c.n_head * 4));
     HIP_TRY(hipMemset(e->counters, 0, (size_t)R * c.n_head * 4));
     HIP_TRY(hipMalloc((void**)&e->utt, (size_t)U * sizeof(UttState)));
@@ -418,6 +468,35 @@ int mv_finalize(mv_engine* e) {
     HIP_TRY(hipMalloc((void**)&e->n_active, 4));
     HIP_TRY(hipHostMalloc((void**)&e->host_flag, 4, hipHostMallocDefault));
     HIP_TRY(hipMemset(e->x, 0, (size_t)R * c.dim * 2));
+    if (getenv("MV_DEBUG_VECTORS") && c.dim == 2048 && c.intermediate == 5632) {
+        HIP_TRY(hipMalloc((void**)&e->dbg, (size_t)c.n_layer * 5 * 2 * 5632 * 2));
+        HIP_TRY(hipMemset(e->dbg, 0, (size_t)c.n_layer * 5 * 2 * 5632 * 2));
+    }
+    HIP_TRY(hipMalloc((void**)&e->step_counter, 4));
+    HIP_TRY(hipMalloc((void**)&e->abort_flag, 4));
+    {
+        const uint32_t one = 1, zero = 0;
+        HIP_TRY(hipMemcpy(e->step_counter, &one, 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->abort_flag, &zero, 4, hipMemcpyHostToDevice));
+    }
+    {
+        int dev = 0, n_cus = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev));
+        e->mega_ok = mega_supported(c, R, n_cus);
+        if (e->mega_ok) {
+            std::vector<MegaLayer> ml(c.n_layer);
+            for (int l = 0; l < c.n_layer; ++l) {
+                const LayerW& w = e->layers[l];
+                ml[l] = MegaLayer{w.attn_norm, w.wqkv, w.wo, w.ffn_norm, w.w1, w.w3, w.w2};
+            }
+            HIP_TRY(hipMalloc((void**)&e->mega_layers, ml.size() * sizeof(MegaLayer)));
+            HIP_TRY(hipMemcpy(e->mega_layers, ml.data(), ml.size() * sizeof(MegaLayer), hipMemcpyHostToDevice));
+            const size_t ngran = (size_t)c.dim * 6 + c.intermediate;  // x, qkv (3), attn, h, act
+            HIP_TRY(hipMalloc((void**)&e->granules, ngran * 8));
+            HIP_TRY(hipMemset(e->granules, 0, ngran * 8));
+        }
+    }
     HIP_TRY(hipDeviceSynchronize());
     e->finalized = true;
     return build_graph(e);
@@ -532,6 +611,10 @@ int mv_begin(mv_engine* e, int32_t n_utt, const int32_t* prompts, const int32_t*
 int mv_run(mv_engine* e, int32_t max_steps, int32_t poll_every, int32_t* steps_run) {
     if (!e || !e->begun) return fail(MV_ERR_STATE, "mv_begin has not been called");
     if (poll_every < 1) poll_every = 16;
+    if (e->graph_dirty) {  // a tuning knob changed since the last capture
+        const int rc = build_graph(e);
+        if (rc != MV_OK) return rc;
+    }
     int limit = e->steps_budget;
     if (max_steps >= 0 && max_steps < limit) limit = max_steps;
     int done_steps = 0;
@@ -555,6 +638,15 @@ int mv_run(mv_engine* e, int32_t max_steps, int32_t poll_every, int32_t* steps_r
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1));
+    if (e->mega_ok && g_tune.mega) {
+        uint32_t ab = 0;
+        HIP_TRY(hipMemcpy(&ab, e->abort_flag, 4, hipMemcpyDeviceToHost));
+        if (ab) {
+            HIP_TRY(hipMemset(e->abort_flag, 0, 4));
+            return fail(MV_ERR_HIP, "persistent decode kernel timed out waiting for a peer workgroup (grid not co-resident: is "
+                                    "another kernel occupying the GPU?); set mv_tune(\"mega\", 0) to use per-layer launches");
+        }
+    }
     e->steps_budget -= done_steps;
     if (steps_run) *steps_run = done_steps;
     return MV_OK;

@@ -223,10 +223,10 @@ __global__ void __launch_bounds__(256) attn_rows_kernel(const AttnRowsArgs a) {
         for (int u = 0; u < UN; ++u) {
             const float p = (sc[u] == -INFINITY) ? 0.f : fast_exp(sc[u] - mn);
             l += p;
-            o[0] += p * bf_lo(vv[u].x); o[1] += p * bf_hi(vv[u].x);
-            o[2] += p * bf_lo(vv[u].y); o[3] += p * bf_hi(vv[u].y);
-            o[4] += p * bf_lo(vv[u].z); o[5] += p * bf_hi(vv[u].z);
-            o[6] += p * bf_lo(vv[u].w); o[7] += p * bf_hi(vv[u].w);
+            o[0] = fmaf(p, bf_lo(vv[u].x), o[0]); o[1] = fmaf(p, bf_hi(vv[u].x), o[1]);
+            o[2] = fmaf(p, bf_lo(vv[u].y), o[2]); o[3] = fmaf(p, bf_hi(vv[u].y), o[3]);
+            o[4] = fmaf(p, bf_lo(vv[u].z), o[4]); o[5] = fmaf(p, bf_hi(vv[u].z), o[5]);
+            o[6] = fmaf(p, bf_lo(vv[u].w), o[6]); o[7] = fmaf(p, bf_hi(vv[u].w), o[7]);
         }
         m = mn;
     }

@@ -16,7 +16,7 @@
 //     conflict-free ds_read_b128 (lane-linear), reused by the NR weight rows of the wave.
 //   * v_dot2c_f32_bf16 accumulates in fp32; one 64-lane butterfly per output; bf16 rounding points follow the
 //     reference's bf16 tensors (DESIGN.md "Rounding points").
-#include "common.h"
+#include "gemv_core.h"
 #include "kernels.h"
 
 enum { EPI_PLAIN = GEMV_PLAIN, EPI_RESID = GEMV_RESID, EPI_SWIGLU = GEMV_SWIGLU, EPI_QKV = GEMV_QKV };
@@ -59,12 +59,7 @@ __global__ void __launch_bounds__(1024) gemv_kernel(const GemvArgs a) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             xv[r] = in_k ? load16(a.x + (size_t)r * K + c) : u32x4{0, 0, 0, 0};
-            float s = 0.f;
-            s += bf_lo(xv[r].x) * bf_lo(xv[r].x) + bf_hi(xv[r].x) * bf_hi(xv[r].x);
-            s += bf_lo(xv[r].y) * bf_lo(xv[r].y) + bf_hi(xv[r].y) * bf_hi(xv[r].y);
-            s += bf_lo(xv[r].z) * bf_lo(xv[r].z) + bf_hi(xv[r].z) * bf_hi(xv[r].z);
-            s += bf_lo(xv[r].w) * bf_lo(xv[r].w) + bf_hi(xv[r].w) * bf_hi(xv[r].w);
-            ss[r] = wave_sum(s);
+            ss[r] = wave_sum(sumsq8(xv[r]));
         }
         if (lane == 0) {
 #pragma unroll
@@ -77,13 +72,7 @@ __global__ void __launch_bounds__(1024) gemv_kernel(const GemvArgs a) {
             for (int r = 0; r < R; ++r) {
                 float tot = 0.f;
                 for (int wv_i = 0; wv_i < nwaves; ++wv_i) tot += red[wv_i * R + r];
-                const float rstd = rsqrtf(tot / (float)K + a.eps);
-                u32x4 y;
-                y.x = pack_bf2(round_bf(bf_lo(xv[r].x) * rstd) * bf_lo(nw.x), round_bf(bf_hi(xv[r].x) * rstd) * bf_hi(nw.x));
-                y.y = pack_bf2(round_bf(bf_lo(xv[r].y) * rstd) * bf_lo(nw.y), round_bf(bf_hi(xv[r].y) * rstd) * bf_hi(nw.y));
-                y.z = pack_bf2(round_bf(bf_lo(xv[r].z) * rstd) * bf_lo(nw.z), round_bf(bf_hi(xv[r].z) * rstd) * bf_hi(nw.z));
-                y.w = pack_bf2(round_bf(bf_lo(xv[r].w) * rstd) * bf_lo(nw.w), round_bf(bf_hi(xv[r].w) * rstd) * bf_hi(nw.w));
-                *(u32x4*)(xs + r * KP + c) = y;
+                *(u32x4*)(xs + r * KP + c) = rms_apply8(xv[r], rms_rstd(tot, K, a.eps), nw);
             }
         }
     } else {
@@ -136,14 +125,9 @@ __global__ void __launch_bounds__(1024) gemv_kernel(const GemvArgs a) {
             if (EPI == EPI_PLAIN) {
                 a.out[(size_t)r * N + n] = f2bf(mine[0]);
             } else if (EPI == EPI_RESID) {
-                // y = bf16(W x) ; h = bf16(residual + y)     (fast_model.py:179-180)
-                a.out[(size_t)r * N + n] = f2bf(bf2f(a.residual[(size_t)r * N + n]) + round_bf(mine[0]));
+                a.out[(size_t)r * N + n] = epi_resid(a.residual[(size_t)r * N + n], mine[0]);
             } else if (EPI == EPI_SWIGLU) {
-                // bf16(silu(bf16(w1 x))) * bf16(w3 x) -> bf16     (fast_model.py:237)
-                const float g = round_bf(mine[0]);
-                const float u = round_bf(mine[NMAT - 1]);
-                const float s = round_bf(g / (1.0f + __expf(-g)));
-                a.out[(size_t)r * N + n] = f2bf(s * u);
+                a.out[(size_t)r * N + n] = epi_swiglu(mine[0], mine[NMAT - 1]);
             } else {  // EPI_QKV: rows [0,dim) -> q, [dim,2dim) -> K cache, [2dim,3dim) -> V cache at input_pos
                 const bf16_t v = f2bf(mine[0]);
                 const int dim = a.dim;

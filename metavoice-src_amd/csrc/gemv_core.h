@@ -1,0 +1,33 @@
+// Arithmetic shared by the per-launch GEMV kernels (gemv.hip) and the persistent decode-step kernel (decode_mega.hip):
+// one source for every expression whose rounding matters, so the two paths produce identical bits.
+#pragma once
+#include "common.h"
+
+// sum of squares of 8 bf16 (RMSNorm statistics, fam/llm/fast_model.py:256-261), fixed order
+__device__ __forceinline__ float sumsq8(const u32x4& x) {
+    float s = 0.f;
+    s += bf_lo(x.x) * bf_lo(x.x) + bf_hi(x.x) * bf_hi(x.x);
+    s += bf_lo(x.y) * bf_lo(x.y) + bf_hi(x.y) * bf_hi(x.y);
+    s += bf_lo(x.z) * bf_lo(x.z) + bf_hi(x.z) * bf_hi(x.z);
+    s += bf_lo(x.w) * bf_lo(x.w) + bf_hi(x.w) * bf_hi(x.w);
+    return s;
+}
+__device__ __forceinline__ float rms_rstd(float total_sumsq, int K, float eps) { return rsqrtf(total_sumsq / (float)K + eps); }
+// bf16(bf16(x * rstd) * w) for 8 elements
+__device__ __forceinline__ u32x4 rms_apply8(const u32x4& x, float rstd, const u32x4& nw) {
+    u32x4 y;
+    y.x = pack_bf2(round_bf(bf_lo(x.x) * rstd) * bf_lo(nw.x), round_bf(bf_hi(x.x) * rstd) * bf_hi(nw.x));
+    y.y = pack_bf2(round_bf(bf_lo(x.y) * rstd) * bf_lo(nw.y), round_bf(bf_hi(x.y) * rstd) * bf_hi(nw.y));
+    y.z = pack_bf2(round_bf(bf_lo(x.z) * rstd) * bf_lo(nw.z), round_bf(bf_hi(x.z) * rstd) * bf_hi(nw.z));
+    y.w = pack_bf2(round_bf(bf_lo(x.w) * rstd) * bf_lo(nw.w), round_bf(bf_hi(x.w) * rstd) * bf_hi(nw.w));
+    return y;
+}
+// y = bf16(W x); h = bf16(residual + y)                       (fast_model.py:179-180)
+__device__ __forceinline__ bf16_t epi_resid(bf16_t residual, float acc) { return f2bf(bf2f(residual) + round_bf(acc)); }
+// bf16(bf16(silu(bf16(w1 x))) * bf16(w3 x))                   (fast_model.py:237)
+__device__ __forceinline__ bf16_t epi_swiglu(float acc1, float acc3) {
+    const float g = round_bf(acc1);
+    const float u = round_bf(acc3);
+    const float s = round_bf(g / (1.0f + __expf(-g)));
+    return f2bf(s * u);
+}

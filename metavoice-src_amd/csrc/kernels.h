@@ -12,6 +12,7 @@ struct MvTune {
     int gemv_nr[4] = {0, 0, 0, 0};       // weight rows per wave: 0 = built-in choice
     int gemv_nt = 1;                     // 1: non-temporal weight loads, 0: default cache policy
     int use_graph = 1;
+    int mega = 1;                        // persistent decode-step kernel (decode_mega.hip) when the shape allows it
 };
 extern MvTune g_tune;
 
@@ -78,6 +79,7 @@ struct SampleArgs {
     int32_t* token_out = nullptr;         // optional (mv_op_sample only)
     uint32_t fixed_step = 0;              // mv_op_sample only
     int32_t vocab = 0, dim = 0, block_size = 0, n_utt = 0;
+    uint32_t* step_counter = nullptr;     // bumped once per launch: the epoch source of decode_mega.hip's hand-off tags
 };
 hipError_t launch_sample(hipStream_t s, const SampleArgs& a, bool standalone);
 hipError_t launch_embed_first(hipStream_t s, const SampleArgs& a);
@@ -129,3 +131,29 @@ struct AttnRowsArgs {
     int32_t T = 0, n_head = 0, batch = 0, head_dim = 128, causal = 0;
 };
 hipError_t launch_attn_rows(hipStream_t s, const AttnRowsArgs& a);
+
+// ---- decode_mega.hip: persistent decode-step kernel (MetaVoice-1B shape, one utterance) -----------------------------
+struct MegaLayer {
+    const bf16_t *attn_norm, *wqkv, *wo, *ffn_norm, *w1, *w3, *w2;
+};
+struct MegaArgs {
+    const bf16_t* x_in = nullptr;          // [2][2048]: input rows of layer 0 (written by the sampler / prefill)
+    const MegaLayer* layers = nullptr;     // device array [n_layer]
+    int32_t n_layer = 0, vocab = 0, cache_len = 0;
+    const bf16_t* final_norm = nullptr;
+    const bf16_t* head = nullptr;
+    bf16_t* logits = nullptr;              // [2][vocab]
+    bf16_t* kcache = nullptr;
+    bf16_t* vcache = nullptr;
+    size_t kv_layer_elems = 0;
+    const int32_t* pos = nullptr;          // [1]
+    const uint32_t* step_counter = nullptr;
+    unsigned long long *g_x = nullptr, *g_qkv = nullptr, *g_attn = nullptr, *g_h = nullptr, *g_act = nullptr;  // granule buffers
+    float* partial = nullptr;
+    uint32_t* counters = nullptr;
+    uint32_t* abort_flag = nullptr;
+    float eps = 1e-5f;
+    bf16_t* dbg = nullptr;                 // optional [n_layer][5 vectors: q|attn|h|act|x][2][5632] (mv_debug_vectors)
+};
+bool mega_supported(const mv_config& c, int rows, int n_cus);
+hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a);

@@ -276,6 +276,7 @@ __global__ void __launch_bounds__(SAMPLE_THREADS) sample_kernel(const SampleArgs
         return;
     }
 
+    if (a.step_counter != nullptr && u == 0 && tid == 0) a.step_counter[0] += 1u;  // next launch's hand-off epoch
     // ---- bookkeeping of decode_n_tokens (fast_inference_utils.py:148-174), on the device -----------------------
     bool done = false;
     if (!forced && tok == st.eoa_token) done = true;   // the EOA token itself is part of the sequence (:161)

@@ -130,7 +130,7 @@ def generate(model: Transformer, prompt: torch.Tensor, spk_emb: torch.Tensor, *,
     engine = model.engine
     sp = _sampling_from_kwargs(seed=seed, **sampling_kwargs)
     engine.begin([prompt], spk_emb, sp, max_new_tokens=max_new_tokens, end_of_audio_token=end_of_audio_token,
-                 dtype=model.config.dtype)
+                 prefill_mode=1, dtype=model.config.dtype)  # batched (MFMA) prefill, fast_inference_utils.py:123-132
     engine.run()
     seq = engine.tokens(0)
     T = prompt.size(0)

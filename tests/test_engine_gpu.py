@@ -220,3 +220,30 @@ def test_batched_prefill_ragged_two_utterances():
         T = len(prompts[u])
         assert out[0][u][: T + 4] == out[1][u][: T + 4]
     engine2.close()
+
+
+@pytest.mark.parametrize("n_layer,T,n_new,combo", [(2, 16, 24, dict(top_k=1)), (4, 40, 48, dict(top_p=0.95)), (3, 300, 40, dict(top_p=0.9, temperature=0.8))])
+def test_persistent_decode_kernel_is_bit_identical_to_per_layer_launches(n_layer, T, n_new, combo):
+    """decode_mega.hip (one launch per token: 24 layers + head, granule hand-offs) runs the same arithmetic in the same order
+    as gemv.hip / attention.hip: logits and token streams must be IDENTICAL, not merely close -- any difference is a
+    hand-off bug (stale or torn activation), which a tolerance would hide."""
+    cfgk = dict(WIDE2, n_layer=n_layer)
+    engine, sd, cfg = build(cfgk, 7)
+    prompt = synthetic.prompt_tokens(T, seed=7)
+    spk = synthetic.speaker_embedding(7)
+    sp = mv.SamplingParams(guidance_scale=3.0, seed=21, **combo)
+    engine.capture_logits(True)
+    out = {}
+    for mega in (1, 0, 1):
+        engine.tune(mega=mega)
+        engine.begin([prompt], spk, sp, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
+        engine.run()
+        res = (engine.tokens(0), engine.captured_logits(T - 1, n_new))
+        if mega in out:
+            assert res[0] == out[mega][0] and torch.equal(res[1], out[mega][1])  # run-to-run reproducible
+        out[mega] = res
+    engine.tune(mega=1)
+    assert out[1][0] == out[0][0], "token streams differ between the persistent kernel and the per-layer launches"
+    assert torch.equal(out[1][1], out[0][1]), f"logits differ: max {float((out[1][1] - out[0][1]).abs().max())}"
+    assert len(out[1][0]) == T + n_new
+    engine.close()
