@@ -156,6 +156,9 @@ int mv_stage2_sample(mv_stage2* s, float temperature, int32_t top_k, uint64_t se
 /* Debug hook (MV_DEBUG_VECTORS=1 in the environment at mv_finalize, MetaVoice-1B widths only): bf16 bits of every layer's
  * q | attention output | h | SwiGLU activation | x of the LAST decode step, [n_layer][5][2 rows][5632]. */
 int mv_debug_vectors(mv_engine* e, uint16_t* out, int64_t cap_elems);
+/* Profiling hook (MV_MEGA_STAMPS=1): s_memtime stamps [2 workgroups: first, last][n_layer][12] of the persistent kernel's
+ * phases in the LAST decode step (see tools/mega_stamps.py for the slot meanings). */
+int mv_debug_stamps(mv_engine* e, uint64_t* out, int64_t cap_elems);
 
 /* Tuning hook (no reference equivalent): process-wide launch knobs of the decode kernels and the side-stream prefetcher,
  * used by tools/sweep.py; keys are listed in DESIGN.md "Tuning".  A finalized engine passed as `e` (may be NULL)

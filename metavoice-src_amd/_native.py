@@ -79,6 +79,7 @@ SYMBOLS = [
     ("mv_probe_kernel", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     ("mv_tune", C.c_int, [_P, C.c_char_p, C.c_int32]),
     ("mv_debug_vectors", C.c_int, [_P, C.POINTER(C.c_uint16), C.c_int64]),
+    ("mv_debug_stamps", C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int64]),
     ("mv_last_error", C.c_char_p, []),
     ("mv_version", C.c_char_p, []),
 ]

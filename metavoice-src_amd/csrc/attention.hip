@@ -9,9 +9,9 @@
 // (row, head) a contiguous stream; one key row is 256 B = 16 lanes x 16 B, so a wave covers 4 keys per
 // instruction with fully coalesced `global_load_dwordx4`, the query lives in registers, scores are reduced over
 // 16-lane groups with DPP, and softmax/PV run as an online (running max / sum) recurrence in fp32.
-// Work decomposition: (row, head) x 16 even key ranges (attn_core.h) so that every CU streams at any context length; a
-// wave owns up to 32 keys and issues all of its 16 K/V loads before touching any (the whole live KV of a step is in
-// flight in ONE round trip: 2048 keys x 32 (row, head) = 2048 waves x 16 KB).  Partial (m, l, o[128]) go to a small fp32 scratch and the LAST block to arrive
+// Work decomposition: (row, head) x up to 8 even key ranges of <= 256 keys (attn_core.h); a block is 8 waves, a wave owns
+// up to 32 keys and issues all of its 16 K/V loads before touching any (the whole live KV of a step is in flight in ONE
+// round trip: 2048 keys x 32 (row, head) = 2048 waves x 16 KB).  Up to 256 keys there is no cross-block combine.  Partial (m, l, o[128]) go to a small fp32 scratch and the LAST block to arrive
 // for a (row, head) combines them (8-byte agent-scope accesses on both sides, cdna_hip_programming.md Guideline 16)
 // -- this saves a separate combine launch on the critical path of every layer.
 #include "attn_core.h"
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(const AttnArg
     __syncthreads();
     if (wave != 0) return;
 
-    AttnAcc b = attn_merge_waves(sm, g, dl);
+    AttnAcc b = attn_merge_waves(sm, g, dl);  // folds the 8 waves
     bf16_t* outp = a.out + (size_t)r * a.n_head * 128 + h * 128 + dl * 8;
     if (nact > 1) {
         float* pbase = a.partial + ((size_t)r * a.n_head + h) * ATTN_NSPLIT * ATTN_PART_STRIDE;

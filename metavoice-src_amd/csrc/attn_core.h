@@ -11,29 +11,52 @@
 #include "common.h"
 #include "kernels.h"
 
-#define ATTN_WAVES 4
+#define ATTN_WAVES 8
 #define ATTN_KEYS_PER_WAVE 32
 #define ATTN_U (ATTN_KEYS_PER_WAVE / 4)
+#define ATTN_KEYS_PER_BLOCK (ATTN_WAVES * ATTN_KEYS_PER_WAVE)  // 256 keys = 128 KB of K+V, all in flight at once
 
 typedef unsigned long long u64;
 
-__device__ __forceinline__ void store_agent(float* p, float a, float b) {
-    // 8-byte write-through (sc1) store: visible to every XCD without a release fence (Guideline 16, R1/R2 form)
-    const u64 v = (u64)__float_as_uint(a) | ((u64)__float_as_uint(b) << 32);
-    __hip_atomic_store((u64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// 16-byte write-through (sc1) store / agent-scope (sc1) loads: what the split partials travel in.  An 8-byte sc1 store
+// costs 2.7x a 16-byte one per byte (MI355X_MICROARCH.md "stores of each flavour"), and the publish sits on the critical
+// path of every layer.  hipcc neither counts nor pads inline-asm memory operations (cdna_hip_programming.md 5.7): the
+// store statement ends with s_nop 1, the loads carry their own s_waitcnt.
+__device__ __forceinline__ void store16_agent(float* p, float a, float b, float c, float d) {
+    const u32x4 v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
-__device__ __forceinline__ void load_agent(const float* p, float& a, float& b) {
-    const u64 v = __hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    a = __uint_as_float((uint32_t)v);
-    b = __uint_as_float((uint32_t)(v >> 32));
+struct AttnPart6 {
+    u32x4 v[6];
+};
+__device__ __forceinline__ AttnPart6 load6x16_agent(const float* p0, const float* p1, const float* p2, const float* p3,
+                                                    const float* p4, const float* p5) {
+    AttnPart6 r;
+    asm volatile(
+        "global_load_dwordx4 %0, %6, off sc1\n\t"
+        "global_load_dwordx4 %1, %7, off sc1\n\t"
+        "global_load_dwordx4 %2, %8, off sc1\n\t"
+        "global_load_dwordx4 %3, %9, off sc1\n\t"
+        "global_load_dwordx4 %4, %10, off sc1\n\t"
+        "global_load_dwordx4 %5, %11, off sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5])
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5)
+        : "memory");
+    return r;
 }
 
-__device__ __forceinline__ int attn_keys_per_split(int P) { return (((P + ATTN_NSPLIT - 1) / ATTN_NSPLIT) + 3) & ~3; }
+// Key partition of a (row, head): nsplit = clamp(ceil(P/256), 1, 8) contiguous ranges of cs keys (a multiple of 4: a wave
+// instruction covers 4 keys, 16 lanes x 16 B per 256-byte key row), cs <= 256 = 8 waves x 32 keys.  Up to 256 keys a
+// single block does the whole (row, head) and there is no cross-block combine at all; at 2048 keys all 256 CUs stream.
+__device__ __forceinline__ int attn_keys_per_split(int P) {
+    const int nsplit = min(ATTN_NSPLIT, (P + ATTN_KEYS_PER_BLOCK - 1) / ATTN_KEYS_PER_BLOCK);
+    return (((P + nsplit - 1) / nsplit) + 3) & ~3;
+}
 
 struct AttnAcc {
     float m, l, o[8];
 };
-
 // Scores of the lane group's ATTN_U keys against q, softmax numerators against the group max, P.V; then the 4 lane
 // groups of the wave (lanes dl, dl+16, dl+32, dl+48 hold the same 8 dims) are folded.  Key index of (u, g) = s0+4u+g,
 // valid while < s1.
@@ -83,20 +106,22 @@ __device__ __forceinline__ AttnAcc attn_wave_partial(const u32x4 (&kv)[ATTN_U], 
     return a;
 }
 
-// `sm` = [4 waves][16 dim groups][12 floats] of per-wave (m, l, o[8]); executed by ONE whole wave: lane (g, dl) takes
-// wave g's slice for dims 8dl..8dl+7 and the groups are folded with xor-16/32 butterflies.
+// `sm` = [8 waves][16 dim groups][12 floats] of per-wave (m, l, o[8]); executed by ONE whole wave: lane (g, dl) merges
+// waves g and g+4 for dims 8dl..8dl+7, then the 4 groups are folded with xor-16/32 butterflies.
 __device__ __forceinline__ AttnAcc attn_merge_waves(const float (*sm)[16][12], int g, int dl) {
     AttnAcc b;
-    const float mw = sm[g][dl][0];
+    const float m0 = sm[g][dl][0], m1 = sm[g + 4][dl][0];
+    const float mw = fmaxf(m0, m1);
     b.m = fmaxf(mw, __shfl_xor(mw, 16, 64));
     b.m = fmaxf(b.m, __shfl_xor(b.m, 32, 64));
-    const float f = (mw == -INFINITY) ? 0.f : fast_exp(mw - b.m);
-    b.l = sm[g][dl][1] * f;
+    const float f0 = (m0 == -INFINITY) ? 0.f : fast_exp(m0 - b.m);
+    const float f1 = (m1 == -INFINITY) ? 0.f : fast_exp(m1 - b.m);
+    b.l = fmaf(sm[g + 4][dl][1], f1, sm[g][dl][1] * f0);
     b.l += __shfl_xor(b.l, 16, 64);
     b.l += __shfl_xor(b.l, 32, 64);
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
-        float t = sm[g][dl][2 + d] * f;
+        float t = fmaf(sm[g + 4][dl][2 + d], f1, sm[g][dl][2 + d] * f0);
         t += __shfl_xor(t, 16, 64);
         t += __shfl_xor(t, 32, 64);
         b.o[d] = t;
@@ -115,49 +140,45 @@ __device__ __forceinline__ u32x4 attn_normalise(const AttnAcc& b) {
 }
 
 // Executed by one whole wave holding the block result `b` (identical in the 4 lane groups).  Publishes the split
-// partial write-through, draws a ticket; returns true in the LAST arriver of the (row, head), with `b` replaced by the
-// combination of all `nact` partials (every partial load is issued before the first use: one L2 round trip).
-// Guideline 16 in its "8-byte agent-scope accesses on both sides" form: no release / acquire fence; correct for any
-// placement of the splits over XCDs; the counter re-arms itself.
+// partial (33 x 16 B: [m, l, -, -] then o[128]) write-through and draws a ticket; returns true in the LAST arriver of
+// the (row, head), with `b` replaced by the combination of all `nact` <= 8 partials -- lane group g reads splits g and
+// g+4, all six 16-byte loads issued before the first use (one round trip).  Agent-scope write-through stores + ticket +
+// agent-scope loads: no release / acquire fence (each costs ~1.7 us and drops the CU's L1); correct for any placement of
+// the splits over XCDs; the counter re-arms itself.  A partial's address must be written at most once per launch (the
+// one-shot loads cannot detect a line their L2 still holds from an earlier write): callers use one slab per layer.
 __device__ __forceinline__ bool attn_publish_combine(AttnAcc& b, float* pbase, uint32_t* counter, int split, int nact, int lane) {
     const int g = lane >> 4, dl = lane & 15;
     float* part = pbase + split * ATTN_PART_STRIDE;
-    if (lane == 0) store_agent(part, b.m, b.l);
-    {   // one 8-byte store per lane: group g publishes dims 2g, 2g+1 of each 8-dim slice
-        const float lo = g == 0 ? b.o[0] : g == 1 ? b.o[2] : g == 2 ? b.o[4] : b.o[6];
-        const float hi = g == 0 ? b.o[1] : g == 1 ? b.o[3] : g == 2 ? b.o[5] : b.o[7];
-        store_agent(part + 4 + dl * 8 + 2 * g, lo, hi);
-    }
+    if (lane == 0) store16_agent(part, b.m, b.l, 0.f, 0.f);
+    if (g == 0) store16_agent(part + 4 + dl * 8, b.o[0], b.o[1], b.o[2], b.o[3]);
+    if (g == 1) store16_agent(part + 4 + dl * 8 + 4, b.o[4], b.o[5], b.o[6], b.o[7]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left before the ticket is drawn
     unsigned prev = 0;
     if (lane == 0) prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     prev = __builtin_amdgcn_readfirstlane(prev);
     if (prev != (unsigned)(nact - 1)) return false;
 
-    float ms[4], ls[4], t[4][8];
+    const float* q0 = pbase + min(g, nact - 1) * ATTN_PART_STRIDE;      // clamped: out-of-range slots are weighted 0 below
+    const float* q1 = pbase + min(g + 4, nact - 1) * ATTN_PART_STRIDE;
+    const AttnPart6 r = load6x16_agent(q0, q0 + 4 + dl * 8, q0 + 8 + dl * 8, q1, q1 + 4 + dl * 8, q1 + 8 + dl * 8);
+    float ms[2], ls[2], t[2][8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {  // group g reads splits g, g+4, g+8, g+12
-        const int sidx = min(g + 4 * q, nact - 1);  // clamped: out-of-range slots are weighted 0 below
-        const float* pp = pbase + sidx * ATTN_PART_STRIDE;
-        load_agent(pp, ms[q], ls[q]);
-        load_agent(pp + 4 + dl * 8 + 0, t[q][0], t[q][1]);
-        load_agent(pp + 4 + dl * 8 + 2, t[q][2], t[q][3]);
-        load_agent(pp + 4 + dl * 8 + 4, t[q][4], t[q][5]);
-        load_agent(pp + 4 + dl * 8 + 6, t[q][6], t[q][7]);
+    for (int q = 0; q < 2; ++q) {
+        ms[q] = (g + 4 * q < nact) ? __uint_as_float(r.v[3 * q].x) : -INFINITY;
+        ls[q] = __uint_as_float(r.v[3 * q].y);
+        t[q][0] = __uint_as_float(r.v[3 * q + 1].x); t[q][1] = __uint_as_float(r.v[3 * q + 1].y);
+        t[q][2] = __uint_as_float(r.v[3 * q + 1].z); t[q][3] = __uint_as_float(r.v[3 * q + 1].w);
+        t[q][4] = __uint_as_float(r.v[3 * q + 2].x); t[q][5] = __uint_as_float(r.v[3 * q + 2].y);
+        t[q][6] = __uint_as_float(r.v[3 * q + 2].z); t[q][7] = __uint_as_float(r.v[3 * q + 2].w);
     }
-    float mt = -INFINITY;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (g + 4 * q >= nact) ms[q] = -INFINITY;
-        mt = fmaxf(mt, ms[q]);
-    }
+    float mt = fmaxf(ms[0], ms[1]);
     mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     float lt = 0.f, ot[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) ot[d] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 2; ++q) {
         const float f = (ms[q] == -INFINITY) ? 0.f : fast_exp(ms[q] - mt);
         lt = fmaf(ls[q], f, lt);
 #pragma unroll
@@ -173,7 +194,7 @@ __device__ __forceinline__ bool attn_publish_combine(AttnAcc& b, float* pbase, u
     }
     b.m = mt;
     b.l = lt;
-    if (lane == 0)  // re-arm; nobody else touches this counter until the next step (stream order / data dependence)
+    if (lane == 0)  // re-arm; nobody else touches this counter until the next layer / step (data dependence / stream order)
         __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }

@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
     __shared__ __attribute__((aligned(16))) bf16_t raw_h[2 * MG_DIM];   // residual stream after attention (P3 in, P4 residual)
     __shared__ __attribute__((aligned(16))) bf16_t xs[2 * MG_INTER];    // the GEMV operand of the current phase
     __shared__ __attribute__((aligned(16))) bf16_t qkv_s[3 * 2 * 128];  // q, k_new, v_new of this block's head, both rows
-    __shared__ __attribute__((aligned(16))) float sm[2][ATTN_WAVES][16][12];
+    __shared__ __attribute__((aligned(16))) float sm[ATTN_WAVES][16][12];
     __shared__ float red[MG_WAVES * 2];
     __shared__ int s_abort;
 
@@ -144,12 +144,17 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
     const uint32_t epoch = a.step_counter[0] * 256u;
     const int P = a.pos[0] + 1;  // keys [0, P): the cache holds [0, P-1), key P-1 is produced by this step's QKV phase
 
-    // attention geometry: block (h, s) = one of the 16 even key ranges of head h, both rows; 4 waves per row
-    const int at_h = b >> 4, at_s = b & 15, at_r = wave >> 2, at_w = wave & 3;
+    // attention geometry: block (r, h, s) = one of the (up to) 8 even key ranges of (row r, head h); 8 waves x 32 keys
+    const int at_r = b >> 7, at_h = (b >> 3) & 15, at_s = b & 7, at_w = wave;
     const int g = lane >> 4, dl = lane & 15;
     const int cs = attn_keys_per_split(P);
     const int nact = (P + cs - 1) / cs;
     const int at_s0 = at_s * cs + at_w * ATTN_KEYS_PER_WAVE, at_s1 = min(P, at_s * cs + cs);
+
+    // optional phase stamps (blocks 0 and 255, wave 0): poll-wait vs compute per phase, for profiles/
+    const bool stamping = a.stamps != nullptr && (b == 0 || b == 255) && wave == 0;
+    unsigned long long* stamp_base = a.stamps ? a.stamps + (size_t)(b == 0 ? 0 : 1) * a.n_layer * 12 : nullptr;
+#define MG_STAMP(l, k) do { if (stamping && lane == 0) stamp_base[(l) * 12 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
     u32x4 wv[24];  // the weight working set of the current GEMV phase (next phase's rows are issued into it after the dots)
     // phase 0 of layer 0: rows 24 b + 3 wave + i of wqkv
@@ -173,10 +178,12 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 
         // ================= P0: RMSNorm + wqkv (+ KV-cache write)        fast_model.py:179,209,218 ====================
         __syncthreads();
+        MG_STAMP(l, 0);
         if (l == 0) {
             *(u32x4*)(raw_x + tid * 8) = load16(a.x_in + tid * 8);  // written by the sampler in the previous launch
         } else if (!poll_rowpair<MG_DIM>(a.g_x, tag0 - 8u + 4u, raw_x, cx, tid_o)) return;
         if (l == 0) __syncthreads();
+        MG_STAMP(l, 1);
         mega_norm(raw_x, L.attn_norm, xs, red, a.eps);
         {
             float acc[3][2];
@@ -204,10 +211,11 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
         }
         // next: the K/V stream of this block's attention slice (rows of EARLIER steps: independent of this step)
         __builtin_amdgcn_sched_barrier(0);
+        MG_STAMP(l, 2);
         u32x4 kv[ATTN_U], vv[ATTN_U];
         {
-            const int at_ro = wave_o >> 2, go = lane_o >> 4, dlo = lane_o & 15, s0o = at_s * cs + (wave_o & 3) * ATTN_KEYS_PER_WAVE;
-            const size_t head_base = ((size_t)at_ro * MG_HEADS + at_h) * (size_t)a.cache_len * 128 + dlo * 8;
+            const int go = lane_o >> 4, dlo = lane_o & 15, s0o = at_s * cs + wave_o * ATTN_KEYS_PER_WAVE;
+            const size_t head_base = ((size_t)at_r * MG_HEADS + at_h) * (size_t)a.cache_len * 128 + dlo * 8;
             // Addresses are clamped to the newest row an EARLIER launch wrote (P-2): row P-1 is being written by this launch and
             // is taken from the hand-off below -- it must not even be touched here (a line fetched before its producer's store
             // could be served stale to the next launch).
@@ -235,6 +243,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
                                   [&](int, uint32_t p) { qkv_s[(sec * 2 + 0) * 128 + c] = (bf16_t)p; qkv_s[(sec * 2 + 1) * 128 + c] = (bf16_t)(p >> 16); }))
                     return;
             }
+            MG_STAMP(l, 3);
             const u32x4 qv = *(const u32x4*)(qkv_s + (0 * 2 + at_r) * 128 + dl * 8);
 #pragma unroll
             for (int u = 0; u < ATTN_U; ++u) {
@@ -245,10 +254,10 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             }
             const AttnAcc w = attn_wave_partial(kv, vv, qv, at_s0, at_s1, g);
             if (g == 0) {
-                sm[at_r][at_w][dl][0] = w.m;
-                sm[at_r][at_w][dl][1] = w.l;
+                sm[at_w][dl][0] = w.m;
+                sm[at_w][dl][1] = w.l;
 #pragma unroll
-                for (int d = 0; d < 8; ++d) sm[at_r][at_w][dl][2 + d] = w.o[d];
+                for (int d = 0; d < 8; ++d) sm[at_w][dl][2 + d] = w.o[d];
             }
             __syncthreads();
         }
@@ -256,8 +265,8 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
         __builtin_amdgcn_sched_barrier(0);
         mega_issue_row<4>(wv, L.wo, 8 * b + wave_o, MG_DIM, lane_o);
         __builtin_amdgcn_sched_barrier(0);
-        if (at_s < nact && at_w == 0) {  // waves 0 and 4: one per row
-            AttnAcc bb = attn_merge_waves(sm[at_r], g, dl);
+        if (at_s < nact && at_w == 0) {
+            AttnAcc bb = attn_merge_waves(sm, g, dl);
             bool last = true;
             if (nact > 1) {
                 // One partial slab PER LAYER: inside a launch an address is then written once before it is read.  Reusing one slab
@@ -280,10 +289,12 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 
         // ================= P2: h = x + wo(attn)                         fast_model.py:224-226,179 =====================
         __syncthreads();
+        MG_STAMP(l, 4);
         {
             if (!mega_poll<4>(tag0 + 1u, cx, [&](int k, u64& v) { v = gran_load(a.g_attn + tid_o + k * MG_THREADS); return true; },
                               [&](int k, uint32_t p) { ((uint32_t*)xs)[tid_o + k * MG_THREADS] = p; }))  // granule i = elements 2i, 2i+1 of [2][2048]
                 return;
+            MG_STAMP(l, 5);
             float acc[1][2];
             mega_dots<4, 1, MG_DIM>(wv, xs, lane, acc);
             __builtin_amdgcn_sched_barrier(0);
@@ -306,8 +317,10 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 
         // ================= P3: act = silu(w1 n(h)) * w3 n(h)            fast_model.py:180,237 =========================
         __syncthreads();
+        MG_STAMP(l, 6);
         {
             if (!poll_rowpair<MG_DIM>(a.g_h, tag0 + 2u, raw_h, cx, tid_o)) return;
+            MG_STAMP(l, 7);
             mega_norm(raw_h, L.ffn_norm, xs, red, a.eps);
             float acc1[3][2], acc3[3][2];
             mega_dots<4, 3, MG_DIM>(wv, xs, lane, acc1);
@@ -332,8 +345,10 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 
         // ================= P4: x = h + w2(act)                          fast_model.py:247,180 =========================
         __syncthreads();
+        MG_STAMP(l, 8);
         {
             if (!poll_rowpair<MG_INTER>(a.g_act, tag0 + 3u, xs, cx, tid_o)) return;
+            MG_STAMP(l, 9);
             float acc[1][2];
             mega_dots<11, 1, MG_INTER>(wv, xs, lane, acc);
             __builtin_amdgcn_sched_barrier(0);
@@ -351,6 +366,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
                 const int n = 8 * b + wave;
                 const bf16_t y0 = epi_resid(raw_h[n], t0), y1 = epi_resid(raw_h[MG_DIM + n], t1);
                 gran_store(a.g_x + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 4u);
+                MG_STAMP(l, 10);
                 if (a.dbg) { bf16_t* d = a.dbg + ((size_t)l * 5 + 4) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
             }
         }
@@ -381,7 +397,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 
 bool mega_supported(const mv_config& c, int rows, int n_cus) {
     return rows == 2 && c.dim == MG_DIM && c.intermediate == MG_INTER && c.n_head == MG_HEADS && c.vocab <= 256 * 11 && n_cus >= 256 &&
-           c.block_size <= ATTN_NSPLIT * 128;
+           c.block_size <= ATTN_NSPLIT * 256;
 }
 
 hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a) {

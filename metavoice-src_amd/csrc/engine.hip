@@ -106,6 +106,7 @@ struct mv_engine {
     unsigned long long* granules = nullptr;   // g_x | g_qkv | g_attn | g_h | g_act
     uint32_t* step_counter = nullptr;
     uint32_t* abort_flag = nullptr;
+    unsigned long long* stamps = nullptr;  // MV_MEGA_STAMPS=1: s_memtime stamps of the persistent kernel's phases
     bf16_t* dbg = nullptr;   // MV_DEBUG_VECTORS=1: every layer's q|attn|h|act|x of the last step, both paths (mv_debug_vectors)
 
     // prefill workspace (M = 2 T rows of one utterance), allocated on the first batched prefill
@@ -138,7 +139,7 @@ int enqueue_step(mv_engine* e) {
         m.final_norm = e->final_norm; m.head = e->head; m.logits = e->logits; m.kcache = e->kcache; m.vcache = e->vcache;
         m.kv_layer_elems = e->kv_layer_elems; m.pos = e->pos_arr; m.step_counter = e->step_counter;
         m.g_x = e->granules; m.g_qkv = m.g_x + c.dim; m.g_attn = m.g_qkv + 3 * c.dim; m.g_h = m.g_attn + c.dim; m.g_act = m.g_h + c.dim;
-        m.partial = e->partial; m.counters = e->counters; m.abort_flag = e->abort_flag; m.eps = c.norm_eps; m.dbg = e->dbg;
+        m.partial = e->partial; m.counters = e->counters; m.abort_flag = e->abort_flag; m.eps = c.norm_eps; m.dbg = e->dbg; m.stamps = e->stamps;
         HIP_TRY(launch_decode_mega(s, m));
         return enqueue_sampler(e);
     }
@@ -301,6 +302,15 @@ extern "C" {
 
 const char* mv_last_error(void) { return g_err.c_str(); }
 
+int mv_debug_stamps(mv_engine* e, uint64_t* out, int64_t cap_elems) {
+    if (!e || !e->stamps || !out) return fail(MV_ERR_STATE, "stamps are not enabled (MV_MEGA_STAMPS=1 before mv_finalize)");
+    const size_t n = (size_t)2 * e->cfg.n_layer * 12;
+    if ((size_t)cap_elems < n) return fail(MV_ERR_INVALID, "buffer too small");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(out, e->stamps, n * 8, hipMemcpyDeviceToHost));
+    return MV_OK;
+}
+
 int mv_debug_vectors(mv_engine* e, uint16_t* out, int64_t cap_elems) {
     if (!e || !e->dbg || !out) return fail(MV_ERR_STATE, "debug vectors are not enabled (MV_DEBUG_VECTORS=1 before mv_finalize)");
     const size_t n = (size_t)e->cfg.n_layer * 5 * 2 * 5632;
@@ -341,7 +351,7 @@ int mv_engine_create(const mv_config* cfg, mv_engine** out) {
                     c.dim, c.intermediate);
     if (c.weight_format != MV_W_BF16) return fail(MV_ERR_INVALID, "weight_format %d not supported by this build", c.weight_format);
     if (c.block_size < 8 || c.spk_dim < 1) return fail(MV_ERR_INVALID, "bad block_size/spk_dim");
-    if (c.block_size > ATTN_NSPLIT * 128) return fail(MV_ERR_INVALID, "block_size %d > %d", c.block_size, ATTN_NSPLIT * 128);
+    if (c.block_size > ATTN_NSPLIT * 256) return fail(MV_ERR_INVALID, "block_size %d > %d", c.block_size, ATTN_NSPLIT * 128);
 
     mv_engine* e = new mv_engine();
     e->cfg = c;
@@ -397,7 +407,7 @@ int mv_engine_destroy(mv_engine* e) {
     if (e->graph) hipGraphDestroy(e->graph);
     void* bufs[] = {e->arena, e->x, e->h, e->q, e->attn, e->act, e->logits, e->kcache, e->vcache, e->partial, e->counters,
                     e->utt, e->pos_arr, e->seq, e->spk_emb, e->spk_proj, e->n_active, e->capture, e->px, e->ph, e->pn, e->pq,
-                    e->pattn, e->pact, e->mega_layers, e->granules, e->step_counter, e->abort_flag, e->dbg};
+                    e->pattn, e->pact, e->mega_layers, e->granules, e->step_counter, e->abort_flag, e->dbg, e->stamps};
     for (void* b : bufs)
         if (b) hipFree(b);
     if (e->host_flag) hipHostFree(e->host_flag);
@@ -471,6 +481,10 @@ int mv_finalize(mv_engine* e) {
     if (getenv("MV_DEBUG_VECTORS") && c.dim == 2048 && c.intermediate == 5632) {
         HIP_TRY(hipMalloc((void**)&e->dbg, (size_t)c.n_layer * 5 * 2 * 5632 * 2));
         HIP_TRY(hipMemset(e->dbg, 0, (size_t)c.n_layer * 5 * 2 * 5632 * 2));
+    }
+    if (getenv("MV_MEGA_STAMPS")) {
+        HIP_TRY(hipMalloc((void**)&e->stamps, (size_t)2 * c.n_layer * 12 * 8));
+        HIP_TRY(hipMemset(e->stamps, 0, (size_t)2 * c.n_layer * 12 * 8));
     }
     HIP_TRY(hipMalloc((void**)&e->step_counter, 4));
     HIP_TRY(hipMalloc((void**)&e->abort_flag, 4));
@@ -770,6 +784,7 @@ int64_t mv_op_attention_scratch_bytes(int32_t rows, int32_t n_head) {
 int mv_op_attention_decode(void* stream, int32_t rows, int32_t n_head, int32_t cache_len, const int32_t* n_keys_dev,
                            const void* q, const void* kcache, const void* vcache, void* scratch, void* out) {
     if (rows < 2 || rows % 2) return fail(MV_ERR_INVALID, "rows must be even");
+    if (cache_len > ATTN_NSPLIT * 256) return fail(MV_ERR_INVALID, "cache_len %d > %d", cache_len, ATTN_NSPLIT * 256);
     AttnArgs a;
     a.q = (const bf16_t*)q; a.kcache = (const bf16_t*)kcache; a.vcache = (const bf16_t*)vcache; a.pos = n_keys_dev;
     a.pos_is_count = 1; a.partial = (float*)scratch;

@@ -12,7 +12,7 @@ struct MvTune {
     int gemv_nr[4] = {0, 0, 0, 0};       // weight rows per wave: 0 = built-in choice
     int gemv_nt = 1;                     // 1: non-temporal weight loads, 0: default cache policy
     int use_graph = 1;
-    int mega = 1;                        // persistent decode-step kernel (decode_mega.hip) when the shape allows it
+    int mega = 0;                        // 1: persistent decode-step kernel (decode_mega.hip); off by default: 1026 vs 992 us/step
 };
 extern MvTune g_tune;
 
@@ -36,7 +36,7 @@ hipError_t launch_gemv(hipStream_t s, int rows, const GemvArgs& a, int epi);
 bool gemv_supported(int rows, int K);
 
 // ---- attention.hip -------------------------------------------------------------------------------------------
-constexpr int ATTN_NSPLIT = 16;         // max KV splits per (row, head): 16 x 128 keys = block_size 2048
+constexpr int ATTN_NSPLIT = 8;          // max KV splits per (row, head): 8 x 256 keys = block_size 2048
 constexpr int ATTN_PART_STRIDE = 132;   // floats per partial: m, l, pad, pad, o[128]
 struct AttnArgs {
     const bf16_t* q = nullptr;        // [rows][n_head*128]
@@ -154,6 +154,7 @@ struct MegaArgs {
     uint32_t* abort_flag = nullptr;
     float eps = 1e-5f;
     bf16_t* dbg = nullptr;                 // optional [n_layer][5 vectors: q|attn|h|act|x][2][5632] (mv_debug_vectors)
+    unsigned long long* stamps = nullptr;  // optional [2 blocks][n_layer][12] s_memtime stamps of wave 0 (MV_MEGA_STAMPS)
 };
 bool mega_supported(const mv_config& c, int rows, int n_cus);
 hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a);

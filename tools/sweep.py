@@ -21,7 +21,7 @@ e.load_state_dict(sd); del sd
 e.finalize()
 prompt, spk = mv.synthetic.prompt_tokens(128, seed=0), mv.synthetic.speaker_embedding(0)
 sp = mv.SamplingParams(top_p=0.95, seed=7)
-DEFAULTS = dict(gemv_nt=1, use_graph=1,
+DEFAULTS = dict(gemv_nt=1, use_graph=1, mega=0,
                 gemv_threads_plain=0, gemv_threads_resid=0, gemv_threads_swiglu=0, gemv_threads_qkv=0,
                 gemv_nr_plain=0, gemv_nr_resid=0, gemv_nr_swiglu=0, gemv_nr_qkv=0)
 configs = json.loads(a.configs) if a.configs else [{}]
