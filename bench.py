@@ -177,7 +177,7 @@ def main():
         ms, nbytes = C.c_float(0), C.c_double(0)
         N.check(N.lib().mv_probe_kernel(engine._h, 3, 24 * 20, C.byref(ms), C.byref(nbytes)))
         ach = nbytes.value / (ms.value * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "gemv_kernel<2,4,2,SWIGLU> (RMSNorm + w1|w3 + SiLU gate)",
+        roofline = {"bound": "hbm", "kernel": "gemv_kernel<2,4,1,SWIGLU,nt> (RMSNorm + w1|w3 + SiLU gate)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": None, "bytes_per_launch": nbytes.value, "avg_launch_us": round(ms.value * 1e3, 2)}
         per_kernel = {}
