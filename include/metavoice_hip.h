@@ -109,6 +109,14 @@ int64_t mv_op_attention_scratch_bytes(int32_t rows, int32_t n_head);
 int mv_op_sample(void* stream, int32_t vocab, const void* logits_pair, const mv_sampling* s, uint32_t step,
                  int32_t* token_out, float* probs_out);
 
+/* int4 group-128 weight-only path (fam/llm/fast_quantize.py:70-132,204-216).  w: [N][K] bf16 -> codes [N][K/2] bytes (column
+ * 2j low nibble, 2j+1 high nibble of byte j), scales_zeros [N][K/128] uint32 (bf16 scale | bf16 zero << 16), optional
+ * dequantised [N][K] bf16 (may alias w).  mv_op_gemv_int4: out = epilogue(x . dequant(W)^T) like mv_op_gemv /
+ * mv_op_swiglu_gemv (codes2 != NULL selects the SwiGLU form). */
+int mv_op_quantize_int4(void* stream, int32_t N, int32_t K, const void* w, void* codes, void* scales_zeros, void* dequantised);
+int mv_op_gemv_int4(void* stream, int32_t rows, int32_t N, int32_t K, const void* x, const void* codes, const void* scales_zeros,
+                    const void* codes2, const void* scales_zeros2, const void* norm_w, float eps, const void* residual, void* out);
+
 /* Many-row blocks (first-stage prefill, second stage): out[M][N] = epilogue(a[M][K] . w[N][K]^T), bf16 in/out, fp32 MFMA
  * accumulate; w2 != NULL: SwiGLU gate bf16(bf16(silu(a.w^T + bias)) * bf16(a.w2^T + bias2)); gelu: exact-erf GELU;
  * residual [M][N] bf16 added after the bf16 rounding of the product (fam/llm/fast_model.py:179-180,237). */

@@ -67,6 +67,8 @@ SYMBOLS = [
     ("mv_op_attention_decode", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
     ("mv_op_attention_scratch_bytes", C.c_int64, [C.c_int32, C.c_int32]),
     ("mv_op_sample", C.c_int, [_P, C.c_int32, _P, C.POINTER(mv_sampling), C.c_uint32, _P, _P]),
+    ("mv_op_quantize_int4", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    ("mv_op_gemv_int4", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P]),
     ("mv_op_gemm", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
     ("mv_op_attention_rows", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("mv_stage2_create", C.c_int, [C.POINTER(mv_stage2_config), C.POINTER(_P)]),

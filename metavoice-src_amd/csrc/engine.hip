@@ -48,6 +48,9 @@ __global__ void f32_to_bf16_kernel(const float* in, bf16_t* out, size_t n) {
 struct LayerW {
     bf16_t *attn_norm = nullptr, *wqkv = nullptr, *wo = nullptr, *ffn_norm = nullptr, *w1 = nullptr, *w3 = nullptr,
            *w2 = nullptr;
+    // int4 mode: packed codes + (scale, zero) per matrix, in the order wqkv, wo, w1, w3, w2
+    unsigned char* q[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t* sz[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 struct Slot {
@@ -83,6 +86,8 @@ struct mv_engine {
     std::vector<LayerW> layers;
     std::vector<Slot> slots;
     bool finalized = false;
+    unsigned char* q_arena = nullptr;   // int4 mode: all codes and (scale, zero) words
+    size_t q_arena_bytes = 0;
 
     // activations / state
     bf16_t *x = nullptr, *h = nullptr, *q = nullptr, *attn = nullptr, *act = nullptr, *logits = nullptr;
@@ -129,6 +134,13 @@ namespace {
 int enqueue_tail(mv_engine* e);
 int enqueue_sampler(mv_engine* e);
 
+GemvI4Args to_i4(const GemvArgs& a, const unsigned char* codes, const uint32_t* sz) {
+    GemvI4Args q;
+    q.x = a.x; q.codes = codes; q.sz = sz; q.norm_w = a.norm_w; q.residual = a.residual; q.out = a.out; q.kcache = a.kcache;
+    q.vcache = a.vcache; q.pos = a.pos; q.cache_len = a.cache_len; q.n_head = a.n_head; q.dim = a.dim; q.N = a.N; q.K = a.K; q.eps = a.eps;
+    return q;
+}
+
 int enqueue_step(mv_engine* e) {
     const mv_config& c = e->cfg;
     const int R = e->R;
@@ -152,7 +164,8 @@ int enqueue_step(mv_engine* e) {
             a.x = e->x; a.w = w.wqkv; a.norm_w = w.attn_norm; a.out = e->q; a.kcache = kc; a.vcache = vc;
             a.pos = e->pos_arr; a.cache_len = c.block_size; a.n_head = c.n_head; a.dim = c.dim;
             a.N = 3 * c.dim; a.K = c.dim; a.eps = c.norm_eps;
-            HIP_TRY(launch_gemv(s, R, a, GEMV_QKV));
+            if (c.weight_format == MV_W_INT4_G128) HIP_TRY(launch_gemv_i4(s, R, to_i4(a, w.q[0], w.sz[0]), GEMV_QKV));
+            else HIP_TRY(launch_gemv(s, R, a, GEMV_QKV));
         }
         auto dbg_copy = [&](int which, const bf16_t* src, int cols) -> hipError_t {
             if (!e->dbg || R != 2) return hipSuccess;
@@ -175,20 +188,26 @@ int enqueue_step(mv_engine* e) {
         {   // h = x + wo(attn)                            (fast_model.py:226,179)
             GemvArgs a;
             a.x = e->attn; a.w = w.wo; a.residual = e->x; a.out = e->h; a.N = c.dim; a.K = c.dim;
-            HIP_TRY(launch_gemv(s, R, a, GEMV_RESID));
+            if (c.weight_format == MV_W_INT4_G128) HIP_TRY(launch_gemv_i4(s, R, to_i4(a, w.q[1], w.sz[1]), GEMV_RESID));
+            else HIP_TRY(launch_gemv(s, R, a, GEMV_RESID));
         }
         HIP_TRY(dbg_copy(2, e->h, c.dim));
         {   // act = silu(w1 n(h)) * w3 n(h)               (fast_model.py:180,237)
             GemvArgs a;
             a.x = e->h; a.w = w.w1; a.w2 = w.w3; a.norm_w = w.ffn_norm; a.out = e->act; a.N = c.intermediate;
             a.K = c.dim; a.eps = c.norm_eps;
-            HIP_TRY(launch_gemv(s, R, a, GEMV_SWIGLU));
+            if (c.weight_format == MV_W_INT4_G128) {
+                GemvI4Args q = to_i4(a, w.q[2], w.sz[2]);
+                q.codes2 = w.q[3]; q.sz2 = w.sz[3];
+                HIP_TRY(launch_gemv_i4(s, R, q, GEMV_SWIGLU));
+            } else HIP_TRY(launch_gemv(s, R, a, GEMV_SWIGLU));
         }
         HIP_TRY(dbg_copy(3, e->act, c.intermediate));
         {   // x = h + w2(act)                             (fast_model.py:247,180)
             GemvArgs a;
             a.x = e->act; a.w = w.w2; a.residual = e->h; a.out = e->x; a.N = c.dim; a.K = c.intermediate;
-            HIP_TRY(launch_gemv(s, R, a, GEMV_RESID));
+            if (c.weight_format == MV_W_INT4_G128) HIP_TRY(launch_gemv_i4(s, R, to_i4(a, w.q[4], w.sz[4]), GEMV_RESID));
+            else HIP_TRY(launch_gemv(s, R, a, GEMV_RESID));
         }
         HIP_TRY(dbg_copy(4, e->x, c.dim));
     }
@@ -349,7 +368,11 @@ int mv_engine_create(const mv_config* cfg, mv_engine** out) {
     if (!gemv_supported(2 * c.max_utterances, c.dim) || !gemv_supported(2 * c.max_utterances, c.intermediate))
         return fail(MV_ERR_INVALID, "unsupported dim/intermediate %d/%d (K must be a multiple of 8 with ceil(K/512) in {1,2,4,11})",
                     c.dim, c.intermediate);
-    if (c.weight_format != MV_W_BF16) return fail(MV_ERR_INVALID, "weight_format %d not supported by this build", c.weight_format);
+    if (c.weight_format != MV_W_BF16 && c.weight_format != MV_W_INT4_G128)
+        return fail(MV_ERR_INVALID, "weight_format %d not supported by this build (bf16 and int4 are)", c.weight_format);
+    if (c.weight_format == MV_W_INT4_G128 && (!gemv_i4_supported(2 * c.max_utterances, c.dim) || !gemv_i4_supported(2 * c.max_utterances, c.intermediate)))
+        return fail(MV_ERR_INVALID, "int4: dim/intermediate %d/%d must be multiples of 128 in (0,2048] or (4096,6144], <= 2 utterances",
+                    c.dim, c.intermediate);
     if (c.block_size < 8 || c.spk_dim < 1) return fail(MV_ERR_INVALID, "bad block_size/spk_dim");
     if (c.block_size > ATTN_NSPLIT * 256) return fail(MV_ERR_INVALID, "block_size %d > %d", c.block_size, ATTN_NSPLIT * 128);
 
@@ -405,7 +428,7 @@ int mv_engine_destroy(mv_engine* e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
     if (e->graph) hipGraphDestroy(e->graph);
-    void* bufs[] = {e->arena, e->x, e->h, e->q, e->attn, e->act, e->logits, e->kcache, e->vcache, e->partial, e->counters,
+    void* bufs[] = {e->q_arena, e->arena, e->x, e->h, e->q, e->attn, e->act, e->logits, e->kcache, e->vcache, e->partial, e->counters,
                     e->utt, e->pos_arr, e->seq, e->spk_emb, e->spk_proj, e->n_active, e->capture, e->px, e->ph, e->pn, e->pq,
                     e->pattn, e->pact, e->mega_layers, e->granules, e->step_counter, e->abort_flag, e->dbg, e->stamps};
     for (void* b : bufs)
@@ -455,6 +478,34 @@ int mv_finalize(mv_engine* e) {
         if (!s.loaded) return fail(MV_ERR_MISSING_WEIGHT, "tensor '%s' was never loaded", s.name.c_str());
     const mv_config& c = e->cfg;
     const int R = e->R, U = c.max_utterances;
+    if (c.weight_format == MV_W_INT4_G128) {
+        // WeightOnlyInt4QuantHandler (fast_quantize.py:258-361): every nn.Linear with out_features % 8 == 0 -- wqkv, wo, w1, w3,
+        // w2 and speaker_cond_pos; the 2562-row LM head stays bf16.  The bf16 arena is overwritten with the DEQUANTISED
+        // weights, so the MFMA prefill and the (hoisted) speaker projection see exactly what the int4 decode kernels see.
+        const int64_t shapes[5][2] = {{3 * (int64_t)c.dim, c.dim}, {c.dim, c.dim}, {c.intermediate, c.dim}, {c.intermediate, c.dim},
+                                      {c.dim, c.intermediate}};
+        size_t per_layer = 0;
+        for (auto& sh : shapes) per_layer += align_up((size_t)sh[0] * sh[1] / 2, 256) + align_up((size_t)sh[0] * (sh[1] / 128) * 4, 256);
+        const size_t spk_bytes = align_up((size_t)c.dim * c.spk_dim / 2, 256) + align_up((size_t)c.dim * ((c.spk_dim + 127) / 128) * 4, 256);
+        e->q_arena_bytes = per_layer * c.n_layer + spk_bytes;
+        HIP_TRY(hipMalloc((void**)&e->q_arena, e->q_arena_bytes));
+        size_t off = 0;
+        for (int l = 0; l < c.n_layer; ++l) {
+            LayerW& w = e->layers[l];
+            bf16_t* src[5] = {w.wqkv, w.wo, w.w1, w.w3, w.w2};
+            for (int m = 0; m < 5; ++m) {
+                w.q[m] = e->q_arena + off; off += align_up((size_t)shapes[m][0] * shapes[m][1] / 2, 256);
+                w.sz[m] = (uint32_t*)(e->q_arena + off); off += align_up((size_t)shapes[m][0] * (shapes[m][1] / 128) * 4, 256);
+                HIP_TRY(launch_quantize_i4(e->stream, src[m], (int)shapes[m][0], (int)shapes[m][1], w.q[m], w.sz[m], src[m]));
+            }
+        }
+        if (c.spk_dim % 128 == 0) {  // speaker_cond_pos: only its dequantised values are ever used (the projection is hoisted)
+            unsigned char* qs = e->q_arena + off;
+            uint32_t* ss = (uint32_t*)(qs + align_up((size_t)c.dim * c.spk_dim / 2, 256));
+            HIP_TRY(launch_quantize_i4(e->stream, e->spk_w, c.dim, c.spk_dim, qs, ss, e->spk_w));
+        }
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     e->kv_layer_elems = (size_t)R * c.n_head * c.block_size * 128;
     HIP_TRY(hipMalloc((void**)&e->x, (size_t)R * c.dim * 2));
     HIP_TRY(hipMalloc((void**)&e->h, (size_t)R * c.dim * 2));
@@ -497,7 +548,7 @@ int mv_finalize(mv_engine* e) {
         int dev = 0, n_cus = 0;
         HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev));
-        e->mega_ok = mega_supported(c, R, n_cus);
+        e->mega_ok = mega_supported(c, R, n_cus) && c.weight_format == MV_W_BF16;
         if (e->mega_ok) {
             std::vector<MegaLayer> ml(c.n_layer);
             for (int l = 0; l < c.n_layer; ++l) {
@@ -519,7 +570,11 @@ int mv_finalize(mv_engine* e) {
 int64_t mv_model_bytes(const mv_engine* e) {
     if (!e) return 0;
     int64_t b = 0;
-    for (auto& s : e->slots) b += s.rows * s.cols * 2;
+    for (auto& s : e->slots) {
+        const bool quantised = e->cfg.weight_format == MV_W_INT4_G128 && s.rows % 8 == 0 && s.cols % 128 == 0 && s.rows > 1 &&
+                               s.name.find("embeddings") == std::string::npos;
+        b += quantised ? s.rows * s.cols / 2 + s.rows * (s.cols / 128) * 4 : s.rows * s.cols * 2;
+    }
     return b;
 }
 
@@ -792,6 +847,24 @@ int mv_op_attention_decode(void* stream, int32_t rows, int32_t n_head, int32_t c
     a.out = (bf16_t*)out; a.n_head = n_head; a.cache_len = cache_len;
     HIP_TRY(hipMemsetAsync(a.counters, 0, (size_t)rows * n_head * 4, (hipStream_t)stream));
     HIP_TRY(launch_attention_decode((hipStream_t)stream, rows, a));
+    return MV_OK;
+}
+
+int mv_op_quantize_int4(void* stream, int32_t N, int32_t K, const void* w, void* codes, void* scales_zeros, void* dequantised) {
+    if (launch_quantize_i4((hipStream_t)stream, (const bf16_t*)w, N, K, (unsigned char*)codes, (uint32_t*)scales_zeros, (bf16_t*)dequantised) != hipSuccess)
+        return fail(MV_ERR_INVALID, "quantize_int4: K=%d must be a multiple of 128", K);
+    return MV_OK;
+}
+
+int mv_op_gemv_int4(void* stream, int32_t rows, int32_t N, int32_t K, const void* x, const void* codes, const void* scales_zeros,
+                    const void* codes2, const void* scales_zeros2, const void* norm_w, float eps, const void* residual, void* out) {
+    GemvI4Args a;
+    a.x = (const bf16_t*)x; a.codes = (const unsigned char*)codes; a.sz = (const uint32_t*)scales_zeros;
+    a.codes2 = (const unsigned char*)codes2; a.sz2 = (const uint32_t*)scales_zeros2; a.norm_w = (const bf16_t*)norm_w;
+    a.residual = (const bf16_t*)residual; a.out = (bf16_t*)out; a.N = N; a.K = K; a.eps = eps;
+    const int epi = codes2 ? GEMV_SWIGLU : residual ? GEMV_RESID : GEMV_PLAIN;
+    if (launch_gemv_i4((hipStream_t)stream, rows, a, epi) != hipSuccess)
+        return fail(MV_ERR_INVALID, "gemv_int4: unsupported rows=%d K=%d", rows, K);
     return MV_OK;
 }
 

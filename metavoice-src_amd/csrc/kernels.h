@@ -35,6 +35,28 @@ struct GemvArgs {
 hipError_t launch_gemv(hipStream_t s, int rows, const GemvArgs& a, int epi);
 bool gemv_supported(int rows, int K);
 
+// ---- gemv_i4.hip: int4 group-128 weight-only projections + the quantiser ---------------------------------------
+struct GemvI4Args {
+    const bf16_t* x = nullptr;            // [rows][K]
+    const unsigned char* codes = nullptr; // [N][K/2]: column 2j in the low, 2j+1 in the high nibble of byte j
+    const uint32_t* sz = nullptr;         // [N][K/128]: bf16 scale | bf16 zero << 16
+    const unsigned char* codes2 = nullptr;  // SWIGLU only (w3)
+    const uint32_t* sz2 = nullptr;
+    const bf16_t* norm_w = nullptr;
+    const bf16_t* residual = nullptr;
+    bf16_t* out = nullptr;
+    bf16_t* kcache = nullptr;
+    bf16_t* vcache = nullptr;
+    const int32_t* pos = nullptr;
+    int32_t cache_len = 0, n_head = 0, dim = 0;
+    int32_t N = 0, K = 0;
+    float eps = 1e-5f;
+};
+hipError_t launch_gemv_i4(hipStream_t s, int rows, const GemvI4Args& a, int epi);
+bool gemv_i4_supported(int rows, int K);
+// codes/sz as above; `deq` (may alias `w`) receives bf16((q - 8) * scale + zero) when non-null
+hipError_t launch_quantize_i4(hipStream_t s, const bf16_t* w, int N, int K, unsigned char* codes, uint32_t* sz, bf16_t* deq);
+
 // ---- attention.hip -------------------------------------------------------------------------------------------
 constexpr int ATTN_NSPLIT = 8;          // max KV splits per (row, head): 8 x 256 keys = block_size 2048
 constexpr int ATTN_PART_STRIDE = 132;   // floats per partial: m, l, pad, pad, o[128]

@@ -10,15 +10,17 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--configs", default="", help="JSON list of {knob: value} dicts; each is applied on top of the defaults")
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--new", type=int, default=1920)
+ap.add_argument("--quant", default=None, help="int4: run the weight-only quantised engine (BASELINE config 4)")
 a = ap.parse_args()
 mv = importlib.import_module("metavoice-src_amd")
 fiu = importlib.import_module("metavoice-src_amd.fast_inference_utils")
 args = mv.ModelArgs.from_name("metavoice-1B")
 cfgk = dict(n_layer=args.n_layer, n_head=args.n_head, dim=args.dim, vocab_size=args.vocab_size, block_size=args.block_size)
 sd = fiu.remap_checkpoint_keys(mv.synthetic.stage1_state_dict(seed=0, device="cuda", **cfgk))
-e = mv.Stage1Engine(args, max_utterances=1)
+e = mv.Stage1Engine(args, max_utterances=1, quantisation_mode=a.quant)
 e.load_state_dict(sd); del sd
 e.finalize()
+print(f"model bytes {e.model_bytes / 1e9:.3f} GB ({a.quant or 'bf16'})")
 prompt, spk = mv.synthetic.prompt_tokens(128, seed=0), mv.synthetic.speaker_embedding(0)
 sp = mv.SamplingParams(top_p=0.95, seed=7)
 DEFAULTS = dict(gemv_nt=1, use_graph=1, mega=0,
