@@ -352,6 +352,7 @@ int mv_tune(mv_engine* e, const char* key, int32_t value) {
     else if (k == "gemv_nt") g_tune.gemv_nt = value;
     else if (k == "use_graph") g_tune.use_graph = value;
     else if (k == "mega") g_tune.mega = value;
+    else if (k == "gemv_ablate") g_tune.gemv_ablate = value;
     else return fail(MV_ERR_INVALID, "unknown tuning key '%s'", key);
     if (e && e->finalized) e->graph_dirty = true;  // launch geometry is frozen in the captured graph: re-capture at mv_begin
     return MV_OK;

@@ -38,6 +38,11 @@ __global__ void __launch_bounds__(1024) gemv_kernel(const GemvArgs a) {
     // ---- 1. put the whole weight working set of this wave in flight ------------------------------------
     u32x4 wv[NMAT][NR][KCH];
 #pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) { wv[0][i][j] = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}; wv[NMAT - 1][i][j] = wv[0][i][j]; }
+    if (!(a.ablate & 1))
+#pragma unroll
     for (int i = 0; i < NR; ++i) {
         const int n = min(n0 + i, N - 1);
 #pragma unroll
@@ -48,8 +53,21 @@ __global__ void __launch_bounds__(1024) gemv_kernel(const GemvArgs a) {
         }
     }
 
+    // The epilogue's own operands (this lane's residual element, the cache position) are fetched NOW: left in the
+    // epilogue they are a dependent ~1 us round trip at the very end of every launch (profiles/r01e ablation).
+    bf16_t res_pre = 0;
+    int pos_pre = 0;
+    {
+        const int i = lane / R, r = lane % R, n = n0 + i;
+        if (lane < NR * R && n < N) {
+            if (EPI == EPI_RESID) res_pre = a.residual[(size_t)r * N + n];
+            if (EPI == EPI_QKV) pos_pre = a.pos[r >> 1];
+        }
+    }
+
     // ---- 2. activation prologue -> LDS ------------------------------------------------------------------
-    if (a.norm_w != nullptr) {
+    if (a.ablate & 4) {
+    } else if (a.norm_w != nullptr) {
         // RMSNorm (fast_model.py:250-261): fp32 x * rsqrt(mean(x^2) + eps) -> bf16 -> * weight -> bf16.
         // Thread t owns columns 8t..8t+7 of every row (host guarantees blockDim.x * 8 >= KP).
         const int c = threadIdx.x * 8;
@@ -91,6 +109,7 @@ __global__ void __launch_bounds__(1024) gemv_kernel(const GemvArgs a) {
         for (int i = 0; i < NR; ++i)
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[m][i][r] = 0.f;
+    if (!(a.ablate & 2))
 #pragma unroll
     for (int j = 0; j < KCH; ++j) {
 #pragma unroll
@@ -107,6 +126,17 @@ __global__ void __launch_bounds__(1024) gemv_kernel(const GemvArgs a) {
     float mine[NMAT];
 #pragma unroll
     for (int m = 0; m < NMAT; ++m) mine[m] = 0.f;
+    if (a.ablate & 8) {
+        float t = 0.f;
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+            for (int i = 0; i < NR; ++i)
+#pragma unroll
+                for (int r = 0; r < R; ++r) t += acc[m][i][r];
+        if (t == 12345.678f) a.out[0] = 0;  // keep the accumulators alive
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < NMAT; ++m)
 #pragma unroll
@@ -125,7 +155,7 @@ __global__ void __launch_bounds__(1024) gemv_kernel(const GemvArgs a) {
             if (EPI == EPI_PLAIN) {
                 a.out[(size_t)r * N + n] = f2bf(mine[0]);
             } else if (EPI == EPI_RESID) {
-                a.out[(size_t)r * N + n] = epi_resid(a.residual[(size_t)r * N + n], mine[0]);
+                a.out[(size_t)r * N + n] = epi_resid(res_pre, mine[0]);
             } else if (EPI == EPI_SWIGLU) {
                 a.out[(size_t)r * N + n] = epi_swiglu(mine[0], mine[NMAT - 1]);
             } else {  // EPI_QKV: rows [0,dim) -> q, [dim,2dim) -> K cache, [2dim,3dim) -> V cache at input_pos
@@ -137,9 +167,8 @@ __global__ void __launch_bounds__(1024) gemv_kernel(const GemvArgs a) {
                     const int which = (n - dim) / dim;
                     const int hd = (n - dim) % dim;
                     const int h = hd / 128, d = hd % 128;
-                    const int p = a.pos[r >> 1];
                     bf16_t* cache = which ? a.vcache : a.kcache;
-                    cache[(((size_t)r * a.n_head + h) * a.cache_len + p) * 128 + d] = v;
+                    cache[(((size_t)r * a.n_head + h) * a.cache_len + pos_pre) * 128 + d] = v;
                 }
             }
         }
@@ -216,8 +245,10 @@ bool gemv_supported(int rows, int K) {
     return (rows == 2 || rows == 4 || rows == 8) && (kch == 1 || kch == 2 || kch == 4 || kch == 11) && K % 8 == 0 && K >= 8;
 }
 
-hipError_t launch_gemv(hipStream_t s, int rows, const GemvArgs& a, int epi) {
-    if (!gemv_supported(rows, a.K)) return hipErrorInvalidValue;
+hipError_t launch_gemv(hipStream_t s, int rows, const GemvArgs& a0, int epi) {
+    if (!gemv_supported(rows, a0.K)) return hipErrorInvalidValue;
+    GemvArgs a = a0;
+    a.ablate = g_tune.gemv_ablate;
     const int threads = gemv_default_threads(epi, a.N, a.K);
     switch (rows) {
         case 2: return launch_kch<2>(s, a, epi, threads);

@@ -66,6 +66,16 @@ __global__ void __launch_bounds__(1024) gemv_i4_kernel(const GemvI4Args a) {
         }
     }
 
+    bf16_t res_pre = 0;   // epilogue operands fetched up front (see gemv.hip)
+    int pos_pre = 0;
+    {
+        const int i = lane / R, r = lane % R, n = n0 + i;
+        if (lane < NR * R && n < N) {
+            if (EPI == GEMV_RESID) res_pre = a.residual[(size_t)r * N + n];
+            if (EPI == GEMV_QKV) pos_pre = a.pos[r >> 1];
+        }
+    }
+
     // ---- 2. activation prologue -> LDS (identical to gemv.hip: thread t owns columns 8t..8t+7) ---------------------------
     if (a.norm_w != nullptr) {
         const int c = threadIdx.x * 8;
@@ -154,7 +164,7 @@ __global__ void __launch_bounds__(1024) gemv_i4_kernel(const GemvI4Args a) {
             if (EPI == GEMV_PLAIN) {
                 a.out[(size_t)r * N + n] = f2bf(mine[0]);
             } else if (EPI == GEMV_RESID) {
-                a.out[(size_t)r * N + n] = epi_resid(a.residual[(size_t)r * N + n], mine[0]);
+                a.out[(size_t)r * N + n] = epi_resid(res_pre, mine[0]);
             } else if (EPI == GEMV_SWIGLU) {
                 a.out[(size_t)r * N + n] = epi_swiglu(mine[0], mine[NMAT - 1]);
             } else {  // QKV
@@ -164,9 +174,8 @@ __global__ void __launch_bounds__(1024) gemv_i4_kernel(const GemvI4Args a) {
                     a.out[(size_t)r * dim + n] = v;
                 } else {
                     const int which = (n - dim) / dim, hd = (n - dim) % dim;
-                    const int p = a.pos[r >> 1];
                     bf16_t* cache = which ? a.vcache : a.kcache;
-                    cache[(((size_t)r * a.n_head + hd / 128) * a.cache_len + p) * 128 + hd % 128] = v;
+                    cache[(((size_t)r * a.n_head + hd / 128) * a.cache_len + pos_pre) * 128 + hd % 128] = v;
                 }
             }
         }

@@ -12,6 +12,7 @@ struct MvTune {
     int gemv_nr[4] = {0, 0, 0, 0};       // weight rows per wave: 0 = built-in choice
     int gemv_nt = 1;                     // 1: non-temporal weight loads, 0: default cache policy
     int use_graph = 1;
+    int gemv_ablate = 0;                 // profiling only (results are wrong): 1 no weight loads, 2 no dots, 4 no prologue, 8 no reductions
     int mega = 0;                        // 1: persistent decode-step kernel (decode_mega.hip); off by default: 1026 vs 992 us/step
 };
 extern MvTune g_tune;
@@ -31,6 +32,7 @@ struct GemvArgs {
     int32_t cache_len = 0, n_head = 0, dim = 0;
     int32_t N = 0, K = 0;
     float eps = 1e-5f;
+    int32_t ablate = 0;                // MvTune::gemv_ablate
 };
 hipError_t launch_gemv(hipStream_t s, int rows, const GemvArgs& a, int epi);
 bool gemv_supported(int rows, int K);
