@@ -108,7 +108,7 @@ def main():
     prompt = mv.synthetic.prompt_tokens(T_PROMPT, seed=rank)
     spk = mv.synthetic.speaker_embedding(rank)
     sp = mv.SamplingParams(guidance_scale=3.0, temperature=1.0, top_p=0.95, seed=1337 + rank)  # TTS.synthesise defaults
-    gathered = [torch.empty(8 * 1024, dtype=torch.int32, device="cuda") for _ in range(world)] if world > 1 else None
+    dispatch = importlib.import_module("metavoice-src_amd.batch_dispatch")
 
     # second stage (fam/llm/inference.py Model + model.py GPT, non-causal): placeholder sizes, block_size 2048 so that the
     # 960 frames + 128 text ids of this workload fit untruncated
@@ -137,11 +137,10 @@ def main():
         stage_ms["stage1_prefill+decode"] += (t1 - t0) * 1e3
         stage_ms["stage1_decode_gpu"] += engine.last_run_ms
         stage_ms["adapters+stage2"] += (t2 - t1) * 1e3
-        if world > 1:  # batched-serving path: every rank ends up with every utterance's (8, f) token grid
-            flat = torch.tensor(audio_ids, dtype=torch.int32).flatten()
-            t = torch.zeros(8 * 1024, dtype=torch.int32)
-            t[: flat.numel()] = flat[: 8 * 1024]
-            dist.all_gather(gathered, t.cuda())
+        if world > 1:  # batched-serving path: every rank ends up with every utterance's (8, f) token grid, in input order
+            mine = torch.tensor(audio_ids, dtype=torch.int32, device="cuda").flatten()
+            everyone = dispatch.gather_variable([mine], world, device=torch.device("cuda", local_rank))
+            assert len(everyone) == world
         return toks, engine.last_run_ms
 
     def fence():
