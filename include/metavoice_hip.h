@@ -161,6 +161,34 @@ int mv_stage2_get_logits(mv_stage2* s, int32_t head, float* out);  /* parity hoo
 /* One draw per (position, target hierarchy): /temperature, top-k mask, softmax, multinomial; out: host [batch][n_out][T]. */
 int mv_stage2_sample(mv_stage2* s, float temperature, int32_t top_k, uint64_t seed, int32_t* out);
 
+/* ---- EnCodec 24 kHz token -> waveform decode (residual-VQ lookup + SEANet decoder, fp32).  Replaces the codec half of
+ * `mbd.tokens_to_wav` / `codec_model.decode` reached through fam/llm/decoders.py:13,84-85 (audiocraft==1.2.0 / encodec==0.1.1,
+ * third party).  Tensor names are those of transformers' EncodecModel state dict with weight-norm folded
+ * ("decoder.layers.3.conv.weight", "decoder.layers.1.lstm.weight_hh_l0", "quantizer.layers.0.codebook.embed", ...). */
+typedef struct mv_codec mv_codec;
+typedef struct mv_codec_config {
+    int32_t hidden;              /* 128: codebook / latent dimension */
+    int32_t num_filters;         /* 32  */
+    int32_t n_ratios;            /* 4   */
+    int32_t ratios[8];           /* 8, 5, 4, 2 (decoder order) */
+    int32_t kernel_size;         /* 7   */
+    int32_t last_kernel_size;    /* 7   */
+    int32_t residual_kernel_size;/* 3   */
+    int32_t compress;            /* 2   */
+    int32_t lstm_layers;         /* 2   */
+    int32_t n_q;                 /* 8 codebooks at 6 kbps */
+    int32_t bins;                /* 1024 */
+    int32_t audio_channels;      /* 1   */
+} mv_codec_config;
+int mv_codec_create(const mv_codec_config* cfg, mv_codec** out);
+int mv_codec_destroy(mv_codec* c);
+int mv_codec_load_weight(mv_codec* c, const char* name, const float* data, int64_t numel);  /* host fp32 */
+int mv_codec_finalize(mv_codec* c);
+int64_t mv_codec_samples(const mv_codec* c, int32_t frames);   /* frames x prod(ratios) */
+/* tokens: host int32 [n_q][frames]; wav_out: host fp32 [audio_channels][samples]; latent_out (optional): host fp32
+ * [hidden][frames], the summed codebook vectors (`decode_latent`, the diffusion decoder's conditioning). */
+int mv_codec_decode(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t frames, float* wav_out, float* latent_out);
+
 /* Debug hook (MV_DEBUG_VECTORS=1 in the environment at mv_finalize, MetaVoice-1B widths only): bf16 bits of every layer's
  * q | attention output | h | SwiGLU activation | x of the LAST decode step, [n_layer][5][2 rows][5632]. */
 int mv_debug_vectors(mv_engine* e, uint16_t* out, int64_t cap_elems);

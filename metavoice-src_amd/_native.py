@@ -40,6 +40,14 @@ class mv_stage2_config(C.Structure):
     ]
 
 
+class mv_codec_config(C.Structure):
+    _fields_ = [
+        ("hidden", C.c_int32), ("num_filters", C.c_int32), ("n_ratios", C.c_int32), ("ratios", C.c_int32 * 8),
+        ("kernel_size", C.c_int32), ("last_kernel_size", C.c_int32), ("residual_kernel_size", C.c_int32), ("compress", C.c_int32),
+        ("lstm_layers", C.c_int32), ("n_q", C.c_int32), ("bins", C.c_int32), ("audio_channels", C.c_int32),
+    ]
+
+
 class mv_sampling(C.Structure):
     _fields_ = [
         ("guidance_scale", C.c_float), ("one_minus_guidance", C.c_float), ("temperature", C.c_float),
@@ -78,6 +86,12 @@ SYMBOLS = [
     ("mv_stage2_forward", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint16)]),
     ("mv_stage2_get_logits", C.c_int, [_P, C.c_int32, C.POINTER(C.c_float)]),
     ("mv_stage2_sample", C.c_int, [_P, C.c_float, C.c_int32, C.c_uint64, C.POINTER(C.c_int32)]),
+    ("mv_codec_create", C.c_int, [C.POINTER(mv_codec_config), C.POINTER(_P)]),
+    ("mv_codec_destroy", C.c_int, [_P]),
+    ("mv_codec_load_weight", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_float), C.c_int64]),
+    ("mv_codec_finalize", C.c_int, [_P]),
+    ("mv_codec_samples", C.c_int64, [_P, C.c_int32]),
+    ("mv_codec_decode", C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("mv_probe_kernel", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     ("mv_tune", C.c_int, [_P, C.c_char_p, C.c_int32]),
     ("mv_debug_vectors", C.c_int, [_P, C.POINTER(C.c_uint16), C.c_int64]),
