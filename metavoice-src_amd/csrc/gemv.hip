@@ -187,18 +187,12 @@ static hipError_t launch_one(hipStream_t s, const GemvArgs& a, int threads) {
     return hipGetLastError();
 }
 
-// Weight rows per wave.  Built-in: 1 (2 for the two matrices of SwiGLU, 3 for the fused QKV).
+// Weight rows per wave.  Built-in: 1 (3 for the fused QKV); the alternative (2, or 1 for QKV) is kept for tools/sweep.py.
 template <int R, int KCH, int EPI>
 static hipError_t launch_nr(hipStream_t s, const GemvArgs& a, int threads, int nr) {
-    if (R * nr > 64) nr = 64 / R;  // a lane per (row of W, row of x) in the epilogue
-    if (KCH * nr * (EPI == EPI_SWIGLU ? 2 : 1) > 24) nr = 1;  // keep the in-flight working set <= 96 VGPRs
-    switch (nr) {
-        case 1: return launch_one<R, KCH, 1, EPI>(s, a, threads);
-        case 2: return launch_one<R, KCH, 2, EPI>(s, a, threads);
-        case 3: return launch_one<R, KCH, 3, EPI>(s, a, threads);
-        case 4: return launch_one<R, KCH, 4, EPI>(s, a, threads);
-    }
-    return hipErrorInvalidValue;
+    constexpr int ALT = (EPI == EPI_QKV) ? 3 : 2;
+    if (nr != 1 && KCH * ALT * (EPI == EPI_SWIGLU ? 2 : 1) <= 24 && R * ALT <= 64) return launch_one<R, KCH, ALT, EPI>(s, a, threads);
+    return launch_one<R, KCH, 1, EPI>(s, a, threads);
 }
 
 template <int R, int KCH>

@@ -162,3 +162,44 @@ def write_model_dir(path: str, *, stage1: Optional[dict] = None, stage2_args: Op
         "meta": {"tokenizer": byte_level_tokenizer_info(offset=1025), "speaker_cond": True, "speaker_emb_size": 256},
     }, os.path.join(path, "second_stage.pt"))
     return path
+
+
+def encodec_state_dict(seed: int = 0, *, hidden: int = 128, num_filters: int = 32, ratios=(8, 5, 4, 2), kernel_size: int = 7,
+                       last_kernel_size: int = 7, residual_kernel_size: int = 3, compress: int = 2, lstm_layers: int = 2, n_q: int = 8,
+                       bins: int = 1024) -> Dict[str, torch.Tensor]:
+    """Seeded weights of the EnCodec 24 kHz decoder + codebooks under transformers' EncodecModel names, weight-norm already
+    folded (fp32).  Scales follow torch's default Conv/LSTM initialisation (uniform +-1/sqrt(fan_in)) so that activations
+    stay O(1) through the stack."""
+    g = torch.Generator().manual_seed(7000 + seed)
+
+    def uni(shape, fan_in):
+        b = 1.0 / math.sqrt(fan_in)
+        return (torch.rand(shape, generator=g) * 2 - 1) * b
+
+    sd: Dict[str, torch.Tensor] = {}
+    for q in range(n_q):
+        sd[f"quantizer.layers.{q}.codebook.embed"] = torch.randn(bins, hidden, generator=g) * 0.5
+    ch = num_filters << len(ratios)
+    sd["decoder.layers.0.conv.weight"] = uni((ch, hidden, kernel_size), hidden * kernel_size)
+    sd["decoder.layers.0.conv.bias"] = uni((ch,), hidden * kernel_size)
+    for l in range(lstm_layers):
+        for kind in ("ih", "hh"):
+            sd[f"decoder.layers.1.lstm.weight_{kind}_l{l}"] = uni((4 * ch, ch), ch)
+            sd[f"decoder.layers.1.lstm.bias_{kind}_l{l}"] = uni((4 * ch,), ch)
+    idx = 2
+    for r in ratios:
+        half = ch // 2
+        sd[f"decoder.layers.{idx + 1}.conv.weight"] = uni((ch, half, 2 * r), ch * 2)  # ConvTranspose1d: [Cin][Cout][K]
+        sd[f"decoder.layers.{idx + 1}.conv.bias"] = uni((half,), ch * 2)
+        p = f"decoder.layers.{idx + 2}."
+        sd[p + "block.1.conv.weight"] = uni((half // compress, half, residual_kernel_size), half * residual_kernel_size)
+        sd[p + "block.1.conv.bias"] = uni((half // compress,), half * residual_kernel_size)
+        sd[p + "block.3.conv.weight"] = uni((half, half // compress, 1), half // compress)
+        sd[p + "block.3.conv.bias"] = uni((half,), half // compress)
+        sd[p + "shortcut.conv.weight"] = uni((half, half, 1), half)
+        sd[p + "shortcut.conv.bias"] = uni((half,), half)
+        ch = half
+        idx += 3
+    sd[f"decoder.layers.{idx + 1}.conv.weight"] = uni((1, ch, last_kernel_size), ch * last_kernel_size)
+    sd[f"decoder.layers.{idx + 1}.conv.bias"] = uni((1,), ch * last_kernel_size)
+    return sd
