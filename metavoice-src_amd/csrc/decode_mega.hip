@@ -97,12 +97,13 @@ __device__ __forceinline__ void mega_norm(const bf16_t* raw, const bf16_t* norm_
     }
     const u32x4 nw = in_k ? load16(norm_w + c) : u32x4{0, 0, 0, 0};
     __syncthreads();
+    float tots[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) tots[r] = block_total(red + r, 2, MG_WAVES, lane);
     if (in_k) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            float tot = 0.f;
-            for (int w = 0; w < MG_WAVES; ++w) tot += red[w * 2 + r];
-            *(u32x4*)(xs + r * MG_DIM + c) = rms_apply8(xv[r], rms_rstd(tot, MG_DIM, eps), nw);
+            *(u32x4*)(xs + r * MG_DIM + c) = rms_apply8(xv[r], rms_rstd(tots[r], MG_DIM, eps), nw);
         }
     }
     __syncthreads();

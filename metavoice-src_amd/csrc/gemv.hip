@@ -85,12 +85,13 @@ __global__ void __launch_bounds__(1024) gemv_kernel(const GemvArgs a) {
         }
         const u32x4 nw = in_k ? load16(a.norm_w + c) : u32x4{0, 0, 0, 0};
         __syncthreads();
+        float tots[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) tots[r] = block_total(red + r, R, nwaves, lane);
         if (c < KP) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                float tot = 0.f;
-                for (int wv_i = 0; wv_i < nwaves; ++wv_i) tot += red[wv_i * R + r];
-                *(u32x4*)(xs + r * KP + c) = rms_apply8(xv[r], rms_rstd(tot, K, a.eps), nw);
+                *(u32x4*)(xs + r * KP + c) = rms_apply8(xv[r], rms_rstd(tots[r], K, a.eps), nw);
             }
         }
     } else {

@@ -13,6 +13,13 @@ __device__ __forceinline__ float sumsq8(const u32x4& x) {
     return s;
 }
 __device__ __forceinline__ float rms_rstd(float total_sumsq, int K, float eps) { return rsqrtf(total_sumsq / (float)K + eps); }
+// Sum of the per-wave partial sums `red[w * stride]`, w < nwaves <= 64, identical in every lane: lane w fetches partial w and
+// the 64-lane DPP tree adds them in one fixed order (a serial `for w: tot += red[w]` loop is nwaves dependent LDS round
+// trips, ~1 us of the prologue at 11 waves).  Waves beyond the K columns contribute exact zeros, so the result does not
+// depend on the block size.
+__device__ __forceinline__ float block_total(const float* red, int stride, int nwaves, int lane) {
+    return wave_sum(lane < nwaves ? red[lane * stride] : 0.f);
+}
 // bf16(bf16(x * rstd) * w) for 8 elements
 __device__ __forceinline__ u32x4 rms_apply8(const u32x4& x, float rstd, const u32x4& nw) {
     u32x4 y;
