@@ -51,6 +51,9 @@ struct LayerW {
     // int4 mode: packed codes + (scale, zero) per matrix, in the order wqkv, wo, w1, w3, w2
     unsigned char* q[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t* sz[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // int8 mode: codes + bf16 per-row scales, same order
+    signed char* q8[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bf16_t* s8[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 struct Slot {
@@ -86,7 +89,9 @@ struct mv_engine {
     std::vector<LayerW> layers;
     std::vector<Slot> slots;
     bool finalized = false;
-    unsigned char* q_arena = nullptr;   // int4 mode: all codes and (scale, zero) words
+    signed char* head_q8 = nullptr;     // int8 mode: the LM head and the speaker projection are quantised too
+    bf16_t *head_s8 = nullptr, *spk_s8 = nullptr;
+    unsigned char* q_arena = nullptr;   // int4 / int8 mode: all codes and scales
     size_t q_arena_bytes = 0;
 
     // activations / state
@@ -134,6 +139,13 @@ namespace {
 int enqueue_tail(mv_engine* e);
 int enqueue_sampler(mv_engine* e);
 
+GemvI8Args to_i8(const GemvArgs& a, const signed char* q, const bf16_t* scales) {
+    GemvI8Args r;
+    r.x = a.x; r.q = q; r.scales = scales; r.norm_w = a.norm_w; r.residual = a.residual; r.out = a.out; r.kcache = a.kcache;
+    r.vcache = a.vcache; r.pos = a.pos; r.cache_len = a.cache_len; r.n_head = a.n_head; r.dim = a.dim; r.N = a.N; r.K = a.K; r.eps = a.eps;
+    return r;
+}
+
 GemvI4Args to_i4(const GemvArgs& a, const unsigned char* codes, const uint32_t* sz) {
     GemvI4Args q;
     q.x = a.x; q.codes = codes; q.sz = sz; q.norm_w = a.norm_w; q.residual = a.residual; q.out = a.out; q.kcache = a.kcache;
@@ -165,6 +177,7 @@ int enqueue_step(mv_engine* e) {
             a.pos = e->pos_arr; a.cache_len = c.block_size; a.n_head = c.n_head; a.dim = c.dim;
             a.N = 3 * c.dim; a.K = c.dim; a.eps = c.norm_eps;
             if (c.weight_format == MV_W_INT4_G128) HIP_TRY(launch_gemv_i4(s, R, to_i4(a, w.q[0], w.sz[0]), GEMV_QKV));
+            else if (c.weight_format == MV_W_INT8) HIP_TRY(launch_gemv_i8(s, R, to_i8(a, w.q8[0], w.s8[0]), GEMV_QKV));
             else HIP_TRY(launch_gemv(s, R, a, GEMV_QKV));
         }
         auto dbg_copy = [&](int which, const bf16_t* src, int cols) -> hipError_t {
@@ -189,6 +202,7 @@ int enqueue_step(mv_engine* e) {
             GemvArgs a;
             a.x = e->attn; a.w = w.wo; a.residual = e->x; a.out = e->h; a.N = c.dim; a.K = c.dim;
             if (c.weight_format == MV_W_INT4_G128) HIP_TRY(launch_gemv_i4(s, R, to_i4(a, w.q[1], w.sz[1]), GEMV_RESID));
+            else if (c.weight_format == MV_W_INT8) HIP_TRY(launch_gemv_i8(s, R, to_i8(a, w.q8[1], w.s8[1]), GEMV_RESID));
             else HIP_TRY(launch_gemv(s, R, a, GEMV_RESID));
         }
         HIP_TRY(dbg_copy(2, e->h, c.dim));
@@ -200,6 +214,10 @@ int enqueue_step(mv_engine* e) {
                 GemvI4Args q = to_i4(a, w.q[2], w.sz[2]);
                 q.codes2 = w.q[3]; q.sz2 = w.sz[3];
                 HIP_TRY(launch_gemv_i4(s, R, q, GEMV_SWIGLU));
+            } else if (c.weight_format == MV_W_INT8) {
+                GemvI8Args q = to_i8(a, w.q8[2], w.s8[2]);
+                q.q2 = w.q8[3]; q.scales2 = w.s8[3];
+                HIP_TRY(launch_gemv_i8(s, R, q, GEMV_SWIGLU));
             } else HIP_TRY(launch_gemv(s, R, a, GEMV_SWIGLU));
         }
         HIP_TRY(dbg_copy(3, e->act, c.intermediate));
@@ -207,6 +225,7 @@ int enqueue_step(mv_engine* e) {
             GemvArgs a;
             a.x = e->act; a.w = w.w2; a.residual = e->h; a.out = e->x; a.N = c.dim; a.K = c.intermediate;
             if (c.weight_format == MV_W_INT4_G128) HIP_TRY(launch_gemv_i4(s, R, to_i4(a, w.q[4], w.sz[4]), GEMV_RESID));
+            else if (c.weight_format == MV_W_INT8) HIP_TRY(launch_gemv_i8(s, R, to_i8(a, w.q8[4], w.s8[4]), GEMV_RESID));
             else HIP_TRY(launch_gemv(s, R, a, GEMV_RESID));
         }
         HIP_TRY(dbg_copy(4, e->x, c.dim));
@@ -223,7 +242,8 @@ int enqueue_tail(mv_engine* e) {
         GemvArgs a;
         a.x = e->x; a.w = e->head; a.norm_w = e->final_norm; a.out = e->logits; a.N = c.vocab; a.K = c.dim;
         a.eps = c.norm_eps;
-        HIP_TRY(launch_gemv(s, R, a, GEMV_PLAIN));
+        if (c.weight_format == MV_W_INT8) HIP_TRY(launch_gemv_i8(s, R, to_i8(a, e->head_q8, e->head_s8), GEMV_PLAIN));
+        else HIP_TRY(launch_gemv(s, R, a, GEMV_PLAIN));
     }
     return enqueue_sampler(e);
 }
@@ -369,8 +389,11 @@ int mv_engine_create(const mv_config* cfg, mv_engine** out) {
     if (!gemv_supported(2 * c.max_utterances, c.dim) || !gemv_supported(2 * c.max_utterances, c.intermediate))
         return fail(MV_ERR_INVALID, "unsupported dim/intermediate %d/%d (K must be a multiple of 8 with ceil(K/512) in {1,2,4,11})",
                     c.dim, c.intermediate);
-    if (c.weight_format != MV_W_BF16 && c.weight_format != MV_W_INT4_G128)
-        return fail(MV_ERR_INVALID, "weight_format %d not supported by this build (bf16 and int4 are)", c.weight_format);
+    if (c.weight_format != MV_W_BF16 && c.weight_format != MV_W_INT4_G128 && c.weight_format != MV_W_INT8)
+        return fail(MV_ERR_INVALID, "weight_format %d unknown", c.weight_format);
+    if (c.weight_format == MV_W_INT8 && (!gemv_i8_supported(2 * c.max_utterances, c.dim) || !gemv_i8_supported(2 * c.max_utterances, c.intermediate)))
+        return fail(MV_ERR_INVALID, "int8: dim/intermediate %d/%d must be multiples of 16 within 1, 2 or 6 chunks of 1024, <= 2 utterances",
+                    c.dim, c.intermediate);
     if (c.weight_format == MV_W_INT4_G128 && (!gemv_i4_supported(2 * c.max_utterances, c.dim) || !gemv_i4_supported(2 * c.max_utterances, c.intermediate)))
         return fail(MV_ERR_INVALID, "int4: dim/intermediate %d/%d must be multiples of 128 in (0,2048] or (4096,6144], <= 2 utterances",
                     c.dim, c.intermediate);
@@ -507,6 +530,41 @@ int mv_finalize(mv_engine* e) {
         }
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
+    if (c.weight_format == MV_W_INT8) {
+        // WeightOnlyInt8QuantHandler (fast_quantize.py:137-178): every nn.Linear, the LM head and speaker_cond_pos included
+        const int64_t shapes[5][2] = {{3 * (int64_t)c.dim, c.dim}, {c.dim, c.dim}, {c.intermediate, c.dim}, {c.intermediate, c.dim},
+                                      {c.dim, c.intermediate}};
+        size_t per_layer = 0;
+        for (auto& sh : shapes) per_layer += align_up((size_t)sh[0] * sh[1], 256) + align_up((size_t)sh[0] * 2, 256);
+        const size_t extra = align_up((size_t)c.vocab * c.dim, 256) + align_up((size_t)c.vocab * 2, 256) + align_up((size_t)c.dim * 2, 256);
+        e->q_arena_bytes = per_layer * c.n_layer + extra;
+        HIP_TRY(hipMalloc((void**)&e->q_arena, e->q_arena_bytes));
+        size_t off = 0;
+        for (int l = 0; l < c.n_layer; ++l) {
+            LayerW& w = e->layers[l];
+            bf16_t* src[5] = {w.wqkv, w.wo, w.w1, w.w3, w.w2};
+            for (int m = 0; m < 5; ++m) {
+                w.q8[m] = (signed char*)(e->q_arena + off); off += align_up((size_t)shapes[m][0] * shapes[m][1], 256);
+                w.s8[m] = (bf16_t*)(e->q_arena + off); off += align_up((size_t)shapes[m][0] * 2, 256);
+                HIP_TRY(launch_quantize_i8(e->stream, src[m], (int)shapes[m][0], (int)shapes[m][1], w.q8[m], w.s8[m]));
+            }
+        }
+        e->head_q8 = (signed char*)(e->q_arena + off); off += align_up((size_t)c.vocab * c.dim, 256);
+        e->head_s8 = (bf16_t*)(e->q_arena + off); off += align_up((size_t)c.vocab * 2, 256);
+        HIP_TRY(launch_quantize_i8(e->stream, e->head, c.vocab, c.dim, e->head_q8, e->head_s8));
+        // speaker_cond_pos: its int8 codes are written back into the bf16 arena (exact), the scales go with the projection
+        e->spk_s8 = (bf16_t*)(e->q_arena + off);
+        {
+            signed char* tmp = nullptr;
+            HIP_TRY(hipMalloc((void**)&tmp, (size_t)c.dim * c.spk_dim));
+            hipError_t ce = launch_quantize_i8(e->stream, e->spk_w, c.dim, c.spk_dim, tmp, e->spk_s8);
+            if (ce == hipSuccess) ce = launch_i8_to_bf16(e->stream, tmp, e->spk_w, (size_t)c.dim * c.spk_dim);
+            if (ce == hipSuccess) ce = hipStreamSynchronize(e->stream);
+            (void)hipFree(tmp);
+            if (ce != hipSuccess) return fail(MV_ERR_HIP, "int8 quantisation of speaker_cond_pos failed: %s", hipGetErrorString(ce));
+        }
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     e->kv_layer_elems = (size_t)R * c.n_head * c.block_size * 128;
     HIP_TRY(hipMalloc((void**)&e->x, (size_t)R * c.dim * 2));
     HIP_TRY(hipMalloc((void**)&e->h, (size_t)R * c.dim * 2));
@@ -574,7 +632,8 @@ int64_t mv_model_bytes(const mv_engine* e) {
     for (auto& s : e->slots) {
         const bool quantised = e->cfg.weight_format == MV_W_INT4_G128 && s.rows % 8 == 0 && s.cols % 128 == 0 && s.rows > 1 &&
                                s.name.find("embeddings") == std::string::npos;
-        b += quantised ? s.rows * s.cols / 2 + s.rows * (s.cols / 128) * 4 : s.rows * s.cols * 2;
+        const bool q8 = e->cfg.weight_format == MV_W_INT8 && s.rows > 1 && s.name.find("embeddings") == std::string::npos;
+        b += quantised ? s.rows * s.cols / 2 + s.rows * (s.cols / 128) * 4 : q8 ? s.rows * s.cols + s.rows * 2 : s.rows * s.cols * 2;
     }
     return b;
 }
@@ -620,7 +679,9 @@ int mv_begin(mv_engine* e, int32_t n_utt, const int32_t* prompts, const int32_t*
     int budget = 0;
     // batched (MFMA) prefill needs every prompt to have >= 2 tokens and GEMM-tileable widths; otherwise the prompt is
     // teacher-forced through the decode graph
-    bool use_prefill = prefill_mode == 1;
+    // int8: the Linear output is bf16(bf16(x.q^T) * scale) -- two roundings the bf16 GEMM epilogue does not do -- so its
+    // prompt is teacher-forced through the int8 decode kernels
+    bool use_prefill = prefill_mode == 1 && c.weight_format != MV_W_INT8;
     for (int u = 0; u < n_utt && u < U; ++u) use_prefill = use_prefill && prompt_lens[u] >= 2;
     for (int u = 0; u < U; ++u) {
         UttState& s = st[u];
@@ -654,7 +715,7 @@ int mv_begin(mv_engine* e, int32_t n_utt, const int32_t* prompts, const int32_t*
     HIP_TRY(hipMemcpy(e->n_active, &n_utt, 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(e->spk_emb, 0, (size_t)U * c.spk_dim * 2));
     HIP_TRY(hipMemcpy(e->spk_emb, spk_emb, (size_t)n_utt * c.spk_dim * 2, hipMemcpyHostToDevice));
-    HIP_TRY(launch_spk_proj(e->stream, U, c.dim, c.spk_dim, e->spk_emb, e->spk_w, e->spk_proj));
+    HIP_TRY(launch_spk_proj(e->stream, U, c.dim, c.spk_dim, e->spk_emb, e->spk_w, e->spk_s8, e->spk_proj));
     SampleArgs a;
     a.seq = e->seq; a.tok_emb = e->tok_emb; a.pos_emb = e->pos_emb; a.spk_proj = e->spk_proj; a.x_next = e->x;
     a.dim = c.dim; a.block_size = c.block_size; a.n_utt = U;

@@ -59,6 +59,27 @@ bool gemv_i4_supported(int rows, int K);
 // codes/sz as above; `deq` (may alias `w`) receives bf16((q - 8) * scale + zero) when non-null
 hipError_t launch_quantize_i4(hipStream_t s, const bf16_t* w, int N, int K, unsigned char* codes, uint32_t* sz, bf16_t* deq);
 
+// ---- gemv_i8.hip: int8 per-channel weight-only projections + the quantiser ----------------------------------------
+struct GemvI8Args {
+    const bf16_t* x = nullptr;
+    const signed char* q = nullptr;     // [N][K] int8
+    const bf16_t* scales = nullptr;     // [N] bf16
+    const signed char* q2 = nullptr;    // SWIGLU only (w3)
+    const bf16_t* scales2 = nullptr;
+    const bf16_t* norm_w = nullptr;
+    const bf16_t* residual = nullptr;
+    bf16_t* out = nullptr;
+    bf16_t* kcache = nullptr;
+    bf16_t* vcache = nullptr;
+    const int32_t* pos = nullptr;
+    int32_t cache_len = 0, n_head = 0, dim = 0;
+    int32_t N = 0, K = 0;
+    float eps = 1e-5f;
+};
+hipError_t launch_gemv_i8(hipStream_t s, int rows, const GemvI8Args& a, int epi);
+bool gemv_i8_supported(int rows, int K);
+hipError_t launch_quantize_i8(hipStream_t s, const bf16_t* w, int N, int K, signed char* q, bf16_t* scales);
+
 // ---- attention.hip -------------------------------------------------------------------------------------------
 constexpr int ATTN_NSPLIT = 8;          // max KV splits per (row, head): 8 x 256 keys = block_size 2048
 constexpr int ATTN_PART_STRIDE = 132;   // floats per partial: m, l, pad, pad, o[128]
@@ -110,7 +131,8 @@ hipError_t launch_embed_first(hipStream_t s, const SampleArgs& a);
 hipError_t launch_embed_rows(hipStream_t s, const int32_t* seq, int T, int dim, const bf16_t* tok_emb, const bf16_t* pos_emb,
                              const bf16_t* spk, bf16_t* out);
 hipError_t launch_spk_proj(hipStream_t s, int n_utt, int dim, int spk_dim, const bf16_t* spk_emb, const bf16_t* w,
-                           bf16_t* out);
+                           const bf16_t* scales, bf16_t* out);
+hipError_t launch_i8_to_bf16(hipStream_t s, const signed char* in, bf16_t* out, size_t n);
 
 
 // ---- gemm.hip: many-row blocks shared by the first-stage prefill and the second-stage forward ---------------------

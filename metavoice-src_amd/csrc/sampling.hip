@@ -327,14 +327,23 @@ __global__ void embed_first_kernel(const SampleArgs a) {
 
 // spk_proj[u][n] = bf16(sum_k spk_emb[u][k] * W[n][k])  -- `speaker_cond_pos` (fast_model.py:123,156).  It is
 // step-invariant, so it is hoisted out of the decode step (the reference recomputes it every token).
-__global__ void spk_proj_kernel(int dim, int spk_dim, const bf16_t* spk_emb, const bf16_t* w, bf16_t* out) {
+__global__ void spk_proj_kernel(int dim, int spk_dim, const bf16_t* spk_emb, const bf16_t* w, const bf16_t* scales, bf16_t* out) {
     const int u = blockIdx.y;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= dim) return;
     float acc = 0.f;
     for (int k = lane; k < spk_dim; k += 64) acc += bf2f(spk_emb[(size_t)u * spk_dim + k]) * bf2f(w[(size_t)wave * spk_dim + k]);
     acc = wave_sum(acc);
-    if (lane == 0) out[(size_t)u * dim + wave] = f2bf(acc);
+    // int8 mode: w holds the int8 codes (exact in bf16) and the Linear is bf16(bf16(x.q^T) * scale)  (fast_quantize.py:197-198)
+    if (lane == 0) out[(size_t)u * dim + wave] = scales ? f2bf(round_bf(acc) * bf2f(scales[wave])) : f2bf(acc);
+}
+__global__ void i8_to_bf16_kernel(const signed char* in, bf16_t* out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f2bf((float)in[i]);
+}
+hipError_t launch_i8_to_bf16(hipStream_t s, const signed char* in, bf16_t* out, size_t n) {
+    hipLaunchKernelGGL(i8_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+    return hipGetLastError();
 }
 
 // Prefill input rows: x[(r*T + t)] for the conditioned (r=0) and unconditioned (r=1) copy of the prompt (fast_model.py:152-157).
@@ -367,9 +376,9 @@ hipError_t launch_embed_first(hipStream_t s, const SampleArgs& a) {
     return hipGetLastError();
 }
 hipError_t launch_spk_proj(hipStream_t s, int n_utt, int dim, int spk_dim, const bf16_t* spk_emb, const bf16_t* w,
-                           bf16_t* out) {
+                           const bf16_t* scales, bf16_t* out) {
     const int waves_per_block = 4;
     hipLaunchKernelGGL(spk_proj_kernel, dim3((dim + waves_per_block - 1) / waves_per_block, n_utt), dim3(64 * waves_per_block),
-                       0, s, dim, spk_dim, spk_emb, w, out);
+                       0, s, dim, spk_dim, spk_emb, w, scales, out);
     return hipGetLastError();
 }

@@ -103,10 +103,28 @@ class Stage1Oracle:
         self.k_cache = [torch.zeros(shape) for _ in range(c.n_layer)]
         self.v_cache = [torch.zeros(shape) for _ in range(c.n_layer)]
 
+    def quantise_int8(self):
+        """`WeightOnlyInt8QuantHandler` (fam/llm/fast_quantize.py:137-178): every nn.Linear -- wqkv, wo, w1, w3, w2, the LM head
+        and speaker_cond_pos -- becomes (int8 codes, bf16 per-row scale); `_lin` then evaluates `WeightOnlyInt8Linear.forward`
+        (:197-198): F.linear(x, q.to(bf16)) * scales, i.e. bf16(bf16(x @ q^T) * scale) on the bf16 path."""
+        from . import quantize as _q
+
+        self.int8 = {}
+        for name, wt in self.w.items():
+            if wt.dim() == 2 and "embeddings" not in name:
+                codes, scales = _q.quantize_per_channel_int8(wt.float())
+                self.int8[name] = (codes.float(), scales.to(torch.bfloat16).float())
+
+    def _lin(self, x: torch.Tensor, name: str) -> torch.Tensor:
+        q = getattr(self, "int8", {}).get(name)
+        if q is not None:
+            return self.rnd(self.rnd(x @ q[0].T) * q[1])
+        return self.rnd(x @ self.w[name].T)
+
     def spk_proj(self, spk_emb: torch.Tensor) -> torch.Tensor:
         """`speaker_cond_pos(spk_emb) * spk_cond_mask` (fast_model.py:132-134,156): row 0 keeps the
         speaker projection, every odd CFG row (the unconditioned one) gets zero."""
-        proj = self.rnd(spk_emb.float() @ self.w["speaker_cond_pos.weight"].T)  # (1, dim)
+        proj = self._lin(spk_emb.float(), "speaker_cond_pos.weight")  # (1, dim)
         return proj
 
     def forward(self, idx: torch.Tensor, spk_emb: torch.Tensor, input_pos: torch.Tensor) -> torch.Tensor:
@@ -133,7 +151,7 @@ class Stage1Oracle:
             p = f"layers.{li}."
             # --- attention (fast_model.py:200-227)
             h_in = rms_norm(x, w[p + "attention_norm.weight"], c.norm_eps, rnd)
-            qkv = rnd(h_in @ w[p + "attention.wqkv.weight"].T)
+            qkv = self._lin(h_in, p + "attention.wqkv.weight")
             q, k, v = qkv.split([c.dim, c.dim, c.dim], dim=-1)
             q = q.view(B, S, c.n_head, c.head_dim).transpose(1, 2)
             k = k.view(B, S, c.n_head, c.head_dim).transpose(1, 2)
@@ -147,18 +165,18 @@ class Stage1Oracle:
             probs = torch.softmax(scores, dim=-1)
             y = rnd(probs @ vv)
             y = y.transpose(1, 2).contiguous().view(B, S, c.dim)
-            y = rnd(y @ w[p + "attention.wo.weight"].T)
+            y = self._lin(y, p + "attention.wo.weight")
             h = rnd(x + y)
             # --- feed forward (fast_model.py:230-247)
             f_in = rms_norm(h, w[p + "ffn_norm.weight"], c.norm_eps, rnd)
-            g = rnd(f_in @ w[p + "feed_forward.swiglu.w1.weight"].T)
-            u = rnd(f_in @ w[p + "feed_forward.swiglu.w3.weight"].T)
+            g = self._lin(f_in, p + "feed_forward.swiglu.w1.weight")
+            u = self._lin(f_in, p + "feed_forward.swiglu.w3.weight")
             act = rnd(rnd(torch.nn.functional.silu(g)) * u)
-            d = rnd(act @ w[p + "feed_forward.w2.weight"].T)
+            d = self._lin(act, p + "feed_forward.w2.weight")
             x = rnd(h + d)
 
         x = rms_norm(x, w["norm.weight"], c.norm_eps, rnd)
-        return rnd(x @ w["output.weight"].T)
+        return self._lin(x, "output.weight")
 
 
 # ----------------------------------------------------------------------------------------------

@@ -144,3 +144,32 @@ def test_int4_engine_follows_the_oracle_on_dequantised_weights():
         print(f"[int4 prefill_mode={mode}] first-token max|dlogit| {d:.4f} (logit std {scale:.3f}); {same}/{n_new} greedy tokens identical")
         assert d <= 0.06 * scale and same >= n_new // 2
     engine.close()
+
+
+def test_int8_engine_follows_the_oracle():
+    """`quantisation_mode="int8"` (fast_quantize.py:137-198): every Linear incl. the LM head and the speaker projection;
+    greedy stream and logits against the oracle evaluating WeightOnlyInt8Linear.forward on the same bf16 checkpoint."""
+    for cfgk, T, n_new in ((dict(n_layer=2, n_head=2, dim=256, vocab_size=2562, block_size=64), 10, 16),
+                           (dict(n_layer=2, n_head=16, dim=2048, vocab_size=2562, block_size=2048), 16, 8)):
+        sd = o_s1.remap_checkpoint_keys(synthetic.stage1_state_dict(seed=2, **cfgk))
+        engine = mv.Stage1Engine(mv.ModelArgs(**cfgk), max_utterances=1, quantisation_mode="int8")
+        engine.load_state_dict(sd)
+        engine.finalize()
+        assert engine.model_bytes < 0.62 * sum(v.numel() * 2 for v in sd.values())
+        cfg = o_s1.Stage1Config(**cfgk)
+        orc = o_s1.Stage1Oracle({k: v.float() for k, v in sd.items()}, cfg, rounding="bf16", max_seq_length=64)
+        orc.quantise_int8()
+        prompt, spk = synthetic.prompt_tokens(T, seed=2), synthetic.speaker_embedding(2)
+        oseq, ologits = o_s1.generate(orc, prompt, spk, max_new_tokens=n_new, end_of_audio_token=9999, top_k=1, seed=5, return_logits=True)
+        scale = float(ologits.std())
+        engine.capture_logits(True)
+        engine.begin([prompt], spk, mv.SamplingParams(top_k=1, seed=5), max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
+        steps = engine.run()
+        assert steps == T + n_new - 1  # int8 prompts are teacher-forced through the decode kernels
+        seq = engine.tokens(0)
+        got = engine.captured_logits(T - 1, n_new)
+        d = float((got[0] - ologits[0]).abs().max())
+        same = sum(1 for a, b in zip(seq, oseq) if a == b) - T
+        print(f"[int8 dim={cfgk['dim']}] first-token max|dlogit| {d:.4f} (logit std {scale:.3f}); {same}/{n_new} greedy tokens identical")
+        assert d <= 0.06 * scale and same >= n_new // 2
+        engine.close()

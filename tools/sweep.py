@@ -11,7 +11,7 @@ ap.add_argument("--configs", default="", help="JSON list of {knob: value} dicts;
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--new", type=int, default=1920)
 ap.add_argument("--utterances", type=int, default=1, help="utterances decoded together on this GPU (2 CFG rows each)")
-ap.add_argument("--quant", default=None, help="int4: run the weight-only quantised engine (BASELINE config 4)")
+ap.add_argument("--quant", default=None, help="int4 / int8: run the weight-only quantised engine (BASELINE config 4)")
 a = ap.parse_args()
 mv = importlib.import_module("metavoice-src_amd")
 fiu = importlib.import_module("metavoice-src_amd.fast_inference_utils")
