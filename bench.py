@@ -15,7 +15,8 @@ over ranks is reported.  Utterances are independent, so N GPUs run N utterances 
 finished token streams are all-gathered over RCCL once per step (batched-serving path), inside the timed region.
 
 Extra objects on the JSON line:
-  roofline      -- dominant kernel of the decode step (fused RMSNorm + w1|w3 + SiLU-gate GEMV, 46 MB of weights per
+  roofline      -- dominant kernel: the persistent decode-step kernel (one launch per token) where supported, else the
+                   largest per-layer kernel of the decode step (fused RMSNorm + w1|w3 + SiLU-gate GEMV, 46 MB of weights per
                    launch): algorithmic bytes / average launch duration measured with HIP events on the engine stream.
   step_roofline -- the same ratio for a whole decode step (all ~122 launches), the number RTF actually follows.
   cpu_baseline  -- the CPU oracle (a torch-CPU fp32 restatement of the reference, golden-pinned to it) timed on this
@@ -182,9 +183,16 @@ def main():
         import ctypes as C
         N = importlib.import_module("metavoice-src_amd._native")
         ms, nbytes = C.c_float(0), C.c_double(0)
-        N.check(N.lib().mv_probe_kernel(engine._h, 3, 24 * 20, C.byref(ms), C.byref(nbytes)))
+        # the decode step is ONE persistent launch per token (decode_mega.hip: 24 layers + LM head) when the configuration
+        # supports it; probe 6 times that kernel alone at the position the utterance ended on.  Otherwise (per-layer launches)
+        # the dominant kernel is the fused RMSNorm + w1|w3 + SiLU-gate GEMV (probe 3).
+        if N.lib().mv_probe_kernel(engine._h, 6, 200, C.byref(ms), C.byref(nbytes)) == 0:
+            kname = "decode_mega_kernel (persistent: 24 layers + LM head of one token, context %d)" % (T_PROMPT + N_NEW - 1)
+        else:
+            N.check(N.lib().mv_probe_kernel(engine._h, 3, 24 * 20, C.byref(ms), C.byref(nbytes)))
+            kname = "gemv_kernel<2,4,1,SWIGLU,nt> (RMSNorm + w1|w3 + SiLU gate)"
         ach = nbytes.value / (ms.value * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "gemv_kernel<2,4,1,SWIGLU,nt> (RMSNorm + w1|w3 + SiLU gate)",
+        roofline = {"bound": "hbm", "kernel": kname,
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": None, "bytes_per_launch": nbytes.value, "avg_launch_us": round(ms.value * 1e3, 2)}
         per_kernel = {}

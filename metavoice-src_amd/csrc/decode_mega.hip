@@ -262,9 +262,18 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             }
             __syncthreads();
         }
-        // next: wo row 8 b + wave
+        // next: wo row 8 b + wave.  Publish-before-prefetch (profiles/r01g_handoff/NOTES.md): a wave that still has something to
+        // publish does so BEFORE it queues its next weight loads -- the memory pipeline accepts loads only as fast as it
+        // drains them, so a publish behind 100-200 KB of requests reaches its consumers microseconds late.
         __builtin_amdgcn_sched_barrier(0);
-        mega_issue_row<4>(wv, L.wo, 8 * b + wave_o, MG_DIM, lane_o);
+        // wo goes to wv[12..15]; the w1 rows of P3 ride along in wv[0..11] (the w3 rows follow after P2's dots into wv[12..23]):
+        // w1|w3 is 45 % of a layer's bytes, asked for in one go it made P2 -> P3 the one stream-bound hand-off (8 us).
+        const int rb13 = 22 * b + (wave_o < 6 ? 3 * wave_o : 18 + 2 * (wave_o - 6));
+        if (wave_o != 0) {
+            mega_issue_row<4>(wv + 12, L.wo, 8 * b + wave_o, MG_DIM, lane_o);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) mega_issue_row<4>(wv + 4 * i, L.w1, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (at_s < nact && at_w == 0) {
             AttnAcc bb = attn_merge_waves(sm, g, dl);
@@ -287,6 +296,13 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
                 if (a.dbg) *(u32x4*)(a.dbg + ((size_t)l * 5 + 1) * 2 * MG_INTER + at_r * MG_INTER + at_h * 128 + dl * 8) = y;
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (wave_o == 0) {
+            mega_issue_row<4>(wv + 12, L.wo, 8 * b + wave_o, MG_DIM, lane_o);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) mega_issue_row<4>(wv + 4 * i, L.w1, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 
         // ================= P2: h = x + wo(attn)                         fast_model.py:224-226,179 =====================
         __syncthreads();
@@ -297,16 +313,8 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
                 return;
             MG_STAMP(l, 5);
             float acc[1][2];
-            mega_dots<4, 1, MG_DIM>(wv, xs, lane, acc);
+            mega_dots<4, 1, MG_DIM>(wv + 12, xs, lane, acc);
             __builtin_amdgcn_sched_barrier(0);
-            // next: w1 / w3 rows.  22 rows per block: waves 0..5 take 3, waves 6,7 take 2 (third slot clamped, masked)
-            const int rb = 22 * b + (wave_o < 6 ? 3 * wave_o : 18 + 2 * (wave_o - 6));
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int n = min(rb + i, MG_INTER - 1);
-                mega_issue_row<4>(wv + 4 * i, L.w1, n, MG_DIM, lane_o);
-                mega_issue_row<4>(wv + 12 + 4 * i, L.w3, n, MG_DIM, lane_o);
-            }
             const float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
             if (lane == 0) {
                 const int n = 8 * b + wave;
@@ -314,6 +322,12 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
                 gran_store(a.g_h + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 2u);
                 if (a.dbg) { bf16_t* d = a.dbg + ((size_t)l * 5 + 2) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            // next: the w3 rows (w1 is already in flight).  22 rows per block: waves 0..5 take 3, waves 6,7 take 2 (third slot
+            // clamped, masked)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) mega_issue_row<4>(wv + 12 + 4 * i, L.w3, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         // ================= P3: act = silu(w1 n(h)) * w3 n(h)            fast_model.py:180,237 =========================
@@ -327,8 +341,6 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             mega_dots<4, 3, MG_DIM>(wv, xs, lane, acc1);
             mega_dots<4, 3, MG_DIM>(wv + 12, xs, lane, acc3);
             __builtin_amdgcn_sched_barrier(0);
-            // next: w2 row 8 b + wave (K = 5632: 11 chunks)
-            mega_issue_row<11>(wv, L.w2, 8 * b + wave_o, MG_INTER, lane_o);
             const int nrows = wave < 6 ? 3 : 2;
             const int rb = 22 * b + (wave < 6 ? 3 * wave : 18 + 2 * (wave - 6));
             float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
@@ -342,6 +354,10 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
                 gran_store(a.g_act + rb + lane, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 3u);
                 if (a.dbg) { bf16_t* d = a.dbg + ((size_t)l * 5 + 3) * 2 * MG_INTER; d[rb + lane] = y0; d[MG_INTER + rb + lane] = y1; }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            // next: w2 row 8 b + wave (K = 5632: 11 chunks)
+            mega_issue_row<11>(wv, L.w2, 8 * b + wave_o, MG_INTER, lane_o);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         // ================= P4: x = h + w2(act)                          fast_model.py:247,180 =========================
@@ -353,6 +369,15 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             float acc[1][2];
             mega_dots<11, 1, MG_INTER>(wv, xs, lane, acc);
             __builtin_amdgcn_sched_barrier(0);
+            const float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
+            if (lane == 0) {
+                const int n = 8 * b + wave;
+                const bf16_t y0 = epi_resid(raw_h[n], t0), y1 = epi_resid(raw_h[MG_DIM + n], t1);
+                gran_store(a.g_x + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 4u);
+                MG_STAMP(l, 10);
+                if (a.dbg) { bf16_t* d = a.dbg + ((size_t)l * 5 + 4) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
             // next: the following layer's wqkv rows, or the LM-head rows 11 b + wave + 8 i
             if (l + 1 < a.n_layer) {
                 const bf16_t* w = a.layers[l + 1].wqkv;
@@ -362,14 +387,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 #pragma unroll
                 for (int i = 0; i < 2; ++i) mega_issue_row<4>(wv + 4 * i, a.head, min(11 * b + wave_o + 8 * i, a.vocab - 1), MG_DIM, lane_o);
             }
-            const float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
-            if (lane == 0) {
-                const int n = 8 * b + wave;
-                const bf16_t y0 = epi_resid(raw_h[n], t0), y1 = epi_resid(raw_h[MG_DIM + n], t1);
-                gran_store(a.g_x + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 4u);
-                MG_STAMP(l, 10);
-                if (a.dbg) { bf16_t* d = a.dbg + ((size_t)l * 5 + 4) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
-            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -399,6 +417,12 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 bool mega_supported(const mv_config& c, int rows, int n_cus) {
     return rows == 2 && c.dim == MG_DIM && c.intermediate == MG_INTER && c.n_head == MG_HEADS && c.vocab <= 256 * 11 && n_cus >= 256 &&
            c.block_size <= ATTN_NSPLIT * 256;
+}
+
+__global__ void bump_counter_kernel(uint32_t* c) { c[0] += 1u; }
+hipError_t launch_bump_counter(hipStream_t s, uint32_t* c) {
+    hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, s, c);
+    return hipGetLastError();
 }
 
 hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a) {

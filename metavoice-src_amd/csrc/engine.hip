@@ -153,18 +153,23 @@ GemvI4Args to_i4(const GemvArgs& a, const unsigned char* codes, const uint32_t* 
     return q;
 }
 
+static MegaArgs mega_args(mv_engine* e) {
+    const mv_config& c = e->cfg;
+    MegaArgs m;
+    m.x_in = e->x; m.layers = e->mega_layers; m.n_layer = c.n_layer; m.vocab = c.vocab; m.cache_len = c.block_size;
+    m.final_norm = e->final_norm; m.head = e->head; m.logits = e->logits; m.kcache = e->kcache; m.vcache = e->vcache;
+    m.kv_layer_elems = e->kv_layer_elems; m.pos = e->pos_arr; m.step_counter = e->step_counter;
+    m.g_x = e->granules; m.g_qkv = m.g_x + c.dim; m.g_attn = m.g_qkv + 3 * c.dim; m.g_h = m.g_attn + c.dim; m.g_act = m.g_h + c.dim;
+    m.partial = e->partial; m.counters = e->counters; m.abort_flag = e->abort_flag; m.eps = c.norm_eps; m.dbg = e->dbg; m.stamps = e->stamps;
+    return m;
+}
+
 int enqueue_step(mv_engine* e) {
     const mv_config& c = e->cfg;
     const int R = e->R;
     hipStream_t s = e->stream;
     if (e->mega_ok && g_tune.mega) {  // one persistent launch for the 24 layers + LM head, then the sampler
-        MegaArgs m;
-        m.x_in = e->x; m.layers = e->mega_layers; m.n_layer = c.n_layer; m.vocab = c.vocab; m.cache_len = c.block_size;
-        m.final_norm = e->final_norm; m.head = e->head; m.logits = e->logits; m.kcache = e->kcache; m.vcache = e->vcache;
-        m.kv_layer_elems = e->kv_layer_elems; m.pos = e->pos_arr; m.step_counter = e->step_counter;
-        m.g_x = e->granules; m.g_qkv = m.g_x + c.dim; m.g_attn = m.g_qkv + 3 * c.dim; m.g_h = m.g_attn + c.dim; m.g_act = m.g_h + c.dim;
-        m.partial = e->partial; m.counters = e->counters; m.abort_flag = e->abort_flag; m.eps = c.norm_eps; m.dbg = e->dbg; m.stamps = e->stamps;
-        HIP_TRY(launch_decode_mega(s, m));
+        HIP_TRY(launch_decode_mega(s, mega_args(e)));
         return enqueue_sampler(e);
     }
     for (int l = 0; l < c.n_layer; ++l) {
@@ -804,11 +809,40 @@ int mv_probe_kernel(mv_engine* e, int32_t kind, int32_t iters, float* avg_ms, do
     if (!e || !e->finalized || !avg_ms || !bytes_per_launch) return fail(MV_ERR_STATE, "engine not finalized / null argument");
     const bool warm = (kind & 0x100) != 0;      // same layer every launch: operands stay on die (L2 / Infinity Cache)
     kind &= 0xFF;
-    if (iters < 1 || kind < 0 || kind > 5) return fail(MV_ERR_INVALID, "bad probe arguments");
+    if (iters < 1 || kind < 0 || kind > 6) return fail(MV_ERR_INVALID, "bad probe arguments");
     const mv_config& c = e->cfg;
     const int R = e->R;
     hipStream_t s = e->stream;
     double bytes = 0;
+    if (kind == 6) {
+        // The persistent decode-step kernel at the current position.  Its hand-off epoch comes from the step counter the
+        // sampler bumps, so every probe launch is preceded by a one-thread bump kernel; the bump-only loop is timed too and
+        // subtracted.  The kernel rewrites this position's K/V rows and the logits with the values they already hold.
+        if (!e->mega_ok) return fail(MV_ERR_STATE, "the persistent decode kernel does not support this configuration");
+        std::vector<int32_t> pos(c.max_utterances);
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(pos.data(), e->pos_arr, pos.size() * 4, hipMemcpyDeviceToHost));
+        const double per_layer = (3.0 * c.dim * c.dim + (double)c.dim * c.dim + 3.0 * c.intermediate * c.dim) * 2 + 2.0 * c.dim * 2;
+        bytes = c.n_layer * (per_layer + 2.0 /*rows*/ * c.n_head * (pos[0] + 1.0) * 128 * 2 * 2) + (double)c.vocab * c.dim * 2 + c.dim * 2;
+        const MegaArgs m = mega_args(e);
+        float t[2] = {0.f, 0.f};
+        for (int pass = 0; pass < 2; ++pass) {  // pass 0: bump + persistent kernel, pass 1: bump only
+            for (int i = -2; i < iters; ++i) {
+                if (i == 0) HIP_TRY(hipEventRecord(e->ev0, s));
+                HIP_TRY(launch_bump_counter(s, e->step_counter));
+                if (pass == 0) HIP_TRY(launch_decode_mega(s, m));
+            }
+            HIP_TRY(hipEventRecord(e->ev1, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipEventElapsedTime(&t[pass], e->ev0, e->ev1));
+        }
+        uint32_t ab = 0;
+        HIP_TRY(hipMemcpy(&ab, e->abort_flag, 4, hipMemcpyDeviceToHost));
+        if (ab) return fail(MV_ERR_HIP, "persistent decode kernel: a hand-off timed out (grid not co-resident?)");
+        *avg_ms = (t[0] - t[1]) / iters;
+        *bytes_per_launch = bytes;
+        return MV_OK;
+    }
     if (kind == 1) {
         std::vector<int32_t> pos(c.max_utterances);
         HIP_TRY(hipStreamSynchronize(s));

@@ -13,7 +13,8 @@ struct MvTune {
     int gemv_nt = 1;                     // 1: non-temporal weight loads, 0: default cache policy
     int use_graph = 1;
     int gemv_ablate = 0;                 // profiling only (results are wrong): 1 no weight loads, 2 no dots, 4 no prologue, 8 no reductions
-    int mega = 0;                        // 1: persistent decode-step kernel (decode_mega.hip); off by default: 1026 vs 992 us/step
+    int mega = 1;                        // 1: persistent decode-step kernel (decode_mega.hip) when the configuration supports it
+                                         // (one utterance, bf16, MetaVoice-1B shape, >= 256 CUs): 874 vs 996 us/step; 0: per-layer launches
 };
 extern MvTune g_tune;
 
@@ -204,3 +205,4 @@ struct MegaArgs {
 };
 bool mega_supported(const mv_config& c, int rows, int n_cus);
 hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a);
+hipError_t launch_bump_counter(hipStream_t s, uint32_t* counter);  // mv_probe_kernel: advances the hand-off epoch like the sampler does

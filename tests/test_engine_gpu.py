@@ -242,7 +242,7 @@ def test_persistent_decode_kernel_is_bit_identical_to_per_layer_launches(n_layer
         if mega in out:
             assert res[0] == out[mega][0] and torch.equal(res[1], out[mega][1])  # run-to-run reproducible
         out[mega] = res
-    engine.tune(mega=0)
+    engine.tune(mega=1)  # the default
     assert out[1][0] == out[0][0], "token streams differ between the persistent kernel and the per-layer launches"
     assert torch.equal(out[1][1], out[0][1]), f"logits differ: max {float((out[1][1] - out[0][1]).abs().max())}"
     assert len(out[1][0]) == T + n_new

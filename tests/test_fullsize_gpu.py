@@ -42,6 +42,7 @@ def test_full_size_path_equivalences(full):
     prompt, spk = synthetic.prompt_tokens(T, seed=0), synthetic.speaker_embedding(0)
     sp = mv.SamplingParams(top_p=0.95, guidance_scale=3.0, seed=1337)
     engine.capture_logits(True)
+    engine.tune(mega=0)  # per-layer launches
     a = run(engine, prompt, spk, sp, n_new, prefill_mode=1)
     la = engine.captured_logits(T - 1, n_new)
     b = run(engine, prompt, spk, sp, n_new, prefill_mode=1)
@@ -49,7 +50,6 @@ def test_full_size_path_equivalences(full):
     engine.tune(mega=1)  # persistent one-launch-per-token kernel: identical bits
     c = run(engine, prompt, spk, sp, n_new, prefill_mode=1)
     lc = engine.captured_logits(T - 1, n_new)
-    engine.tune(mega=0)
     assert a == c and torch.equal(la, lc)
     # MFMA prefill vs the prompt teacher-forced through the decode kernels: same first-token logits to summation order
     d = run(engine, prompt, spk, sp, n_new, prefill_mode=0)

@@ -26,7 +26,7 @@ U = a.utterances
 prompt = [mv.synthetic.prompt_tokens(128, seed=u) for u in range(U)]
 spk = torch.cat([mv.synthetic.speaker_embedding(u) for u in range(U)])
 sp = [mv.SamplingParams(top_p=0.95, seed=7 + u) for u in range(U)]
-DEFAULTS = dict(gemv_nt=1, use_graph=1, mega=0, gemv_ablate=0,
+DEFAULTS = dict(gemv_nt=1, use_graph=1, mega=1, gemv_ablate=0,
                 gemv_threads_plain=0, gemv_threads_resid=0, gemv_threads_swiglu=0, gemv_threads_qkv=0,
                 gemv_nr_plain=0, gemv_nr_resid=0, gemv_nr_swiglu=0, gemv_nr_qkv=0)
 configs = json.loads(a.configs) if a.configs else [{}]
