@@ -169,7 +169,7 @@ int enqueue_step(mv_engine* e) {
     const int R = e->R;
     hipStream_t s = e->stream;
     if (e->mega_ok && g_tune.mega) {  // one persistent launch for the 24 layers + LM head, then the sampler
-        HIP_TRY(launch_decode_mega(s, mega_args(e)));
+        HIP_TRY(g_tune.mega == 2 ? launch_decode_mega_lds(s, mega_args(e)) : launch_decode_mega(s, mega_args(e)));
         return enqueue_sampler(e);
     }
     for (int l = 0; l < c.n_layer; ++l) {
@@ -830,7 +830,7 @@ int mv_probe_kernel(mv_engine* e, int32_t kind, int32_t iters, float* avg_ms, do
             for (int i = -2; i < iters; ++i) {
                 if (i == 0) HIP_TRY(hipEventRecord(e->ev0, s));
                 HIP_TRY(launch_bump_counter(s, e->step_counter));
-                if (pass == 0) HIP_TRY(launch_decode_mega(s, m));
+                if (pass == 0) HIP_TRY(g_tune.mega == 2 ? launch_decode_mega_lds(s, m) : launch_decode_mega(s, m));
             }
             HIP_TRY(hipEventRecord(e->ev1, s));
             HIP_TRY(hipStreamSynchronize(s));

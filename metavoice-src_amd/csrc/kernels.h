@@ -204,5 +204,6 @@ struct MegaArgs {
     unsigned long long* stamps = nullptr;  // optional [2 blocks][n_layer][12] s_memtime stamps of wave 0 (MV_MEGA_STAMPS)
 };
 bool mega_supported(const mv_config& c, int rows, int n_cus);
-hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a);
+hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a);      // v2: every wave prefetches its weight rows into registers
+hipError_t launch_decode_mega_lds(hipStream_t s, const MegaArgs& a);  // v3: 4 loader waves stream the weights through an LDS ring
 hipError_t launch_bump_counter(hipStream_t s, uint32_t* counter);  // mv_probe_kernel: advances the hand-off epoch like the sampler does

@@ -234,7 +234,7 @@ def test_persistent_decode_kernel_is_bit_identical_to_per_layer_launches(n_layer
     sp = mv.SamplingParams(guidance_scale=3.0, seed=21, **combo)
     engine.capture_logits(True)
     out = {}
-    for mega in (1, 0, 1):
+    for mega in (1, 0, 2, 1):  # 1: persistent kernel (default), 0: per-layer launches, 2: experimental loader-wave / LDS-ring variant
         engine.tune(mega=mega)
         engine.begin([prompt], spk, sp, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
         engine.run()
@@ -243,7 +243,8 @@ def test_persistent_decode_kernel_is_bit_identical_to_per_layer_launches(n_layer
             assert res[0] == out[mega][0] and torch.equal(res[1], out[mega][1])  # run-to-run reproducible
         out[mega] = res
     engine.tune(mega=1)  # the default
-    assert out[1][0] == out[0][0], "token streams differ between the persistent kernel and the per-layer launches"
-    assert torch.equal(out[1][1], out[0][1]), f"logits differ: max {float((out[1][1] - out[0][1]).abs().max())}"
+    for m in (1, 2):
+        assert out[m][0] == out[0][0], f"token streams differ between the persistent kernel (mega={m}) and the per-layer launches"
+        assert torch.equal(out[m][1], out[0][1]), f"logits differ (mega={m}): max {float((out[m][1] - out[0][1]).abs().max())}"
     assert len(out[1][0]) == T + n_new
     engine.close()

@@ -17,7 +17,7 @@ sd = fiu.remap_checkpoint_keys(mv.synthetic.stage1_state_dict(seed=0, device="cu
 e = mv.Stage1Engine(args, max_utterances=1)
 e.load_state_dict(sd); del sd
 e.finalize()
-e.tune(mega=1)
+e.tune(mega=int(os.environ.get("MV_MEGA", "1")))
 e.begin([mv.synthetic.prompt_tokens(pos, seed=0)], mv.synthetic.speaker_embedding(0), mv.SamplingParams(top_p=0.95), max_new_tokens=64,
         end_of_audio_token=9999, prefill_mode=1)
 e.run(max_steps=32)
