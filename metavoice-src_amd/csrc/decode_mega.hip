@@ -33,56 +33,6 @@ __device__ __forceinline__ void gran_store(gran_t* g, uint32_t payload, uint32_t
 }
 __device__ __forceinline__ u64 gran_load(const gran_t* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-struct MegaCtx {
-    uint32_t* abort_flag;
-    int* s_abort;  // LDS word
-};
-
-// Block-wide wait until every granule this block needs carries `tag`.  `fetch(k, &value)` loads the k-th granule of the
-// calling thread (or returns false when the thread has no k-th granule); `sink(k, payload)` writes its payload to LDS.
-// The LDS writes of the successful round are ordered before the return by the voting barrier.
-template <int PER, typename Fetch, typename Sink>
-__device__ __forceinline__ bool mega_poll(uint32_t tag, const MegaCtx& cx, Fetch fetch, Sink sink) {
-    for (int tries = 0;; ++tries) {
-        u64 v[PER];
-        bool have[PER];
-#pragma unroll
-        for (int k = 0; k < PER; ++k) have[k] = fetch(k, v[k]);
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) ok = ok && (!have[k] || (uint32_t)(v[k] >> 32) == tag);
-        if (ok) {
-#pragma unroll
-            for (int k = 0; k < PER; ++k)
-                if (have[k]) sink(k, (uint32_t)v[k]);
-        }
-        if (__syncthreads_and(ok)) return true;
-        if ((tries & 1023) == 1023) {  // rare slow path: peer missing (grid not co-resident?) or a peer already gave up
-            if (threadIdx.x == 0) {
-                int ab = __hip_atomic_load(cx.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-                if (tries >= MG_SPIN_LIMIT) {
-                    __hip_atomic_store(cx.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ab = 1;
-                }
-                *cx.s_abort = ab;
-            }
-            __syncthreads();
-            if (*cx.s_abort) return false;
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-
-// Row-paired vector of NCOL columns (granule n = {row0[n], row1[n]}) -> raw[2][NCOL] bf16 in LDS.
-template <int NCOL>
-__device__ __forceinline__ bool poll_rowpair(const gran_t* g, uint32_t tag, bf16_t* raw, const MegaCtx& cx, int tid) {
-    constexpr int PER = (NCOL + MG_THREADS - 1) / MG_THREADS;
-    return mega_poll<PER>(
-        tag, cx,
-        [&](int k, u64& v) { const int n = tid + k * MG_THREADS; if (n >= NCOL) return false; v = gran_load(g + n); return true; },
-        [&](int k, uint32_t p) { const int n = tid + k * MG_THREADS; raw[n] = (bf16_t)p; raw[NCOL + n] = (bf16_t)(p >> 16); });
-}
-
 // RMSNorm of raw[2][2048] into xs[2][2048], bit-identical to gemv.hip's prologue (threads 0..255 own 8 columns each).
 __device__ __forceinline__ void mega_norm(const bf16_t* raw, const bf16_t* norm_w, bf16_t* xs, float* red, float eps) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -131,6 +81,85 @@ __device__ __forceinline__ void mega_issue_row(u32x4* wv, const bf16_t* w, int n
     for (int j = 0; j < KCH; ++j) wv[j] = load_stream16(row + min(j * 512 + lane * 8, K - 8));
 }
 
+// One wave waits until all of ITS granules carry `tag` (no block barrier inside: the loaders only mirror the barrier after).
+template <int PER, typename Fetch, typename Sink>
+__device__ __forceinline__ void wave_poll(uint32_t tag, uint32_t* abort_flag, int* s_abort, Fetch fetch, Sink sink) {
+    for (int tries = 0;; ++tries) {
+        u64 v[PER];
+        bool have[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) have[k] = fetch(k, v[k]);
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) ok = ok && (!have[k] || (uint32_t)(v[k] >> 32) == tag);
+        if (__all(ok)) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                if (have[k]) sink(k, (uint32_t)v[k]);
+            return;
+        }
+        if ((tries & 1023) == 1023) {  // a peer is missing (grid not co-resident?) or already gave up
+            const bool peer = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (peer || tries >= MG_SPIN_LIMIT) {
+                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *(volatile int*)s_abort = 1;
+                return;
+            }
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+template <int NCOL>
+__device__ __forceinline__ void wave_poll_rowpair(const gran_t* g, uint32_t tag, bf16_t* raw, uint32_t* abort_flag, int* s_abort, int tid) {
+    constexpr int PER = (NCOL + MG_THREADS - 1) / MG_THREADS;
+    wave_poll<PER>(
+        tag, abort_flag, s_abort,
+        [&](int k, u64& v) { const int n = tid + k * MG_THREADS; if (n >= NCOL) return false; v = gran_load(g + n); return true; },
+        [&](int k, uint32_t p) { const int n = tid + k * MG_THREADS; raw[n] = (bf16_t)p; raw[NCOL + n] = (bf16_t)(p >> 16); });
+}
+
+// The same with 16-byte agent-scope loads: two granules per lane per request, each 8-byte half validated by its own tag
+// (profiles/r01g_handoff: 2.0 vs 2.3 us per idle 2048-granule hand-off).  index(k) = pair index of the lane's k-th request or -1.
+template <int PER, typename Index, typename Sink>
+__device__ __forceinline__ void wave_poll16(const gran_t* g, uint32_t tag, uint32_t* abort_flag, int* s_abort, Index index, Sink sink) {
+    for (int tries = 0;; ++tries) {
+        u32x4 v[PER];
+        int n[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            n[k] = index(k);
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[k]) : "v"(g + 2 * max(n[k], 0)) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) ok = ok && (n[k] < 0 || (v[k].y == tag && v[k].w == tag));
+        if (__all(ok)) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                if (n[k] >= 0) sink(n[k], v[k].x, v[k].z);
+            return;
+        }
+        if ((tries & 1023) == 1023) {
+            const bool peer = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (peer || tries >= MG_SPIN_LIMIT) {
+                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *(volatile int*)s_abort = 1;
+                return;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// row-paired vector of 2048 columns: pair n = granules 2n, 2n+1 = columns 2n, 2n+1 of both rows
+__device__ __forceinline__ void wave_poll_rowpair16(const gran_t* g, uint32_t tag, bf16_t* raw, uint32_t* abort_flag, int* s_abort, int tid) {
+    wave_poll16<2>(g, tag, abort_flag, s_abort, [&](int k) { return tid + k * MG_THREADS; },
+                   [&](int n, uint32_t p0, uint32_t p1) {
+                       *(uint32_t*)(raw + 2 * n) = (p0 & 0xFFFFu) | (p1 << 16);
+                       *(uint32_t*)(raw + MG_DIM + 2 * n) = (p0 >> 16) | (p1 & 0xFFFF0000u);
+                   });
+}
+
 __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t raw_x[2 * MG_DIM];   // residual stream entering the layer (P0 in, P2 residual)
     __shared__ __attribute__((aligned(16))) bf16_t raw_h[2 * MG_DIM];   // residual stream after attention (P3 in, P4 residual)
@@ -141,7 +170,9 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
     __shared__ int s_abort;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
-    const MegaCtx cx{a.abort_flag, &s_abort};
+    if (tid == 0) s_abort = 0;
+    __syncthreads();
+#define MG_ABORTED() (*(volatile int*)&s_abort != 0)
     const uint32_t epoch = a.step_counter[0] * 256u;
     const int P = a.pos[0] + 1;  // keys [0, P): the cache holds [0, P-1), key P-1 is produced by this step's QKV phase
 
@@ -182,8 +213,9 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
         MG_STAMP(l, 0);
         if (l == 0) {
             *(u32x4*)(raw_x + tid * 8) = load16(a.x_in + tid * 8);  // written by the sampler in the previous launch
-        } else if (!poll_rowpair<MG_DIM>(a.g_x, tag0 - 8u + 4u, raw_x, cx, tid_o)) return;
-        if (l == 0) __syncthreads();
+        } else wave_poll_rowpair16(a.g_x, tag0 - 8u + 4u, raw_x, a.abort_flag, &s_abort, tid_o);
+        __syncthreads();
+        if (MG_ABORTED()) return;
         MG_STAMP(l, 1);
         // The K/V stream of this block's attention slice (rows of EARLIER steps: independent of this step) is requested here,
         // before the norm and the wqkv dots: it lands while they run instead of sitting in front of the q/k/v poll.
@@ -242,10 +274,11 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
                 const bool mine = tid_o < 384;
                 const int sec = tid_o >> 7, c = tid_o & 127;
                 const gran_t* gp = a.g_qkv + sec * MG_DIM + at_h * 128 + c;
-                if (!mega_poll<1>(tag0 + 0u, cx, [&](int, u64& v) { if (!mine) return false; v = gran_load(gp); return true; },
-                                  [&](int, uint32_t p) { qkv_s[(sec * 2 + 0) * 128 + c] = (bf16_t)p; qkv_s[(sec * 2 + 1) * 128 + c] = (bf16_t)(p >> 16); }))
-                    return;
+                wave_poll<1>(tag0 + 0u, a.abort_flag, &s_abort, [&](int, u64& v) { if (!mine) return false; v = gran_load(gp); return true; },
+                             [&](int, uint32_t p) { qkv_s[(sec * 2 + 0) * 128 + c] = (bf16_t)p; qkv_s[(sec * 2 + 1) * 128 + c] = (bf16_t)(p >> 16); });
             }
+            __syncthreads();
+            if (MG_ABORTED()) return;
             MG_STAMP(l, 3);
             const u32x4 qv = *(const u32x4*)(qkv_s + (0 * 2 + at_r) * 128 + dl * 8);
 #pragma unroll
@@ -310,9 +343,10 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
         __syncthreads();
         MG_STAMP(l, 4);
         {
-            if (!mega_poll<4>(tag0 + 1u, cx, [&](int k, u64& v) { v = gran_load(a.g_attn + tid_o + k * MG_THREADS); return true; },
-                              [&](int k, uint32_t p) { ((uint32_t*)xs)[tid_o + k * MG_THREADS] = p; }))  // granule i = elements 2i, 2i+1 of [2][2048]
-                return;
+            wave_poll16<2>(a.g_attn, tag0 + 1u, a.abort_flag, &s_abort, [&](int k) { return tid_o + k * MG_THREADS; },
+                           [&](int n, uint32_t p0, uint32_t p1) { ((uint2*)xs)[n] = make_uint2(p0, p1); });  // granule i = elements 2i, 2i+1 of [2][2048]
+            __syncthreads();
+            if (MG_ABORTED()) return;
             MG_STAMP(l, 5);
             float acc[1][2];
             mega_dots<4, 1, MG_DIM>(wv + 12, xs, lane, acc);
@@ -336,7 +370,9 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
         __syncthreads();
         MG_STAMP(l, 6);
         {
-            if (!poll_rowpair<MG_DIM>(a.g_h, tag0 + 2u, raw_h, cx, tid_o)) return;
+            wave_poll_rowpair16(a.g_h, tag0 + 2u, raw_h, a.abort_flag, &s_abort, tid_o);
+            __syncthreads();
+            if (MG_ABORTED()) return;
             MG_STAMP(l, 7);
             mega_norm(raw_h, L.ffn_norm, xs, red, a.eps);
             float acc1[3][2], acc3[3][2];
@@ -366,7 +402,9 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
         __syncthreads();
         MG_STAMP(l, 8);
         {
-            if (!poll_rowpair<MG_INTER>(a.g_act, tag0 + 3u, xs, cx, tid_o)) return;
+            wave_poll_rowpair<MG_INTER>(a.g_act, tag0 + 3u, xs, a.abort_flag, &s_abort, tid_o);
+            __syncthreads();
+            if (MG_ABORTED()) return;
             MG_STAMP(l, 9);
             float acc[1][2];
             mega_dots<11, 1, MG_INTER>(wv, xs, lane, acc);
@@ -395,7 +433,9 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 
     // ================= LM head on the last position: logits = head(norm(x))     fast_model.py:161-162 =================
     __syncthreads();
-    if (!poll_rowpair<MG_DIM>(a.g_x, epoch + (uint32_t)(a.n_layer - 1) * 8u + 1u + 4u, raw_x, cx, tid)) return;
+    wave_poll_rowpair16(a.g_x, epoch + (uint32_t)(a.n_layer - 1) * 8u + 1u + 4u, raw_x, a.abort_flag, &s_abort, tid);
+    __syncthreads();
+    if (MG_ABORTED()) return;
     mega_norm(raw_x, a.final_norm, xs, red, a.eps);
     {
         float acc[2][2];
@@ -442,43 +482,6 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 __device__ __forceinline__ void line_load(const bf16_t* src, u32x4* ring, int line) {
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                      (void __attribute__((address_space(3)))*)(ring + line * 64), 16, 0, 2 /* nt */);
-}
-
-// One wave waits until all of ITS granules carry `tag` (no block barrier inside: the loaders only mirror the barrier after).
-template <int PER, typename Fetch, typename Sink>
-__device__ __forceinline__ void wave_poll(uint32_t tag, uint32_t* abort_flag, int* s_abort, Fetch fetch, Sink sink) {
-    for (int tries = 0;; ++tries) {
-        u64 v[PER];
-        bool have[PER];
-#pragma unroll
-        for (int k = 0; k < PER; ++k) have[k] = fetch(k, v[k]);
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) ok = ok && (!have[k] || (uint32_t)(v[k] >> 32) == tag);
-        if (__all(ok)) {
-#pragma unroll
-            for (int k = 0; k < PER; ++k)
-                if (have[k]) sink(k, (uint32_t)v[k]);
-            return;
-        }
-        if ((tries & 1023) == 1023) {  // a peer is missing (grid not co-resident?) or already gave up
-            const bool peer = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-            if (peer || tries >= MG_SPIN_LIMIT) {
-                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *(volatile int*)s_abort = 1;
-                return;
-            }
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-template <int NCOL>
-__device__ __forceinline__ void wave_poll_rowpair(const gran_t* g, uint32_t tag, bf16_t* raw, uint32_t* abort_flag, int* s_abort, int tid) {
-    constexpr int PER = (NCOL + MG_THREADS - 1) / MG_THREADS;
-    wave_poll<PER>(
-        tag, abort_flag, s_abort,
-        [&](int k, u64& v) { const int n = tid + k * MG_THREADS; if (n >= NCOL) return false; v = gran_load(g + n); return true; },
-        [&](int k, uint32_t p) { const int n = tid + k * MG_THREADS; raw[n] = (bf16_t)p; raw[NCOL + n] = (bf16_t)(p >> 16); });
 }
 
 // acc[i][r] = weight row i (KCH lines of the ring, line_of(i, j)) . x row r (LDS); same accumulation order as mega_dots

@@ -125,6 +125,75 @@ __global__ void __launch_bounds__(HB_THREADS, 2) hb_kernel(const Args a) {
                 if (tries > HB_SPIN) { if (tid == 0) a.abort_flag[0] = 1; return; }
                 if (!NO_SLEEP) __builtin_amdgcn_s_sleep(1);
             }
+        } else if (MODE == 6) {
+            // every wave spins on its own granules, no barrier inside the retry loop (decode_mega.hip since r01i); NPW & 4: keep
+            // TWO staggered polls in flight so that a miss costs half a round trip instead of a whole one
+            constexpr int PER = (NG + HB_THREADS - 1) / HB_THREADS;
+            constexpr bool TWO = (NPW & 4) != 0;
+            auto fetch = [&](u64 (&v)[PER]) {
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const int n = tid + k * HB_THREADS;
+                    v[k] = n < NG ? gran_load(buf + n) : ((u64)tag << 32);
+                }
+            };
+            auto good = [&](const u64 (&v)[PER]) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < PER; ++k) ok = ok && (uint32_t)(v[k] >> 32) == tag;
+                return __all(ok) != 0;
+            };
+            auto sink = [&](const u64 (&v)[PER]) {
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const int n = tid + k * HB_THREADS;
+                    if (n < NG) xs[n] = (uint32_t)v[k];
+                }
+            };
+            u64 va[PER], vb[PER];
+            fetch(va);
+            for (int tries = 0;; ++tries) {
+                if (TWO) { __builtin_amdgcn_s_sleep(6); fetch(vb); }
+                if (good(va)) { sink(va); break; }
+                if (TWO) {
+                    __builtin_amdgcn_s_sleep(6);
+                    fetch(va);
+                    if (good(vb)) { sink(vb); break; }
+                } else {
+                    __builtin_amdgcn_s_sleep(1);
+                    fetch(va);
+                }
+                if (tries > HB_SPIN) { a.abort_flag[0] = 1; s_flag = 1; break; }
+            }
+            lds_barrier();
+            if (s_flag) return;
+        } else if (MODE == 7) {
+            // per-wave spin with 16-byte agent-scope loads: two granules per lane per request (each 8-byte half carries its own tag)
+            constexpr int PAIRS = NG / 2, PER = (PAIRS + HB_THREADS - 1) / HB_THREADS;
+            for (int tries = 0;; ++tries) {
+                u32x4 v[PER];
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const int n = min(tid + k * HB_THREADS, PAIRS - 1);
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[k]) : "v"(buf + 2 * n) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < PER; ++k) ok = ok && v[k].y == tag && v[k].w == tag;
+                if (__all(ok)) {
+#pragma unroll
+                    for (int k = 0; k < PER; ++k) {
+                        const int n = tid + k * HB_THREADS;
+                        if (n < PAIRS) { xs[2 * n] = v[k].x; xs[2 * n + 1] = v[k].z; }
+                    }
+                    break;
+                }
+                if (tries > HB_SPIN) { a.abort_flag[0] = 1; s_flag = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            lds_barrier();
+            if (s_flag) return;
         } else if (MODE == 1) {
             if (poller) {
                 constexpr int SHARE = NG / (NPW > 0 ? NPW : 1);  // granules per poller wave
@@ -442,14 +511,12 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&a.abort_flag, 4));
     const uint32_t e2048 = host_expect<2048>(rounds), e5632 = host_expect<5632>(rounds);
 #define ALL(NL)                                                        \
-    run<0, 0, 2048, NL>("vector_all_waves", a, e2048);                 \
     run<0, 1, 2048, NL>("vector_all_waves+publish_first", a, e2048);   \
-    run<0, 3, 2048, NL>("vector_all_waves+publish_first+nosleep", a, e2048); \
-    run<3, 1, 2048, NL>("sample_then_full+publish_first", a, e2048);   \
-    run<0, 0, 5632, NL>("vector_all_waves", a, e5632);                 \
+    run<6, 1, 2048, NL>("per_wave_spin+publish_first", a, e2048);      \
+    run<7, 1, 2048, NL>("per_wave_spin_16B+publish_first", a, e2048);  \
     run<0, 1, 5632, NL>("vector_all_waves+publish_first", a, e5632);   \
-    run<0, 3, 5632, NL>("vector_all_waves+publish_first+nosleep", a, e5632); \
-    run<3, 1, 5632, NL>("sample_then_full+publish_first", a, e5632);
+    run<6, 1, 5632, NL>("per_wave_spin+publish_first", a, e5632);      \
+    run<7, 1, 5632, NL>("per_wave_spin_16B+publish_first", a, e5632);
     if (argc > 2) {  // the dedicated-poller and scalar-path variants (slow / no gain: profiles/r01g_handoff/NOTES.md)
         run<1, 1, 2048, 12>("vector_1_poller", a, e2048);
         run<1, 2, 2048, 12>("vector_2_pollers", a, e2048);
