@@ -195,6 +195,17 @@ def main():
         roofline = {"bound": "hbm", "kernel": kname,
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": None, "bytes_per_launch": nbytes.value, "avg_launch_us": round(ms.value * 1e3, 2)}
+        # HBM traffic per launch comes from a separate rocprofv3 --pmc FETCH_SIZE pass (it cannot be collected from inside this
+        # process); the committed summary of the last pass is quoted with the launches it was measured on
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "roofline_traffic.json")) as f:
+                tr = json.load(f)
+            if tr["kernel"] in kname:
+                roofline["traffic"] = tr["traffic_bytes_per_launch"]
+                roofline["traffic_note"] = (f"{tr['source']}; {tr['launch_contexts']}; algorithmic bytes of those launches "
+                                            f"{tr['algorithmic_bytes_same_launches']} (ratio {tr['ratio']})")
+        except (OSError, KeyError, ValueError):
+            pass
         per_kernel = {}
         for kind, name in [(0, "norm+wqkv+kv"), (1, "attention@pos"), (2, "wo+res"), (4, "w2+res"), (5, "norm+head")]:
             N.check(N.lib().mv_probe_kernel(engine._h, kind, 24 * 10, C.byref(ms), C.byref(nbytes)))

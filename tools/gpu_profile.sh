@@ -9,7 +9,7 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
 find /tmp/prof_stats -name '*stats*.csv' -exec cp {} $OUT/ \;
 for ctr in ${PMC_CTRS:-}; do
-  timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/prof_$ctr -o probe -- python $GRAFT_REPO_ROOT/tools/probe_kernels.py --iters 24 > $OUT/probe_$ctr.log 2>&1
+  timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/prof_$ctr -o probe -- python $GRAFT_REPO_ROOT/tools/probe_kernels.py ${PROBE_ARGS:---iters 24} > $OUT/probe_$ctr.log 2>&1
   f=$(find /tmp/prof_$ctr -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python $GRAFT_REPO_ROOT/tools/summarise_pmc.py "$f" $ctr > $OUT/pmc_$ctr.txt 2>&1
 done

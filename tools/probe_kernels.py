@@ -24,7 +24,8 @@ e.finalize()
 e.begin([mv.synthetic.prompt_tokens(a.pos, seed=0)], mv.synthetic.speaker_embedding(0), mv.SamplingParams(top_p=0.95),
         max_new_tokens=4, end_of_audio_token=9999)
 e.run(max_steps=a.pos)  # teacher-forced prompt: fills the KV cache up to `pos`
-names = ["norm+wqkv+kv", "attention", "wo+res", "norm+w1|w3+silu", "w2+res", "norm+head"]
+# kind 6 = the persistent decode-step kernel (decode_mega.hip), one launch = 24 layers + LM head at context `pos`
+names = ["norm+wqkv+kv", "attention", "wo+res", "norm+w1|w3+silu", "w2+res", "norm+head", "persistent step"]
 for ab in [int(x, 0) for x in a.ablate.split(",")]:
   e.tune(gemv_ablate=ab)
   if ab: print(f"--- gemv_ablate = {ab}")
