@@ -139,6 +139,35 @@ __device__ __forceinline__ u32x4 attn_normalise(const AttnAcc& b) {
     return y;
 }
 
+// Combination of up to 8 split partials by one whole wave: lane group g contributes splits g and g+4 (ms[q] = -inf marks a
+// missing split), the 4 groups are folded with xor-16/32 butterflies.  Shared by the ticket form below and the tagged form of
+// the persistent kernel: identical arithmetic, identical bits.
+__device__ __forceinline__ void attn_combine_math(AttnAcc& b, const float (&ms)[2], const float (&ls)[2], const float (&t)[2][8]) {
+    float mt = fmaxf(ms[0], ms[1]);
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    float lt = 0.f, ot[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) ot[d] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float f = (ms[q] == -INFINITY) ? 0.f : fast_exp(ms[q] - mt);
+        lt = fmaf(ls[q], f, lt);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) ot[d] = fmaf(t[q][d], f, ot[d]);
+    }
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        ot[d] += __shfl_xor(ot[d], 16, 64);
+        ot[d] += __shfl_xor(ot[d], 32, 64);
+        b.o[d] = ot[d];
+    }
+    b.m = mt;
+    b.l = lt;
+}
+
 // Executed by one whole wave holding the block result `b` (identical in the 4 lane groups).  Publishes the split
 // partial (33 x 16 B: [m, l, -, -] then o[128]) write-through and draws a ticket; returns true in the LAST arriver of
 // the (row, head), with `b` replaced by the combination of all `nact` <= 8 partials -- lane group g reads splits g and
@@ -171,30 +200,63 @@ __device__ __forceinline__ bool attn_publish_combine(AttnAcc& b, float* pbase, u
         t[q][4] = __uint_as_float(r.v[3 * q + 2].x); t[q][5] = __uint_as_float(r.v[3 * q + 2].y);
         t[q][6] = __uint_as_float(r.v[3 * q + 2].z); t[q][7] = __uint_as_float(r.v[3 * q + 2].w);
     }
-    float mt = fmaxf(ms[0], ms[1]);
-    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    float lt = 0.f, ot[8];
-#pragma unroll
-    for (int d = 0; d < 8; ++d) ot[d] = 0.f;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const float f = (ms[q] == -INFINITY) ? 0.f : fast_exp(ms[q] - mt);
-        lt = fmaf(ls[q], f, lt);
-#pragma unroll
-        for (int d = 0; d < 8; ++d) ot[d] = fmaf(t[q][d], f, ot[d]);
-    }
-    lt += __shfl_xor(lt, 16, 64);
-    lt += __shfl_xor(lt, 32, 64);
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-        ot[d] += __shfl_xor(ot[d], 16, 64);
-        ot[d] += __shfl_xor(ot[d], 32, 64);
-        b.o[d] = ot[d];
-    }
-    b.m = mt;
-    b.l = lt;
+    attn_combine_math(b, ms, ls, t);
     if (lane == 0)  // re-arm; nobody else touches this counter until the next layer / step (data dependence / stream order)
         __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
+}
+
+// ---- the same exchange through TAGGED granules (persistent kernel): no ticket, no one-shot loads ------------------------
+// A partial is 130 floats sent as 130 granules {float, 32-bit tag}, two per 16-byte store: lane (g, dl) stores o[2g], o[2g+1]
+// of its 8 dims (the 4 lane groups hold identical values), lane 0 adds {m, l}.  The workgroup of split 0 polls the partials of
+// all `nact` splits (its own included) until every tag matches and combines them with attn_combine_math: one hand-off
+// instead of store + vmcnt(0) + ticket round trip + load round trip.  Slots are reused across layers and steps: the tag makes
+// a stale line harmless (the poll just retries).
+__device__ __forceinline__ void attn_publish_tagged(const AttnAcc& b, u64* slot, uint32_t tag, int lane) {
+    const int g = lane >> 4, dl = lane & 15;
+    const float lo = g == 0 ? b.o[0] : g == 1 ? b.o[2] : g == 2 ? b.o[4] : b.o[6];
+    const float hi = g == 0 ? b.o[1] : g == 1 ? b.o[3] : g == 2 ? b.o[5] : b.o[7];
+    const u32x4 v = {__float_as_uint(lo), tag, __float_as_uint(hi), tag};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slot + dl * 8 + 2 * g), "v"(v) : "memory");
+    if (lane == 0) {
+        const u32x4 w = {__float_as_uint(b.m), tag, __float_as_uint(b.l), tag};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slot + 128), "v"(w) : "memory");
+    }
+}
+// returns false on a timeout (caller raises the abort flag)
+__device__ __forceinline__ bool attn_combine_tagged(AttnAcc& b, const u64* slots, uint32_t tag, int nact, int lane, int spin_limit) {
+    const int g = lane >> 4, dl = lane & 15;
+    for (int tries = 0;; ++tries) {
+        u32x4 v[2][5];
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const u64* p = slots + (size_t)min(g + 4 * q, nact - 1) * ATTN_TPART_STRIDE;  // clamped: weighted 0 below
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[q][0]) : "v"(p + 128) : "memory");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[q][1 + k]) : "v"(p + dl * 8 + 2 * k) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) ok = ok && v[q][k].y == tag && v[q][k].w == tag;
+        if (__all(ok)) {
+            float ms[2], ls[2], t[2][8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                ms[q] = (g + 4 * q < nact) ? __uint_as_float(v[q][0].x) : -INFINITY;
+                ls[q] = __uint_as_float(v[q][0].z);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    t[q][2 * k] = __uint_as_float(v[q][1 + k].x);
+                    t[q][2 * k + 1] = __uint_as_float(v[q][1 + k].z);
+                }
+            }
+            attn_combine_math(b, ms, ls, t);
+            return true;
+        }
+        if (tries >= spin_limit) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
 }

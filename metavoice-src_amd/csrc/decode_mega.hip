@@ -314,12 +314,16 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             AttnAcc bb = attn_merge_waves(sm, g, dl);
             bool last = true;
             if (nact > 1) {
-                // One partial slab PER LAYER: inside a launch an address is then written once before it is read.  Reusing one slab
-                // across layers is wrong without tags: the combiner's one-shot agent-scope load can be served a line its XCD's
-                // L2 still holds from the previous layer's combine (remote write-through stores invalidate other L2s with a
-                // delay; a polled granule just retries, a one-shot load cannot) -- seen as 1-ulp drifts in one CFG row.
-                float* pbase = a.partial + (((size_t)l * 2 + at_r) * MG_HEADS + at_h) * ATTN_NSPLIT * ATTN_PART_STRIDE;
-                last = attn_publish_combine(bb, pbase, a.counters + at_r * MG_HEADS + at_h, at_s, nact, lane);
+                // split partials as tagged granules: every split publishes, the workgroup of split 0 polls all of them and
+                // combines (attn_core.h) -- one hand-off instead of store + vmcnt(0) + ticket round trip + load round trip
+                u64* slots = (u64*)a.partial + ((size_t)at_r * MG_HEADS + at_h) * ATTN_NSPLIT * ATTN_TPART_STRIDE;
+                attn_publish_tagged(bb, slots + (size_t)at_s * ATTN_TPART_STRIDE, tag0 + 5u, lane);
+                last = at_s == 0;
+                if (last && !attn_combine_tagged(bb, slots, tag0 + 5u, nact, lane, MG_SPIN_LIMIT)) {
+                    __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *(volatile int*)&s_abort = 1;
+                    last = false;
+                }
             }
             if (last && g == 0) {  // 8 dims per lane = 4 column-paired granules
                 const u32x4 y = attn_normalise(bb);

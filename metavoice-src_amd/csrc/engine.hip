@@ -582,7 +582,13 @@ int mv_finalize(mv_engine* e) {
     HIP_TRY(hipMemset(e->kcache, 0, e->kv_layer_elems * c.n_layer * 2));
     HIP_TRY(hipMemset(e->vcache, 0, e->kv_layer_elems * c.n_layer * 2));
     // one slab per layer: the persistent kernel must not reuse a partial's address inside a launch (decode_mega.hip)
-    HIP_TRY(hipMalloc((void**)&e->partial, (size_t)c.n_layer * R * c.n_head * ATTN_NSPLIT * ATTN_PART_STRIDE * 4));
+    {   // split-attention partials: one slab per layer for the launches (ticket form), tagged slots for the persistent kernel
+        const size_t ticket_bytes = (size_t)c.n_layer * R * c.n_head * ATTN_NSPLIT * ATTN_PART_STRIDE * 4;
+        const size_t tagged_bytes = (size_t)R * c.n_head * ATTN_NSPLIT * ATTN_TPART_STRIDE * 8;
+        const size_t bytes = ticket_bytes > tagged_bytes ? ticket_bytes : tagged_bytes;
+        HIP_TRY(hipMalloc((void**)&e->partial, bytes));
+        HIP_TRY(hipMemset(e->partial, 0, bytes));
+    }
     HIP_TRY(hipMalloc((void**)&e->counters, (size_t)R * c.n_head * 4));
     HIP_TRY(hipMemset(e->counters, 0, (size_t)R * c.n_head * 4));
     HIP_TRY(hipMalloc((void**)&e->utt, (size_t)U * sizeof(UttState)));

@@ -84,6 +84,7 @@ hipError_t launch_quantize_i8(hipStream_t s, const bf16_t* w, int N, int K, sign
 // ---- attention.hip -------------------------------------------------------------------------------------------
 constexpr int ATTN_NSPLIT = 8;          // max KV splits per (row, head): 8 x 256 keys = block_size 2048
 constexpr int ATTN_PART_STRIDE = 132;   // floats per partial: m, l, pad, pad, o[128]
+constexpr int ATTN_TPART_STRIDE = 264;  // persistent kernel: u64 tagged granules per partial slot (130 used; 2112 B, 64-byte aligned)
 struct AttnArgs {
     const bf16_t* q = nullptr;        // [rows][n_head*128]
     const bf16_t* kcache = nullptr;   // [rows][n_head][cache_len][128]
