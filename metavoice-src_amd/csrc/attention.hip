@@ -29,19 +29,20 @@ __global__ void __launch_bounds__(ATTN_THREADS) attn_decode_kernel(const AttnArg
     const int cs = attn_keys_per_split(P);
     const int nact = (P + cs - 1) / cs;
     if (split >= nact) return;
-    const int s0 = split * cs + wave * ATTN_KEYS_PER_WAVE;  // first key of this wave
-    const int s1 = min(P, split * cs + cs);                 // end of this block's keys
+    const int kw = attn_keys_per_wave(cs);
+    const int s0 = split * cs + wave * kw;                   // first key of this wave
+    const int s1 = min(min(P, split * cs + cs), s0 + kw);  // end of this wave's keys
 
     const size_t head_base = ((size_t)r * a.n_head + h) * (size_t)a.cache_len * 128;
     const bf16_t* kb = a.kcache + head_base + dl * 8;
     const bf16_t* vb = a.vcache + head_base + dl * 8;
 
-    // the wave's whole K and V working set goes in flight at once (16 x 16 B per lane); clamped addresses, masked later
+    // the wave's whole K and V working set goes in flight at once (up to 16 x 16 B per lane); clamped addresses, masked later
     u32x4 kv[ATTN_U], vv[ATTN_U];
 #pragma unroll
-    for (int u = 0; u < ATTN_U; ++u) kv[u] = load_stream16(kb + (size_t)min(s0 + u * 4 + g, P - 1) * 128);
+    for (int u = 0; u < ATTN_U; ++u) kv[u] = u * 4 < kw ? load_stream16(kb + (size_t)min(s0 + u * 4 + g, P - 1) * 128) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int u = 0; u < ATTN_U; ++u) vv[u] = load_stream16(vb + (size_t)min(s0 + u * 4 + g, P - 1) * 128);
+    for (int u = 0; u < ATTN_U; ++u) vv[u] = u * 4 < kw ? load_stream16(vb + (size_t)min(s0 + u * 4 + g, P - 1) * 128) : u32x4{0u, 0u, 0u, 0u};
     const u32x4 qv = load16(a.q + (size_t)r * a.n_head * 128 + h * 128 + dl * 8);
 
     const AttnAcc w = attn_wave_partial(kv, vv, qv, s0, s1, g);

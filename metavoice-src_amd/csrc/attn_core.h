@@ -4,9 +4,6 @@
 // SAME source expression was fused in one kernel and not in the other (1-ulp fp32 differences, a bf16 flip every ~1e6
 // outputs).
 //
-// Key partition of a (row, head): ATTN_NSPLIT = 16 contiguous ranges of `cs` keys, cs = ceil(P/16) rounded up to a
-// multiple of 4 (a wave instruction covers 4 keys: 16 lanes x 16 B per 256-byte key row); only the first
-// nact = ceil(P/cs) ranges are non-empty.  Inside a range 4 waves take 32 keys each (cs <= 128 for P <= 2048).
 #pragma once
 #include "common.h"
 #include "kernels.h"
@@ -46,13 +43,16 @@ __device__ __forceinline__ AttnPart6 load6x16_agent(const float* p0, const float
     return r;
 }
 
-// Key partition of a (row, head): nsplit = clamp(ceil(P/256), 1, 8) contiguous ranges of cs keys (a multiple of 4: a wave
-// instruction covers 4 keys, 16 lanes x 16 B per 256-byte key row), cs <= 256 = 8 waves x 32 keys.  Up to 256 keys a
-// single block does the whole (row, head) and there is no cross-block combine at all; at 2048 keys all 256 CUs stream.
+// Key partition of a (row, head): up to 256 keys ONE block does the whole (row, head) and there is no cross-block combine;
+// beyond that always ATTN_NSPLIT = 8 contiguous ranges of cs = ceil(P/8) keys (rounded up to a multiple of 4: a wave instruction
+// covers 4 keys, 16 lanes x 16 B per 256-byte key row), so every CU streams 1/8 of a head at any context -- with
+// ceil(P/256) ranges the K/V burst of a block was 64-128 KB at every context above 256, now it grows linearly to 128 KB at 2048.
+// Inside a range the 8 waves take kw = ceil(cs/8) keys each (multiple of 4, <= 32) and request only those rows.
 __device__ __forceinline__ int attn_keys_per_split(int P) {
-    const int nsplit = min(ATTN_NSPLIT, (P + ATTN_KEYS_PER_BLOCK - 1) / ATTN_KEYS_PER_BLOCK);
+    const int nsplit = P <= ATTN_KEYS_PER_BLOCK ? 1 : ATTN_NSPLIT;
     return (((P + nsplit - 1) / nsplit) + 3) & ~3;
 }
+__device__ __forceinline__ int attn_keys_per_wave(int cs) { return (((cs + ATTN_WAVES - 1) / ATTN_WAVES) + 3) & ~3; }
 
 struct AttnAcc {
     float m, l, o[8];

@@ -181,7 +181,8 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
     const int g = lane >> 4, dl = lane & 15;
     const int cs = attn_keys_per_split(P);
     const int nact = (P + cs - 1) / cs;
-    const int at_s0 = at_s * cs + at_w * ATTN_KEYS_PER_WAVE, at_s1 = min(P, at_s * cs + cs);
+    const int kw = attn_keys_per_wave(cs);
+    const int at_s0 = at_s * cs + at_w * kw, at_s1 = min(min(P, at_s * cs + cs), at_s0 + kw);
 
     // optional phase stamps (blocks 0 and 255, wave 0): poll-wait vs compute per phase, for profiles/
     const bool stamping = a.stamps != nullptr && (b == 0 || b == 255) && wave == 0;
@@ -221,7 +222,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
         // before the norm and the wqkv dots: it lands while they run instead of sitting in front of the q/k/v poll.
         u32x4 kv[ATTN_U], vv[ATTN_U];
         {
-            const int go = lane_o >> 4, dlo = lane_o & 15, s0o = at_s * cs + wave_o * ATTN_KEYS_PER_WAVE;
+            const int go = lane_o >> 4, dlo = lane_o & 15, s0o = at_s * cs + wave_o * kw;
             const size_t head_base = ((size_t)at_r * MG_HEADS + at_h) * (size_t)a.cache_len * 128 + dlo * 8;
             // Addresses are clamped to the newest row an EARLIER launch wrote (P-2): row P-1 is being written by this launch and
             // is taken from the hand-off below -- it must not even be touched here (a line fetched before its producer's store
@@ -233,9 +234,11 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             for (int u = 0; u < ATTN_U; ++u) vv[u] = u32x4{0u, 0u, 0u, 0u};
             if (P > 1) {
 #pragma unroll
-                for (int u = 0; u < ATTN_U; ++u) kv[u] = load_stream16(kc + head_base + (size_t)min(s0o + u * 4 + go, last_old) * 128);
+                for (int u = 0; u < ATTN_U; ++u)
+                    if (u * 4 < kw) kv[u] = load_stream16(kc + head_base + (size_t)min(s0o + u * 4 + go, last_old) * 128);
 #pragma unroll
-                for (int u = 0; u < ATTN_U; ++u) vv[u] = load_stream16(vc + head_base + (size_t)min(s0o + u * 4 + go, last_old) * 128);
+                for (int u = 0; u < ATTN_U; ++u)
+                    if (u * 4 < kw) vv[u] = load_stream16(vc + head_base + (size_t)min(s0o + u * 4 + go, last_old) * 128);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -540,30 +543,44 @@ __shared__ float ml_red[MG_WAVES * 2];
 __shared__ int ml_abort;
 #define ML_ABORTED() (*(volatile int*)&ml_abort != 0)
 
+// ---- v4 synchronisation: the compute waves never execute s_barrier (it would include the loader waves); they meet through
+// one LDS progress word per wave (a barrier id, monotonic) -- ~0.15 us per meeting instead of ~0.05, and in exchange the loaders
+// run free: they wait for ring slots by watching the same words and announce filled groups through one counter per loader.
+__shared__ uint32_t ml_prog[MG_WAVES];
+__shared__ uint32_t ml_ready[ML_LOADERS];
+#define ML_SPIN_GUARD (1 << 24)
+__device__ __forceinline__ void prog_wait(uint32_t id, int lane) {  // until every compute wave has reached barrier `id`
+    for (int tries = 0; tries < ML_SPIN_GUARD; ++tries) {
+        const uint32_t v = *(volatile uint32_t*)&ml_prog[lane & (MG_WAVES - 1)];
+        if (__all((int)(v - id) >= 0)) return;
+    }
+    *(volatile int*)&ml_abort = 1;
+}
+__device__ __forceinline__ void cbar(uint32_t id, int wave, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS traffic is done
+    if (lane == 0) *(volatile uint32_t*)&ml_prog[wave] = id;
+    prog_wait(id, lane);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void ready_wait(uint32_t groups, int lane) {  // until every loader has filled `groups` groups
+    for (int tries = 0; tries < ML_SPIN_GUARD; ++tries) {
+        const uint32_t v = *(volatile uint32_t*)&ml_ready[lane & (ML_LOADERS - 1)];
+        if (__all((int)(v - groups) >= 0)) return;
+    }
+    *(volatile int*)&ml_abort = 1;
+}
+
 __device__ __forceinline__ void mega_lds_loader(const MegaArgs a) {
     const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6, b = blockIdx.x;
-    const uint32_t epoch = a.step_counter[0] * 256u;
-    const int P = a.pos[0] + 1;
-    const int at_r = b >> 7, at_h = (b >> 3) & 15, at_s = b & 7;
-    const int cs = attn_keys_per_split(P);
-    const int nact = (P + cs - 1) / cs;
-    const bool attending = at_s < nact;  // workgroup-uniform: loaders and compute waves take the same barriers
-
-    // ========================================= loader wave q: chunk q of every 2048-column row, every 4th line of w2 rows
-    // Every line goes global -> loader registers -> LDS.  Requests are issued a full phase pair ahead of their use, in four
-    // batches per layer placed right after a barrier that follows a publish (the compute waves are about to wait for a
-    // hand-off, so a loader that is held up by memory back-pressure delays nobody); a line is copied into the ring
-    // (ds_write_b128) as soon as the barrier that frees its slot has passed.  28 register slots, per layer:
-    //   after 16': w1|w3 rows i=0,1 lines 0..95 -> R[0..23]                                  copied after 4  (wqkv consumed)
-    //   after 4  : lines 96..127 -> R[0..7], wo -> R[8..15], rows i=2 -> R[16..27]          copied after 8 / before 7 / after 12
-    //   after 8  : w2 lines 0..63 -> R[0..15]                                              copied after 13
-    //   after 13 : w2 lines 64..87 -> R[16..21], next wqkv (or LM head) rows 0..21 -> R[0..15], R[22..27]   copied after 14 / 16
-    //   after 14 : next wqkv rows 22, 23 -> R[16..17]                                        copied after 16
+    // Loader wave q: chunk q of every 2048-column row, every 4th line of the w2 rows.  Lines go global -> registers -> LDS in
+    // consumption order, in groups of <= 12 lines, two register buffers: group g+1 is requested before group g is waited for,
+    // copied into the ring as soon as the compute waves' progress words say its slots are free, then announced (ml_ready).
+    // Groups per layer (10, so that buffer parity repeats):  0,1 wqkv rows 0-11 / 12-23 -> ring [0,96)   free at 16 of layer l-1
+    //   2 wo -> [96,128) (16')   3,4 w1|w3 rows i=0,1 lines 0-47 / 48-95 (barrier 4)   5 lines 96-127 (8)   6 rows i=2 -> [0,48) (12)
+    //   7 w2 lines 0-39 -> [48,..) (12)   8 w2 lines 40-87 (the last 8 -> [0,8)) (14)   9 empty
     int q = __builtin_amdgcn_readfirstlane(wave0) - MG_WAVES, bo = b, lo = lane0;
-    u32x4 R[28];
+    u32x4 R[2][12];
     auto rb13 = [&](int w) { return 22 * bo + (w < 6 ? 3 * w : 18 + 2 * (w - 6)); };
-    // row pointers are wave-uniform (SGPR base), the lane only contributes a 32-bit index: one shared offset register for
-    // all requests instead of a 64-bit address pair each
     auto src4 = [&](const bf16_t* w, int row) { return (const u32x4*)(w + (size_t)row * MG_DIM + q * 512); };
     auto ld = [&](const u32x4* base) { return __builtin_nontemporal_load(base + lo); };
     auto w13_row = [&](const MegaLayer& L, int idx) {  // idx = (i * 8 + w) * 2 + m
@@ -575,128 +592,90 @@ __device__ __forceinline__ void mega_lds_loader(const MegaArgs a) {
         return (const u32x4*)(L.w2 + (size_t)(8 * bo + w) * MG_INTER + c * 512);
     };
     auto put = [&](int line, const u32x4& v) { ring[line * 64 + lo] = v; };
-#define ML_QKV_SLOT(k) ((k) < 16 ? (k) : (k) + 6)  /* R[0..15], R[22..29] -> with 28 slots: R[22..27] + R[16..17] for k = 22, 23 */
-    {   // prologue: layer 0's wqkv rows, then its first w1|w3 lines
-        const MegaLayer L = a.layers[0];
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < 24; ++k) R[k] = ld(src4(L.wqkv, 24 * bo + k));
-        wait_vm<0>();
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < 24; ++k) put(k * 4 + q, R[k]);
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int idx = 0; idx < 24; ++idx) R[idx] = ld(w13_row(L, idx));
-    }
-    for (int l = 0; l < a.n_layer; ++l) {
+    auto announce = [&](uint32_t groups) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lo == 0) *(volatile uint32_t*)&ml_ready[q] = groups;
+    };
+    // request group g of layer L into buffer B; returns nothing (counts are compile-time: see ML_GROUP_N)
+#define ML_REQ(B, g, L, is_head)                                                                                             \
+    do {                                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        if ((g) == 0 || (g) == 1) {                                                                                        \
+            _Pragma("unroll") for (int k = 0; k < 12; ++k) {                                                               \
+                const int row = (is_head) ? min(11 * bo + min(12 * (g) + k, 10), a.vocab - 1) : 24 * bo + 12 * (g) + k;    \
+                R[B][k] = ld(src4((is_head) ? a.head : (L).wqkv, row));                                                    \
+            }                                                                                                              \
+        } else if ((g) == 2) {                                                                                             \
+            _Pragma("unroll") for (int w = 0; w < 8; ++w) R[B][w] = ld(src4((L).wo, 8 * bo + w));                          \
+        } else if ((g) == 3 || (g) == 4) {                                                                                 \
+            _Pragma("unroll") for (int k = 0; k < 12; ++k) R[B][k] = ld(w13_row((L), 12 * ((g) - 3) + k));                 \
+        } else if ((g) == 5) {                                                                                             \
+            _Pragma("unroll") for (int k = 0; k < 8; ++k) R[B][k] = ld(w13_row((L), 24 + k));                              \
+        } else if ((g) == 6) {                                                                                             \
+            _Pragma("unroll") for (int k = 0; k < 12; ++k) R[B][k] = ld(src4((k & 1) ? (L).w3 : (L).w1, rb13(k >> 1) + 2)); \
+        } else if ((g) == 7) {                                                                                             \
+            _Pragma("unroll") for (int t = 0; t < 10; ++t) R[B][t] = ld(w2_src((L), t));                                   \
+        } else if ((g) == 8) {                                                                                             \
+            _Pragma("unroll") for (int t = 10; t < 22; ++t) R[B][t - 10] = ld(w2_src((L), t));                             \
+        }                                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    } while (0)
+    // copy group g from buffer B into its ring slots
+#define ML_PUT(B, g)                                                                                                       \
+    do {                                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        if ((g) == 0 || (g) == 1) { _Pragma("unroll") for (int k = 0; k < 12; ++k) put((12 * (g) + k) * 4 + q, R[B][k]); } \
+        else if ((g) == 2) { _Pragma("unroll") for (int w = 0; w < 8; ++w) put(96 + w * 4 + q, R[B][w]); }                 \
+        else if ((g) == 3 || (g) == 4) { _Pragma("unroll") for (int k = 0; k < 12; ++k) put((12 * ((g) - 3) + k) * 4 + q, R[B][k]); } \
+        else if ((g) == 5) { _Pragma("unroll") for (int k = 0; k < 8; ++k) put((24 + k) * 4 + q, R[B][k]); }               \
+        else if ((g) == 6) { _Pragma("unroll") for (int k = 0; k < 12; ++k) put(k * 4 + q, R[B][k]); }                     \
+        else if ((g) == 7) { _Pragma("unroll") for (int t = 0; t < 10; ++t) put(48 + 4 * t + q, R[B][t]); }                \
+        else if ((g) == 8) {                                                                                               \
+            _Pragma("unroll") for (int t = 10; t < 20; ++t) put(48 + 4 * t + q, R[B][t - 10]);                             \
+            _Pragma("unroll") for (int t = 20; t < 22; ++t) put(4 * t + q - 80, R[B][t - 10]);                             \
+        }                                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    } while (0)
+    // one pipeline stage: request the NEXT group (NN = its request count), wait for THIS group's data, wait for its slots, copy, announce
+#define ML_STAGE(g, NN, free_id, REQ_NEXT)                                                                                 \
+    do {                                                                                                                   \
+        REQ_NEXT;                                                                                                          \
+        wait_vm<NN>();                                                                                                     \
+        prog_wait((free_id), lo);                                                                                          \
+        if (ML_ABORTED()) return;                                                                                          \
+        ML_PUT((g) & 1, (g));                                                                                              \
+        announce((uint32_t)l * 10u + (g) + 1u);                                                                            \
+    } while (0)
+
+    ML_REQ(0, 0, a.layers[0], false);
+    int l = 0;
+    for (; l < a.n_layer; ++l) {
         asm volatile("" : "+s"(q), "+s"(bo), "+v"(lo));
         const MegaLayer L = a.layers[l];
         const bool last_layer = l + 1 == a.n_layer;
-        lds_barrier();  // 1: x is in LDS
-        if (ML_ABORTED()) return;
-        lds_barrier();  // 2
-        lds_barrier();  // 3: wqkv lines in the ring
-        lds_barrier();  // 4: wqkv consumed, q/k/v published
-        wait_vm<0>();
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int idx = 0; idx < 24; ++idx) put(idx * 4 + q, R[idx]);                        // w1|w3 rows i=0,1, lines 0..95
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int idx = 24; idx < 32; ++idx) R[idx - 24] = ld(w13_row(L, idx));  // lines 96..127 -> R[0..7]
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int w = 0; w < 8; ++w) R[8 + w] = ld(src4(L.wo, 8 * bo + w));      // wo -> R[8..15]
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < 12; ++k) R[16 + k] = ld(src4((k & 1) ? L.w3 : L.w1, rb13(k >> 1) + 2));  // rows i=2 -> R[16..27]
-        if (attending) {
-            __builtin_amdgcn_sched_barrier(0);
-            lds_barrier();  // 5
-            if (ML_ABORTED()) return;
-            __builtin_amdgcn_sched_barrier(0);
-            lds_barrier();  // 6
-        }
-        wait_vm<12>();
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int w = 0; w < 8; ++w) put(96 + w * 4 + q, R[8 + w]);
-        lds_barrier();  // 7: wo lines in the ring
-        if (ML_ABORTED()) return;
-        lds_barrier();  // 8: wo consumed, h published
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int idx = 24; idx < 32; ++idx) put(idx * 4 + q, R[idx - 24]);
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 16; ++t) R[t] = ld(w2_src(L, t));  // w2 lines 0..63+q -> R[0..15]
-        lds_barrier();  // 9
-        if (ML_ABORTED()) return;
-        lds_barrier();  // 10
-        lds_barrier();  // 11: w1|w3 rows i=0,1 in the ring
-        lds_barrier();  // 12: rows i=0,1 consumed
-        wait_vm<16>();
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < 12; ++k) put(k * 4 + q, R[16 + k]);
-        lds_barrier();  // 13: rows i=2 in the ring
-        wait_vm<0>();
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 16; ++t) put(48 + 4 * t + q, R[t]);
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 16; t < 22; ++t) R[t] = ld(w2_src(L, t));  // w2 lines 64.. -> R[16..21]
-        {   // next layer's wqkv rows (after the last layer: the LM-head rows 11 b + slot; slots 11..: duplicates, never read)
-            const bf16_t* wn = last_layer ? a.head : a.layers[l + 1].wqkv;
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < 22; ++k) {
-                const int row = last_layer ? min(11 * bo + min(k, 10), a.vocab - 1) : 24 * bo + k;
-                R[ML_QKV_SLOT(k)] = ld(src4(wn, row));
-            }
-        }
-        lds_barrier();  // 14: rows i=2 consumed, act published
-        wait_vm<22>();
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 16; t < 20; ++t) put(48 + 4 * t + q, R[t]);
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 20; t < 22; ++t) put(4 * t + q - 80, R[t]);
-        {
-            const bf16_t* wn = last_layer ? a.head : a.layers[l + 1].wqkv;
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 22; k < 24; ++k) {
-                const int row = last_layer ? min(11 * bo + 10, a.vocab - 1) : 24 * bo + k;
-                R[k - 6] = ld(src4(wn, row));  // R[16..17]
-            }
-        }
-        lds_barrier();  // 15: w2 lines in the ring
-        if (ML_ABORTED()) return;
-        lds_barrier();  // 16: w2 consumed, x published
-        wait_vm<0>();
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < 22; ++k) put(k * 4 + q, R[ML_QKV_SLOT(k)]);
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 22; k < 24; ++k) put(k * 4 + q, R[k - 6]);
-        if (!last_layer) {
-            const MegaLayer Ln = a.layers[l + 1];
-__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int idx = 0; idx < 24; ++idx) R[idx] = ld(w13_row(Ln, idx));
-        }
+        const MegaLayer Ln = a.layers[last_layer ? l : l + 1];
+        const uint32_t id0 = (uint32_t)l * 16u;  // = barrier 16 of the previous layer
+        ML_STAGE(0, 12, id0, ML_REQ(1, 1, L, false));
+        ML_STAGE(1, 8, id0, ML_REQ(0, 2, L, false));
+        ML_STAGE(2, 12, id0, ML_REQ(1, 3, L, false));
+        ML_STAGE(3, 12, id0 + 4u, ML_REQ(0, 4, L, false));
+        ML_STAGE(4, 8, id0 + 4u, ML_REQ(1, 5, L, false));
+        ML_STAGE(5, 12, id0 + 8u, ML_REQ(0, 6, L, false));
+        ML_STAGE(6, 10, id0 + 12u, ML_REQ(1, 7, L, false));
+        ML_STAGE(7, 12, id0 + 12u, ML_REQ(0, 8, L, false));
+        ML_STAGE(8, 0, id0 + 14u, (void)0);
+        if (!last_layer) ML_STAGE(9, 12, id0, ML_REQ(0, 0, Ln, false));
+        else ML_STAGE(9, 12, id0, ML_REQ(0, 0, Ln, true));
     }
-#undef ML_QKV_SLOT
-    lds_barrier();  // h1
+    // LM head: rows 11 b + slot, slots 0..10 (the 12th line of the group is a duplicate, never read) -> ring [0,48)
+    wait_vm<0>();
+    prog_wait((uint32_t)a.n_layer * 16u, lo);
     if (ML_ABORTED()) return;
-    lds_barrier();  // h2
-    lds_barrier();  // h3
-    return;
+    ML_PUT(0, 0);
+    announce((uint32_t)a.n_layer * 10u + 1u);
+#undef ML_STAGE
+#undef ML_PUT
+#undef ML_REQ
 }
 
 __device__ __forceinline__ void mega_lds_compute(const MegaArgs a) {
@@ -723,7 +702,8 @@ __device__ __forceinline__ void mega_lds_compute(const MegaArgs a) {
         asm volatile("" : "+v"(lane_v), "+v"(wave_v));
         const int lane = lane_v, wave = wave_v, tid = wave * 64 + lane, lane_o = lane, wave_o = wave, tid_o = tid;
         const int at_w = wave, g = lane >> 4, dl = lane & 15;
-        const int at_s0 = at_s * cs + at_w * ATTN_KEYS_PER_WAVE, at_s1 = min(P, at_s * cs + cs);
+        const int kw = attn_keys_per_wave(cs);
+        const int at_s0 = at_s * cs + at_w * kw, at_s1 = min(min(P, at_s * cs + cs), at_s0 + kw);
         const int nrow = 8 * b + wave;  // the wo / w2 output row of this wave
         const MegaLayer L = a.layers[l];
         const uint32_t tag0 = epoch + (uint32_t)l * 8u + 1u;
@@ -734,12 +714,12 @@ __device__ __forceinline__ void mega_lds_compute(const MegaArgs a) {
         MG_STAMP(l, 0);
         if (l == 0) *(u32x4*)(xs + tid * 8) = load16(a.x_in + tid * 8);
         else wave_poll_rowpair<MG_DIM>(a.g_x, tag0 - 8u + 4u, xs, a.abort_flag, &ml_abort, tid_o);
-        lds_barrier();  // 1
+        cbar((uint32_t)l * 16u + 1u, wave, lane);  // 1
         if (ML_ABORTED()) return;
         MG_STAMP(l, 1);
         u32x4 kv[ATTN_U], vv[ATTN_U];
         {   // K/V rows of EARLIER steps for this block's attention slice: independent of this step, requested first
-            const int go = lane_o >> 4, dlo = lane_o & 15, s0o = at_s * cs + wave_o * ATTN_KEYS_PER_WAVE;
+            const int go = lane_o >> 4, dlo = lane_o & 15, s0o = at_s * cs + wave_o * kw;
             const size_t head_base = ((size_t)at_r * MG_HEADS + at_h) * (size_t)a.cache_len * 128 + dlo * 8;
             const int last_old = max(P - 2, 0);  // row P-1 is written by this launch: taken from the hand-off, never touched here
 #pragma unroll
@@ -748,17 +728,20 @@ __device__ __forceinline__ void mega_lds_compute(const MegaArgs a) {
             for (int u = 0; u < ATTN_U; ++u) vv[u] = u32x4{0u, 0u, 0u, 0u};
             if (P > 1 && attending) {
 #pragma unroll
-                for (int u = 0; u < ATTN_U; ++u) kv[u] = load_stream16(kc + head_base + (size_t)min(s0o + u * 4 + go, last_old) * 128);
+                for (int u = 0; u < ATTN_U; ++u)
+                    if (u * 4 < kw) kv[u] = load_stream16(kc + head_base + (size_t)min(s0o + u * 4 + go, last_old) * 128);
 #pragma unroll
-                for (int u = 0; u < ATTN_U; ++u) vv[u] = load_stream16(vc + head_base + (size_t)min(s0o + u * 4 + go, last_old) * 128);
+                for (int u = 0; u < ATTN_U; ++u)
+                    if (u * 4 < kw) vv[u] = load_stream16(vc + head_base + (size_t)min(s0o + u * 4 + go, last_old) * 128);
             }
         }
         const bf16_t rx0 = xs[nrow], rx1 = xs[MG_DIM + nrow];  // residual operands of P2, before the norm overwrites them
         NormState ns;
         norm_part1(xs, L.attn_norm, red, ns, tid);
-        lds_barrier();  // 2
+        cbar((uint32_t)l * 16u + 2u, wave, lane);  // 2
         norm_part2(xs, red, ns, a.eps, tid);
-        lds_barrier();  // 3: normalised x complete, wqkv lines in the ring
+        cbar((uint32_t)l * 16u + 3u, wave, lane);  // 3: normalised x complete, wqkv lines in the ring
+        ready_wait((uint32_t)l * 10u + 2u, lane);
         {
             float acc[3][2];
             lds_dots<4, 3, MG_DIM>(ring, [&](int i, int j) { return (wave * 3 + i) * 4 + j; }, xs, lane, acc);
@@ -783,7 +766,7 @@ __device__ __forceinline__ void mega_lds_compute(const MegaArgs a) {
             }
         }
         MG_STAMP(l, 2);
-        lds_barrier();  // 4
+        cbar((uint32_t)l * 16u + 4u, wave, lane);  // 4
 
         // ================= P1: attention over keys [0, P)
         if (attending) {
@@ -794,7 +777,7 @@ __device__ __forceinline__ void mega_lds_compute(const MegaArgs a) {
                 wave_poll<1>(tag0 + 0u, a.abort_flag, &ml_abort, [&](int, u64& v) { if (!mine) return false; v = gran_load(gp); return true; },
                              [&](int, uint32_t p) { qkv_s[(sec * 2 + 0) * 128 + c] = (bf16_t)p; qkv_s[(sec * 2 + 1) * 128 + c] = (bf16_t)(p >> 16); });
             }
-            lds_barrier();  // 5
+            cbar((uint32_t)l * 16u + 5u, wave, lane);  // 5
             if (ML_ABORTED()) return;
             MG_STAMP(l, 3);
             const u32x4 qv = *(const u32x4*)(qkv_s + (0 * 2 + at_r) * 128 + dl * 8);
@@ -812,7 +795,7 @@ __device__ __forceinline__ void mega_lds_compute(const MegaArgs a) {
 #pragma unroll
                 for (int d = 0; d < 8; ++d) sm[at_w][dl][2 + d] = w.o[d];
             }
-            lds_barrier();  // 6
+            cbar((uint32_t)l * 16u + 6u, wave, lane);  // 6
             if (at_w == 0) {
                 AttnAcc bb = attn_merge_waves(sm, g, dl);
                 bool last = true;
@@ -836,7 +819,8 @@ __device__ __forceinline__ void mega_lds_compute(const MegaArgs a) {
         MG_STAMP(l, 4);
         wave_poll<4>(tag0 + 1u, a.abort_flag, &ml_abort, [&](int k, u64& v) { v = gran_load(a.g_attn + tid_o + k * MG_THREADS); return true; },
                      [&](int k, uint32_t p) { ((uint32_t*)xs)[tid_o + k * MG_THREADS] = p; });
-        lds_barrier();  // 7: attention vector complete, wo lines in the ring
+        cbar((uint32_t)l * 16u + 7u, wave, lane);  // 7: attention vector complete, wo lines in the ring
+        ready_wait((uint32_t)l * 10u + 3u, lane);
         if (ML_ABORTED()) return;
         MG_STAMP(l, 5);
         {
@@ -849,24 +833,26 @@ __device__ __forceinline__ void mega_lds_compute(const MegaArgs a) {
                 if (a.dbg) { bf16_t* d = a.dbg + ((size_t)l * 5 + 2) * 2 * MG_INTER; d[nrow] = y0; d[MG_INTER + nrow] = y1; }
             }
         }
-        lds_barrier();  // 8
+        cbar((uint32_t)l * 16u + 8u, wave, lane);  // 8
 
         // ================= P3: act = silu(w1 n(h)) * w3 n(h)
         MG_STAMP(l, 6);
         wave_poll_rowpair<MG_DIM>(a.g_h, tag0 + 2u, xs, a.abort_flag, &ml_abort, tid_o);
-        lds_barrier();  // 9
+        cbar((uint32_t)l * 16u + 9u, wave, lane);  // 9
         if (ML_ABORTED()) return;
         MG_STAMP(l, 7);
         const bf16_t rh0 = xs[nrow], rh1 = xs[MG_DIM + nrow];
         norm_part1(xs, L.ffn_norm, red, ns, tid);
-        lds_barrier();  // 10
+        cbar((uint32_t)l * 16u + 10u, wave, lane);  // 10
         norm_part2(xs, red, ns, a.eps, tid);
-        lds_barrier();  // 11: normalised h complete, w1|w3 rows i=0,1 in the ring
+        cbar((uint32_t)l * 16u + 11u, wave, lane);  // 11: normalised h complete, w1|w3 rows i=0,1 in the ring
+        ready_wait((uint32_t)l * 10u + 6u, lane);
         {
             float acc01[4][2], acc2[2][2];  // (i, m) = (0,w1) (0,w3) (1,w1) (1,w3); then (2,w1) (2,w3)
             lds_dots<4, 4, MG_DIM>(ring, [&](int k, int j) { return (((k >> 1) * 8 + wave) * 2 + (k & 1)) * 4 + j; }, xs, lane, acc01);
-            lds_barrier();  // 12
-            lds_barrier();  // 13: rows i=2 in the ring
+            cbar((uint32_t)l * 16u + 12u, wave, lane);  // 12
+            cbar((uint32_t)l * 16u + 13u, wave, lane);  // 13: rows i=2 in the ring
+        ready_wait((uint32_t)l * 10u + 7u, lane);
             lds_dots<4, 2, MG_DIM>(ring, [&](int m, int j) { return (min(wave, 5) * 2 + m) * 4 + j; }, xs, lane, acc2);
             const int nrows = wave < 6 ? 3 : 2;
             const int rb = 22 * b + (wave < 6 ? 3 * wave : 18 + 2 * (wave - 6));
@@ -883,12 +869,13 @@ __device__ __forceinline__ void mega_lds_compute(const MegaArgs a) {
                 if (a.dbg) { bf16_t* d = a.dbg + ((size_t)l * 5 + 3) * 2 * MG_INTER; d[rb + lane] = y0; d[MG_INTER + rb + lane] = y1; }
             }
         }
-        lds_barrier();  // 14
+        cbar((uint32_t)l * 16u + 14u, wave, lane);  // 14
 
         // ================= P4: x = h + w2(act)
         MG_STAMP(l, 8);
         wave_poll_rowpair<MG_INTER>(a.g_act, tag0 + 3u, xs, a.abort_flag, &ml_abort, tid_o);
-        lds_barrier();  // 15: act complete, w2 lines in the ring
+        cbar((uint32_t)l * 16u + 15u, wave, lane);  // 15: act complete, w2 lines in the ring
+        ready_wait((uint32_t)l * 10u + 9u, lane);
         if (ML_ABORTED()) return;
         MG_STAMP(l, 9);
         {
@@ -902,21 +889,22 @@ __device__ __forceinline__ void mega_lds_compute(const MegaArgs a) {
                 if (a.dbg) { bf16_t* d = a.dbg + ((size_t)l * 5 + 4) * 2 * MG_INTER; d[nrow] = y0; d[MG_INTER + nrow] = y1; }
             }
         }
-        lds_barrier();  // 16
+        cbar((uint32_t)l * 16u + 16u, wave, lane);  // 16
     }
 
     // ================= LM head on the last position
     const int lane = lane0, wave = wave0, tid = tid0;
     wave_poll_rowpair<MG_DIM>(a.g_x, epoch + (uint32_t)(a.n_layer - 1) * 8u + 1u + 4u, xs, a.abort_flag, &ml_abort, tid);
-    lds_barrier();  // h1
+    cbar((uint32_t)a.n_layer * 16u + 1u, wave, lane);  // h1
     if (ML_ABORTED()) return;
     {
         NormState ns;
         norm_part1(xs, a.final_norm, red, ns, tid);
-        lds_barrier();  // h2
+        cbar((uint32_t)a.n_layer * 16u + 2u, wave, lane);  // h2
         norm_part2(xs, red, ns, a.eps, tid);
     }
-    lds_barrier();  // h3
+    cbar((uint32_t)a.n_layer * 16u + 3u, wave, lane);  // h3
+    ready_wait((uint32_t)a.n_layer * 10u + 1u, lane);
     {
         float acc[2][2];
         lds_dots<4, 2, MG_DIM>(ring, [&](int i, int j) { return min(wave + 8 * i, 10) * 4 + j; }, xs, lane, acc);
@@ -938,6 +926,8 @@ __device__ __forceinline__ void mega_lds_compute(const MegaArgs a) {
 
 __global__ void __launch_bounds__(ML_THREADS, 1) decode_mega_lds_kernel(const MegaArgs a) {
     if (threadIdx.x == 0) ml_abort = 0;
+    if (threadIdx.x < MG_WAVES) ml_prog[threadIdx.x] = 0;
+    if (threadIdx.x < ML_LOADERS) ml_ready[threadIdx.x] = 0;
     __syncthreads();
     if ((threadIdx.x >> 6) >= MG_WAVES) mega_lds_loader(a);
     else mega_lds_compute(a);
