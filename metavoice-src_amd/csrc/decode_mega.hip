@@ -25,6 +25,7 @@
 #define MG_INTER 5632
 #define MG_HEADS 16
 #define MG_SPIN_LIMIT (1 << 18)
+#define MG_STAMP_SLOTS 24  // s_memtime stamps per layer (MV_MEGA_STAMPS=1, tools/mega_stamps.py)
 
 typedef u64 gran_t;
 
@@ -34,7 +35,9 @@ __device__ __forceinline__ void gran_store(gran_t* g, uint32_t payload, uint32_t
 __device__ __forceinline__ u64 gran_load(const gran_t* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // RMSNorm of raw[2][2048] into xs[2][2048], bit-identical to gemv.hip's prologue (threads 0..255 own 8 columns each).
-__device__ __forceinline__ void mega_norm(const bf16_t* raw, const bf16_t* norm_w, bf16_t* xs, float* red, float eps) {
+// The norm weights `nw` (columns 8 tid .. 8 tid + 7) are requested by the caller a phase ahead: loaded here, their load would
+// return in order behind the K/V and weight requests already in flight and the norm would wait ~2 us for data it does not need.
+__device__ __forceinline__ void mega_norm(const bf16_t* raw, const u32x4& nw, bf16_t* xs, float* red, float eps) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = tid * 8;
     const bool in_k = c < MG_DIM;
@@ -45,7 +48,6 @@ __device__ __forceinline__ void mega_norm(const bf16_t* raw, const bf16_t* norm_
         const float s = wave_sum(sumsq8(xv[r]));
         if (lane == 0) red[wave * 2 + r] = s;
     }
-    const u32x4 nw = in_k ? load16(norm_w + c) : u32x4{0, 0, 0, 0};
     __syncthreads();
     float tots[2];
 #pragma unroll
@@ -186,8 +188,8 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 
     // optional phase stamps (blocks 0 and 255, wave 0): poll-wait vs compute per phase, for profiles/
     const bool stamping = a.stamps != nullptr && (b == 0 || b == 255) && wave == 0;
-    unsigned long long* stamp_base = a.stamps ? a.stamps + (size_t)(b == 0 ? 0 : 1) * a.n_layer * 12 : nullptr;
-#define MG_STAMP(l, k) do { if (stamping && lane == 0) stamp_base[(l) * 12 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    unsigned long long* stamp_base = a.stamps ? a.stamps + (size_t)(b == 0 ? 0 : 1) * a.n_layer * MG_STAMP_SLOTS : nullptr;
+#define MG_STAMP(l, k) do { if (stamping && lane == 0) stamp_base[(l) * MG_STAMP_SLOTS + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
     u32x4 wv[24];  // the weight working set of the current GEMV phase (next phase's rows are issued into it after the dots)
     // phase 0 of layer 0: rows 24 b + 3 wave + i of wqkv
@@ -196,6 +198,8 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 #pragma unroll
         for (int i = 0; i < 3; ++i) mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave + i, MG_DIM, lane);
     }
+    // RMSNorm weights of the next norm, requested together with the weight rows of its phase (threads 0..255 own 8 columns each)
+    u32x4 nw_attn = load16(a.layers[0].attn_norm + min(tid * 8, MG_DIM - 8)), nw_ffn = u32x4{0u, 0u, 0u, 0u};
 
     for (int l = 0; l < a.n_layer; ++l) {
         // Address arithmetic below is a function of (lane, wave): left alone, the compiler hoists ~60 loop-invariant 64-bit
@@ -242,11 +246,14 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        mega_norm(raw_x, L.attn_norm, xs, red, a.eps);
+        MG_STAMP(l, 11);  // K/V requested
+        mega_norm(raw_x, nw_attn, xs, red, a.eps);
+        MG_STAMP(l, 12);  // norm done
         {
             float acc[3][2];
             mega_dots<4, 3, MG_DIM>(wv, xs, lane, acc);
             __builtin_amdgcn_sched_barrier(0);
+            MG_STAMP(l, 13);  // wqkv dots done
             float v0 = 0.f, v1 = 0.f;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -292,6 +299,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
                 }
             }
             const AttnAcc w = attn_wave_partial(kv, vv, qv, at_s0, at_s1, g);
+            MG_STAMP(l, 14);  // wave partial done
             if (g == 0) {
                 sm[at_w][dl][0] = w.m;
                 sm[at_w][dl][1] = w.l;
@@ -307,11 +315,18 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
         // wo goes to wv[12..15]; the w1 rows of P3 ride along in wv[0..11] (the w3 rows follow after P2's dots into wv[12..23]):
         // w1|w3 is 45 % of a layer's bytes, asked for in one go it made P2 -> P3 the one stream-bound hand-off (8 us).
         const int rb13 = 22 * b + (wave_o < 6 ? 3 * wave_o : 18 + 2 * (wave_o - 6));
-        if (wave_o != 0) {
+        auto request_wo_w1 = [&]() {
             mega_issue_row<4>(wv + 12, L.wo, 8 * b + wave_o, MG_DIM, lane_o);
 #pragma unroll
             for (int i = 0; i < 3; ++i) mega_issue_row<4>(wv + 4 * i, L.w1, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
-        }
+            nw_ffn = load16(L.ffn_norm + min(tid_o * 8, MG_DIM - 8));
+        };
+        // Publish-before-prefetch holds for the WORKGROUP here, not just per wave: wave 0 still has the block's partial (and, in
+        // the workgroup of split 0, the combined output) to publish, and a store queued behind 112 KB of the other waves' bulk
+        // requests in this CU's memory pipeline reaches the combiner -- on everybody's critical path -- microseconds late.  So the
+        // other waves of an attending workgroup hold their requests until wave 0 is through.
+        const bool attending = at_s < nact;
+        if (!attending) request_wo_w1();
         __builtin_amdgcn_sched_barrier(0);
         if (at_s < nact && at_w == 0) {
             AttnAcc bb = attn_merge_waves(sm, g, dl);
@@ -339,10 +354,10 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (wave_o == 0) {
-            mega_issue_row<4>(wv + 12, L.wo, 8 * b + wave_o, MG_DIM, lane_o);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) mega_issue_row<4>(wv + 4 * i, L.w1, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
+        MG_STAMP(l, 15);  // wave 0: attention output (or partial) published
+        if (attending) {
+            __syncthreads();
+            request_wo_w1();
         }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -358,6 +373,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             float acc[1][2];
             mega_dots<4, 1, MG_DIM>(wv + 12, xs, lane, acc);
             __builtin_amdgcn_sched_barrier(0);
+            MG_STAMP(l, 16);  // wo dots done
             const float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
             if (lane == 0) {
                 const int n = 8 * b + wave;
@@ -366,6 +382,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
                 if (a.dbg) { bf16_t* d = a.dbg + ((size_t)l * 5 + 2) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
             }
             __builtin_amdgcn_sched_barrier(0);
+            MG_STAMP(l, 17);  // h published
             // next: the w3 rows (w1 is already in flight).  22 rows per block: waves 0..5 take 3, waves 6,7 take 2 (third slot
             // clamped, masked)
 #pragma unroll
@@ -381,11 +398,13 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             __syncthreads();
             if (MG_ABORTED()) return;
             MG_STAMP(l, 7);
-            mega_norm(raw_h, L.ffn_norm, xs, red, a.eps);
+            mega_norm(raw_h, nw_ffn, xs, red, a.eps);
+            MG_STAMP(l, 18);  // norm done
             float acc1[3][2], acc3[3][2];
             mega_dots<4, 3, MG_DIM>(wv, xs, lane, acc1);
             mega_dots<4, 3, MG_DIM>(wv + 12, xs, lane, acc3);
             __builtin_amdgcn_sched_barrier(0);
+            MG_STAMP(l, 19);  // w1|w3 dots done
             const int nrows = wave < 6 ? 3 : 2;
             const int rb = 22 * b + (wave < 6 ? 3 * wave : 18 + 2 * (wave - 6));
             float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
@@ -400,6 +419,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
                 if (a.dbg) { bf16_t* d = a.dbg + ((size_t)l * 5 + 3) * 2 * MG_INTER; d[rb + lane] = y0; d[MG_INTER + rb + lane] = y1; }
             }
             __builtin_amdgcn_sched_barrier(0);
+            MG_STAMP(l, 20);  // act published
             // next: w2 row 8 b + wave (K = 5632: 11 chunks)
             mega_issue_row<11>(wv, L.w2, 8 * b + wave_o, MG_INTER, lane_o);
             __builtin_amdgcn_sched_barrier(0);
@@ -416,6 +436,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             float acc[1][2];
             mega_dots<11, 1, MG_INTER>(wv, xs, lane, acc);
             __builtin_amdgcn_sched_barrier(0);
+            MG_STAMP(l, 21);  // w2 dots done
             const float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
             if (lane == 0) {
                 const int n = 8 * b + wave;
@@ -434,6 +455,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 #pragma unroll
                 for (int i = 0; i < 2; ++i) mega_issue_row<4>(wv + 4 * i, a.head, min(11 * b + wave_o + 8 * i, a.vocab - 1), MG_DIM, lane_o);
             }
+            nw_attn = load16((l + 1 < a.n_layer ? a.layers[l + 1].attn_norm : a.final_norm) + min(tid_o * 8, MG_DIM - 8));
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -443,7 +465,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
     wave_poll_rowpair16(a.g_x, epoch + (uint32_t)(a.n_layer - 1) * 8u + 1u + 4u, raw_x, a.abort_flag, &s_abort, tid);
     __syncthreads();
     if (MG_ABORTED()) return;
-    mega_norm(raw_x, a.final_norm, xs, red, a.eps);
+    mega_norm(raw_x, nw_attn, xs, red, a.eps);
     {
         float acc[2][2];
         mega_dots<4, 2, MG_DIM>(wv, xs, lane, acc);
@@ -693,7 +715,7 @@ __device__ __forceinline__ void mega_lds_compute(const MegaArgs a) {
 
     // ============================================= compute waves ======================================================
     const bool stamping = a.stamps != nullptr && (b == 0 || b == 255) && wave0 == 0;
-    unsigned long long* stamp_base = a.stamps ? a.stamps + (size_t)(b == 0 ? 0 : 1) * a.n_layer * 12 : nullptr;
+    unsigned long long* stamp_base = a.stamps ? a.stamps + (size_t)(b == 0 ? 0 : 1) * a.n_layer * MG_STAMP_SLOTS : nullptr;
     int lane_v = lane0, wave_v = wave0;
 
     for (int l = 0; l < a.n_layer; ++l) {

@@ -348,7 +348,7 @@ const char* mv_last_error(void) { return g_err.c_str(); }
 
 int mv_debug_stamps(mv_engine* e, uint64_t* out, int64_t cap_elems) {
     if (!e || !e->stamps || !out) return fail(MV_ERR_STATE, "stamps are not enabled (MV_MEGA_STAMPS=1 before mv_finalize)");
-    const size_t n = (size_t)2 * e->cfg.n_layer * 12;
+    const size_t n = (size_t)2 * e->cfg.n_layer * 24;
     if ((size_t)cap_elems < n) return fail(MV_ERR_INVALID, "buffer too small");
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(out, e->stamps, n * 8, hipMemcpyDeviceToHost));
@@ -604,8 +604,8 @@ int mv_finalize(mv_engine* e) {
         HIP_TRY(hipMemset(e->dbg, 0, (size_t)c.n_layer * 5 * 2 * 5632 * 2));
     }
     if (getenv("MV_MEGA_STAMPS")) {
-        HIP_TRY(hipMalloc((void**)&e->stamps, (size_t)2 * c.n_layer * 12 * 8));
-        HIP_TRY(hipMemset(e->stamps, 0, (size_t)2 * c.n_layer * 12 * 8));
+        HIP_TRY(hipMalloc((void**)&e->stamps, (size_t)2 * c.n_layer * 24 * 8));
+        HIP_TRY(hipMemset(e->stamps, 0, (size_t)2 * c.n_layer * 24 * 8));
     }
     HIP_TRY(hipMalloc((void**)&e->step_counter, 4));
     HIP_TRY(hipMalloc((void**)&e->abort_flag, 4));

@@ -506,7 +506,11 @@ int main(int argc, char** argv) {
     a.rounds = rounds;
     CK(hipMalloc(&a.w, region * a.nregions * sizeof(u32x4)));
     CK(hipMemset((void*)a.w, 0, region * a.nregions * sizeof(u32x4)));
-    CK(hipMalloc(&a.gran, sizeof(u64) * 2 * 5632));
+    // argv[2] = granule memory kind: 0 plain hipMalloc (default), 1 fine-grained, 3 uncached (hipExtMallocWithFlags)
+    const int gran_kind = argc > 2 ? atoi(argv[2]) : 0;
+    if (gran_kind == 0) CK(hipMalloc(&a.gran, sizeof(u64) * 2 * 5632));
+    else CK(hipExtMallocWithFlags((void**)&a.gran, sizeof(u64) * 2 * 5632, (unsigned)gran_kind));
+    printf("{\"granule_memory\": %d}\n", gran_kind);
     CK(hipMalloc(&a.out, 4 * HB_WGS));
     CK(hipMalloc(&a.abort_flag, 4));
     const uint32_t e2048 = host_expect<2048>(rounds), e5632 = host_expect<5632>(rounds);
@@ -517,7 +521,7 @@ int main(int argc, char** argv) {
     run<0, 1, 5632, NL>("vector_all_waves+publish_first", a, e5632);   \
     run<6, 1, 5632, NL>("per_wave_spin+publish_first", a, e5632);      \
     run<7, 1, 5632, NL>("per_wave_spin_16B+publish_first", a, e5632);
-    if (argc > 2) {  // the dedicated-poller and scalar-path variants (slow / no gain: profiles/r01g_handoff/NOTES.md)
+    if (argc > 3) {  // the dedicated-poller and scalar-path variants (slow / no gain: profiles/r01g_handoff/NOTES.md)
         run<1, 1, 2048, 12>("vector_1_poller", a, e2048);
         run<1, 2, 2048, 12>("vector_2_pollers", a, e2048);
         run<2, 0, 2048, 12>("scalar_all_waves", a, e2048);

@@ -23,14 +23,28 @@ e.begin([mv.synthetic.prompt_tokens(pos, seed=0)], mv.synthetic.speaker_embeddin
 e.run(max_steps=32)
 print(f"32 steps at pos~{pos}: {e.last_run_ms / 32 * 1e3:.1f} us/step")
 L = args.n_layer
-buf = np.zeros(2 * L * 12, dtype=np.uint64)
+S = 24
+buf = np.zeros(2 * L * S, dtype=np.uint64)
 N.check(N.lib().mv_debug_stamps(e._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size))
-st = buf.reshape(2, L, 12).astype(np.int64)
+st = buf.reshape(2, L, S).astype(np.int64)
+TICK_US = 1 / 2340.0  # s_memtime ticks per us on this part (measured against HIP events)
+# coarse segments (slots 0..10) and, for the register-prefetch kernel, the fine order of slots inside a layer
 names = ["wait x", "norm+qkv", "wait qkv", "attention", "wait attn", "wo -> P3", "wait h", "norm+w13 -> P4", "wait act", "w2+publish"]
+fine_order = [0, 1, 11, 12, 13, 2, 3, 14, 15, 4, 5, 16, 17, 6, 7, 18, 19, 20, 8, 9, 21, 10]
+fine_names = {0: "layer top", 1: "x ready", 11: "K/V requested", 12: "norm done", 13: "wqkv dots done", 2: "qkv published", 3: "q/k/v ready",
+              14: "wave partial done", 15: "wave 0: attn output / partial published", 4: "P2 top (attn combined+published, wo|w1 requested)", 5: "attn vector ready", 16: "wo dots done",
+              17: "h published", 6: "P3 top (w3 requested)", 7: "h ready", 18: "norm done", 19: "w1|w3 dots done", 20: "act published",
+              8: "P4 top (w2 requested)", 9: "act ready", 21: "w2 dots done", 10: "x published"}
 for blk in range(2):
     d = np.diff(st[blk, :, :11], axis=1)[2:-2]  # skip the first/last layers
     per = d.mean(axis=0)
     tot = (st[blk, 1:, 0] - st[blk, :-1, 0])[2:-2].mean()
-    print(f"workgroup {'first' if blk == 0 else 'last'}: {tot:.0f} ticks per layer; per segment (ticks): " +
+    print(f"workgroup {'first' if blk == 0 else 'last'}: {tot:.0f} ticks = {tot * TICK_US:.1f} us per layer; per segment (ticks): " +
           ", ".join(f"{n} {v:.0f}" for n, v in zip(names, per)))
-print("(s_memtime ticks; 100 MHz constant clock if the numbers are ~100x smaller than cycles)")
+    if st[blk, 2, 12] > 0 and blk == 0:  # fine stamps present (v2 kernel)
+        seq = st[blk][:, fine_order][2:-2]
+        dd = np.diff(seq, axis=1).mean(axis=0)
+        nxt = (st[blk, 3:-1, 0] - st[blk, 2:-2, 10]).mean()
+        print("  fine (us since the previous stamp): " + "; ".join(f"{fine_names[k]} +{v * TICK_US:.2f}" for k, v in zip(fine_order[1:], dd)) +
+              f"; next layer top (next wqkv requested) +{nxt * TICK_US:.2f}")
+print("(s_memtime ticks)")
