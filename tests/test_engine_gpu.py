@@ -222,7 +222,9 @@ def test_batched_prefill_ragged_two_utterances():
     engine2.close()
 
 
-@pytest.mark.parametrize("n_layer,T,n_new,combo", [(2, 16, 24, dict(top_k=1)), (4, 40, 48, dict(top_p=0.95)), (3, 300, 40, dict(top_p=0.9, temperature=0.8))])
+@pytest.mark.parametrize("n_layer,T,n_new,combo", [(2, 16, 24, dict(top_k=1)), (4, 40, 48, dict(top_p=0.95)), (3, 300, 40, dict(top_p=0.9, temperature=0.8)),
+                                                   (2, 250, 16, dict(top_k=1)),       # crosses 256 keys: one key range -> 8 ranges + combine
+                                                   (2, 2030, 17, dict(top_p=0.95))])  # up to the last cache row (block_size - 1)
 def test_persistent_decode_kernel_is_bit_identical_to_per_layer_launches(n_layer, T, n_new, combo):
     """decode_mega.hip (one launch per token: 24 layers + head, granule hand-offs) runs the same arithmetic in the same order
     as gemv.hip / attention.hip: logits and token streams must be IDENTICAL, not merely close -- any difference is a

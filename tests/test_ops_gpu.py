@@ -90,7 +90,7 @@ def test_swiglu_gemv(rows, N_, K):
     assert nbad == 0, f"{nbad} outputs off, worst {worst:.2f}"
 
 
-@pytest.mark.parametrize("n_keys", [[1, 1], [5, 64], [63, 65], [200, 129], [520, 513], [1000, 897], [2048, 2047]])
+@pytest.mark.parametrize("n_keys", [[1, 1], [5, 64], [63, 65], [200, 129], [256, 257], [258, 300], [520, 513], [1000, 897], [2048, 2047]])
 def test_attention_decode(n_keys):
     H, S, rows = 16, 2048, 4
     g = torch.Generator().manual_seed(sum(n_keys))
