@@ -18,6 +18,7 @@
 // residency guarantee: if another kernel occupies CUs the grid may not be co-resident).
 #include "attn_core.h"
 #include "gemv_core.h"
+#include "gemv_i4_core.h"
 
 #define MG_THREADS 512
 #define MG_WAVES 8
@@ -162,6 +163,30 @@ __device__ __forceinline__ void wave_poll_rowpair16(const gran_t* g, uint32_t ta
                    });
 }
 
+// int4 (group-128) weight rows: per 2048-column chunk a lane requests 16 B of codes (32 columns) and the (scale, zero) word of
+// their 128-column group -- the same loads, and through i4_dots the same arithmetic, as gemv_i4.hip.
+template <int KCH>
+__device__ __forceinline__ void mega_issue_row_i4(u32x4* cq, uint32_t* cz, const unsigned char* codes, const uint32_t* sz, int n, int K,
+                                                  int lane) {
+#pragma unroll
+    for (int j = 0; j < KCH; ++j) {
+        const int c = min(j * 2048 + lane * 32, K - 32);
+        cq[j] = load_stream16(codes + ((size_t)n * K + c) / 2);
+        cz[j] = sz[(size_t)n * (K / 128) + c / 128];
+    }
+}
+template <int KCH, int NR, int KP>
+__device__ __forceinline__ void mega_dots_i4(const u32x4* cq, const uint32_t* cz, const bf16_t* xs, int K, int lane, float (&acc)[NR][2]) {
+    u32x4 cw[NR][KCH];
+    uint32_t sw[NR][KCH];
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) { cw[i][j] = cq[i * KCH + j]; sw[i][j] = cz[i * KCH + j]; }
+    i4_dots<2, KCH, NR>(cw, sw, xs, KP, K, lane, acc);
+}
+
+template <int WF>  // MV_W_BF16 or MV_W_INT4_G128 (the LM head is bf16 in both)
 __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t raw_x[2 * MG_DIM];   // residual stream entering the layer (P0 in, P2 residual)
     __shared__ __attribute__((aligned(16))) bf16_t raw_h[2 * MG_DIM];   // residual stream after attention (P3 in, P4 residual)
@@ -192,11 +217,18 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 #define MG_STAMP(l, k) do { if (stamping && lane == 0) stamp_base[(l) * MG_STAMP_SLOTS + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
     u32x4 wv[24];  // the weight working set of the current GEMV phase (next phase's rows are issued into it after the dots)
+    // int4: codes / (scale, zero) words.  Slots: wqkv rows 0..2 | w1 rows 0..2, w3 rows 3..5, wo 6 | w2 (3 chunks) 6..8
+    constexpr bool I4 = WF == MV_W_INT4_G128;
+    u32x4 cq[9];
+    uint32_t cz[9];
     // phase 0 of layer 0: rows 24 b + 3 wave + i of wqkv
     {
         const bf16_t* w = a.layers[0].wqkv;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave + i, MG_DIM, lane);
+        for (int i = 0; i < 3; ++i) {
+            if (I4) mega_issue_row_i4<1>(cq + i, cz + i, a.layers[0].q[0], a.layers[0].sz[0], 24 * b + 3 * wave + i, MG_DIM, lane);
+            else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave + i, MG_DIM, lane);
+        }
     }
     // RMSNorm weights of the next norm, requested together with the weight rows of its phase (threads 0..255 own 8 columns each)
     u32x4 nw_attn = load16(a.layers[0].attn_norm + min(tid * 8, MG_DIM - 8)), nw_ffn = u32x4{0u, 0u, 0u, 0u};
@@ -251,7 +283,8 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
         MG_STAMP(l, 12);  // norm done
         {
             float acc[3][2];
-            mega_dots<4, 3, MG_DIM>(wv, xs, lane, acc);
+            if (I4) mega_dots_i4<1, 3, MG_DIM>(cq, cz, xs, MG_DIM, lane, acc);
+            else mega_dots<4, 3, MG_DIM>(wv, xs, lane, acc);
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 13);  // wqkv dots done
             float v0 = 0.f, v1 = 0.f;
@@ -316,9 +349,15 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
         // w1|w3 is 45 % of a layer's bytes, asked for in one go it made P2 -> P3 the one stream-bound hand-off (8 us).
         const int rb13 = 22 * b + (wave_o < 6 ? 3 * wave_o : 18 + 2 * (wave_o - 6));
         auto request_wo_w1 = [&]() {
-            mega_issue_row<4>(wv + 12, L.wo, 8 * b + wave_o, MG_DIM, lane_o);
+            if (I4) {
+                mega_issue_row_i4<1>(cq + 6, cz + 6, L.q[1], L.sz[1], 8 * b + wave_o, MG_DIM, lane_o);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) mega_issue_row<4>(wv + 4 * i, L.w1, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
+                for (int i = 0; i < 3; ++i) mega_issue_row_i4<1>(cq + i, cz + i, L.q[2], L.sz[2], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
+            } else {
+                mega_issue_row<4>(wv + 12, L.wo, 8 * b + wave_o, MG_DIM, lane_o);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) mega_issue_row<4>(wv + 4 * i, L.w1, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
+            }
             nw_ffn = load16(L.ffn_norm + min(tid_o * 8, MG_DIM - 8));
         };
         // Publish-before-prefetch holds for the WORKGROUP here, not just per wave: wave 0 still has the block's partial (and, in
@@ -371,7 +410,8 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             if (MG_ABORTED()) return;
             MG_STAMP(l, 5);
             float acc[1][2];
-            mega_dots<4, 1, MG_DIM>(wv + 12, xs, lane, acc);
+            if (I4) mega_dots_i4<1, 1, MG_DIM>(cq + 6, cz + 6, xs, MG_DIM, lane, acc);
+            else mega_dots<4, 1, MG_DIM>(wv + 12, xs, lane, acc);
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 16);  // wo dots done
             const float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
@@ -386,7 +426,10 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             // next: the w3 rows (w1 is already in flight).  22 rows per block: waves 0..5 take 3, waves 6,7 take 2 (third slot
             // clamped, masked)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) mega_issue_row<4>(wv + 12 + 4 * i, L.w3, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
+            for (int i = 0; i < 3; ++i) {
+                if (I4) mega_issue_row_i4<1>(cq + 3 + i, cz + 3 + i, L.q[3], L.sz[3], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
+                else mega_issue_row<4>(wv + 12 + 4 * i, L.w3, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -401,8 +444,13 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             mega_norm(raw_h, nw_ffn, xs, red, a.eps);
             MG_STAMP(l, 18);  // norm done
             float acc1[3][2], acc3[3][2];
-            mega_dots<4, 3, MG_DIM>(wv, xs, lane, acc1);
-            mega_dots<4, 3, MG_DIM>(wv + 12, xs, lane, acc3);
+            if (I4) {
+                mega_dots_i4<1, 3, MG_DIM>(cq, cz, xs, MG_DIM, lane, acc1);
+                mega_dots_i4<1, 3, MG_DIM>(cq + 3, cz + 3, xs, MG_DIM, lane, acc3);
+            } else {
+                mega_dots<4, 3, MG_DIM>(wv, xs, lane, acc1);
+                mega_dots<4, 3, MG_DIM>(wv + 12, xs, lane, acc3);
+            }
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 19);  // w1|w3 dots done
             const int nrows = wave < 6 ? 3 : 2;
@@ -421,7 +469,8 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 20);  // act published
             // next: w2 row 8 b + wave (K = 5632: 11 chunks)
-            mega_issue_row<11>(wv, L.w2, 8 * b + wave_o, MG_INTER, lane_o);
+            if (I4) mega_issue_row_i4<3>(cq + 6, cz + 6, L.q[4], L.sz[4], 8 * b + wave_o, MG_INTER, lane_o);
+            else mega_issue_row<11>(wv, L.w2, 8 * b + wave_o, MG_INTER, lane_o);
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -434,7 +483,8 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             if (MG_ABORTED()) return;
             MG_STAMP(l, 9);
             float acc[1][2];
-            mega_dots<11, 1, MG_INTER>(wv, xs, lane, acc);
+            if (I4) mega_dots_i4<3, 1, MG_INTER>(cq + 6, cz + 6, xs, MG_INTER, lane, acc);
+            else mega_dots<11, 1, MG_INTER>(wv, xs, lane, acc);
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 21);  // w2 dots done
             const float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
@@ -450,7 +500,10 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             if (l + 1 < a.n_layer) {
                 const bf16_t* w = a.layers[l + 1].wqkv;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave_o + i, MG_DIM, lane_o);
+                for (int i = 0; i < 3; ++i) {
+                    if (I4) mega_issue_row_i4<1>(cq + i, cz + i, a.layers[l + 1].q[0], a.layers[l + 1].sz[0], 24 * b + 3 * wave_o + i, MG_DIM, lane_o);
+                    else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave_o + i, MG_DIM, lane_o);
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) mega_issue_row<4>(wv + 4 * i, a.head, min(11 * b + wave_o + 8 * i, a.vocab - 1), MG_DIM, lane_o);
@@ -971,7 +1024,8 @@ hipError_t launch_bump_counter(hipStream_t s, uint32_t* c) {
     return hipGetLastError();
 }
 
-hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a) {
-    hipLaunchKernelGGL(decode_mega_kernel, dim3(256), dim3(MG_THREADS), 0, s, a);
+hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a, int weight_format) {
+    if (weight_format == MV_W_INT4_G128) hipLaunchKernelGGL(decode_mega_kernel<MV_W_INT4_G128>, dim3(256), dim3(MG_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(decode_mega_kernel<MV_W_BF16>, dim3(256), dim3(MG_THREADS), 0, s, a);
     return hipGetLastError();
 }

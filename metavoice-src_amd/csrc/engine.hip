@@ -169,7 +169,8 @@ int enqueue_step(mv_engine* e) {
     const int R = e->R;
     hipStream_t s = e->stream;
     if (e->mega_ok && g_tune.mega) {  // one persistent launch for the 24 layers + LM head, then the sampler
-        HIP_TRY(g_tune.mega == 2 ? launch_decode_mega_lds(s, mega_args(e)) : launch_decode_mega(s, mega_args(e)));
+        HIP_TRY(g_tune.mega == 2 && c.weight_format == MV_W_BF16 ? launch_decode_mega_lds(s, mega_args(e))
+                                                                 : launch_decode_mega(s, mega_args(e), c.weight_format));
         return enqueue_sampler(e);
     }
     for (int l = 0; l < c.n_layer; ++l) {
@@ -618,12 +619,13 @@ int mv_finalize(mv_engine* e) {
         int dev = 0, n_cus = 0;
         HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev));
-        e->mega_ok = mega_supported(c, R, n_cus) && c.weight_format == MV_W_BF16;
+        e->mega_ok = mega_supported(c, R, n_cus) && (c.weight_format == MV_W_BF16 || c.weight_format == MV_W_INT4_G128);
         if (e->mega_ok) {
             std::vector<MegaLayer> ml(c.n_layer);
             for (int l = 0; l < c.n_layer; ++l) {
                 const LayerW& w = e->layers[l];
-                ml[l] = MegaLayer{w.attn_norm, w.wqkv, w.wo, w.ffn_norm, w.w1, w.w3, w.w2};
+                ml[l] = MegaLayer{w.attn_norm, w.wqkv, w.wo, w.ffn_norm, w.w1, w.w3, w.w2,
+                                  {w.q[0], w.q[1], w.q[2], w.q[3], w.q[4]}, {w.sz[0], w.sz[1], w.sz[2], w.sz[3], w.sz[4]}};
             }
             HIP_TRY(hipMalloc((void**)&e->mega_layers, ml.size() * sizeof(MegaLayer)));
             HIP_TRY(hipMemcpy(e->mega_layers, ml.data(), ml.size() * sizeof(MegaLayer), hipMemcpyHostToDevice));
@@ -828,7 +830,8 @@ int mv_probe_kernel(mv_engine* e, int32_t kind, int32_t iters, float* avg_ms, do
         std::vector<int32_t> pos(c.max_utterances);
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipMemcpy(pos.data(), e->pos_arr, pos.size() * 4, hipMemcpyDeviceToHost));
-        const double per_layer = (3.0 * c.dim * c.dim + (double)c.dim * c.dim + 3.0 * c.intermediate * c.dim) * 2 + 2.0 * c.dim * 2;
+        const double weights = 3.0 * c.dim * c.dim + (double)c.dim * c.dim + 3.0 * c.intermediate * c.dim;  // elements per layer
+        const double per_layer = (c.weight_format == MV_W_INT4_G128 ? weights * 0.5 + weights / 128 * 4 : weights * 2) + 2.0 * c.dim * 2;
         bytes = c.n_layer * (per_layer + 2.0 /*rows*/ * c.n_head * (pos[0] + 1.0) * 128 * 2 * 2) + (double)c.vocab * c.dim * 2 + c.dim * 2;
         const MegaArgs m = mega_args(e);
         float t[2] = {0.f, 0.f};
@@ -836,7 +839,8 @@ int mv_probe_kernel(mv_engine* e, int32_t kind, int32_t iters, float* avg_ms, do
             for (int i = -2; i < iters; ++i) {
                 if (i == 0) HIP_TRY(hipEventRecord(e->ev0, s));
                 HIP_TRY(launch_bump_counter(s, e->step_counter));
-                if (pass == 0) HIP_TRY(g_tune.mega == 2 ? launch_decode_mega_lds(s, m) : launch_decode_mega(s, m));
+                if (pass == 0)
+                    HIP_TRY(g_tune.mega == 2 && c.weight_format == MV_W_BF16 ? launch_decode_mega_lds(s, m) : launch_decode_mega(s, m, c.weight_format));
             }
             HIP_TRY(hipEventRecord(e->ev1, s));
             HIP_TRY(hipStreamSynchronize(s));

@@ -17,23 +17,7 @@
 // (122 dependent launches x ~2.8 us), which is why the reference's "roughly 2x" (README.md:92) is also what we get.
 #include "gemv_core.h"
 #include "kernels.h"
-
-typedef __bf16 bf16pair_t __attribute__((ext_vector_type(2)));
-
-// 8 nibbles of one word -> 4 bf16 pairs (columns 0|1, 2|3, 4|5, 6|7): bf16(fma(q - 8, s, z)), one rounding like tinygemm
-__device__ __forceinline__ void deq8(uint32_t w, float s, float z, bf16pair_t (&out)[4]) {
-    const uint32_t lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu;
-    // (float)((x >> 8k) & 0xFF) selects v_cvt_f32_ubyte<k>
-    const float a0 = (float)(lo & 0xFFu), a1 = (float)((lo >> 8) & 0xFFu), a2 = (float)((lo >> 16) & 0xFFu), a3 = (float)(lo >> 24);
-    const float c0 = (float)(hi & 0xFFu), c1 = (float)((hi >> 8) & 0xFFu), c2 = (float)((hi >> 16) & 0xFFu), c3 = (float)(hi >> 24);
-    out[0] = bf16pair_t{(__bf16)fmaf(a0 - 8.f, s, z), (__bf16)fmaf(c0 - 8.f, s, z)};
-    out[1] = bf16pair_t{(__bf16)fmaf(a1 - 8.f, s, z), (__bf16)fmaf(c1 - 8.f, s, z)};
-    out[2] = bf16pair_t{(__bf16)fmaf(a2 - 8.f, s, z), (__bf16)fmaf(c2 - 8.f, s, z)};
-    out[3] = bf16pair_t{(__bf16)fmaf(a3 - 8.f, s, z), (__bf16)fmaf(c3 - 8.f, s, z)};
-}
-__device__ __forceinline__ float dot2p(bf16pair_t w, uint32_t x, float acc) {
-    return __builtin_amdgcn_fdot2_f32_bf16(w, __builtin_bit_cast(bf16pair_t, x), acc, false);
-}
+#include "gemv_i4_core.h"
 
 // One wave owns NR rows of W; per 2048-column chunk a lane holds 32 columns (16 B of codes) of each row.
 template <int R, int KCH, int NR, int EPI>
@@ -106,45 +90,10 @@ __global__ void __launch_bounds__(1024) gemv_i4_kernel(const GemvI4Args a) {
     }
     __syncthreads();
 
-    // ---- 3. dequantise each word once, dot it with every activation row ------------------------------------------------
+    // ---- 3. dequantise each word once, dot it with every activation row (gemv_i4_core.h, shared with decode_mega.hip) --------
     float acc[NMAT][NR][R];
 #pragma unroll
-    for (int m = 0; m < NMAT; ++m)
-#pragma unroll
-        for (int i = 0; i < NR; ++i)
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[m][i][r] = 0.f;
-#pragma unroll
-    for (int j = 0; j < KCH; ++j) {
-        const bool live = j * 2048 + lane * 32 < K;  // a clamped (duplicate) fragment of the ragged last chunk contributes nothing
-        u32x4 xv[R][4];
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                xv[r][q] = live ? *(const u32x4*)(xs + r * KP + j * 2048 + lane * 32 + q * 8) : u32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int m = 0; m < NMAT; ++m)
-#pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const float s = bf_lo(sz[m][i][j]), z = bf_hi(sz[m][i][j]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    bf16pair_t wp[4];
-                    const uint32_t word = q == 0 ? cw[m][i][j].x : q == 1 ? cw[m][i][j].y : q == 2 ? cw[m][i][j].z : cw[m][i][j].w;
-                    deq8(word, s, z, wp);
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        float t = acc[m][i][r];
-                        t = dot2p(wp[0], xv[r][q].x, t);
-                        t = dot2p(wp[1], xv[r][q].y, t);
-                        t = dot2p(wp[2], xv[r][q].z, t);
-                        t = dot2p(wp[3], xv[r][q].w, t);
-                        acc[m][i][r] = t;
-                    }
-                }
-            }
-    }
+    for (int m = 0; m < NMAT; ++m) i4_dots<R, KCH, NR>(cw[m], sz[m], xs, KP, K, lane, acc[m]);
 
     // ---- 4. reductions + epilogue (same as gemv.hip) ------------------------------------------------------------------
     float mine[NMAT];

@@ -183,6 +183,9 @@ hipError_t launch_attn_rows(hipStream_t s, const AttnRowsArgs& a);
 // ---- decode_mega.hip: persistent decode-step kernel (MetaVoice-1B shape, one utterance) -----------------------------
 struct MegaLayer {
     const bf16_t *attn_norm, *wqkv, *wo, *ffn_norm, *w1, *w3, *w2;
+    // int4 (group-128) engines: packed codes and (scale, zero) words of wqkv, wo, w1, w3, w2 (gemv_i4.hip layout), else null
+    const unsigned char* q[5];
+    const uint32_t* sz[5];
 };
 struct MegaArgs {
     const bf16_t* x_in = nullptr;          // [2][2048]: input rows of layer 0 (written by the sampler / prefill)
@@ -205,6 +208,6 @@ struct MegaArgs {
     unsigned long long* stamps = nullptr;  // optional [2 blocks][n_layer][24] s_memtime stamps of wave 0 (MV_MEGA_STAMPS)
 };
 bool mega_supported(const mv_config& c, int rows, int n_cus);
-hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a);      // v2: every wave prefetches its weight rows into registers
+hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a, int weight_format);  // every wave prefetches its weight rows into registers; bf16 or int4
 hipError_t launch_decode_mega_lds(hipStream_t s, const MegaArgs& a);  // v3: 4 loader waves stream the weights through an LDS ring
 hipError_t launch_bump_counter(hipStream_t s, uint32_t* counter);  // mv_probe_kernel: advances the hand-off epoch like the sampler does

@@ -146,6 +146,31 @@ def test_int4_engine_follows_the_oracle_on_dequantised_weights():
     engine.close()
 
 
+@pytest.mark.parametrize("n_layer,T,n_new", [(2, 16, 24), (3, 300, 24)])
+def test_int4_persistent_kernel_is_bit_identical_to_the_int4_launches(n_layer, T, n_new):
+    """decode_mega.hip instantiated for int4 weights shares i4_dots (gemv_i4_core.h) with gemv_i4.hip: same bits."""
+    cfgk = dict(n_layer=n_layer, n_head=16, dim=2048, vocab_size=2562, block_size=2048)
+    sd = o_s1.remap_checkpoint_keys(synthetic.stage1_state_dict(seed=2, **cfgk))
+    engine = mv.Stage1Engine(mv.ModelArgs(**cfgk), max_utterances=1, quantisation_mode="int4")
+    engine.load_state_dict(sd)
+    engine.finalize()
+    prompt, spk = synthetic.prompt_tokens(T, seed=2), synthetic.speaker_embedding(2)
+    engine.capture_logits(True)
+    out = {}
+    for mega in (1, 0, 1):
+        engine.tune(mega=mega)
+        engine.begin([prompt], spk, mv.SamplingParams(top_p=0.95, seed=9), max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
+        engine.run()
+        res = (engine.tokens(0), engine.captured_logits(T - 1, n_new).clone())
+        if mega in out:
+            assert res[0] == out[mega][0] and torch.equal(res[1], out[mega][1])
+        out[mega] = res
+    engine.tune(mega=1)
+    assert out[1][0] == out[0][0], "token streams differ between the int4 persistent kernel and the int4 launches"
+    assert torch.equal(out[1][1], out[0][1]), f"logits differ: max {float((out[1][1].float() - out[0][1].float()).abs().max())}"
+    engine.close()
+
+
 def test_int8_engine_follows_the_oracle():
     """`quantisation_mode="int8"` (fast_quantize.py:137-198): every Linear incl. the LM head and the speaker projection;
     greedy stream and logits against the oracle evaluating WeightOnlyInt8Linear.forward on the same bf16 checkpoint."""

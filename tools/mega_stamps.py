@@ -14,7 +14,7 @@ pos = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 args = mv.ModelArgs.from_name("metavoice-1B")
 cfgk = dict(n_layer=args.n_layer, n_head=args.n_head, dim=args.dim, vocab_size=args.vocab_size, block_size=args.block_size)
 sd = fiu.remap_checkpoint_keys(mv.synthetic.stage1_state_dict(seed=0, device="cuda", **cfgk))
-e = mv.Stage1Engine(args, max_utterances=1)
+e = mv.Stage1Engine(args, max_utterances=1, quantisation_mode=os.environ.get("MV_QUANT") or None)
 e.load_state_dict(sd); del sd
 e.finalize()
 e.tune(mega=int(os.environ.get("MV_MEGA", "1")))
