@@ -78,8 +78,13 @@ __device__ __forceinline__ void mega_dots(const u32x4* wv, const bf16_t* xs, int
     }
 }
 template <int KCH>
-__device__ __forceinline__ void mega_issue_row(u32x4* wv, const bf16_t* w, int n, int K, int lane) {
+__device__ __forceinline__ void mega_issue_row(u32x4* wv, const bf16_t* w, int n, int K, int lane, int ablate = 0) {
     const bf16_t* row = w + (size_t)n * K;
+    if (ablate & 1) {  // profiling only (mv_tune gemv_ablate bit 0): no weight requests at all, results are garbage
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) wv[j] = u32x4{0u, 0u, 0u, 0u};
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < KCH; ++j) wv[j] = load_stream16(row + min(j * 512 + lane * 8, K - 8));
 }
@@ -227,7 +232,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             if (I4) mega_issue_row_i4<1>(cq + i, cz + i, a.layers[0].q[0], a.layers[0].sz[0], 24 * b + 3 * wave + i, MG_DIM, lane);
-            else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave + i, MG_DIM, lane);
+            else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave + i, MG_DIM, lane, a.ablate);
         }
     }
     // RMSNorm weights of the next norm, requested together with the weight rows of its phase (threads 0..255 own 8 columns each)
@@ -354,9 +359,9 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 #pragma unroll
                 for (int i = 0; i < 3; ++i) mega_issue_row_i4<1>(cq + i, cz + i, L.q[2], L.sz[2], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
             } else {
-                mega_issue_row<4>(wv + 12, L.wo, 8 * b + wave_o, MG_DIM, lane_o);
+                mega_issue_row<4>(wv + 12, L.wo, 8 * b + wave_o, MG_DIM, lane_o, a.ablate);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) mega_issue_row<4>(wv + 4 * i, L.w1, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
+                for (int i = 0; i < 3; ++i) mega_issue_row<4>(wv + 4 * i, L.w1, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o, a.ablate);
             }
             nw_ffn = load16(L.ffn_norm + min(tid_o * 8, MG_DIM - 8));
         };
@@ -428,7 +433,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 if (I4) mega_issue_row_i4<1>(cq + 3 + i, cz + 3 + i, L.q[3], L.sz[3], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
-                else mega_issue_row<4>(wv + 12 + 4 * i, L.w3, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
+                else mega_issue_row<4>(wv + 12 + 4 * i, L.w3, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o, a.ablate);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -470,7 +475,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             MG_STAMP(l, 20);  // act published
             // next: w2 row 8 b + wave (K = 5632: 11 chunks)
             if (I4) mega_issue_row_i4<3>(cq + 6, cz + 6, L.q[4], L.sz[4], 8 * b + wave_o, MG_INTER, lane_o);
-            else mega_issue_row<11>(wv, L.w2, 8 * b + wave_o, MG_INTER, lane_o);
+            else mega_issue_row<11>(wv, L.w2, 8 * b + wave_o, MG_INTER, lane_o, a.ablate);
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -502,11 +507,11 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     if (I4) mega_issue_row_i4<1>(cq + i, cz + i, a.layers[l + 1].q[0], a.layers[l + 1].sz[0], 24 * b + 3 * wave_o + i, MG_DIM, lane_o);
-                    else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave_o + i, MG_DIM, lane_o);
+                    else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave_o + i, MG_DIM, lane_o, a.ablate);
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) mega_issue_row<4>(wv + 4 * i, a.head, min(11 * b + wave_o + 8 * i, a.vocab - 1), MG_DIM, lane_o);
+                for (int i = 0; i < 2; ++i) mega_issue_row<4>(wv + 4 * i, a.head, min(11 * b + wave_o + 8 * i, a.vocab - 1), MG_DIM, lane_o, a.ablate);
             }
             nw_attn = load16((l + 1 < a.n_layer ? a.layers[l + 1].attn_norm : a.final_norm) + min(tid_o * 8, MG_DIM - 8));
             __builtin_amdgcn_sched_barrier(0);

@@ -161,6 +161,7 @@ static MegaArgs mega_args(mv_engine* e) {
     m.kv_layer_elems = e->kv_layer_elems; m.pos = e->pos_arr; m.step_counter = e->step_counter;
     m.g_x = e->granules; m.g_qkv = m.g_x + c.dim; m.g_attn = m.g_qkv + 3 * c.dim; m.g_h = m.g_attn + c.dim; m.g_act = m.g_h + c.dim;
     m.partial = e->partial; m.counters = e->counters; m.abort_flag = e->abort_flag; m.eps = c.norm_eps; m.dbg = e->dbg; m.stamps = e->stamps;
+    m.ablate = g_tune.gemv_ablate;
     return m;
 }
 

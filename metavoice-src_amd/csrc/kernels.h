@@ -206,6 +206,7 @@ struct MegaArgs {
     float eps = 1e-5f;
     bf16_t* dbg = nullptr;                 // optional [n_layer][5 vectors: q|attn|h|act|x][2][5632] (mv_debug_vectors)
     unsigned long long* stamps = nullptr;  // optional [2 blocks][n_layer][24] s_memtime stamps of wave 0 (MV_MEGA_STAMPS)
+    int32_t ablate = 0;                    // MvTune::gemv_ablate bit 0: no weight requests (profiling only)
 };
 bool mega_supported(const mv_config& c, int rows, int n_cus);
 hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a, int weight_format);  // every wave prefetches its weight rows into registers; bf16 or int4
