@@ -17,6 +17,8 @@ from typing import Callable, List, Optional, Tuple, Union
 
 import torch
 
+from .loudness import normalize_loudness
+
 
 class Decoder(ABC):
     @abstractmethod
@@ -48,10 +50,11 @@ class EncodecDecoder(Decoder):
         os.makedirs(self.output_dir, exist_ok=True)
 
     def _save_audio(self, name, wav: torch.Tensor):
-        # the reference normalises loudness (strategy="loudness", compressor) inside audiocraft's audio_write; here: peak
-        # normalisation to -1 dBFS, documented difference (waveform parity is stated before this step)
-        peak = wav.abs().max().clamp(min=1e-8)
-        write_wav_pcm16(str(name) + ".wav", wav / peak * 0.891, self._mbd_sample_rate)
+        # audio_write(..., strategy="loudness", loudness_compressor=True) of the reference (`decoders.py:40-47`): BS.1770
+        # loudness to -14 LKFS + tanh compressor (loudness.py), then 16-bit PCM; waveform parity is stated before this step
+        out = normalize_loudness(wav.detach().float().cpu().reshape(1, -1), self._mbd_sample_rate, loudness_headroom_db=14.0,
+                                 loudness_compressor=True)
+        write_wav_pcm16(str(name) + ".wav", out, self._mbd_sample_rate)
 
     def decode(self, tokens: List[List[int]], causal: bool = True, ref_audio_path: Optional[str] = None) -> Union[str, torch.Tensor]:
         """`decoders.py:66-102`: adapter -> (1, n, f) grid padded with 0 up to 8 codebooks; causal=True returns the grid,

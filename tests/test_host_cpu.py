@@ -58,3 +58,29 @@ def test_tokeniser_round_trip_and_layout():
     ids = tok.encode("Hello there, this is a test.")
     assert ids[-1] == 2561 and min(ids) >= 2049 and max(ids) <= 2561  # 513 text ids after the audio ids + EOA
     assert tok.decode(ids[:-1]) == "Hello there, this is a test."
+
+
+def test_loudness_normalisation():
+    """loudness.py (BS.1770-4 as torchaudio / audiocraft evaluate it, restated; parity unpinned): the standard's calibration
+    tone, gain linearity, the -14 LKFS target of `audio_write(strategy="loudness")`, silence and short clips."""
+    import math
+    import torch
+    L = load_pkg("loudness")
+    sr = 24000
+    t = torch.arange(sr * 3) / sr
+    tone = torch.sin(2 * math.pi * 997 * t)
+    # a 997 Hz sine 20 dB below full scale in one channel reads -23.01 LKFS (BS.1770 calibration: 0 dBFS -> -3.01)
+    assert abs(L.integrated_loudness(0.1 * tone, sr) - (-23.01)) < 0.1
+    # +6.02 dB of gain is +6.02 LU
+    a, b = L.integrated_loudness(0.05 * tone, sr), L.integrated_loudness(0.1 * tone, sr)
+    assert abs((b - a) - 20 * math.log10(2)) < 1e-3
+    g = torch.Generator().manual_seed(0)
+    noise = 0.03 * torch.randn(1, sr * 4, generator=g)
+    out = L.normalize_loudness(noise, sr, loudness_compressor=False)
+    assert abs(L.integrated_loudness(out, sr) - (-14.0)) < 1e-3
+    comp = L.normalize_loudness(noise, sr, loudness_compressor=True)
+    assert float(comp.abs().max()) < 1.0 and torch.allclose(comp, torch.tanh(out))
+    quiet = 1e-4 * torch.randn(1, sr, generator=g)
+    assert L.normalize_loudness(quiet, sr) is quiet                      # below the energy floor: untouched
+    assert L.integrated_loudness(torch.zeros(sr), sr) == float("-inf")   # digital silence
+    assert L.integrated_loudness(tone[: sr // 10], sr) == float("-inf")  # shorter than one 400 ms block
