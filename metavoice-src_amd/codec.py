@@ -9,7 +9,7 @@ This is EnCodec's own decoder; the multi-band diffusion refinement of the refere
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Optional, Sequence
+from typing import Dict, Sequence
 
 import numpy as np
 import torch

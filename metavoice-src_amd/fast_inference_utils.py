@@ -6,7 +6,6 @@ inside libmetavoice_hip.so (one hipGraph replay per token, no per-token host syn
 """
 from __future__ import annotations
 
-import itertools
 import time
 import warnings
 from pathlib import Path
