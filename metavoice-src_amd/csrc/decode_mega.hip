@@ -421,7 +421,9 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 16);  // wo dots done
             const float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
-            if (lane == 0) {
+            // test hook (mv_tune "mega_fault"): one workgroup withholds this publish -> every peer's wait has to time out, raise the
+            // abort flag and leave the kernel; mv_run then reports the error (tests/test_engine_gpu.py)
+            if (lane == 0 && !(a.fault != 0 && b == ((a.fault - 1) & 255) && l == 1)) {
                 const int n = 8 * b + wave;
                 const bf16_t y0 = epi_resid(raw_x[n], t0), y1 = epi_resid(raw_x[MG_DIM + n], t1);
                 gran_store(a.g_h + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 2u);

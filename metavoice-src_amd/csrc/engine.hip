@@ -162,6 +162,7 @@ static MegaArgs mega_args(mv_engine* e) {
     m.g_x = e->granules; m.g_qkv = m.g_x + c.dim; m.g_attn = m.g_qkv + 3 * c.dim; m.g_h = m.g_attn + c.dim; m.g_act = m.g_h + c.dim;
     m.partial = e->partial; m.counters = e->counters; m.abort_flag = e->abort_flag; m.eps = c.norm_eps; m.dbg = e->dbg; m.stamps = e->stamps;
     m.ablate = g_tune.gemv_ablate;
+    m.fault = g_tune.mega_fault;
     return m;
 }
 
@@ -380,6 +381,7 @@ int mv_tune(mv_engine* e, const char* key, int32_t value) {
     else if (k == "use_graph") g_tune.use_graph = value;
     else if (k == "mega") g_tune.mega = value;
     else if (k == "gemv_ablate") g_tune.gemv_ablate = value;
+    else if (k == "mega_fault") g_tune.mega_fault = value;
     else return fail(MV_ERR_INVALID, "unknown tuning key '%s'", key);
     if (e && e->finalized) e->graph_dirty = true;  // launch geometry is frozen in the captured graph: re-capture at mv_begin
     return MV_OK;

@@ -12,6 +12,7 @@ struct MvTune {
     int gemv_nr[4] = {0, 0, 0, 0};       // weight rows per wave: 0 = built-in choice
     int gemv_nt = 1;                     // 1: non-temporal weight loads, 0: default cache policy
     int use_graph = 1;
+    int mega_fault = 0;                  // test hook: workgroup (mega_fault - 1) withholds one publish per step -> every wait must time out cleanly
     int gemv_ablate = 0;                 // profiling only (results are wrong): 1 no weight loads, 2 no dots, 4 no prologue, 8 no reductions
     int mega = 1;                        // 1: persistent decode-step kernel (decode_mega.hip) when the configuration supports it
                                          // (one utterance, bf16, MetaVoice-1B shape, >= 256 CUs): 874 vs 996 us/step; 0: per-layer launches
@@ -207,6 +208,7 @@ struct MegaArgs {
     bf16_t* dbg = nullptr;                 // optional [n_layer][5 vectors: q|attn|h|act|x][2][5632] (mv_debug_vectors)
     unsigned long long* stamps = nullptr;  // optional [2 blocks][n_layer][24] s_memtime stamps of wave 0 (MV_MEGA_STAMPS)
     int32_t ablate = 0;                    // MvTune::gemv_ablate bit 0: no weight requests (profiling only)
+    int32_t fault = 0;                     // MvTune::mega_fault (test hook)
 };
 bool mega_supported(const mv_config& c, int rows, int n_cus);
 hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a, int weight_format);  // every wave prefetches its weight rows into registers; bf16 or int4

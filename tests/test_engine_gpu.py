@@ -250,3 +250,26 @@ def test_persistent_decode_kernel_is_bit_identical_to_per_layer_launches(n_layer
         assert torch.equal(out[m][1], out[0][1]), f"logits differ (mega={m}): max {float((out[m][1] - out[0][1]).abs().max())}"
     assert len(out[1][0]) == T + n_new
     engine.close()
+
+
+def test_persistent_kernel_times_out_cleanly_when_a_peer_never_publishes():
+    """A persistent kernel whose grid is not co-resident (or whose peer dies) must not hang: every wait is bounded, the first
+    workgroup to give up raises a device flag, the rest leave within a polling interval, and mv_run reports the error.  The
+    `mega_fault` hook makes one workgroup withhold one publish; afterwards the same engine must work again."""
+    engine, sd, cfg = build(WIDE2, 11)
+    prompt, spk = synthetic.prompt_tokens(16, seed=11), synthetic.speaker_embedding(11)
+    sp = mv.SamplingParams(top_k=1, seed=3)
+    engine.begin([prompt], spk, sp, max_new_tokens=8, end_of_audio_token=9999, prefill_mode=1)
+    engine.run()
+    good = engine.tokens(0)
+    try:
+        engine.tune(mega=1, mega_fault=8)
+        engine.begin([prompt], spk, sp, max_new_tokens=8, end_of_audio_token=9999, prefill_mode=1)
+        with pytest.raises(RuntimeError, match="timed out"):
+            engine.run(max_steps=1)
+    finally:
+        engine.tune(mega_fault=0)
+    engine.begin([prompt], spk, sp, max_new_tokens=8, end_of_audio_token=9999, prefill_mode=1)
+    engine.run()
+    assert engine.tokens(0) == good
+    engine.close()
