@@ -186,8 +186,14 @@ def main():
         # the decode step is ONE persistent launch per token (decode_mega.hip: 24 layers + LM head) when the configuration
         # supports it; probe 6 times that kernel alone at the position the utterance ended on.  Otherwise (per-layer launches)
         # the dominant kernel is the fused RMSNorm + w1|w3 + SiLU-gate GEMV (probe 3).
+        # The kernel's duration grows linearly with the context; it is probed at the MEAN context of the timed utterance, so that
+        # `avg_launch_us` is the average launch of the timed region (what the rocprofv3 --stats average in profiles/ shows) and
+        # `bytes_per_launch` the average algorithmic bytes of those launches.
+        mean_ctx = T_PROMPT + (N_NEW - 1) // 2
+        engine.begin([mv.synthetic.prompt_tokens(mean_ctx, seed=rank)], spk, sp, max_new_tokens=2, end_of_audio_token=9999, prefill_mode=1)
+        engine.run(max_steps=1)
         if N.lib().mv_probe_kernel(engine._h, 6, 200, C.byref(ms), C.byref(nbytes)) == 0:
-            kname = "decode_mega_kernel (persistent: 24 layers + LM head of one token, context %d)" % (T_PROMPT + N_NEW - 1)
+            kname = "decode_mega_kernel (persistent: 24 layers + LM head of one token; probed at context %d = the mean of the utterance)" % (mean_ctx + 1)
         else:
             N.check(N.lib().mv_probe_kernel(engine._h, 3, 24 * 20, C.byref(ms), C.byref(nbytes)))
             kname = "gemv_kernel<2,4,1,SWIGLU,nt> (RMSNorm + w1|w3 + SiLU gate)"
