@@ -84,3 +84,16 @@ def test_loudness_normalisation():
     assert L.normalize_loudness(quiet, sr) is quiet                      # below the energy floor: untouched
     assert L.integrated_loudness(torch.zeros(sr), sr) == float("-inf")   # digital silence
     assert L.integrated_loudness(tone[: sr // 10], sr) == float("-inf")  # shorter than one 400 ms block
+
+
+def test_bench_byte_accounting():
+    """bench.py prices a decode step with SURVEY 8d's figure: 2 476 945 408 B of weights + 393 216 B per cached position."""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cfg = types.SimpleNamespace(n_layer=24, n_head=16, dim=2048, intermediate_size=5632, vocab_size=2562)
+    assert bench.step_bytes(cfg, -1) == 2_476_945_408
+    assert bench.step_bytes(cfg, 99) - bench.step_bytes(cfg, 98) == 393_216
+    assert bench.TOKENS_PER_AUDIO_SECOND == 150 and (bench.T_PROMPT, bench.N_NEW) == (128, 1920)
