@@ -301,6 +301,7 @@ int enqueue_prefill(mv_engine* e, int u, int T) {
         GemmArgs g;
         g.a = e->pn; g.w = w.wqkv; g.out_bf16 = e->pq; g.M = M; g.N = 3 * c.dim; g.K = c.dim; g.lda = c.dim; g.ldc = c.dim;
         g.qkv_dim = c.dim; g.seq_len = T; g.n_head = c.n_head; g.cache_len = c.block_size; g.kcache = kc; g.vcache = vc;
+        g.scale = w.s8[0];  // null unless int8
         HIP_TRY(launch_gemm(s, g));
         AttnRowsArgs at;
         at.q = e->pq; at.k = kc; at.v = vc; at.out = e->pattn; at.k_batch_stride = (int64_t)c.n_head * c.block_size * 128;
@@ -309,16 +310,17 @@ int enqueue_prefill(mv_engine* e, int u, int T) {
         HIP_TRY(launch_attn_rows(s, at));
         g = GemmArgs();
         g.a = e->pattn; g.w = w.wo; g.res_bf16 = e->px; g.out_bf16 = e->ph; g.M = M; g.N = c.dim; g.K = c.dim; g.lda = c.dim; g.ldc = c.dim;
+        g.scale = w.s8[1];
         HIP_TRY(launch_gemm(s, g));
         n.x_bf16 = e->ph; n.w_bf16 = w.ffn_norm;
         HIP_TRY(launch_norm_rows(s, n));
         g = GemmArgs();
         g.a = e->pn; g.w = w.w1; g.w2 = w.w3; g.out_bf16 = e->pact; g.M = M; g.N = c.intermediate; g.K = c.dim; g.lda = c.dim;
-        g.ldc = c.intermediate;
+        g.ldc = c.intermediate; g.scale = w.s8[2]; g.scale2 = w.s8[3];
         HIP_TRY(launch_gemm(s, g));
         g = GemmArgs();
         g.a = e->pact; g.w = w.w2; g.res_bf16 = e->ph; g.out_bf16 = e->px; g.M = M; g.N = c.dim; g.K = c.intermediate;
-        g.lda = c.intermediate; g.ldc = c.dim;
+        g.lda = c.intermediate; g.ldc = c.dim; g.scale = w.s8[4];
         HIP_TRY(launch_gemm(s, g));
     }
     for (int r = 0; r < 2; ++r)
@@ -556,6 +558,9 @@ int mv_finalize(mv_engine* e) {
                 w.q8[m] = (signed char*)(e->q_arena + off); off += align_up((size_t)shapes[m][0] * shapes[m][1], 256);
                 w.s8[m] = (bf16_t*)(e->q_arena + off); off += align_up((size_t)shapes[m][0] * 2, 256);
                 HIP_TRY(launch_quantize_i8(e->stream, src[m], (int)shapes[m][0], (int)shapes[m][1], w.q8[m], w.s8[m]));
+                // the bf16 arena now holds the CODES (integers up to 127: exact in bf16): operand of the MFMA prefill, whose
+                // epilogue applies the row scale with the reference's two roundings
+                HIP_TRY(launch_i8_to_bf16(e->stream, w.q8[m], src[m], (size_t)shapes[m][0] * shapes[m][1]));
             }
         }
         e->head_q8 = (signed char*)(e->q_arena + off); off += align_up((size_t)c.vocab * c.dim, 256);
@@ -695,9 +700,8 @@ int mv_begin(mv_engine* e, int32_t n_utt, const int32_t* prompts, const int32_t*
     int budget = 0;
     // batched (MFMA) prefill needs every prompt to have >= 2 tokens and GEMM-tileable widths; otherwise the prompt is
     // teacher-forced through the decode graph
-    // int8: the Linear output is bf16(bf16(x.q^T) * scale) -- two roundings the bf16 GEMM epilogue does not do -- so its
-    // prompt is teacher-forced through the int8 decode kernels
-    bool use_prefill = prefill_mode == 1 && c.weight_format != MV_W_INT8;
+    // (int8: the arena holds the codes as bf16 and the GEMM epilogue applies the row scale with the reference's two roundings)
+    bool use_prefill = prefill_mode == 1;
     for (int u = 0; u < n_utt && u < U; ++u) use_prefill = use_prefill && prompt_lens[u] >= 2;
     for (int u = 0; u < U; ++u) {
         UttState& s = st[u];

@@ -95,13 +95,17 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs a) {
             if (n >= N) continue;
             const float b1 = a.bias ? bf2f(a.bias[n]) : 0.f;
             const float b2 = (gated && a.bias2) ? bf2f(a.bias2[n]) : 0.f;
+            const float s1 = a.scale ? bf2f(a.scale[n]) : 0.f;
+            const float s2 = (gated && a.scale2) ? bf2f(a.scale2[n]) : 0.f;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int m = tile_m + wm * 32 + i * 16 + (lane >> 4) * 4 + reg;
                 if (m >= M) continue;
                 float y = round_bf(acc[i][j][reg] + b1);  // the bf16 Linear output
+                if (a.scale) y = round_bf(y * s1);        // int8 weight-only: the codes were the GEMM operand, the row scale follows
                 if (gated) {  // bf16(bf16(silu(w1 x)) * bf16(w3 x))   (fast_model.py:237, layers.py:62-72)
-                    const float u = round_bf(acc2[i][j][reg] + b2);
+                    float u = round_bf(acc2[i][j][reg] + b2);
+                    if (a.scale2) u = round_bf(u * s2);
                     y = round_bf(round_bf(y / (1.0f + __expf(-y))) * u);
                 } else if (a.act == GEMM_ACT_GELU) {
                     y = round_bf(gelu_erf(y));

@@ -146,6 +146,8 @@ struct GemmArgs {
     const bf16_t* w2 = nullptr;     // [N][K]: gated (SwiGLU) second matrix, or null
     const bf16_t* bias = nullptr;   // [N] or null
     const bf16_t* bias2 = nullptr;
+    const bf16_t* scale = nullptr;  // [N] or null: int8 weight-only Linear, out = bf16(bf16(x . q^T) * scale)  (fast_quantize.py:197-198)
+    const bf16_t* scale2 = nullptr; // the same for w2 of a gated pair
     const bf16_t* res_bf16 = nullptr;  // [M][ldc] residual (bf16 stream) or null
     const float* res_f32 = nullptr;    // [M][ldc] residual (fp32 stream) or null
     bf16_t* out_bf16 = nullptr;     // [M][ldc]

@@ -188,13 +188,14 @@ def test_int8_engine_follows_the_oracle():
         oseq, ologits = o_s1.generate(orc, prompt, spk, max_new_tokens=n_new, end_of_audio_token=9999, top_k=1, seed=5, return_logits=True)
         scale = float(ologits.std())
         engine.capture_logits(True)
-        engine.begin([prompt], spk, mv.SamplingParams(top_k=1, seed=5), max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
-        steps = engine.run()
-        assert steps == T + n_new - 1  # int8 prompts are teacher-forced through the decode kernels
-        seq = engine.tokens(0)
-        got = engine.captured_logits(T - 1, n_new)
-        d = float((got[0] - ologits[0]).abs().max())
-        same = sum(1 for a, b in zip(seq, oseq) if a == b) - T
-        print(f"[int8 dim={cfgk['dim']}] first-token max|dlogit| {d:.4f} (logit std {scale:.3f}); {same}/{n_new} greedy tokens identical")
-        assert d <= 0.06 * scale and same >= n_new // 2
+        for mode in (0, 1):  # prompt teacher-forced through the int8 decode kernels / MFMA prefill on the codes + row-scale epilogue
+            engine.begin([prompt], spk, mv.SamplingParams(top_k=1, seed=5), max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=mode)
+            steps = engine.run()
+            assert steps == (T + n_new - 1 if mode == 0 else n_new - 1)  # mode 1: the prompt did not go through decode steps
+            seq = engine.tokens(0)
+            got = engine.captured_logits(T - 1, n_new)
+            d = float((got[0] - ologits[0]).abs().max())
+            same = sum(1 for a, b in zip(seq, oseq) if a == b) - T
+            print(f"[int8 dim={cfgk['dim']} prefill_mode={mode}] first-token max|dlogit| {d:.4f} (logit std {scale:.3f}); {same}/{n_new} greedy tokens identical")
+            assert d <= 0.06 * scale and same >= n_new // 2
         engine.close()
