@@ -19,6 +19,7 @@
 #include "attn_core.h"
 #include "gemv_core.h"
 #include "gemv_i4_core.h"
+#include "gemv_i8_core.h"
 
 #define MG_THREADS 512
 #define MG_WAVES 8
@@ -191,7 +192,25 @@ __device__ __forceinline__ void mega_dots_i4(const u32x4* cq, const uint32_t* cz
     i4_dots<2, KCH, NR>(cw, sw, xs, KP, K, lane, acc);
 }
 
-template <int WF>  // MV_W_BF16 or MV_W_INT4_G128 (the LM head is bf16 in both)
+// int8 (per output channel) weight rows: per 1024-column chunk a lane requests 16 B = 16 codes; the bf16 row scale rides in a
+// scalar.  Same loads and, through i8_dots, the same arithmetic as gemv_i8.hip; the Linear output is bf16(bf16(sum) * scale).
+template <int KCH>
+__device__ __forceinline__ void mega_issue_row_i8(u32x4* cq, const signed char* codes, int n, int K, int lane) {
+#pragma unroll
+    for (int j = 0; j < KCH; ++j) cq[j] = load_stream16(codes + (size_t)n * K + min(j * 1024 + lane * 16, K - 16));
+}
+template <int KCH, int NR, int KP>
+__device__ __forceinline__ void mega_dots_i8(const u32x4* cq, const bf16_t* xs, int K, int lane, float (&acc)[NR][2]) {
+    u32x4 cw[NR][KCH];
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) cw[i][j] = cq[i * KCH + j];
+    i8_dots<2, KCH, NR>(cw, xs, KP, K, lane, acc);
+}
+__device__ __forceinline__ float i8_out(float wave_total, float scale) { return round_bf(round_bf(wave_total) * scale); }
+
+template <int WF>  // MV_W_BF16, MV_W_INT4_G128 (LM head bf16) or MV_W_INT8 (LM head int8 too)
 __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t raw_x[2 * MG_DIM];   // residual stream entering the layer (P0 in, P2 residual)
     __shared__ __attribute__((aligned(16))) bf16_t raw_h[2 * MG_DIM];   // residual stream after attention (P3 in, P4 residual)
@@ -223,15 +242,17 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 
     u32x4 wv[24];  // the weight working set of the current GEMV phase (next phase's rows are issued into it after the dots)
     // int4: codes / (scale, zero) words.  Slots: wqkv rows 0..2 | w1 rows 0..2, w3 rows 3..5, wo 6 | w2 (3 chunks) 6..8
-    constexpr bool I4 = WF == MV_W_INT4_G128;
-    u32x4 cq[9];
+    constexpr bool I4 = WF == MV_W_INT4_G128, I8 = WF == MV_W_INT8;
+    u32x4 cq[I8 ? 14 : 9];  // int8 slots (2 chunks per 2048-column row, 6 per w2 row): wqkv 0..5 | w1 0..5, w3 6..11, wo 12..13 | w2 0..5 | head 0..3
     uint32_t cz[9];
+    float sc_a[3] = {1.f, 1.f, 1.f}, sc_b[3] = {1.f, 1.f, 1.f}, sc_c = 1.f;  // int8 row scales: wqkv|w1|head rows, w3 rows, wo|w2 row
     // phase 0 of layer 0: rows 24 b + 3 wave + i of wqkv
     {
         const bf16_t* w = a.layers[0].wqkv;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             if (I4) mega_issue_row_i4<1>(cq + i, cz + i, a.layers[0].q[0], a.layers[0].sz[0], 24 * b + 3 * wave + i, MG_DIM, lane);
+            else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, a.layers[0].q8[0], 24 * b + 3 * wave + i, MG_DIM, lane); sc_a[i] = bf2f(a.layers[0].s8[0][24 * b + 3 * wave + i]); }
             else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave + i, MG_DIM, lane, a.ablate);
         }
     }
@@ -290,13 +311,15 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
         {
             float acc[3][2];
             if (I4) mega_dots_i4<1, 3, MG_DIM>(cq, cz, xs, MG_DIM, lane, acc);
+            else if (I8) mega_dots_i8<2, 3, MG_DIM>(cq, xs, MG_DIM, lane, acc);
             else mega_dots<4, 3, MG_DIM>(wv, xs, lane, acc);
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 13);  // wqkv dots done
             float v0 = 0.f, v1 = 0.f;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const float t0 = wave_sum(acc[i][0]), t1 = wave_sum(acc[i][1]);
+                float t0 = wave_sum(acc[i][0]), t1 = wave_sum(acc[i][1]);
+                if (I8) { t0 = i8_out(t0, sc_a[i]); t1 = i8_out(t1, sc_a[i]); }
                 if (lane == i) { v0 = t0; v1 = t1; }
             }
             if (lane < 3) {
@@ -359,6 +382,14 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
                 mega_issue_row_i4<1>(cq + 6, cz + 6, L.q[1], L.sz[1], 8 * b + wave_o, MG_DIM, lane_o);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) mega_issue_row_i4<1>(cq + i, cz + i, L.q[2], L.sz[2], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
+            } else if (I8) {
+                mega_issue_row_i8<2>(cq + 12, L.q8[1], 8 * b + wave_o, MG_DIM, lane_o);
+                sc_c = bf2f(L.s8[1][8 * b + wave_o]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    mega_issue_row_i8<2>(cq + 2 * i, L.q8[2], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
+                    sc_a[i] = bf2f(L.s8[2][min(rb13 + i, MG_INTER - 1)]);
+                }
             } else {
                 mega_issue_row<4>(wv + 12, L.wo, 8 * b + wave_o, MG_DIM, lane_o, a.ablate);
 #pragma unroll
@@ -417,10 +448,12 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             MG_STAMP(l, 5);
             float acc[1][2];
             if (I4) mega_dots_i4<1, 1, MG_DIM>(cq + 6, cz + 6, xs, MG_DIM, lane, acc);
+            else if (I8) mega_dots_i8<2, 1, MG_DIM>(cq + 12, xs, MG_DIM, lane, acc);
             else mega_dots<4, 1, MG_DIM>(wv + 12, xs, lane, acc);
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 16);  // wo dots done
-            const float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
+            float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
+            if (I8) { t0 = i8_out(t0, sc_c); t1 = i8_out(t1, sc_c); }
             // test hook (mv_tune "mega_fault"): one workgroup withholds this publish -> every peer's wait has to time out, raise the
             // abort flag and leave the kernel; mv_run then reports the error (tests/test_engine_gpu.py)
             if (lane == 0 && !(a.fault != 0 && b == ((a.fault - 1) & 255) && l == 1)) {
@@ -436,6 +469,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 if (I4) mega_issue_row_i4<1>(cq + 3 + i, cz + 3 + i, L.q[3], L.sz[3], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
+                else if (I8) { mega_issue_row_i8<2>(cq + 6 + 2 * i, L.q8[3], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o); sc_b[i] = bf2f(L.s8[3][min(rb13 + i, MG_INTER - 1)]); }
                 else mega_issue_row<4>(wv + 12 + 4 * i, L.w3, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o, a.ablate);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -455,6 +489,9 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             if (I4) {
                 mega_dots_i4<1, 3, MG_DIM>(cq, cz, xs, MG_DIM, lane, acc1);
                 mega_dots_i4<1, 3, MG_DIM>(cq + 3, cz + 3, xs, MG_DIM, lane, acc3);
+            } else if (I8) {
+                mega_dots_i8<2, 3, MG_DIM>(cq, xs, MG_DIM, lane, acc1);
+                mega_dots_i8<2, 3, MG_DIM>(cq + 6, xs, MG_DIM, lane, acc3);
             } else {
                 mega_dots<4, 3, MG_DIM>(wv, xs, lane, acc1);
                 mega_dots<4, 3, MG_DIM>(wv + 12, xs, lane, acc3);
@@ -466,7 +503,8 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const float a0 = wave_sum(acc1[i][0]), a1 = wave_sum(acc1[i][1]), c0 = wave_sum(acc3[i][0]), c1 = wave_sum(acc3[i][1]);
+                float a0 = wave_sum(acc1[i][0]), a1 = wave_sum(acc1[i][1]), c0 = wave_sum(acc3[i][0]), c1 = wave_sum(acc3[i][1]);
+                if (I8) { a0 = i8_out(a0, sc_a[i]); a1 = i8_out(a1, sc_a[i]); c0 = i8_out(c0, sc_b[i]); c1 = i8_out(c1, sc_b[i]); }
                 if (lane == i) { g0 = a0; g1 = a1; u0 = c0; u1 = c1; }
             }
             if (lane < nrows) {
@@ -478,6 +516,7 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             MG_STAMP(l, 20);  // act published
             // next: w2 row 8 b + wave (K = 5632: 11 chunks)
             if (I4) mega_issue_row_i4<3>(cq + 6, cz + 6, L.q[4], L.sz[4], 8 * b + wave_o, MG_INTER, lane_o);
+            else if (I8) { mega_issue_row_i8<6>(cq, L.q8[4], 8 * b + wave_o, MG_INTER, lane_o); sc_c = bf2f(L.s8[4][8 * b + wave_o]); }
             else mega_issue_row<11>(wv, L.w2, 8 * b + wave_o, MG_INTER, lane_o, a.ablate);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -492,10 +531,12 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             MG_STAMP(l, 9);
             float acc[1][2];
             if (I4) mega_dots_i4<3, 1, MG_INTER>(cq + 6, cz + 6, xs, MG_INTER, lane, acc);
+            else if (I8) mega_dots_i8<6, 1, MG_INTER>(cq, xs, MG_INTER, lane, acc);
             else mega_dots<11, 1, MG_INTER>(wv, xs, lane, acc);
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 21);  // w2 dots done
-            const float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
+            float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
+            if (I8) { t0 = i8_out(t0, sc_c); t1 = i8_out(t1, sc_c); }
             if (lane == 0) {
                 const int n = 8 * b + wave;
                 const bf16_t y0 = epi_resid(raw_h[n], t0), y1 = epi_resid(raw_h[MG_DIM + n], t1);
@@ -510,11 +551,16 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     if (I4) mega_issue_row_i4<1>(cq + i, cz + i, a.layers[l + 1].q[0], a.layers[l + 1].sz[0], 24 * b + 3 * wave_o + i, MG_DIM, lane_o);
+                    else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, a.layers[l + 1].q8[0], 24 * b + 3 * wave_o + i, MG_DIM, lane_o); sc_a[i] = bf2f(a.layers[l + 1].s8[0][24 * b + 3 * wave_o + i]); }
                     else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave_o + i, MG_DIM, lane_o, a.ablate);
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) mega_issue_row<4>(wv + 4 * i, a.head, min(11 * b + wave_o + 8 * i, a.vocab - 1), MG_DIM, lane_o, a.ablate);
+                for (int i = 0; i < 2; ++i) {
+                    const int hn = min(11 * b + wave_o + 8 * i, a.vocab - 1);
+                    if (I8) { mega_issue_row_i8<2>(cq + 2 * i, a.head_q8, hn, MG_DIM, lane_o); sc_a[i] = bf2f(a.head_s8[hn]); }
+                    else mega_issue_row<4>(wv + 4 * i, a.head, hn, MG_DIM, lane_o, a.ablate);
+                }
             }
             nw_attn = load16((l + 1 < a.n_layer ? a.layers[l + 1].attn_norm : a.final_norm) + min(tid_o * 8, MG_DIM - 8));
             __builtin_amdgcn_sched_barrier(0);
@@ -529,11 +575,13 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
     mega_norm(raw_x, nw_attn, xs, red, a.eps);
     {
         float acc[2][2];
-        mega_dots<4, 2, MG_DIM>(wv, xs, lane, acc);
+        if (I8) mega_dots_i8<2, 2, MG_DIM>(cq, xs, MG_DIM, lane, acc);
+        else mega_dots<4, 2, MG_DIM>(wv, xs, lane, acc);
         float v0 = 0.f, v1 = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float t0 = wave_sum(acc[i][0]), t1 = wave_sum(acc[i][1]);
+            float t0 = wave_sum(acc[i][0]), t1 = wave_sum(acc[i][1]);
+            if (I8) { t0 = i8_out(t0, sc_a[i]); t1 = i8_out(t1, sc_a[i]); }
             if (lane == i) { v0 = t0; v1 = t1; }
         }
         if (lane < 2) {
@@ -1034,6 +1082,7 @@ hipError_t launch_bump_counter(hipStream_t s, uint32_t* c) {
 
 hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a, int weight_format) {
     if (weight_format == MV_W_INT4_G128) hipLaunchKernelGGL(decode_mega_kernel<MV_W_INT4_G128>, dim3(256), dim3(MG_THREADS), 0, s, a);
+    else if (weight_format == MV_W_INT8) hipLaunchKernelGGL(decode_mega_kernel<MV_W_INT8>, dim3(256), dim3(MG_THREADS), 0, s, a);
     else hipLaunchKernelGGL(decode_mega_kernel<MV_W_BF16>, dim3(256), dim3(MG_THREADS), 0, s, a);
     return hipGetLastError();
 }

@@ -157,7 +157,7 @@ static MegaArgs mega_args(mv_engine* e) {
     const mv_config& c = e->cfg;
     MegaArgs m;
     m.x_in = e->x; m.layers = e->mega_layers; m.n_layer = c.n_layer; m.vocab = c.vocab; m.cache_len = c.block_size;
-    m.final_norm = e->final_norm; m.head = e->head; m.logits = e->logits; m.kcache = e->kcache; m.vcache = e->vcache;
+    m.final_norm = e->final_norm; m.head = e->head; m.head_q8 = e->head_q8; m.head_s8 = e->head_s8; m.logits = e->logits; m.kcache = e->kcache; m.vcache = e->vcache;
     m.kv_layer_elems = e->kv_layer_elems; m.pos = e->pos_arr; m.step_counter = e->step_counter;
     m.g_x = e->granules; m.g_qkv = m.g_x + c.dim; m.g_attn = m.g_qkv + 3 * c.dim; m.g_h = m.g_attn + c.dim; m.g_act = m.g_h + c.dim;
     m.partial = e->partial; m.counters = e->counters; m.abort_flag = e->abort_flag; m.eps = c.norm_eps; m.dbg = e->dbg; m.stamps = e->stamps;
@@ -627,13 +627,14 @@ int mv_finalize(mv_engine* e) {
         int dev = 0, n_cus = 0;
         HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev));
-        e->mega_ok = mega_supported(c, R, n_cus) && (c.weight_format == MV_W_BF16 || c.weight_format == MV_W_INT4_G128);
+        e->mega_ok = mega_supported(c, R, n_cus);  // every weight format has an instance of the persistent kernel
         if (e->mega_ok) {
             std::vector<MegaLayer> ml(c.n_layer);
             for (int l = 0; l < c.n_layer; ++l) {
                 const LayerW& w = e->layers[l];
                 ml[l] = MegaLayer{w.attn_norm, w.wqkv, w.wo, w.ffn_norm, w.w1, w.w3, w.w2,
-                                  {w.q[0], w.q[1], w.q[2], w.q[3], w.q[4]}, {w.sz[0], w.sz[1], w.sz[2], w.sz[3], w.sz[4]}};
+                                  {w.q[0], w.q[1], w.q[2], w.q[3], w.q[4]}, {w.sz[0], w.sz[1], w.sz[2], w.sz[3], w.sz[4]},
+                                  {w.q8[0], w.q8[1], w.q8[2], w.q8[3], w.q8[4]}, {w.s8[0], w.s8[1], w.s8[2], w.s8[3], w.s8[4]}};
             }
             HIP_TRY(hipMalloc((void**)&e->mega_layers, ml.size() * sizeof(MegaLayer)));
             HIP_TRY(hipMemcpy(e->mega_layers, ml.data(), ml.size() * sizeof(MegaLayer), hipMemcpyHostToDevice));
@@ -838,7 +839,7 @@ int mv_probe_kernel(mv_engine* e, int32_t kind, int32_t iters, float* avg_ms, do
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipMemcpy(pos.data(), e->pos_arr, pos.size() * 4, hipMemcpyDeviceToHost));
         const double weights = 3.0 * c.dim * c.dim + (double)c.dim * c.dim + 3.0 * c.intermediate * c.dim;  // elements per layer
-        const double per_layer = (c.weight_format == MV_W_INT4_G128 ? weights * 0.5 + weights / 128 * 4 : weights * 2) + 2.0 * c.dim * 2;
+        const double per_layer = (c.weight_format == MV_W_INT4_G128 ? weights * 0.5 + weights / 128 * 4 : c.weight_format == MV_W_INT8 ? weights : weights * 2) + 2.0 * c.dim * 2;
         bytes = c.n_layer * (per_layer + 2.0 /*rows*/ * c.n_head * (pos[0] + 1.0) * 128 * 2 * 2) + (double)c.vocab * c.dim * 2 + c.dim * 2;
         const MegaArgs m = mega_args(e);
         float t[2] = {0.f, 0.f};

@@ -3,7 +3,10 @@
 #pragma once
 #include "common.h"
 
+#ifndef MV_BF16PAIR_T
+#define MV_BF16PAIR_T
 typedef __bf16 bf16pair_t __attribute__((ext_vector_type(2)));
+#endif
 
 // 8 nibbles of one word -> 4 bf16 pairs (columns 0|1, 2|3, 4|5, 6|7): bf16(fma(q - 8, s, z)), one rounding like tinygemm
 __device__ __forceinline__ void deq8(uint32_t w, float s, float z, bf16pair_t (&out)[4]) {

@@ -10,18 +10,7 @@
 // Layout: [N][K] int8 row-major as quantised; a lane reads 16 B = 16 columns per load, 1024 columns per wave instruction.
 #include "gemv_core.h"
 #include "kernels.h"
-
-typedef __bf16 bf16pair_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ float dot2p8(bf16pair_t w, uint32_t x, float acc) {
-    return __builtin_amdgcn_fdot2_f32_bf16(w, __builtin_bit_cast(bf16pair_t, x), acc, false);
-}
-// 4 int8 of one word -> 2 bf16 pairs (columns 0|1, 2|3); int8 values are exact in bf16
-__device__ __forceinline__ void cvt4(uint32_t w, bf16pair_t (&out)[2]) {
-    const int v = (int)w;
-    out[0] = bf16pair_t{(__bf16)(float)((v << 24) >> 24), (__bf16)(float)((v << 16) >> 24)};
-    out[1] = bf16pair_t{(__bf16)(float)((v << 8) >> 24), (__bf16)(float)(v >> 24)};
-}
+#include "gemv_i8_core.h"
 
 template <int R, int KCH, int NR, int EPI>
 __global__ void __launch_bounds__(1024) gemv_i8_kernel(const GemvI8Args a) {
@@ -88,41 +77,10 @@ __global__ void __launch_bounds__(1024) gemv_i8_kernel(const GemvI8Args a) {
     }
     __syncthreads();
 
-    // ---- 3. convert each word once, dot it with every activation row ----------------------------------------------------
+    // ---- 3. convert each word once, dot it with every activation row (gemv_i8_core.h, shared with decode_mega.hip) ------------
     float acc[NMAT][NR][R];
 #pragma unroll
-    for (int m = 0; m < NMAT; ++m)
-#pragma unroll
-        for (int i = 0; i < NR; ++i)
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[m][i][r] = 0.f;
-#pragma unroll
-    for (int j = 0; j < KCH; ++j) {
-        const bool live = j * 1024 + lane * 16 < K;
-        u32x4 xv[R][2];
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                xv[r][q] = live ? *(const u32x4*)(xs + r * KP + j * 1024 + lane * 16 + q * 8) : u32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int m = 0; m < NMAT; ++m)
-#pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const uint32_t words[4] = {cw[m][i][j].x, cw[m][i][j].y, cw[m][i][j].z, cw[m][i][j].w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {  // word q = columns 4q .. 4q+3 of the lane's 16
-                    bf16pair_t wp[2];
-                    cvt4(words[q], wp);
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const u32x4& xq = xv[r][q >> 1];
-                        const uint32_t x0 = (q & 1) ? xq.z : xq.x, x1 = (q & 1) ? xq.w : xq.y;
-                        acc[m][i][r] = dot2p8(wp[1], x1, dot2p8(wp[0], x0, acc[m][i][r]));
-                    }
-                }
-            }
-    }
+    for (int m = 0; m < NMAT; ++m) i8_dots<R, KCH, NR>(cw[m], xs, KP, K, lane, acc[m]);
 
     // ---- 4. reductions; y = bf16(bf16(acc) * scale) is the Linear output, then the usual epilogues -----------------------
     float mine[NMAT];

@@ -189,6 +189,9 @@ struct MegaLayer {
     // int4 (group-128) engines: packed codes and (scale, zero) words of wqkv, wo, w1, w3, w2 (gemv_i4.hip layout), else null
     const unsigned char* q[5];
     const uint32_t* sz[5];
+    // int8 (per output channel) engines: codes [N][K] and bf16 row scales, same order (gemv_i8.hip layout), else null
+    const signed char* q8[5];
+    const bf16_t* s8[5];
 };
 struct MegaArgs {
     const bf16_t* x_in = nullptr;          // [2][2048]: input rows of layer 0 (written by the sampler / prefill)
@@ -196,6 +199,8 @@ struct MegaArgs {
     int32_t n_layer = 0, vocab = 0, cache_len = 0;
     const bf16_t* final_norm = nullptr;
     const bf16_t* head = nullptr;
+    const signed char* head_q8 = nullptr;  // int8 engines: the LM head is quantised too
+    const bf16_t* head_s8 = nullptr;
     bf16_t* logits = nullptr;              // [2][vocab]
     bf16_t* kcache = nullptr;
     bf16_t* vcache = nullptr;

@@ -146,12 +146,14 @@ def test_int4_engine_follows_the_oracle_on_dequantised_weights():
     engine.close()
 
 
+@pytest.mark.parametrize("quant", ["int4", "int8"])
 @pytest.mark.parametrize("n_layer,T,n_new", [(2, 16, 24), (3, 300, 24)])
-def test_int4_persistent_kernel_is_bit_identical_to_the_int4_launches(n_layer, T, n_new):
-    """decode_mega.hip instantiated for int4 weights shares i4_dots (gemv_i4_core.h) with gemv_i4.hip: same bits."""
+def test_quantised_persistent_kernel_is_bit_identical_to_the_quantised_launches(n_layer, T, n_new, quant):
+    """decode_mega.hip instantiated for int4 / int8 weights shares i4_dots / i8_dots (gemv_i4_core.h, gemv_i8_core.h) with
+    gemv_i4.hip / gemv_i8.hip: same bits (int8: the LM head is quantised too)."""
     cfgk = dict(n_layer=n_layer, n_head=16, dim=2048, vocab_size=2562, block_size=2048)
     sd = o_s1.remap_checkpoint_keys(synthetic.stage1_state_dict(seed=2, **cfgk))
-    engine = mv.Stage1Engine(mv.ModelArgs(**cfgk), max_utterances=1, quantisation_mode="int4")
+    engine = mv.Stage1Engine(mv.ModelArgs(**cfgk), max_utterances=1, quantisation_mode=quant)
     engine.load_state_dict(sd)
     engine.finalize()
     prompt, spk = synthetic.prompt_tokens(T, seed=2), synthetic.speaker_embedding(2)
@@ -166,7 +168,7 @@ def test_int4_persistent_kernel_is_bit_identical_to_the_int4_launches(n_layer, T
             assert res[0] == out[mega][0] and torch.equal(res[1], out[mega][1])
         out[mega] = res
     engine.tune(mega=1)
-    assert out[1][0] == out[0][0], "token streams differ between the int4 persistent kernel and the int4 launches"
+    assert out[1][0] == out[0][0], f"token streams differ between the {quant} persistent kernel and the {quant} launches"
     assert torch.equal(out[1][1], out[0][1]), f"logits differ: max {float((out[1][1].float() - out[0][1].float()).abs().max())}"
     engine.close()
 
