@@ -1,0 +1,110 @@
+// Shared pieces of the persistent decode-step kernels (decode_mega.hip: register prefetch, the default; decode_mega_lds.hip:
+// experimental loader-wave variant): constants, the tagged-granule hand-off and the per-wave polls.
+//
+// Hand-off (cdna_hip_programming.md Guideline 16, recipe R2): every activation vector is exchanged as 8-byte granules
+// {payload: 2 x bf16, tag: 32-bit epoch}, written with ONE agent-scope (sc1, write-through) store by the producing lane
+// and re-read with agent-scope loads by every consumer until all tags match -- the data is the flag: no fence, no
+// barrier object, no dependence on workgroup placement.  epoch = step counter (bumped by the sampler kernel, i.e. across
+// a kernel boundary) x 256 + layer x 8 + phase + 1: strictly increasing, so a stale granule can never match.
+// Every wait is bounded; a timeout raises a device flag that the host turns into an error (a plain launch gives no
+// residency guarantee: if another kernel occupies CUs the grid may not be co-resident).
+#pragma once
+#include "attn_core.h"
+#include "gemv_core.h"
+
+#define MG_THREADS 512
+#define MG_WAVES 8
+#define MG_DIM 2048
+#define MG_INTER 5632
+#define MG_HEADS 16
+#define MG_SPIN_LIMIT (1 << 18)
+#define MG_STAMP_SLOTS 24  // s_memtime stamps per layer (MV_MEGA_STAMPS=1, tools/mega_stamps.py)
+
+typedef u64 gran_t;
+
+__device__ __forceinline__ void gran_store(gran_t* g, uint32_t payload, uint32_t tag) {
+    __hip_atomic_store(g, ((u64)tag << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 gran_load(const gran_t* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// optional phase stamps: needs `stamping`, `stamp_base` and `lane` in scope (MV_MEGA_STAMPS=1, tools/mega_stamps.py)
+#define MG_STAMP(l, k) do { if (stamping && lane == 0) stamp_base[(l) * MG_STAMP_SLOTS + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+
+// One wave waits until all of ITS granules carry `tag` (no block barrier inside: the loaders only mirror the barrier after).
+template <int PER, typename Fetch, typename Sink>
+__device__ __forceinline__ void wave_poll(uint32_t tag, uint32_t* abort_flag, int* s_abort, Fetch fetch, Sink sink) {
+    for (int tries = 0;; ++tries) {
+        u64 v[PER];
+        bool have[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) have[k] = fetch(k, v[k]);
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) ok = ok && (!have[k] || (uint32_t)(v[k] >> 32) == tag);
+        if (__all(ok)) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                if (have[k]) sink(k, (uint32_t)v[k]);
+            return;
+        }
+        if ((tries & 1023) == 1023) {  // a peer is missing (grid not co-resident?) or already gave up
+            const bool peer = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (peer || tries >= MG_SPIN_LIMIT) {
+                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *(volatile int*)s_abort = 1;
+                return;
+            }
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+template <int NCOL>
+__device__ __forceinline__ void wave_poll_rowpair(const gran_t* g, uint32_t tag, bf16_t* raw, uint32_t* abort_flag, int* s_abort, int tid) {
+    constexpr int PER = (NCOL + MG_THREADS - 1) / MG_THREADS;
+    wave_poll<PER>(
+        tag, abort_flag, s_abort,
+        [&](int k, u64& v) { const int n = tid + k * MG_THREADS; if (n >= NCOL) return false; v = gran_load(g + n); return true; },
+        [&](int k, uint32_t p) { const int n = tid + k * MG_THREADS; raw[n] = (bf16_t)p; raw[NCOL + n] = (bf16_t)(p >> 16); });
+}
+
+// The same with 16-byte agent-scope loads: two granules per lane per request, each 8-byte half validated by its own tag
+// (profiles/r01g_handoff: 2.0 vs 2.3 us per idle 2048-granule hand-off).  index(k) = pair index of the lane's k-th request or -1.
+template <int PER, typename Index, typename Sink>
+__device__ __forceinline__ void wave_poll16(const gran_t* g, uint32_t tag, uint32_t* abort_flag, int* s_abort, Index index, Sink sink) {
+    for (int tries = 0;; ++tries) {
+        u32x4 v[PER];
+        int n[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            n[k] = index(k);
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[k]) : "v"(g + 2 * max(n[k], 0)) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) ok = ok && (n[k] < 0 || (v[k].y == tag && v[k].w == tag));
+        if (__all(ok)) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                if (n[k] >= 0) sink(n[k], v[k].x, v[k].z);
+            return;
+        }
+        if ((tries & 1023) == 1023) {
+            const bool peer = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (peer || tries >= MG_SPIN_LIMIT) {
+                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *(volatile int*)s_abort = 1;
+                return;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// row-paired vector of 2048 columns: pair n = granules 2n, 2n+1 = columns 2n, 2n+1 of both rows
+__device__ __forceinline__ void wave_poll_rowpair16(const gran_t* g, uint32_t tag, bf16_t* raw, uint32_t* abort_flag, int* s_abort, int tid) {
+    wave_poll16<2>(g, tag, abort_flag, s_abort, [&](int k) { return tid + k * MG_THREADS; },
+                   [&](int n, uint32_t p0, uint32_t p1) {
+                       *(uint32_t*)(raw + 2 * n) = (p0 & 0xFFFFu) | (p1 << 16);
+                       *(uint32_t*)(raw + MG_DIM + 2 * n) = (p0 >> 16) | (p1 & 0xFFFF0000u);
+                   });
+}
