@@ -54,7 +54,7 @@ typedef struct mv_sampling {
     float guidance_scale;     /* g          */
     float one_minus_guidance; /* (1 - g) as the reference computes it in the model dtype */
     float temperature;        /* clamped to >= 1e-5 by the engine (fast_inference_utils.py:92) */
-    float top_p;              /* <= 0 : disabled (None) */
+    float top_p;              /* < 0 : disabled (None); 0 keeps only the largest token, as `cum <= 1 - top_p` does */
     int32_t top_k;            /* <= 0 : disabled (None) */
     uint64_t seed;            /* Philox key for the Exp(1) race noise (fast_inference_utils.py:61-65) */
 } mv_sampling;

@@ -23,10 +23,15 @@ def shard_indices(n_items: int, rank: int, world_size: int) -> List[int]:
     return list(range(rank, n_items, world_size))
 
 
+_DTYPE_CODES = [torch.float32, torch.int32, torch.int64, torch.bfloat16, torch.float16, torch.int16, torch.uint8, torch.float64]
+
+
 def gather_variable(local: Sequence[torch.Tensor], n_items: int, group: Optional[dist.ProcessGroup] = None,
-                    device: Optional[torch.device] = None) -> List[torch.Tensor]:
+                    device: Optional[torch.device] = None, dtype: Optional[torch.dtype] = None) -> List[torch.Tensor]:
     """All ranks contribute the 1-D results of THEIR shard (`shard_indices` order); every rank returns the full list in
-    input order.  Two collectives: lengths (int64), then the zero-padded payload."""
+    input order.  Two collectives: lengths (int64) with the payload dtype's code riding along, then the zero-padded payload.
+    A rank whose shard is empty (n_items < world_size) has no tensor to read the dtype from: it takes the one the other ranks
+    announce, so every rank enters the payload collective with the same dtype and size."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         assert len(local) == n_items
         return [t.clone() for t in local]
@@ -34,14 +39,21 @@ def gather_variable(local: Sequence[torch.Tensor], n_items: int, group: Optional
     mine = shard_indices(n_items, rank, world)
     assert len(local) == len(mine), f"rank {rank} produced {len(local)} results for {len(mine)} items"
     per_rank = (n_items + world - 1) // world
-    dtype = local[0].dtype if len(local) else torch.float32
+    if dtype is None and len(local):
+        dtype = local[0].dtype
     dev = device if device is not None else (local[0].device if len(local) else torch.device("cpu"))
-    lens = torch.zeros(per_rank, dtype=torch.int64, device=dev)
+    lens = torch.zeros(per_rank + 1, dtype=torch.int64, device=dev)  # last entry: dtype code, -1 = "no opinion"
+    lens[per_rank] = _DTYPE_CODES.index(dtype) if dtype is not None else -1
     for j, t in enumerate(local):
         assert t.dim() == 1 and t.dtype == dtype
         lens[j] = t.numel()
-    all_lens = torch.empty(world * per_rank, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(all_lens, lens, group=group)
+    all_meta = torch.empty(world * (per_rank + 1), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_meta, lens, group=group)
+    all_meta = all_meta.view(world, per_rank + 1)
+    codes = sorted({int(c) for c in all_meta[:, per_rank].tolist() if int(c) >= 0})
+    assert len(codes) <= 1, f"ranks disagree on the payload dtype: {[_DTYPE_CODES[c] for c in codes]}"
+    dtype = _DTYPE_CODES[codes[0]] if codes else torch.float32
+    all_lens = all_meta[:, :per_rank].reshape(-1)
     width = int(all_lens.max().item()) if n_items else 0
     payload = torch.zeros(per_rank, max(width, 1), dtype=dtype, device=dev)
     for j, t in enumerate(local):

@@ -493,7 +493,8 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 
 bool mega_supported(const mv_config& c, int rows, int n_cus) {
     return rows == 2 && c.dim == MG_DIM && c.intermediate == MG_INTER && c.n_head == MG_HEADS && c.vocab <= 256 * 11 && n_cus >= 256 &&
-           c.block_size <= ATTN_NSPLIT * 256;
+           c.block_size <= ATTN_NSPLIT * 256 &&
+           c.n_layer <= 31;  // hand-off tag = step * 256 + layer * 8 + phase + 1: layer * 8 + 6 must stay below 256
 }
 
 __global__ void bump_counter_kernel(uint32_t* c) { c[0] += 1u; }

@@ -112,6 +112,9 @@ struct mv_engine {
 
     // persistent decode-step kernel (decode_mega.hip)
     bool mega_ok = false;
+    bool mega_failed = false;            // a hand-off timed out once: this engine keeps to the per-layer launches from then on
+    UttState* utt_shadow = nullptr;      // state at the last successful poll (mv_run rolls back to it when the persistent kernel aborts)
+    int32_t* pos_shadow = nullptr;
     MegaLayer* mega_layers = nullptr;
     unsigned long long* granules = nullptr;   // g_x | g_qkv | g_attn | g_h | g_act
     uint32_t* step_counter = nullptr;
@@ -170,9 +173,8 @@ int enqueue_step(mv_engine* e) {
     const mv_config& c = e->cfg;
     const int R = e->R;
     hipStream_t s = e->stream;
-    if (e->mega_ok && g_tune.mega) {  // one persistent launch for the 24 layers + LM head, then the sampler
-        HIP_TRY(g_tune.mega == 2 && c.weight_format == MV_W_BF16 ? launch_decode_mega_lds(s, mega_args(e))
-                                                                 : launch_decode_mega(s, mega_args(e), c.weight_format));
+    if (e->mega_ok && g_tune.mega && !e->mega_failed) {  // one persistent launch for the 24 layers + LM head, then the sampler
+        HIP_TRY(launch_decode_mega(s, mega_args(e), c.weight_format));
         return enqueue_sampler(e);
     }
     for (int l = 0; l < c.n_layer; ++l) {
@@ -381,7 +383,7 @@ int mv_tune(mv_engine* e, const char* key, int32_t value) {
     if (found) {}
     else if (k == "gemv_nt") g_tune.gemv_nt = value;
     else if (k == "use_graph") g_tune.use_graph = value;
-    else if (k == "mega") g_tune.mega = value;
+    else if (k == "mega") { g_tune.mega = value; if (e) e->mega_failed = false; }
     else if (k == "gemv_ablate") g_tune.gemv_ablate = value;
     else if (k == "mega_fault") g_tune.mega_fault = value;
     else return fail(MV_ERR_INVALID, "unknown tuning key '%s'", key);
@@ -409,7 +411,7 @@ int mv_engine_create(const mv_config* cfg, mv_engine** out) {
         return fail(MV_ERR_INVALID, "int4: dim/intermediate %d/%d must be multiples of 128 in (0,2048] or (4096,6144], <= 2 utterances",
                     c.dim, c.intermediate);
     if (c.block_size < 8 || c.spk_dim < 1) return fail(MV_ERR_INVALID, "bad block_size/spk_dim");
-    if (c.block_size > ATTN_NSPLIT * 256) return fail(MV_ERR_INVALID, "block_size %d > %d", c.block_size, ATTN_NSPLIT * 128);
+    if (c.block_size > ATTN_NSPLIT * 256) return fail(MV_ERR_INVALID, "block_size %d > %d", c.block_size, ATTN_NSPLIT * 256);
 
     mv_engine* e = new mv_engine();
     e->cfg = c;
@@ -465,7 +467,8 @@ int mv_engine_destroy(mv_engine* e) {
     if (e->graph) hipGraphDestroy(e->graph);
     void* bufs[] = {e->q_arena, e->arena, e->x, e->h, e->q, e->attn, e->act, e->logits, e->kcache, e->vcache, e->partial, e->counters,
                     e->utt, e->pos_arr, e->seq, e->spk_emb, e->spk_proj, e->n_active, e->capture, e->px, e->ph, e->pn, e->pq,
-                    e->pattn, e->pact, e->mega_layers, e->granules, e->step_counter, e->abort_flag, e->dbg, e->stamps};
+                    e->pattn, e->pact, e->mega_layers, e->granules, e->step_counter, e->abort_flag, e->dbg, e->stamps, e->utt_shadow,
+                    e->pos_shadow};
     for (void* b : bufs)
         if (b) hipFree(b);
     if (e->host_flag) hipHostFree(e->host_flag);
@@ -602,11 +605,13 @@ int mv_finalize(mv_engine* e) {
     HIP_TRY(hipMemset(e->counters, 0, (size_t)R * c.n_head * 4));
     HIP_TRY(hipMalloc((void**)&e->utt, (size_t)U * sizeof(UttState)));
     HIP_TRY(hipMalloc((void**)&e->pos_arr, (size_t)U * 4));
+    HIP_TRY(hipMalloc((void**)&e->utt_shadow, (size_t)U * sizeof(UttState)));
+    HIP_TRY(hipMalloc((void**)&e->pos_shadow, (size_t)U * 4));
     HIP_TRY(hipMalloc((void**)&e->seq, (size_t)U * c.block_size * 4));
     HIP_TRY(hipMalloc((void**)&e->spk_emb, (size_t)U * c.spk_dim * 2));
     HIP_TRY(hipMalloc((void**)&e->spk_proj, (size_t)U * c.dim * 2));
     HIP_TRY(hipMalloc((void**)&e->n_active, 4));
-    HIP_TRY(hipHostMalloc((void**)&e->host_flag, 4, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&e->host_flag, 8, hipHostMallocDefault));  // [0] utterances still running, [1] abort flag
     HIP_TRY(hipMemset(e->x, 0, (size_t)R * c.dim * 2));
     if (getenv("MV_DEBUG_VECTORS") && c.dim == 2048 && c.intermediate == 5632) {
         HIP_TRY(hipMalloc((void**)&e->dbg, (size_t)c.n_layer * 5 * 2 * 5632 * 2));
@@ -737,6 +742,9 @@ int mv_begin(mv_engine* e, int32_t n_utt, const int32_t* prompts, const int32_t*
     HIP_TRY(hipMemset(e->spk_emb, 0, (size_t)U * c.spk_dim * 2));
     HIP_TRY(hipMemcpy(e->spk_emb, spk_emb, (size_t)n_utt * c.spk_dim * 2, hipMemcpyHostToDevice));
     HIP_TRY(launch_spk_proj(e->stream, U, c.dim, c.spk_dim, e->spk_emb, e->spk_w, e->spk_s8, e->spk_proj));
+    // A fresh hand-off epoch for this utterance's first persistent launch: no sampler runs before it when the prompt is teacher-
+    // forced, and the previous utterance's last launches left every granule tagged with the epoch they ran under.
+    HIP_TRY(launch_bump_counter(e->stream, e->step_counter));
     SampleArgs a;
     a.seq = e->seq; a.tok_emb = e->tok_emb; a.pos_emb = e->pos_emb; a.spk_proj = e->spk_proj; a.x_next = e->x;
     a.dim = c.dim; a.block_size = c.block_size; a.n_utt = U;
@@ -770,6 +778,13 @@ int mv_run(mv_engine* e, int32_t max_steps, int32_t poll_every, int32_t* steps_r
     int limit = e->steps_budget;
     if (max_steps >= 0 && max_steps < limit) limit = max_steps;
     int done_steps = 0;
+    const int U = e->cfg.max_utterances;
+    auto snapshot = [&]() -> int {  // the state every live utterance would restart from
+        HIP_TRY(hipMemcpyAsync(e->utt_shadow, e->utt, (size_t)U * sizeof(UttState), hipMemcpyDeviceToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->pos_shadow, e->pos_arr, (size_t)U * 4, hipMemcpyDeviceToDevice, e->stream));
+        return MV_OK;
+    };
+    { const int rc = snapshot(); if (rc != MV_OK) return rc; }
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
     while (done_steps < limit) {
         const int chunk = (limit - done_steps) < poll_every ? (limit - done_steps) : poll_every;
@@ -781,24 +796,44 @@ int mv_run(mv_engine* e, int32_t max_steps, int32_t poll_every, int32_t* steps_r
                 if (rc != MV_OK) return rc;
             }
         }
-        done_steps += chunk;
-        if (done_steps >= limit) break;
+        const bool mega_live = e->mega_ok && g_tune.mega && !e->mega_failed;
+        const bool last_chunk = done_steps + chunk >= limit;
+        if (last_chunk && !mega_live) { done_steps += chunk; break; }
         HIP_TRY(hipMemcpyAsync(e->host_flag, e->n_active, 4, hipMemcpyDeviceToHost, e->stream));
+        if (mega_live) HIP_TRY(hipMemcpyAsync(e->host_flag + 1, e->abort_flag, 4, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
-        if (*e->host_flag <= 0) break;
+        if (mega_live && e->host_flag[1] != 0) {
+            // A hand-off of the persistent kernel timed out (the 256 workgroups were not co-resident: another kernel held CUs).
+            // A plain launch gives no residency guarantee, so this is a condition to survive, not an error: roll every utterance
+            // back to the last poll, rebuild its input rows and redo the chunk -- and everything after it -- with per-layer launches
+            // (bit-identical arithmetic; the Philox noise is keyed by (seed, token, sequence index), so the redo draws the same tokens).
+            HIP_TRY(hipMemsetAsync(e->abort_flag, 0, 4, e->stream));
+            HIP_TRY(hipMemcpyAsync(e->utt, e->utt_shadow, (size_t)U * sizeof(UttState), hipMemcpyDeviceToDevice, e->stream));
+            HIP_TRY(hipMemcpyAsync(e->pos_arr, e->pos_shadow, (size_t)U * 4, hipMemcpyDeviceToDevice, e->stream));
+            std::vector<UttState> st(U);
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            HIP_TRY(hipMemcpy(st.data(), e->utt, (size_t)U * sizeof(UttState), hipMemcpyDeviceToHost));
+            int32_t live = 0;
+            for (int u = 0; u < U; ++u) live += st[u].done ? 0 : 1;
+            HIP_TRY(hipMemcpy(e->n_active, &live, 4, hipMemcpyHostToDevice));
+            SampleArgs a;
+            a.utt = e->utt; a.seq = e->seq; a.tok_emb = e->tok_emb; a.pos_emb = e->pos_emb; a.spk_proj = e->spk_proj; a.x_next = e->x;
+            a.dim = e->cfg.dim; a.block_size = e->cfg.block_size; a.n_utt = U;
+            HIP_TRY(launch_embed_current(e->stream, a));
+            e->mega_failed = true;
+            fprintf(stderr, "metavoice_hip: persistent decode kernel timed out waiting for a peer workgroup (grid not co-resident: is "
+                            "another kernel occupying the GPU?); this engine continues with per-layer launches\n");
+            const int rc = build_graph(e);
+            if (rc != MV_OK) return rc;
+            continue;  // the chunk did not count
+        }
+        done_steps += chunk;
+        if (last_chunk || e->host_flag[0] <= 0) break;
+        { const int rc = snapshot(); if (rc != MV_OK) return rc; }
     }
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1));
-    if (e->mega_ok && g_tune.mega) {
-        uint32_t ab = 0;
-        HIP_TRY(hipMemcpy(&ab, e->abort_flag, 4, hipMemcpyDeviceToHost));
-        if (ab) {
-            HIP_TRY(hipMemset(e->abort_flag, 0, 4));
-            return fail(MV_ERR_HIP, "persistent decode kernel timed out waiting for a peer workgroup (grid not co-resident: is "
-                                    "another kernel occupying the GPU?); set mv_tune(\"mega\", 0) to use per-layer launches");
-        }
-    }
     e->steps_budget -= done_steps;
     if (steps_run) *steps_run = done_steps;
     return MV_OK;
@@ -848,7 +883,7 @@ int mv_probe_kernel(mv_engine* e, int32_t kind, int32_t iters, float* avg_ms, do
                 if (i == 0) HIP_TRY(hipEventRecord(e->ev0, s));
                 HIP_TRY(launch_bump_counter(s, e->step_counter));
                 if (pass == 0)
-                    HIP_TRY(g_tune.mega == 2 && c.weight_format == MV_W_BF16 ? launch_decode_mega_lds(s, m) : launch_decode_mega(s, m, c.weight_format));
+                    HIP_TRY(launch_decode_mega(s, m, c.weight_format));
             }
             HIP_TRY(hipEventRecord(e->ev1, s));
             HIP_TRY(hipStreamSynchronize(s));

@@ -15,7 +15,7 @@ struct MvTune {
     int mega_fault = 0;                  // test hook: workgroup (mega_fault - 1) withholds one publish per step -> every wait must time out cleanly
     int gemv_ablate = 0;                 // profiling only (results are wrong): 1 no weight loads, 2 no dots, 4 no prologue, 8 no reductions
     int mega = 1;                        // 1: persistent decode-step kernel (decode_mega.hip) when the configuration supports it
-                                         // (one utterance, bf16, MetaVoice-1B shape, >= 256 CUs): 874 vs 996 us/step; 0: per-layer launches
+                                         // (MetaVoice-1B shape, >= 256 CUs); 0: per-layer launches
 };
 extern MvTune g_tune;
 
@@ -131,6 +131,7 @@ struct SampleArgs {
 };
 hipError_t launch_sample(hipStream_t s, const SampleArgs& a, bool standalone);
 hipError_t launch_embed_first(hipStream_t s, const SampleArgs& a);
+hipError_t launch_embed_current(hipStream_t s, const SampleArgs& a);  // x rows of every live utterance at utt[].pos (rollback)
 hipError_t launch_embed_rows(hipStream_t s, const int32_t* seq, int T, int dim, const bf16_t* tok_emb, const bf16_t* pos_emb,
                              const bf16_t* spk, bf16_t* out);
 hipError_t launch_spk_proj(hipStream_t s, int n_utt, int dim, int spk_dim, const bf16_t* spk_emb, const bf16_t* w,
@@ -219,5 +220,4 @@ struct MegaArgs {
 };
 bool mega_supported(const mv_config& c, int rows, int n_cus);
 hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a, int weight_format);  // every wave prefetches its weight rows into registers; bf16 or int4
-hipError_t launch_decode_mega_lds(hipStream_t s, const MegaArgs& a);  // v3: 4 loader waves stream the weights through an LDS ring
 hipError_t launch_bump_counter(hipStream_t s, uint32_t* counter);  // mv_probe_kernel: advances the hand-off epoch like the sampler does

@@ -1,5 +1,5 @@
-// Shared pieces of the persistent decode-step kernels (decode_mega.hip: register prefetch, the default; decode_mega_lds.hip:
-// experimental loader-wave variant): constants, the tagged-granule hand-off and the per-wave polls.
+// Shared pieces of the persistent decode-step kernel (decode_mega.hip; tools/experiments/decode_mega_lds.hip is a measured-slower
+// loader-wave variant kept out of the product library): constants, the tagged-granule hand-off and the per-wave polls.
 //
 // Hand-off (cdna_hip_programming.md Guideline 16, recipe R2): every activation vector is exchanged as 8-byte granules
 // {payload: 2 x bf16, tag: 32-bit epoch}, written with ONE agent-scope (sc1, write-through) store by the producing lane

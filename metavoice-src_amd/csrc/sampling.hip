@@ -109,6 +109,10 @@ __global__ void __launch_bounds__(SAMPLE_THREADS) sample_kernel(const SampleArgs
     const int V = a.vocab;
     UttState st = a.utt[u];
     const bool standalone = (a.token_out != nullptr);
+    // The hand-off epoch of decode_mega.hip advances once per LAUNCH, unconditionally: a replay after the utterance has ended
+    // (the trailing launches of an mv_run chunk) must not leave the granules tagged with an epoch the next utterance's first
+    // launch would read again.
+    if (!standalone && a.step_counter != nullptr && u == 0 && tid == 0) a.step_counter[0] += 1u;
     if (!standalone && st.done) return;
 
     const int next_index = st.pos + 1;                  // sequence index of the token decided now
@@ -131,7 +135,7 @@ __global__ void __launch_bounds__(SAMPLE_THREADS) sample_kernel(const SampleArgs
         const mv_sampling sp = st.s;
         const float temp = fmaxf(sp.temperature, 1e-5f);
         const bool use_k = sp.top_k > 0;
-        const bool use_p = sp.top_p > 0.f;
+        const bool use_p = sp.top_p >= 0.f;  // None is encoded as a negative value; top_p = 0 keeps only the largest (reference: cum <= 1 - 0)
         const int npt = (V + SAMPLE_THREADS - 1) / SAMPLE_THREADS;  // thread t owns ids [t*npt, t*npt + npt)
         const int i0 = tid * npt;
 
@@ -276,7 +280,6 @@ __global__ void __launch_bounds__(SAMPLE_THREADS) sample_kernel(const SampleArgs
         return;
     }
 
-    if (a.step_counter != nullptr && u == 0 && tid == 0) a.step_counter[0] += 1u;  // next launch's hand-off epoch
     // ---- bookkeeping of decode_n_tokens (fast_inference_utils.py:148-174), on the device -----------------------
     bool done = false;
     if (!forced && tok == st.eoa_token) done = true;   // the EOA token itself is part of the sequence (:161)
@@ -315,6 +318,26 @@ __global__ void embed_first_kernel(const SampleArgs a) {
     const int dim = a.dim;
     const bf16_t* te = a.tok_emb + (size_t)tok * dim;
     const bf16_t* pe = a.pos_emb;
+    const bf16_t* sp = a.spk_proj + (size_t)u * dim;
+    bf16_t* x0 = a.x_next + (size_t)(2 * u) * dim;
+    bf16_t* x1 = x0 + dim;
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) {
+        const float base = round_bf(bf2f(te[i]) + bf2f(pe[i]));
+        x0[i] = f2bf(base + bf2f(sp[i]));
+        x1[i] = f2bf(base);
+    }
+}
+
+// x rows of every live utterance at its CURRENT position (token seq[pos] at position pos): rebuilds the decode-step input after
+// a rollback (mv_run: a persistent-kernel hand-off timed out and the chunk is redone with per-layer launches).
+__global__ void embed_current_kernel(const SampleArgs a) {
+    const int u = blockIdx.x;
+    const UttState st = a.utt[u];
+    if (st.done) return;
+    const int tok = a.seq[(size_t)u * a.block_size + st.pos];
+    const int dim = a.dim;
+    const bf16_t* te = a.tok_emb + (size_t)tok * dim;
+    const bf16_t* pe = a.pos_emb + (size_t)st.pos * dim;
     const bf16_t* sp = a.spk_proj + (size_t)u * dim;
     bf16_t* x0 = a.x_next + (size_t)(2 * u) * dim;
     bf16_t* x1 = x0 + dim;
@@ -373,6 +396,10 @@ hipError_t launch_sample(hipStream_t s, const SampleArgs& a, bool standalone) {
 }
 hipError_t launch_embed_first(hipStream_t s, const SampleArgs& a) {
     hipLaunchKernelGGL(embed_first_kernel, dim3(a.n_utt), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_embed_current(hipStream_t s, const SampleArgs& a) {
+    hipLaunchKernelGGL(embed_current_kernel, dim3(a.n_utt), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_spk_proj(hipStream_t s, int n_utt, int dim, int spk_dim, const bf16_t* spk_emb, const bf16_t* w,

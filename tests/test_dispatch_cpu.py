@@ -37,12 +37,18 @@ def _worker(rank, world, port, n_items, q):
         # int32 token grids take the same path as fp32 audio
         toks = bd.run_sharded(items, lambda i, it: torch.arange(i + 1, dtype=torch.int32))
         ok = ok and all(torch.equal(t, torch.arange(i + 1, dtype=torch.int32)) for i, t in enumerate(toks))
+        # int64 / bf16 payloads with an EMPTY rank (n_items < world): the empty rank must adopt the others' dtype (8- and 2-byte
+        # elements: a float32 fallback would enter the collective with a different size)
+        big = bd.run_sharded(items, lambda i, it: torch.arange(i + 3, dtype=torch.int64) << 40)
+        ok = ok and all(t.dtype == torch.int64 and torch.equal(t, torch.arange(i + 3, dtype=torch.int64) << 40) for i, t in enumerate(big))
+        half = bd.run_sharded(items, lambda i, it: torch.full((i + 2,), 0.5 * (i + 1), dtype=torch.bfloat16))
+        ok = ok and all(t.dtype == torch.bfloat16 and torch.equal(t, torch.full((i + 2,), 0.5 * (i + 1), dtype=torch.bfloat16)) for i, t in enumerate(half))
         q.put((rank, ok, bd.shard_indices(n_items, rank, world)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_items", [(2, 7), (2, 2), (3, 8), (2, 1)])
+@pytest.mark.parametrize("world,n_items", [(2, 7), (2, 2), (3, 8), (2, 1), (3, 1)])
 def test_sharded_generation_gathers_in_input_order(world, n_items):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
