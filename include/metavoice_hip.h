@@ -189,6 +189,24 @@ int64_t mv_codec_samples(const mv_codec* c, int32_t frames);   /* frames x prod(
  * [hidden][frames], the summed codebook vectors (`decode_latent`, the diffusion decoder's conditioning). */
 int mv_codec_decode(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t frames, float* wav_out, float* latent_out);
 
+/* ---- speaker encoder: replaces SpeakerEncoder.forward (fam/quantiser/audio/speaker_encoder/model.py:21-59): 3-layer LSTM over
+ * 40-bin mel frames of the partial utterances, relu(Linear(h_T)), L2-normalised per partial.  Tensor names are those of
+ * `checkpoint["model_state"]`: lstm.weight_ih_l0 ... lstm.bias_hh_l2, linear.weight, linear.bias (host fp32).  The mel front
+ * end (speaker_encoder/audio.py) and the mean over partials (model.py:98-103) stay on the host, as in the reference. */
+typedef struct mv_spkenc mv_spkenc;
+typedef struct mv_spkenc_config {
+    int32_t n_mels;    /* 40  (mel_n_channels)      */
+    int32_t hidden;    /* 256 (model_hidden_size)   */
+    int32_t n_layers;  /* 3   (model_num_layers)    */
+    int32_t emb;       /* 256 (model_embedding_size)*/
+} mv_spkenc_config;
+int mv_spkenc_create(const mv_spkenc_config* cfg, mv_spkenc** out);
+int mv_spkenc_destroy(mv_spkenc* e);
+int mv_spkenc_load_weight(mv_spkenc* e, const char* name, const float* data, int64_t numel);
+int mv_spkenc_finalize(mv_spkenc* e);
+/* mels: host fp32 [n_partials][frames][n_mels]; out: host fp32 [n_partials][emb]. */
+int mv_spkenc_embed(mv_spkenc* e, const float* mels, int32_t n_partials, int32_t frames, float* out);
+
 /* Debug hook (MV_DEBUG_VECTORS=1 in the environment at mv_finalize, MetaVoice-1B widths only): bf16 bits of every layer's
  * q | attention output | h | SwiGLU activation | x of the LAST decode step, [n_layer][5][2 rows][5632]. */
 int mv_debug_vectors(mv_engine* e, uint16_t* out, int64_t cap_elems);

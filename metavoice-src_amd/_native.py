@@ -48,6 +48,10 @@ class mv_codec_config(C.Structure):
     ]
 
 
+class mv_spkenc_config(C.Structure):
+    _fields_ = [("n_mels", C.c_int32), ("hidden", C.c_int32), ("n_layers", C.c_int32), ("emb", C.c_int32)]
+
+
 class mv_sampling(C.Structure):
     _fields_ = [
         ("guidance_scale", C.c_float), ("one_minus_guidance", C.c_float), ("temperature", C.c_float),
@@ -92,6 +96,11 @@ SYMBOLS = [
     ("mv_codec_finalize", C.c_int, [_P]),
     ("mv_codec_samples", C.c_int64, [_P, C.c_int32]),
     ("mv_codec_decode", C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("mv_spkenc_create", C.c_int, [C.POINTER(mv_spkenc_config), C.POINTER(_P)]),
+    ("mv_spkenc_destroy", C.c_int, [_P]),
+    ("mv_spkenc_load_weight", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_float), C.c_int64]),
+    ("mv_spkenc_finalize", C.c_int, [_P]),
+    ("mv_spkenc_embed", C.c_int, [_P, C.POINTER(C.c_float), C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
     ("mv_probe_kernel", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     ("mv_tune", C.c_int, [_P, C.c_char_p, C.c_int32]),
     ("mv_debug_vectors", C.c_int, [_P, C.POINTER(C.c_uint16), C.c_int64]),

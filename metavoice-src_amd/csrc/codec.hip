@@ -128,41 +128,6 @@ __global__ void __launch_bounds__(256) convt1d_kernel(const ConvArgs a) {
     }
 }
 
-// One LSTM time step (torch.nn.LSTM gate order i, f, g, o): a wave per hidden unit, 4 gate rows of W_hh [4H][H].
-struct LstmArgs {
-    const float* gin;    // [4H][T]: W_ih x_t + b_ih + b_hh for every t (a k=1 convolution)
-    const float* whh;    // [4H][H]
-    const float* h_prev; // [H]
-    float* h_next;       // [H]
-    float* c;            // [H], updated in place
-    float* y;            // [H][T]: y[u][t] = h_t[u] (+ skip[u][t])
-    const float* skip;   // [H][T] or null
-    int H, T, t;
-};
-__global__ void __launch_bounds__(256) lstm_step_kernel(const LstmArgs a) {
-    const int lane = threadIdx.x & 63, u = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (u >= a.H) return;
-    float g[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float* w = a.whh + (size_t)(q * a.H + u) * a.H;
-        float s = 0.f;
-        for (int k = lane * 4; k < a.H; k += 256) {
-            const float4 wv = *(const float4*)(w + k), hv = *(const float4*)(a.h_prev + k);
-            s = fmaf(wv.x, hv.x, s); s = fmaf(wv.y, hv.y, s); s = fmaf(wv.z, hv.z, s); s = fmaf(wv.w, hv.w, s);
-        }
-        g[q] = wave_sum(s) + a.gin[(size_t)(q * a.H + u) * a.T + a.t];
-    }
-    if (lane == 0) {
-        const float ig = 1.f / (1.f + expf(-g[0])), fg = 1.f / (1.f + expf(-g[1])), gg = tanhf(g[2]), og = 1.f / (1.f + expf(-g[3]));
-        const float c = fmaf(fg, a.c[u], ig * gg);
-        const float h = og * tanhf(c);
-        a.c[u] = c;
-        a.h_next[u] = h;
-        a.y[(size_t)u * a.T + a.t] = h + (a.skip ? a.skip[(size_t)u * a.T + a.t] : 0.f);
-    }
-}
-
 struct Conv {
     float *w = nullptr, *b = nullptr;  // device, re-laid out
     int cin = 0, cout = 0, coutp = 0, k = 0, dil = 1, stride = 1;
@@ -175,6 +140,9 @@ struct mv_codec {
     mv_codec_config cfg{};
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;
+    unsigned long long* lstm_hx = nullptr;  // [2][dim0] tagged granules of the persistent LSTM kernel (lstm.hip)
+    uint32_t* lstm_abort = nullptr;
+    uint32_t lstm_serial = 0;
     float* embed = nullptr;  // [n_q][bins][dim]
     std::vector<bool> embed_loaded;
     Conv conv_in, conv_out;
@@ -254,6 +222,15 @@ int mv_codec_create(const mv_codec_config* cfg, mv_codec** out) {
     int rc = alloc_conv(c, c->conv_in, g.hidden, ch, g.kernel_size, 1, false, 1);
     if (rc == MV_OK && hipMalloc((void**)&c->embed, (size_t)g.n_q * g.bins * g.hidden * 4) != hipSuccess) rc = mv_fail(MV_ERR_HIP, "hipMalloc failed");
     if (rc == MV_OK) c->allocs.push_back(c->embed);
+    if (rc == MV_OK && g.lstm_layers > 0) {
+        const int H0 = g.num_filters << g.n_ratios;
+        if (H0 % 8 != 0 || lstm_seq_lds_bytes(1, H0) > 160 * 1024) rc = mv_fail(MV_ERR_INVALID, "LSTM width %d unsupported", H0);
+        if (rc == MV_OK && (hipMalloc((void**)&c->lstm_hx, (size_t)2 * H0 * 8) != hipSuccess || hipMemset(c->lstm_hx, 0, (size_t)2 * H0 * 8) != hipSuccess ||
+                            hipMalloc((void**)&c->lstm_abort, 4) != hipSuccess || hipMemset(c->lstm_abort, 0, 4) != hipSuccess))
+            rc = mv_fail(MV_ERR_HIP, "hipMalloc failed");
+        if (c->lstm_hx) c->allocs.push_back(c->lstm_hx);
+        if (c->lstm_abort) c->allocs.push_back(c->lstm_abort);
+    }
     c->embed_loaded.assign(g.n_q, false);
     c->lstm_ih.resize(g.lstm_layers);
     c->lstm_hh.assign(g.lstm_layers, nullptr);
@@ -395,16 +372,13 @@ int mv_codec_decode(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t fra
     }
     int32_t* d_tok = nullptr;
     float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
-    float *hbuf = nullptr;
     auto cleanup = [&]() {
         if (d_tok) (void)hipFree(d_tok);
         for (float* b : buf) if (b) (void)hipFree(b);
-        if (hbuf) (void)hipFree(hbuf);
     };
 #define CD_TRY2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return mv_fail(MV_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
     CD_TRY2(hipMalloc((void**)&d_tok, (size_t)n_q * frames * 4));
     for (auto& b : buf) CD_TRY2(hipMalloc((void**)&b, widest * 4));
-    CD_TRY2(hipMalloc((void**)&hbuf, (size_t)3 * c->dim0 * 4));
     CD_TRY2(hipMemcpyAsync(d_tok, tokens, (size_t)n_q * frames * 4, hipMemcpyHostToDevice, s));
     int T = frames;
     float *x = buf[0], *e = buf[1], *u = buf[2], *h = buf[3];
@@ -418,13 +392,16 @@ int mv_codec_decode(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t fra
         float* gin = u;   // [4H][T]
         for (int l = 0; l < g.lstm_layers; ++l) {
             CD_TRY2(run_conv(s, c->lstm_ih[l], cur, gin, T, false));
-            CD_TRY2(hipMemsetAsync(hbuf, 0, (size_t)3 * H * 4, s));
             float* y = (l == g.lstm_layers - 1) ? e : h;  // the last layer adds the skip and lands in `e`
-            for (int t = 0; t < T; ++t) {
-                LstmArgs a{gin, c->lstm_hh[l], hbuf + (t & 1) * H, hbuf + ((t + 1) & 1) * H, hbuf + 2 * H, y,
-                           (l == g.lstm_layers - 1) ? x : nullptr, H, T, t};
-                hipLaunchKernelGGL(lstm_step_kernel, dim3((H + 3) / 4), dim3(256), 0, s, a);
-            }
+            if (++c->lstm_serial >= 65535u) { CD_TRY2(hipMemsetAsync(c->lstm_hx, 0, (size_t)2 * H * 8, s)); c->lstm_serial = 1; }
+            LstmSeqArgs a{};   // one persistent launch for all T steps of the layer (was T dependent launches)
+            a.gin = gin; a.gs_b = 0; a.gs_t = 1; a.gs_r = T;
+            a.whh = c->lstm_hh[l];
+            a.y = y; a.ys_b = 0; a.ys_t = 1; a.ys_u = T;
+            a.skip = (l == g.lstm_layers - 1) ? x : nullptr;
+            a.hx = c->lstm_hx; a.tag_base = c->lstm_serial << 16; a.abort_flag = c->lstm_abort;
+            a.B = 1; a.H = H; a.T = T;
+            CD_TRY2(launch_lstm_seq(s, a));
             cur = y;
         }
         if (g.lstm_layers > 0) std::swap(x, e);
@@ -446,9 +423,15 @@ int mv_codec_decode(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t fra
     hipLaunchKernelGGL(elu_kernel, dim3((unsigned)(((size_t)ch * T + 255) / 256)), dim3(256), 0, s, x, e, (size_t)ch * T);
     CD_TRY2(run_conv(s, c->conv_out, e, u, T, false));
     CD_TRY2(hipMemcpyAsync(wav_out, u, (size_t)g.audio_channels * n_out * 4, hipMemcpyDeviceToHost, s));
+    uint32_t aborted = 0;
+    if (c->lstm_abort) CD_TRY2(hipMemcpyAsync(&aborted, c->lstm_abort, 4, hipMemcpyDeviceToHost, s));
     CD_TRY2(hipStreamSynchronize(s));
 #undef CD_TRY2
     cleanup();
+    if (aborted) {
+        (void)hipMemset(c->lstm_abort, 0, 4);
+        return mv_fail(MV_ERR_HIP, "mv_codec_decode: the LSTM workgroups timed out waiting for each other (device shared with another kernel?)");
+    }
     return MV_OK;
 }
 

@@ -184,6 +184,24 @@ struct AttnRowsArgs {
 };
 hipError_t launch_attn_rows(hipStream_t s, const AttnRowsArgs& a);
 
+// ---- lstm.hip: persistent LSTM recurrence (EnCodec decoder LSTMs, speaker encoder) -----------------------------------------
+struct LstmSeqArgs {
+    const float* gin = nullptr;      // W_ih x_t + b_ih + b_hh of (b, t, gate row r) at gin[b*gs_b + t*gs_t + r*gs_r], rows ordered i|f|g|o
+    int64_t gs_b = 0, gs_t = 0, gs_r = 0;
+    const float* whh = nullptr;      // [4H][H]
+    float* y = nullptr;              // h_t[u] (+ skip) of (b, t, u) at y[b*ys_b + t*ys_t + u*ys_u], or null
+    int64_t ys_b = 0, ys_t = 0, ys_u = 0;
+    const float* skip = nullptr;     // same indexing as y, or null
+    float* h_last = nullptr;         // [B][H]: h_T, or null
+    unsigned long long* hx = nullptr;  // [2][B][H] tagged granules (device scratch, zeroed once)
+    uint32_t tag_base = 0;           // launch serial << 16: tags of different launches never collide
+    uint32_t* abort_flag = nullptr;  // device word, raised when a wait times out
+    int32_t B = 1, H = 0, T = 0;
+};
+hipError_t launch_lstm_seq(hipStream_t s, const LstmSeqArgs& a);   // H % 8 == 0, T <= 65535, LDS (32 H + B (H + 8)) * 4 <= 160 KB
+size_t lstm_seq_lds_bytes(int B, int H);
+hipError_t launch_lstm_inproj(hipStream_t s, const float* x, const float* w, const float* bias, float* gin, int BT, int I, int R);
+
 // ---- decode_mega.hip: persistent decode-step kernel (MetaVoice-1B shape, one utterance) -----------------------------
 struct MegaLayer {
     const bf16_t *attn_norm, *wqkv, *wo, *ffn_norm, *w1, *w3, *w2;

@@ -1,0 +1,381 @@
+// LSTM recurrences of the synthesis path on gfx950, fp32: ONE persistent launch per layer for all T time steps.
+//
+//   * the two LSTM layers inside the EnCodec decoder (codec.hip; was 2 x T dependent launches of ~5 us each), and
+//   * the speaker encoder of the reference, `fam/quantiser/audio/speaker_encoder/model.py:21-59`:
+//       nn.LSTM(40 -> 256, 3 layers, batch_first) over N partial utterances x 160 mel frames, then
+//       relu(Linear(256 -> 256)(h_T of the last layer)), L2-normalised per partial            (`forward`, :54-57)
+//     exposed through the C ABI as `mv_spkenc_*`.  The mel front end is host pre-processing, as it is
+//     in the reference (librosa on the CPU, `speaker_encoder/audio.py`).
+//
+// Kernel shape.  The recurrence h_t = f(W_hh h_{t-1} + gin_t) is a chain of T dependent mat-vecs; what bounds it is the
+// latency of handing h_t to whoever holds W_hh, not bytes or flops.  So W_hh (4H x H fp32, 1-4 MB) is split over H/8 workgroups
+// that each keep their 32 gate rows in LDS for the whole sequence (64 KB at H = 512), and h_t travels between them as 8-byte
+// tagged granules {fp32 value, 32-bit tag = launch serial << 16 | t + 1} -- the hand-off of the persistent decode kernel
+// (mega_core.h; cdna_hip_programming.md Guideline 16 recipe R2: one agent-scope store by the producer, agent-scope polling
+// loads by the consumers, the data is the flag, no fence).  Two granule buffers alternate: a workgroup can only publish
+// h_{t+2} after it has read all of h_{t+1}, which exists only once every workgroup has finished reading h_t.
+// Every wait is bounded and raises an abort word (a plain launch is not guaranteed co-resident if the device is shared).
+// gate order i, f, g, o (torch.nn.LSTM); the non-recurrent half W_ih x_t + b_ih + b_hh is a plain batched product computed
+// before the launch (`lstm_inproj_kernel` here, a k = 1 convolution in codec.hip).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+int mv_fail(int code, const char* fmt, ...);  // engine.hip
+
+namespace {
+
+constexpr int LS_UPW = 8;          // hidden units per workgroup
+constexpr int LS_THREADS = 256;    // 4 waves, 2 units each
+constexpr int LS_SPIN_LIMIT = 1 << 20;
+
+typedef unsigned long long gran_t;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void __launch_bounds__(LS_THREADS) lstm_seq_kernel(const LstmSeqArgs a) {
+    extern __shared__ float lds[];
+    const int H = a.H, B = a.B;
+    float* w_s = lds;                       // [4 * LS_UPW][H]: row q * LS_UPW + u  <-  W_hh[q * H + u0 + u]
+    float* h_s = w_s + 4 * LS_UPW * H;      // [B][H]
+    float* c_s = h_s + (size_t)B * H;       // [B][LS_UPW]
+    __shared__ int s_abort;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u0 = blockIdx.x * LS_UPW;
+    if (tid == 0) s_abort = 0;
+    for (int i = tid; i < 4 * LS_UPW * H; i += LS_THREADS) {
+        const int r = i / H, k = i - r * H, q = r / LS_UPW, u = r - q * LS_UPW;
+        w_s[i] = a.whh[(size_t)(q * H + u0 + u) * H + k];
+    }
+    for (int i = tid; i < B * H; i += LS_THREADS) h_s[i] = 0.f;
+    for (int i = tid; i < B * LS_UPW; i += LS_THREADS) c_s[i] = 0.f;
+    __syncthreads();
+    for (int t = 0; t < a.T; ++t) {
+        if (t > 0) {
+            // h_{t-1} of every unit and batch row: granules tagged with this launch's serial and t
+            const gran_t* src = a.hx + (size_t)(t & 1) * B * H;
+            const uint32_t tag = a.tag_base + (uint32_t)t;
+            for (int n = tid; n < B * H; n += LS_THREADS) {
+                unsigned long long v = 0;
+                int tries = 0;
+                for (;; ++tries) {
+                    v = __hip_atomic_load(src + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(v >> 32) == tag) break;
+                    if ((tries & 1023) == 1023) {
+                        const bool peer = __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                        if (peer || tries >= LS_SPIN_LIMIT) {
+                            __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            *(volatile int*)&s_abort = 1;
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                h_s[n] = __uint_as_float((uint32_t)v);
+            }
+            __syncthreads();
+            if (s_abort) return;
+        }
+        // wave w owns units 2w, 2w+1: all four gates of a unit stay in one wave, so the cell update needs no exchange
+        gran_t* dst = a.hx + (size_t)((t + 1) & 1) * B * H;
+        for (int b = 0; b < B; ++b) {
+            const float* hb = h_s + (size_t)b * H;
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) {
+                const int u = wave * 2 + uu;
+                float g[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float* w = w_s + (size_t)(q * LS_UPW + u) * H;
+                    float s = 0.f;
+                    for (int k = lane; k < H; k += 64) s = fmaf(w[k], hb[k], s);
+                    g[q] = wave_sum(s);
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[q] += a.gin[(size_t)b * a.gs_b + (size_t)t * a.gs_t + (size_t)(q * H + u0 + u) * a.gs_r];
+                    const float ig = sigmoidf_(g[0]), fg = sigmoidf_(g[1]), gg = tanhf(g[2]), og = sigmoidf_(g[3]);
+                    const float c = fmaf(fg, c_s[b * LS_UPW + u], ig * gg);
+                    const float h = og * tanhf(c);
+                    c_s[b * LS_UPW + u] = c;
+                    if (t + 1 < a.T)
+                        __hip_atomic_store(dst + (size_t)b * H + u0 + u, ((unsigned long long)(a.tag_base + (uint32_t)t + 1u) << 32) | __float_as_uint(h),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (a.y) {
+                        const size_t o = (size_t)b * a.ys_b + (size_t)t * a.ys_t + (size_t)(u0 + u) * a.ys_u;
+                        a.y[o] = h + (a.skip ? a.skip[o] : 0.f);
+                    }
+                    if (a.h_last && t == a.T - 1) a.h_last[(size_t)b * H + u0 + u] = h;
+                }
+            }
+        }
+        __syncthreads();  // h_s is overwritten by the next poll
+    }
+}
+
+// gin[b][t][row] = bias[row] + sum_k w[row][k] * x[b][t][k]      (the non-recurrent half of every gate, all time steps at once)
+constexpr int IP_TT = 8;
+__global__ void __launch_bounds__(256) lstm_inproj_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ gin, int BT, int I, int R) {
+    extern __shared__ float xs[];  // [IP_TT][I]
+    const int bt0 = blockIdx.x * IP_TT;
+    for (int i = threadIdx.x; i < IP_TT * I; i += 256) {
+        const int j = i / I, k = i - j * I;
+        xs[i] = bt0 + j < BT ? x[(size_t)(bt0 + j) * I + k] : 0.f;
+    }
+    __syncthreads();
+    for (int r = blockIdx.y * 256 + threadIdx.x; r < R; r += gridDim.y * 256) {
+        float acc[IP_TT];
+        const float b = bias[r];
+#pragma unroll
+        for (int j = 0; j < IP_TT; ++j) acc[j] = b;
+        const float* wr = w + (size_t)r * I;
+        for (int k = 0; k < I; ++k) {
+            const float wv = wr[k];
+#pragma unroll
+            for (int j = 0; j < IP_TT; ++j) acc[j] = fmaf(wv, xs[j * I + k], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < IP_TT; ++j)
+            if (bt0 + j < BT) gin[(size_t)(bt0 + j) * R + r] = acc[j];
+    }
+}
+
+// out[b] = v / ||v||_2 with v = relu(W h_last[b] + bias)        (speaker_encoder/model.py:55-57)
+__global__ void __launch_bounds__(256) spk_head_kernel(const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ out, int H, int E) {
+    __shared__ float red[4];
+    __shared__ float hs[1024];
+    const int b = blockIdx.x;
+    for (int k = threadIdx.x; k < H; k += 256) hs[k] = h[(size_t)b * H + k];
+    __syncthreads();
+    float sq = 0.f;
+    float v[4];  // E <= 1024
+    int n = 0;
+    for (int e = threadIdx.x; e < E; e += 256, ++n) {
+        float s = bias[e];
+        const float* wr = w + (size_t)e * H;
+        for (int k = 0; k < H; ++k) s = fmaf(wr[k], hs[k], s);
+        s = fmaxf(s, 0.f);
+        v[n] = s;
+        sq = fmaf(s, s, sq);
+    }
+    sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    n = 0;
+    for (int e = threadIdx.x; e < E; e += 256, ++n) out[(size_t)b * E + e] = v[n] / norm;
+}
+
+}  // namespace
+
+size_t lstm_seq_lds_bytes(int B, int H) { return ((size_t)4 * LS_UPW * H + (size_t)B * H + (size_t)B * LS_UPW) * sizeof(float); }
+
+hipError_t launch_lstm_seq(hipStream_t s, const LstmSeqArgs& a) {
+    if (a.H % LS_UPW != 0 || a.T < 1 || a.T > 65535 || a.B < 1) return hipErrorInvalidValue;
+    const size_t lds = lstm_seq_lds_bytes(a.B, a.H);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL(lstm_seq_kernel, dim3(a.H / LS_UPW), dim3(LS_THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_lstm_inproj(hipStream_t s, const float* x, const float* w, const float* bias, float* gin, int BT, int I, int R) {
+    if ((size_t)IP_TT * I * 4 > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lstm_inproj_kernel, dim3((BT + IP_TT - 1) / IP_TT, (R + 255) / 256 > 4 ? 4 : (R + 255) / 256), dim3(256), (size_t)IP_TT * I * 4, s,
+                       x, w, bias, gin, BT, I, R);
+    return hipGetLastError();
+}
+
+// ---- speaker encoder -------------------------------------------------------------------------------------------------
+
+#define SE_TRY(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess) return mv_fail(MV_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                             __FILE__, __LINE__);                                             \
+    } while (0)
+
+struct mv_spkenc {
+    mv_spkenc_config cfg{};
+    hipStream_t stream = nullptr;
+    std::vector<float*> w_ih, w_hh, bias;   // device; bias = b_ih + b_hh
+    std::vector<std::vector<float>> bias_host;
+    std::vector<int> loaded;                // bitmask per layer: 1 w_ih, 2 w_hh, 4 b_ih, 8 b_hh
+    float *lin_w = nullptr, *lin_b = nullptr;
+    int lin_loaded = 0;
+    unsigned long long* hx = nullptr;
+    size_t hx_cap = 0;
+    uint32_t* abort_flag = nullptr;
+    uint32_t serial = 0;
+    bool finalized = false;
+};
+
+extern "C" {
+
+int mv_spkenc_create(const mv_spkenc_config* cfg, mv_spkenc** out) {
+    if (!cfg || !out) return mv_fail(MV_ERR_INVALID, "mv_spkenc_create: null argument");
+    const mv_spkenc_config& g = *cfg;
+    if (g.n_mels < 1 || g.n_mels > 512 || g.hidden < LS_UPW || g.hidden > 1024 || g.hidden % LS_UPW || g.n_layers < 1 || g.n_layers > 8 ||
+        g.emb < 1 || g.emb > 1024)
+        return mv_fail(MV_ERR_INVALID, "mv_spkenc_create: unsupported sizes (n_mels %d hidden %d layers %d emb %d)", g.n_mels, g.hidden, g.n_layers, g.emb);
+    mv_spkenc* e = new mv_spkenc();
+    e->cfg = g;
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return mv_fail(MV_ERR_HIP, "hipStreamCreate failed"); }
+    const int H = g.hidden;
+    e->w_ih.assign(g.n_layers, nullptr); e->w_hh.assign(g.n_layers, nullptr); e->bias.assign(g.n_layers, nullptr);
+    e->bias_host.assign(g.n_layers, std::vector<float>((size_t)4 * H, 0.f));
+    e->loaded.assign(g.n_layers, 0);
+    bool ok = true;
+    for (int l = 0; l < g.n_layers && ok; ++l) {
+        const int I = l == 0 ? g.n_mels : H;
+        ok = hipMalloc((void**)&e->w_ih[l], (size_t)4 * H * I * 4) == hipSuccess && hipMalloc((void**)&e->w_hh[l], (size_t)4 * H * H * 4) == hipSuccess &&
+             hipMalloc((void**)&e->bias[l], (size_t)4 * H * 4) == hipSuccess;
+    }
+    ok = ok && hipMalloc((void**)&e->lin_w, (size_t)g.emb * H * 4) == hipSuccess && hipMalloc((void**)&e->lin_b, (size_t)g.emb * 4) == hipSuccess &&
+         hipMalloc((void**)&e->abort_flag, 4) == hipSuccess && hipMemset(e->abort_flag, 0, 4) == hipSuccess;
+    if (!ok) { mv_spkenc_destroy(e); return mv_fail(MV_ERR_HIP, "mv_spkenc_create: hipMalloc failed"); }
+    *out = e;
+    return MV_OK;
+}
+
+int mv_spkenc_destroy(mv_spkenc* e) {
+    if (!e) return MV_OK;
+    for (auto* p : e->w_ih) if (p) (void)hipFree(p);
+    for (auto* p : e->w_hh) if (p) (void)hipFree(p);
+    for (auto* p : e->bias) if (p) (void)hipFree(p);
+    if (e->lin_w) (void)hipFree(e->lin_w);
+    if (e->lin_b) (void)hipFree(e->lin_b);
+    if (e->hx) (void)hipFree(e->hx);
+    if (e->abort_flag) (void)hipFree(e->abort_flag);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return MV_OK;
+}
+
+// names of `checkpoint["model_state"]` (speaker_encoder/model.py:33-35,45): lstm.{weight,bias}_{ih,hh}_l{k}, linear.{weight,bias}
+int mv_spkenc_load_weight(mv_spkenc* e, const char* name, const float* data, int64_t numel) {
+    if (!e || !name || !data) return mv_fail(MV_ERR_INVALID, "mv_spkenc_load_weight: null argument");
+    const int H = e->cfg.hidden;
+    char kind[8], leaf[4];
+    int l = -1;
+    if (sscanf(name, "lstm.%7[a-z]_%2[a-z]_l%d", kind, leaf, &l) == 3) {
+        if (l < 0 || l >= e->cfg.n_layers) return mv_fail(MV_ERR_INVALID, "%s: LSTM layer out of range", name);
+        const bool ih = strcmp(leaf, "ih") == 0;
+        const int I = l == 0 ? e->cfg.n_mels : H;
+        if (strcmp(kind, "weight") == 0) {
+            const int64_t want = (int64_t)4 * H * (ih ? I : H);
+            if (numel != want) return mv_fail(MV_ERR_INVALID, "%s: expected %lld elements, got %lld", name, (long long)want, (long long)numel);
+            SE_TRY(hipMemcpy(ih ? e->w_ih[l] : e->w_hh[l], data, (size_t)numel * 4, hipMemcpyHostToDevice));
+            e->loaded[l] |= ih ? 1 : 2;
+        } else if (strcmp(kind, "bias") == 0) {
+            if (numel != 4 * H) return mv_fail(MV_ERR_INVALID, "%s: expected %d elements", name, 4 * H);
+            if (e->loaded[l] & (ih ? 4 : 8)) return mv_fail(MV_ERR_STATE, "%s loaded twice", name);
+            for (int k = 0; k < 4 * H; ++k) e->bias_host[l][k] += data[k];
+            e->loaded[l] |= ih ? 4 : 8;
+        } else return mv_fail(MV_ERR_INVALID, "unknown tensor %s", name);
+        return MV_OK;
+    }
+    if (strcmp(name, "linear.weight") == 0) {
+        if (numel != (int64_t)e->cfg.emb * H) return mv_fail(MV_ERR_INVALID, "linear.weight: wrong size");
+        SE_TRY(hipMemcpy(e->lin_w, data, (size_t)numel * 4, hipMemcpyHostToDevice));
+        e->lin_loaded |= 1;
+        return MV_OK;
+    }
+    if (strcmp(name, "linear.bias") == 0) {
+        if (numel != e->cfg.emb) return mv_fail(MV_ERR_INVALID, "linear.bias: wrong size");
+        SE_TRY(hipMemcpy(e->lin_b, data, (size_t)numel * 4, hipMemcpyHostToDevice));
+        e->lin_loaded |= 2;
+        return MV_OK;
+    }
+    return mv_fail(MV_ERR_INVALID, "unknown speaker-encoder tensor %s", name);
+}
+
+int mv_spkenc_finalize(mv_spkenc* e) {
+    if (!e) return mv_fail(MV_ERR_INVALID, "mv_spkenc_finalize: null engine");
+    for (int l = 0; l < e->cfg.n_layers; ++l)
+        if (e->loaded[l] != 15) return mv_fail(MV_ERR_MISSING_WEIGHT, "speaker encoder: LSTM layer %d incomplete (mask %d)", l, e->loaded[l]);
+    if (e->lin_loaded != 3) return mv_fail(MV_ERR_MISSING_WEIGHT, "speaker encoder: linear.weight / linear.bias missing");
+    for (int l = 0; l < e->cfg.n_layers; ++l)
+        SE_TRY(hipMemcpy(e->bias[l], e->bias_host[l].data(), (size_t)4 * e->cfg.hidden * 4, hipMemcpyHostToDevice));
+    e->finalized = true;
+    return MV_OK;
+}
+
+// mels: host fp32 [B][T][n_mels] (the partial utterances of `embed_utterance`, model.py:88-96); out: host fp32 [B][emb],
+// each row L2-normalised (`forward`, :54-57).  The mean over partials and its normalisation stay with the caller (:98-103).
+int mv_spkenc_embed(mv_spkenc* e, const float* mels, int32_t B, int32_t T, float* out) {
+    if (!e || !mels || !out) return mv_fail(MV_ERR_INVALID, "mv_spkenc_embed: null argument");
+    if (!e->finalized) return mv_fail(MV_ERR_STATE, "mv_spkenc_embed before mv_spkenc_finalize");
+    const int H = e->cfg.hidden, M = e->cfg.n_mels, E = e->cfg.emb;
+    if (B < 1 || T < 1 || T > 65535) return mv_fail(MV_ERR_INVALID, "mv_spkenc_embed: B = %d, T = %d out of range", B, T);
+    const int BMAX = (int)((160 * 1024 / 4 - 4 * LS_UPW * H) / (H + LS_UPW));  // LDS budget of the recurrence kernel
+    hipStream_t s = e->stream;
+    float *x = nullptr, *gin = nullptr, *y0 = nullptr, *y1 = nullptr, *hl = nullptr, *d_out = nullptr;
+    auto cleanup = [&]() { for (float* p : {x, gin, y0, y1, hl, d_out}) if (p) (void)hipFree(p); };
+#define SE_TRY2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return mv_fail(MV_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
+    SE_TRY2(hipMalloc((void**)&x, (size_t)B * T * M * 4));
+    SE_TRY2(hipMalloc((void**)&gin, (size_t)B * T * 4 * H * 4));
+    SE_TRY2(hipMalloc((void**)&y0, (size_t)B * T * H * 4));
+    SE_TRY2(hipMalloc((void**)&y1, (size_t)B * T * H * 4));
+    SE_TRY2(hipMalloc((void**)&hl, (size_t)B * H * 4));
+    SE_TRY2(hipMalloc((void**)&d_out, (size_t)B * E * 4));
+    if (e->hx_cap < (size_t)2 * BMAX * H) {
+        if (e->hx) (void)hipFree(e->hx);
+        e->hx = nullptr;
+        SE_TRY2(hipMalloc((void**)&e->hx, (size_t)2 * BMAX * H * 8));
+        SE_TRY2(hipMemset(e->hx, 0, (size_t)2 * BMAX * H * 8));
+        e->hx_cap = (size_t)2 * BMAX * H;
+        e->serial = 0;
+    }
+    SE_TRY2(hipMemcpyAsync(x, mels, (size_t)B * T * M * 4, hipMemcpyHostToDevice, s));
+    const float* cur = x;
+    int I = M;
+    for (int l = 0; l < e->cfg.n_layers; ++l) {
+        SE_TRY2(launch_lstm_inproj(s, cur, e->w_ih[l], e->bias[l], gin, B * T, I, 4 * H));
+        float* y = (l & 1) ? y1 : y0;
+        const bool last = l == e->cfg.n_layers - 1;
+        for (int b0 = 0; b0 < B; b0 += BMAX) {   // batch tiles that fit the LDS budget; rows are independent sequences
+            const int nb = B - b0 < BMAX ? B - b0 : BMAX;
+            if (++e->serial >= 65535u) { SE_TRY2(hipMemsetAsync(e->hx, 0, e->hx_cap * 8, s)); e->serial = 1; }
+            LstmSeqArgs a{};
+            a.gin = gin + (size_t)b0 * T * 4 * H; a.gs_b = (int64_t)T * 4 * H; a.gs_t = 4 * H; a.gs_r = 1;
+            a.whh = e->w_hh[l];
+            a.y = last ? nullptr : y + (size_t)b0 * T * H; a.ys_b = (int64_t)T * H; a.ys_t = H; a.ys_u = 1;
+            a.skip = nullptr;
+            a.h_last = last ? hl + (size_t)b0 * H : nullptr;
+            a.hx = e->hx; a.tag_base = e->serial << 16; a.abort_flag = e->abort_flag;
+            a.B = nb; a.H = H; a.T = T;
+            SE_TRY2(launch_lstm_seq(s, a));
+        }
+        cur = y;
+        I = H;
+    }
+    hipLaunchKernelGGL(spk_head_kernel, dim3(B), dim3(256), 0, s, hl, e->lin_w, e->lin_b, d_out, H, E);
+    SE_TRY2(hipGetLastError());
+    uint32_t aborted = 0;
+    SE_TRY2(hipMemcpyAsync(out, d_out, (size_t)B * E * 4, hipMemcpyDeviceToHost, s));
+    SE_TRY2(hipMemcpyAsync(&aborted, e->abort_flag, 4, hipMemcpyDeviceToHost, s));
+    SE_TRY2(hipStreamSynchronize(s));
+    cleanup();
+#undef SE_TRY2
+    if (aborted) {
+        (void)hipMemset(e->abort_flag, 0, 4);
+        return mv_fail(MV_ERR_HIP, "mv_spkenc_embed: the LSTM workgroups timed out waiting for each other (device shared with another kernel?)");
+    }
+    return MV_OK;
+}
+
+}  // extern "C"

@@ -1,9 +1,10 @@
 """Mirror of `fam/llm/decoders.py`: token grid -> waveform file.
 
 The reference builds `audiocraft.MultiBandDiffusion.get_mbd_24khz(bw=6)` at import time (`decoders.py:13`) and calls
-`mbd.tokens_to_wav` (`:84-85`).  audiocraft is third-party and absent here; the vocoder is injected as a callable
-`vocoder(tokens: LongTensor (1, 8, f)) -> FloatTensor (1, 1, samples)` at 24 kHz.  Until the HIP vocoder lands
- `EncodecDecoder.decode(causal=False)` raises if no vocoder was given -- it never falls back to CPU.
+`mbd.tokens_to_wav` (`:84-85`).  Here the vocoder is `vocoder.MultiBandDiffusion` (HIP EnCodec decode + diffusion bands), built by
+`TTS` from the weights in the model directory and handed in as a callable
+`vocoder(tokens: LongTensor (1, 8, f)) -> FloatTensor (1, 1, samples)` at 24 kHz.  There is no CPU fallback: an
+`EncodecDecoder` without a vocoder is refused at construction.
 """
 from __future__ import annotations
 
@@ -26,14 +27,18 @@ class Decoder(ABC):
         raise NotImplementedError
 
 
-def write_wav_pcm16(path: str, wav: torch.Tensor, sample_rate: int) -> None:
-    """Mono 16-bit PCM RIFF writer (stands in for audiocraft's `audio_write`, `decoders.py:40-47`)."""
+def write_wav_pcm16(path, wav: torch.Tensor, sample_rate: int) -> None:
+    """Mono 16-bit PCM RIFF writer (stands in for audiocraft's `audio_write`, `decoders.py:40-47`); `path` may be a file
+    name or a binary file object."""
     x = wav.detach().reshape(-1).float().cpu().clamp(-1.0, 1.0)
     pcm = (x * 32767.0).round().to(torch.int16).numpy().tobytes()
-    with open(path, "wb") as f:
-        f.write(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE")
-        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, sample_rate, sample_rate * 2, 2, 16))
-        f.write(b"data" + struct.pack("<I", len(pcm)) + pcm)
+    blob = (b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE" + b"fmt " +
+            struct.pack("<IHHIIHH", 16, 1, 1, sample_rate, sample_rate * 2, 2, 16) + b"data" + struct.pack("<I", len(pcm)) + pcm)
+    if hasattr(path, "write"):
+        path.write(blob)
+    else:
+        with open(path, "wb") as f:
+            f.write(blob)
 
 
 class EncodecDecoder(Decoder):
@@ -43,6 +48,9 @@ class EncodecDecoder(Decoder):
         self._mbd_sample_rate = 24_000
         self._end_of_audio_token = 1024
         self._num_codebooks = 8
+        if vocoder is None:
+            raise ValueError("EncodecDecoder needs a vocoder (vocoder.MultiBandDiffusion.get_mbd_24khz(model_dir=...)); "
+                             "the reference builds one at import time (fam/llm/decoders.py:13)")
         self.vocoder = vocoder
         self.tokeniser_decode_fn = tokeniser_decode_fn
         self._data_adapter_fn = data_adapter_fn
@@ -56,19 +64,39 @@ class EncodecDecoder(Decoder):
                                  loudness_compressor=True)
         write_wav_pcm16(str(name) + ".wav", out, self._mbd_sample_rate)
 
-    def decode(self, tokens: List[List[int]], causal: bool = True, ref_audio_path: Optional[str] = None) -> Union[str, torch.Tensor]:
-        """`decoders.py:66-102`: adapter -> (1, n, f) grid padded with 0 up to 8 codebooks; causal=True returns the grid,
-        causal=False vocodes and SAVES `<output_dir>/synth_<timestamp>_<text[:25]>_<uuid>.wav`, returning the path stem."""
+    def _grid(self, tokens: List[List[int]]) -> Tuple[str, torch.Tensor]:
         text_ids, extracted_audio_ids = self._data_adapter_fn(tokens)
         text = self.tokeniser_decode_fn(text_ids)
         grid = torch.tensor(extracted_audio_ids, dtype=torch.long).unsqueeze(0)
         if grid.shape[1] < self._num_codebooks:
             pad = torch.zeros(1, self._num_codebooks - grid.shape[1], grid.shape[2], dtype=torch.long)
             grid = torch.cat([grid, pad], dim=1)
+        return text, grid
+
+    def decode_wav(self, tokens: List[List[int]]) -> torch.Tensor:
+        """The waveform `decode(causal=False)` would save, (1, 1, samples) fp32, without touching the disk (long-form
+        synthesis concatenates these; serving returns them through `wav_bytes`)."""
+        wav = self.vocoder(self._grid(tokens)[1])
+        if wav.shape[-1] < 9600:
+            raise Exception("wav predicted is shorter than 400ms!")  # decoders.py:88-91
+        return wav
+
+    def wav_bytes(self, wav: torch.Tensor) -> bytes:
+        """Loudness-normalised 16-bit PCM RIFF bytes of `wav`: what `_save_audio` writes, kept in memory."""
+        import io
+
+        out = normalize_loudness(wav.detach().float().cpu().reshape(1, -1), self._mbd_sample_rate, loudness_headroom_db=14.0,
+                                 loudness_compressor=True)
+        buf = io.BytesIO()
+        write_wav_pcm16(buf, out, self._mbd_sample_rate)
+        return buf.getvalue()
+
+    def decode(self, tokens: List[List[int]], causal: bool = True, ref_audio_path: Optional[str] = None) -> Union[str, torch.Tensor]:
+        """`decoders.py:66-102`: adapter -> (1, n, f) grid padded with 0 up to 8 codebooks; causal=True returns the grid,
+        causal=False vocodes and SAVES `<output_dir>/synth_<timestamp>_<text[:25]>_<uuid>.wav`, returning the path stem."""
+        text, grid = self._grid(tokens)
         if causal:
             return grid
-        if self.vocoder is None:
-            raise NotImplementedError("no vocoder: the multiband-diffusion / EnCodec decode stage is not built yet (DESIGN.md section 7)")
         wav = self.vocoder(grid)
         if wav.shape[-1] < 9600:
             raise Exception("wav predicted is shorter than 400ms!")

@@ -9,14 +9,17 @@ all deliberate:
     speaker encoder runs once per voice and is cached on disk by the reference, `fam/llm/inference.py:419-435`; it is outside
     the timed path);
   * the DeepFilterNet enhancer (`:158-163`, third-party Rust) is an optional pluggable post-step, off by default;
-  * the vocoder is injected (`decoders.EncodecDecoder(vocoder=...)`) until the HIP EnCodec / MBD stage lands.
+  * the vocoder (`fam/llm/decoders.py:13`: `MultiBandDiffusion.get_mbd_24khz(bw=6)`, fetched from the hub there) is built from
+    `encodec_24khz.pt` (+ `mbd_comp_8.pt`) in the model directory -- `vocoder.py`; a callable can be injected instead;
+  * additions with no counterpart in the reference: `synthesise_long` (BASELINE configs[4]: the reference stops at 220
+    characters, `fam/llm/inference.py:535-541`) and `synthesise_batch` (several utterances decoded together).
 """
 from __future__ import annotations
 
 import os
 import time
 from pathlib import Path
-from typing import Callable, Literal, Optional
+from typing import Callable, List, Literal, Optional, Sequence
 
 import numpy as np
 import torch
@@ -25,6 +28,7 @@ from .adapters import FlattenedInterleavedEncodec2Codebook, TiltedEncodec
 from .decoders import EncodecDecoder
 from .fast_inference_utils import build_model, main
 from .inference import InferenceConfig, Model
+from .longform import MAX_CHARS, split_text
 from .tokenise import TrainedBPETokeniser
 from .utils import check_audio_file, get_default_dtype, get_device, normalize_text
 
@@ -42,7 +46,8 @@ class TTS:
 
     def __init__(self, model_name: str = "metavoiceio/metavoice-1B-v0.1", *, seed: int = 1337, output_dir: str = "outputs",
                  quantisation_mode: Optional[Literal["int4", "int8"]] = None, first_stage_path: Optional[str] = None,
-                 telemetry_origin: Optional[str] = None, vocoder: Optional[Callable] = None, enhancer: Optional[Callable] = None):
+                 telemetry_origin: Optional[str] = None, vocoder: Optional[Callable] = None, enhancer: Optional[Callable] = None,
+                 max_utterances: int = 1):
         self._dtype = get_default_dtype()
         self._device = get_device()
         self._model_dir = _resolve_model_dir(model_name)
@@ -56,6 +61,11 @@ class TTS:
                                               device=self._device, dtype=self._dtype, compile=False, init_from="resume",
                                               output_dir=self.output_dir)
         data_adapter_second_stage = TiltedEncodec(end_of_audio_token=self.END_OF_AUDIO_TOKEN)
+        if vocoder is None:  # decoders.py:13 builds it at import time; a TTS that cannot vocode fails here, not at the first request
+            from .vocoder import MultiBandDiffusion
+
+            vocoder = MultiBandDiffusion.get_mbd_24khz(bw=6.0, model_dir=self._model_dir, seed=seed)
+        self.vocoder = vocoder
         self.llm_second_stage = Model(config_second_stage, TrainedBPETokeniser, EncodecDecoder,
                                       data_adapter_fn=data_adapter_second_stage.decode, vocoder=vocoder)
         self.enhancer = enhancer
@@ -63,7 +73,8 @@ class TTS:
         self.model, self.tokenizer, self.smodel, self.model_size = build_model(
             precision=self.precision, checkpoint_path=Path(self._first_stage_ckpt),
             spk_emb_ckpt_path=Path(f"{self._model_dir}/speaker_encoder.pt"), device=self._device, compile=True,
-            compile_prefill=True, quantisation_mode=quantisation_mode)
+            compile_prefill=True, quantisation_mode=quantisation_mode, max_utterances=max_utterances)
+        self.max_utterances = max_utterances
         self._seed = seed
         self._quantisation_mode = quantisation_mode
         self._model_name = model_name
@@ -109,3 +120,81 @@ class TTS:
         print(f"\nTotal time to synth (s): {time_to_synth_s}")
         print(f"Real-time factor: {time_to_synth_s / max(duration_s, 1e-9):.2f}")
         return str(wav_file) + ".wav"
+
+    # ---- additions: several utterances per call, long texts ------------------------------------------------------------
+    def _first_stage(self, texts: Sequence[str], spk_embs: torch.Tensor, top_p, guidance_scale, temperature) -> List[List[int]]:
+        """Token streams of up to `max_utterances` texts decoded TOGETHER (one weight stream for all of them; per-utterance
+        positions, end-of-audio and seeds -- the semantics of the reference's batched slow path, `mixins/causal.py:179-287`)."""
+        from .engine import SamplingParams
+
+        engine = self.model.engine
+        out: List[List[int]] = []
+        for i in range(0, len(texts), self.max_utterances):
+            group = list(texts[i:i + self.max_utterances])
+            prompts = [self.tokenizer.encode(t) for t in group]
+            sps = []
+            for _ in group:
+                self._n_calls += 1
+                sps.append(SamplingParams(guidance_scale=float(guidance_scale), temperature=float(temperature), top_p=float(top_p),
+                                          seed=self._seed + self._n_calls))
+            engine.begin(prompts, spk_embs[i:i + len(group)], sps, end_of_audio_token=2048, prefill_mode=1, dtype=self.precision)
+            engine.run()
+            out.extend(engine.tokens(u) for u in range(len(group)))
+        return out
+
+    def synthesise_wavs(self, texts: Sequence[str], spk_refs, top_p=0.95, guidance_scale=3.0, temperature=1.0) -> List[torch.Tensor]:
+        """`synthesise` for a list of texts, waveforms kept in memory: (1, 1, samples) fp32 at 24 kHz each, in input order.
+        `spk_refs`: one reference for all texts or one per text."""
+        texts = [normalize_text(t) for t in texts]
+        if isinstance(spk_refs, (str, os.PathLike, torch.Tensor)):
+            spk_refs = [spk_refs] * len(texts)
+        cache = {}
+        embs = []
+        for r in spk_refs:
+            key = r if isinstance(r, (str, os.PathLike)) else id(r)
+            if key not in cache:
+                cache[key] = self._speaker_embedding(r).to(dtype=self.precision)
+            embs.append(cache[key])
+        spk = torch.cat(embs, dim=0)
+        streams = self._first_stage(texts, spk, top_p, guidance_scale, temperature)
+        wavs: List[torch.Tensor] = []
+        for text, tokens, emb in zip(texts, streams, embs):
+            _, ids = self.first_stage_adapter.decode([tokens])
+            wavs.extend(self.llm_second_stage.non_causal_wavs(
+                texts=[text], encodec_tokens=[torch.tensor(ids, dtype=torch.int32).unsqueeze(0)], speaker_embs=emb.unsqueeze(0),
+                batch_size=1, top_k=200, temperature=1.0))
+        return wavs
+
+    def synthesise_batch(self, texts: Sequence[str], spk_refs, top_p=0.95, guidance_scale=3.0, temperature=1.0) -> List[bytes]:
+        """-> loudness-normalised 16-bit PCM RIFF bytes per text (what `synthesise` writes to disk), in input order; the
+        batched-serving entry point (serving.py)."""
+        dec = self.llm_second_stage.decoder
+        return [dec.wav_bytes(w) for w in self.synthesise_wavs(texts, spk_refs, top_p, guidance_scale, temperature)]
+
+    def synthesise_long(self, text: str, spk_ref_path, top_p=0.95, guidance_scale=3.0, temperature=1.0, max_chars: int = MAX_CHARS,
+                        gap_s: float = 0.15) -> str:
+        """Long-form synthesis: `text` is split at sentence boundaries into chunks of <= `max_chars` characters (`longform.py`),
+        every chunk is an independent generation with the same speaker embedding -- the decode graph captured at load time is
+        replayed for all of them -- and the waveforms are joined with `gap_s` of silence, loudness-normalised once and saved."""
+        chunks = split_text(normalize_text(text), max_chars)
+        if not chunks:
+            raise ValueError("empty text")
+        start = time.time()
+        emb = self._speaker_embedding(spk_ref_path)
+        wavs = self.synthesise_wavs(chunks, emb, top_p, guidance_scale, temperature)
+        gap = torch.zeros(1, 1, int(gap_s * 24000))
+        pieces = []
+        for i, w in enumerate(wavs):
+            pieces.append(w)
+            if i + 1 < len(wavs):
+                pieces.append(gap)
+        wav = torch.cat(pieces, dim=-1)
+        dec = self.llm_second_stage.decoder
+        import uuid
+
+        name = dec.output_dir / f"synth_long_{uuid.uuid4()}"
+        dec._save_audio(name, wav)
+        dur = wav.shape[-1] / 24000.0
+        print(f"\nSaved audio to {name}.wav ({len(chunks)} chunks, {dur:.1f} s)")
+        print(f"Real-time factor: {(time.time() - start) / max(dur, 1e-9):.2f}")
+        return str(name) + ".wav"

@@ -69,9 +69,9 @@ class Model:
                                    data_adapter_fn=data_adapter_fn, **decoder_kwargs)
         self._calls = 0
 
-    def non_causal_sample(self, *, texts: List[str], encodec_tokens: List[torch.Tensor], batch_size: int, top_k: Optional[int],
-                          temperature: Optional[float], speaker_embs: Optional[torch.Tensor] = None) -> list:
-        """`inference.py:248-338`: returns one decoder result (path of the saved audio) per text, `None` where decoding failed."""
+    def _second_stage_token_lists(self, *, texts: List[str], encodec_tokens: List[torch.Tensor], batch_size: int,
+                                  top_k: Optional[int], temperature: Optional[float], speaker_embs: Optional[torch.Tensor]):
+        """Packing + sampling of `inference.py:264-329`: yields one (8 + ..., t) token list per (sample, text)."""
         if speaker_embs is not None:
             assert len(texts) == len(speaker_embs)
         grids = []
@@ -84,19 +84,34 @@ class Model:
         in_x = torch.tensor(grids, dtype=torch.long)
         if not self.speaker_cond:
             speaker_embs = None
-        to_return = []
         for _ in range(self.config.num_samples):
             self._calls += 1
             y = self.model.generate(in_x, None, temperature=temperature, top_k=top_k, top_p=None, speaker_embs=speaker_embs,
                                     batch_size=batch_size, guidance_scale=None, seed=self.config.seed + 7919 * self._calls)
             for tokens in torch.cat([in_x, y], dim=1):
-                try:
-                    to_return.append(self.decoder.decode(tokens=tokens.tolist(), causal=False))
-                except Exception as e:  # the reference swallows vocoder failures into a None entry (:331-336)
-                    print("failed to run MBD.")
-                    print(f"reason: {str(e)}")
-                    to_return.append(None)
+                yield tokens.tolist()
+
+    def non_causal_sample(self, *, texts: List[str], encodec_tokens: List[torch.Tensor], batch_size: int, top_k: Optional[int],
+                          temperature: Optional[float], speaker_embs: Optional[torch.Tensor] = None) -> list:
+        """`inference.py:248-338`: returns one decoder result (path of the saved audio) per text, `None` where decoding failed."""
+        to_return = []
+        for tokens in self._second_stage_token_lists(texts=texts, encodec_tokens=encodec_tokens, batch_size=batch_size, top_k=top_k,
+                                                     temperature=temperature, speaker_embs=speaker_embs):
+            try:
+                to_return.append(self.decoder.decode(tokens=tokens, causal=False))
+            except Exception as e:  # the reference swallows vocoder failures into a None entry (:331-336)
+                print("failed to run MBD.")
+                print(f"reason: {str(e)}")
+                to_return.append(None)
         return to_return
+
+    def non_causal_wavs(self, *, texts: List[str], encodec_tokens: List[torch.Tensor], batch_size: int, top_k: Optional[int],
+                        temperature: Optional[float], speaker_embs: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+        """Same sampling as `non_causal_sample`, but the (1, 1, samples) waveforms stay in memory (long-form concatenation,
+        batched serving: SURVEY.md 8f row 4); errors propagate instead of turning into `None`."""
+        return [self.decoder.decode_wav(tokens) for tokens in self._second_stage_token_lists(
+            texts=texts, encodec_tokens=encodec_tokens, batch_size=batch_size, top_k=top_k, temperature=temperature,
+            speaker_embs=speaker_embs)]
 
     def __call__(self, *, texts: List[str], batch_size: int, max_new_tokens: Optional[int], top_k: Optional[int],
                  top_p: Optional[float], temperature: Optional[float], encodec_tokens: Optional[List[torch.Tensor]] = None,

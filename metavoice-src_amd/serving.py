@@ -4,8 +4,15 @@ Same contract (`serving.py:54-109`): `GET /health -> {"status": "ok"}`; `POST /t
 `speaker_ref_path` (URL / path) xor `audiodata` (uploaded file), `guidance` in [0, 5] (default 3.0), `top_p` in [0, 1]
 (default 0.95) -> `audio/wav` body; 400 when neither speaker input is given; 500 with the reference's fixed text on any
 failure; the synthesised file is deleted after the response.  Same flags (`ServingConfig`, `:29-42`):
---huggingface_repo_id --temperature --seed --port (58003) --quantisation_mode.  Requests are handled one at a time, like
-the reference (its `async def` handler calls the blocking `synthesise`, `:89`).
+--huggingface_repo_id --temperature --seed --port (58003) --quantisation_mode.
+
+Dispatch (the part SURVEY.md 8a row a20 / 8e asks to be new): the reference serialises requests on one global TTS (its
+`async def` handler calls the blocking `synthesise`, `:89`).  Here requests wait in a queue; a dispatcher thread groups the
+pending ones (same guidance / top_p) into a batch of up to `utterances_per_gpu x n_gpus`, shards it round-robin over the ranks
+(`batch_dispatch.run_sharded`: one process per GPU, weights replicated, no collective during generation), every rank decodes its
+utterances together (`TTS.synthesise_batch`), and ONE all-gather of the finished RIFF bytes (RCCL over xGMI; gloo in the CPU
+tests) brings them back to rank 0, which answers the HTTP requests in arrival order.  With one process and one utterance per
+GPU this degenerates to the reference's behaviour.  Launch: `python -m torch.distributed.run --nproc-per-node N -m ...serving`.
 
 The reference builds this on FastAPI + python-multipart + tyro + ffmpeg; of those only FastAPI is in this image and its
 `Form(...)` needs python-multipart, so the same surface is served here with the standard library (`http.server` + `email`
@@ -17,12 +24,15 @@ from __future__ import annotations
 import argparse
 import json
 import logging
+import queue
 import tempfile
+import threading
+import time
 from dataclasses import dataclass
 from email import message_from_bytes
-from http.server import BaseHTTPRequestHandler, HTTPServer
+from http.server import BaseHTTPRequestHandler, HTTPServer, ThreadingHTTPServer
 from pathlib import Path
-from typing import Dict, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 from urllib.parse import parse_qs
 
 logger = logging.getLogger(__name__)
@@ -44,6 +54,131 @@ class ServingConfig:
 class _GlobalState:
     config: ServingConfig
     tts = None
+    dispatcher = None
+
+
+class BatchingDispatcher:
+    """Request queue -> batches -> ranks.  `submit()` blocks the calling (HTTP handler) thread until its result is back.
+
+    Rank 0 owns the queue; ranks > 0 sit in `serve_worker()`.  Every batch starts with a broadcast of the work list (a few
+    hundred bytes), then `run_sharded` (generation, no collective) and the single gather of the results."""
+
+    STOP = "__stop__"
+
+    def __init__(self, tts, utterances_per_gpu: int = 1, max_wait_ms: float = 5.0, group=None):
+        import torch.distributed as dist
+
+        self.tts = tts
+        self.group = group
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.world = self.dist.get_world_size(group) if self.dist else 1
+        self.rank = self.dist.get_rank(group) if self.dist else 0
+        self.max_batch = max(1, utterances_per_gpu) * self.world
+        self.max_wait_s = max_wait_ms / 1e3
+        self.q: "queue.Queue" = queue.Queue()
+        self.batches: List[int] = []  # sizes of the batches dispatched so far (observability / tests)
+        self._thread: Optional[threading.Thread] = None
+
+    # ---- rank 0 --------------------------------------------------------------------------------------------------
+    def start(self):
+        assert self.rank == 0
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def submit(self, text: str, spk_ref: str, top_p: float, guidance: float) -> bytes:
+        done = threading.Event()
+        slot: Dict[str, object] = {}
+        self.q.put((dict(text=text, spk=spk_ref, top_p=top_p, guidance=guidance), done, slot))
+        done.wait()
+        if "error" in slot:
+            raise slot["error"]  # type: ignore[misc]
+        return slot["wav"]  # type: ignore[return-value]
+
+    def stop(self):
+        self.q.put(None)
+        if self._thread is not None:
+            self._thread.join(timeout=30)
+
+    def _take_batch(self):
+        first = self.q.get()
+        if first is None:
+            return None
+        batch = [first]
+        deadline = time.monotonic() + self.max_wait_s
+        held = []
+        while len(batch) < self.max_batch:
+            try:
+                nxt = self.q.get(timeout=max(0.0, deadline - time.monotonic()))
+            except queue.Empty:
+                break
+            if nxt is None:
+                held.append(nxt)
+                break
+            same = (nxt[0]["top_p"], nxt[0]["guidance"]) == (first[0]["top_p"], first[0]["guidance"])
+            (batch if same else held).append(nxt)  # other sampling controls wait for the next batch
+        for h in held:
+            self.q.put(h)
+        return batch
+
+    def _loop(self):
+        while True:
+            batch = self._take_batch()
+            if batch is None:
+                self._broadcast([self.STOP])
+                return
+            items = [b[0] for b in batch]
+            self.batches.append(len(items))
+            try:
+                self._broadcast(items)
+                wavs = self._run(items)
+                for (_, done, slot), w in zip(batch, wavs):
+                    slot["wav"] = w
+                    done.set()
+            except Exception as e:  # every waiter of the batch gets the failure (-> 500 with the fixed text)
+                logger.exception("batch failed")
+                for _, done, slot in batch:
+                    slot["error"] = e
+                    done.set()
+
+    # ---- all ranks -----------------------------------------------------------------------------------------------
+    def _broadcast(self, items: list) -> list:
+        if self.dist is None or self.world == 1:
+            return items
+        box = [items]
+        self.dist.broadcast_object_list(box, src=0, group=self.group)
+        return box[0]
+
+    def _run(self, items: list) -> List[bytes]:
+        import torch
+
+        from .batch_dispatch import gather_variable, shard_indices
+
+        mine = shard_indices(len(items), self.rank, self.world)
+        local: List["torch.Tensor"] = []
+        if mine:
+            blobs = self.tts.synthesise_batch([items[i]["text"] for i in mine], [items[i]["spk"] for i in mine],
+                                              top_p=items[0]["top_p"], guidance_scale=items[0]["guidance"])
+            local = [torch.frombuffer(bytearray(b), dtype=torch.uint8) for b in blobs]
+        device = None
+        if self.dist is not None and self.world > 1 and self.dist.get_backend(self.group) == "nccl":
+            device = torch.device("cuda", torch.cuda.current_device())
+            local = [t.to(device) for t in local]
+        out = gather_variable(local, len(items), group=self.group, device=device, dtype=torch.uint8)
+        return [bytes(t.cpu().numpy().tobytes()) for t in out]
+
+    def serve_worker(self):
+        """Ranks > 0: take part in every batch rank 0 announces until it announces the end."""
+        assert self.rank != 0
+        while True:
+            items = self._broadcast([])
+            if items and items[0] == self.STOP:
+                return
+            try:
+                self._run(items)
+            except Exception:
+                logger.exception("worker rank %d failed on a batch", self.rank)
+                raise
 
 
 GlobalState = _GlobalState()
@@ -97,6 +232,8 @@ def text_to_speech(fields: Dict[str, str], files: Dict[str, bytes]) -> Tuple[int
                 wav_path = wav_tmp.name
             else:
                 wav_path = speaker_ref_path
+            if GlobalState.dispatcher is not None:  # queued, batched, sharded over the GPUs; the waveform never touches the disk
+                return 200, "audio/wav", GlobalState.dispatcher.submit(text, wav_path, top_p, guidance)
             wav_out_path = GlobalState.tts.synthesise(text=text, spk_ref_path=wav_path, top_p=top_p, guidance_scale=guidance)
         with open(wav_out_path, "rb") as f:
             return 200, "audio/wav", f.read()
@@ -135,27 +272,51 @@ class _Handler(BaseHTTPRequestHandler):
         logger.info("%s - %s", self.address_string(), fmt % args)
 
 
-def make_server(tts, config: Optional[ServingConfig] = None, host: str = "0.0.0.0") -> HTTPServer:
-    """One engine, one request at a time (an `mv_engine` is not re-entrant, like the reference's single global TTS)."""
+def make_server(tts, config: Optional[ServingConfig] = None, host: str = "0.0.0.0", dispatcher: Optional[BatchingDispatcher] = None) -> HTTPServer:
+    """Without a dispatcher: one engine, one request at a time (the reference's single global TTS).  With one: handler threads
+    enqueue and wait, the dispatcher thread is the only one that touches the engine (an `mv_engine` is not re-entrant)."""
     GlobalState.config = config or ServingConfig()
     GlobalState.tts = tts
-    return HTTPServer((host, GlobalState.config.port), _Handler)
+    GlobalState.dispatcher = dispatcher
+    cls = ThreadingHTTPServer if dispatcher is not None else HTTPServer
+    return cls((host, GlobalState.config.port), _Handler)
 
 
 def main(argv=None):
+    import os
+
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--huggingface_repo_id", default=ServingConfig.huggingface_repo_id)
     ap.add_argument("--temperature", type=float, default=1.0)
     ap.add_argument("--seed", type=int, default=1337)
     ap.add_argument("--port", type=int, default=58003)
     ap.add_argument("--quantisation_mode", choices=["int4", "int8"], default=None)
+    ap.add_argument("--utterances_per_gpu", type=int, default=1, help="requests decoded together on one GPU (not in the reference)")
     a = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO)
+    import torch
+
     from .fast_inference import TTS
 
-    config = ServingConfig(**vars(a))
-    tts = TTS(config.huggingface_repo_id, seed=config.seed, quantisation_mode=config.quantisation_mode)
-    make_server(tts, config).serve_forever()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:  # one process per GPU (torch.distributed.run); RCCL carries the single gather of finished audio
+        import torch.distributed as dist
+
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    config = ServingConfig(huggingface_repo_id=a.huggingface_repo_id, temperature=a.temperature, seed=a.seed, port=a.port,
+                           quantisation_mode=a.quantisation_mode)
+    tts = TTS(config.huggingface_repo_id, seed=config.seed, quantisation_mode=config.quantisation_mode,
+              max_utterances=a.utterances_per_gpu)
+    if world > 1 or a.utterances_per_gpu > 1:
+        disp = BatchingDispatcher(tts, utterances_per_gpu=a.utterances_per_gpu)
+        if disp.rank != 0:
+            disp.serve_worker()
+            return
+        make_server(tts, config, dispatcher=disp.start()).serve_forever()
+    else:
+        make_server(tts, config).serve_forever()
 
 
 if __name__ == "__main__":

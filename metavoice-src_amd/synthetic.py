@@ -135,7 +135,8 @@ def prompt_tokens(n: int = 128, seed: int = 0, text_offset: int = 2049, n_text: 
 
 
 def write_model_dir(path: str, *, stage1: Optional[dict] = None, stage2_args: Optional[dict] = None, seed: int = 0) -> str:
-    """Write `first_stage.pt` / `second_stage.pt` with the reference's checkpoint layout (`fam/llm/finetune.py:300-313`:
+    """Write `first_stage.pt` / `second_stage.pt` / `speaker_encoder.pt` (+ `encodec_24khz.pt`, which the reference fetches from
+    the hub) with the reference's checkpoint layout (`fam/llm/finetune.py:300-313`:
     {"model", "model_args", "config", "meta"}) and synthetic weights + a synthetic 512-rank BPE table, so that the whole
     `TTS` load path (key remap, tokenizer from `meta`, speaker conditioning flags) can be exercised offline."""
     import os
@@ -161,7 +162,30 @@ def write_model_dir(path: str, *, stage1: Optional[dict] = None, stage2_args: Op
         "config": {"causal": False},
         "meta": {"tokenizer": byte_level_tokenizer_info(offset=1025), "speaker_cond": True, "speaker_emb_size": 256},
     }, os.path.join(path, "second_stage.pt"))
+    torch.save({"model_state": speaker_encoder_state_dict(seed=seed + 2)}, os.path.join(path, "speaker_encoder.pt"))
+    torch.save(encodec_state_dict(seed=seed + 3), os.path.join(path, "encodec_24khz.pt"))
     return path
+
+
+def speaker_encoder_state_dict(seed: int = 0, n_mels: int = 40, hidden: int = 256, n_layers: int = 3, emb: int = 256) -> Dict[str, torch.Tensor]:
+    """`speaker_encoder.pt["model_state"]` (`fam/quantiser/audio/speaker_encoder/model.py:33-35`): nn.LSTM(40, 256, 3) +
+    nn.Linear(256, 256) with torch's default uniform(-1/sqrt(H), 1/sqrt(H)) initialisation, fp32."""
+    g = torch.Generator().manual_seed(9000 + seed)
+    b = 1.0 / math.sqrt(hidden)
+
+    def uni(*shape):
+        return (torch.rand(*shape, generator=g) * 2 - 1) * b
+
+    sd: Dict[str, torch.Tensor] = {}
+    for l in range(n_layers):
+        i = n_mels if l == 0 else hidden
+        sd[f"lstm.weight_ih_l{l}"] = uni(4 * hidden, i)
+        sd[f"lstm.weight_hh_l{l}"] = uni(4 * hidden, hidden)
+        sd[f"lstm.bias_ih_l{l}"] = uni(4 * hidden)
+        sd[f"lstm.bias_hh_l{l}"] = uni(4 * hidden)
+    sd["linear.weight"] = uni(emb, hidden)
+    sd["linear.bias"] = uni(emb)
+    return sd
 
 
 def encodec_state_dict(seed: int = 0, *, hidden: int = 128, num_filters: int = 32, ratios=(8, 5, 4, 2), kernel_size: int = 7,

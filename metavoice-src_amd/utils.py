@@ -28,15 +28,12 @@ def normalize_text(text: str) -> str:
 
 
 def check_audio_file(path_or_uri, threshold_s: int = 30):
-    """`fam/llm/utils.py:55-74`: the speaker reference must be at least `threshold_s` long.  Needs an audio reader
-    (librosa in the reference); without one the check is skipped with a note."""
-    try:
-        import librosa  # type: ignore
-    except ImportError:
-        print("check_audio_file: no audio reader available, skipping the minimum-duration check")
-        return
-    audio, sr = librosa.load(path_or_uri)
-    duration_s = librosa.get_duration(y=audio, sr=sr)
+    """`fam/llm/utils.py:55-74`: the speaker reference must be at least `threshold_s` long (the reference measures it with
+    librosa; here with the .wav reader of speaker_encoder/audio.py)."""
+    from .speaker_encoder import audio
+
+    wav = audio.load_audio(str(path_or_uri), sr=audio.sampling_rate)
+    duration_s = len(wav) / float(audio.sampling_rate)
     if duration_s < threshold_s:
         raise Exception(f"The audio file is too short. Please provide an audio file that is at least {threshold_s} seconds long "
                         f"to proceed. (Provided file is {duration_s:.2f}s)")

@@ -111,6 +111,68 @@ def stage1_case(name, cfg_kwargs, seed, T, n_new, with_bf16):
     np.savez_compressed(os.path.join(HERE, f"stage1_{name}.npz"), **out)
 
 
+FULL = dict(n_layer=24, n_head=16, dim=2048, vocab_size=2562, block_size=2048)
+
+
+def _quantise_like_the_reference(model, mode):
+    """Puts `model` (reference `Transformer`, bf16 weights) into the state the reference's `_load_model` reaches for
+    `quantisation_mode` (fast_inference_utils.py:283-308), as far as that is possible on CPU:
+      int8 -- the reference's own `WeightOnlyInt8QuantHandler` (create_quantized_state_dict + convert_for_runtime);
+      int4 -- `aten::_convert_weight_to_int4pack` has no CPU form (SURVEY 8c gotcha 6), so every Linear the reference would
+              replace (`out_features % 8 == 0`, fast_quantize.py:225) gets the weight the int4 kernel multiplies by:
+              `group_dequantize_tensor_from_qparams(group_quantize_tensor_from_qparams(w))`, all reference functions."""
+    if mode == "int8":
+        h = ref_fq.WeightOnlyInt8QuantHandler(model)
+        qsd = h.create_quantized_state_dict()
+        model = h.convert_for_runtime()
+        model.load_state_dict(qsd, assign=True)
+        return model
+    assert mode == "int4"
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Linear) and mod.out_features % 8 == 0 and ref_fq._check_linear_int4_k(mod.in_features, 128, 8):
+            w = mod.weight.data.to(torch.bfloat16)
+            scales, zeros = ref_fq.get_group_qparams(w, 4, 128)
+            q = ref_fq.group_quantize_tensor_from_qparams(w, scales, zeros, 4, 128)
+            mod.weight.data = ref_fq.group_dequantize_tensor_from_qparams(q, scales, zeros, 4, 128).to(torch.bfloat16)
+    return model
+
+
+def stage1_full_case(T=128, n_new=64, seed=0):
+    """BASELINE.json's own configuration: 24 layers x 2048, the bench prompt (T = 128, seed 0), greedy through the reference's
+    `generate()`, logits of every step recorded from the forward calls `generate` itself makes (fp32 compute on the
+    bf16-rounded synthetic weights).  Three weight formats: bf16, int4 (group 128), int8 (per channel)."""
+    out = dict(cfg=json.dumps(FULL), seed=seed, T=T, n_new=n_new)
+    prompt = synthetic.prompt_tokens(T, seed=seed)
+    spk = synthetic.speaker_embedding(seed)
+    for mode in ("bf16", "int4", "int8"):
+        import time
+        t0 = time.time()
+        model, _ = build_ref_stage1(FULL, seed, torch.bfloat16)
+        if mode != "bf16":
+            model = _quantise_like_the_reference(model, mode)
+        model = model.to(torch.float32).eval()
+        model.config.dtype = torch.float32
+        model.setup_spk_cond_mask()
+        model.setup_caches(max_batch_size=2, max_seq_length=FULL["block_size"])
+        cap = []
+        hook = model.register_forward_hook(lambda m, i, o: cap.append(o[:, -1].float().clone()))
+        torch.manual_seed(0)
+        seq = ref_fiu.generate(model, prompt, spk, max_new_tokens=n_new, temperature=torch.tensor(1.0), top_k=1, top_p=None,
+                               guidance_scale=torch.tensor(3.0), end_of_audio_token=9999).tolist()
+        hook.remove()
+        logits = torch.stack(cap)  # (n_new, 2, V): entry i = logits at input position T - 1 + i
+        assert logits.shape[0] == n_new and len(seq) == T + n_new
+        mix = 3.0 * logits[:, 0] + (1 - 3.0) * logits[:, 1]
+        assert mix.argmax(-1).tolist() == seq[T:]
+        top2 = mix.topk(2, dim=-1).values
+        print(f"[full24 {mode}] {time.time() - t0:.0f} s; raw logit std {float(logits.std()):.3f}, mix std {float(mix.std()):.3f}, "
+              f"top-2 margin min {float((top2[:, 0] - top2[:, 1]).min()):.4f} median {float((top2[:, 0] - top2[:, 1]).median()):.3f}")
+        out[f"seq_{mode}"] = np.array(seq, dtype=np.int32)
+        out[f"logits_{mode}"] = logits.numpy() if mode == "bf16" else logits.numpy().astype(np.float16)
+        del model
+    np.savez_compressed(os.path.join(HERE, "stage1_full24.npz"), **out)
+
+
 def slow_vs_fast_selftest(cfg_kwargs, seed):
     """the nanoGPT-style `GPT` and the gpt-fast `Transformer` are two independent reference
     implementations of stage 1; they must agree on the same checkpoint."""
@@ -209,6 +271,87 @@ def adapters_case():
     print(f"[adapters] {len(cases)} adapter cases + {len(norm)} normalize_text cases pinned")
 
 
+def speaker_encoder_case():
+    """The reference's `SpeakerEncoder` class itself (librosa stubbed: only `embed_utterance_from_file` / the mel front end need it)
+    on this repo's synthetic `speaker_encoder.pt`: `forward` on random mel partials + `compute_partial_slices`."""
+    import tempfile
+
+    from fam.quantiser.audio.speaker_encoder.model import SpeakerEncoder as RefSpeakerEncoder
+    from oracle import speaker_encoder as o_spk
+
+    sd = synthetic.speaker_encoder_state_dict(seed=4)
+    with tempfile.TemporaryDirectory() as d:
+        torch.save({"model_state": sd}, os.path.join(d, "speaker_encoder.pt"))
+        ref = RefSpeakerEncoder(weights_fpath=os.path.join(d, "speaker_encoder.pt"), device="cpu", eval=True, verbose=False)
+    g = torch.Generator().manual_seed(12)
+    mels = torch.rand(5, 160, 40, generator=g) * 3.0  # mel power spectra are non-negative
+    emb = ref(mels)
+    o = o_spk.forward(sd, mels)
+    slices = {}
+    for n in (1, 15999, 25600, 48000, 51234, 160000):
+        w, m = RefSpeakerEncoder.compute_partial_slices(n, rate=1.3, min_coverage=0.75)
+        slices[str(n)] = [[int(s.start), int(s.stop)] for s in m]
+    print(f"[speaker encoder] oracle vs reference forward max|d|={float((o - emb).abs().max()):.3e}; "
+          f"partial counts {[len(v) for v in slices.values()]}")
+    np.savez_compressed(os.path.join(HERE, "speaker_encoder.npz"), seed=4, mels=mels.numpy(), emb=emb.numpy(), slices=json.dumps(slices))
+
+
+def packing_case():
+    """Stage-2 input packing: the reference's own `Model.non_causal_sample` (fam/llm/inference.py:248-338),
+    executed with the modules it imports but does not need for packing (audiocraft, tyro, df, librosa, tiktoken, posthog) stubbed,
+    on an instance whose model / decoder are recorders: what reaches `self.model.generate` is the packed (b, 2, ctx) grid."""
+    import importlib.machinery
+
+    class _Any(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return type(name, (), {"__init__": lambda self, *a, **k: None, "get_mbd_24khz": staticmethod(lambda *a, **k: None)})
+
+    for m in ("audiocraft", "audiocraft.data", "audiocraft.data.audio", "audiocraft.models", "tyro", "df", "df.enhance", "df.io", "julius",
+              "posthog", "pydub"):
+        if m not in sys.modules:
+            mod = _Any(m)
+            mod.__spec__ = importlib.machinery.ModuleSpec(m, None)
+            mod.__path__ = []
+            sys.modules[m] = mod
+    from fam.llm import inference as ref_inf
+
+    class Tok:
+        def encode(self, text):
+            return [1025 + (ord(ch) % 512) for ch in text] + [1537]
+
+    class Rec:
+        def __init__(self):
+            self.seen = []
+
+        def generate(self, in_x, *a, **k):
+            self.seen.append(in_x.clone())
+            return torch.zeros(in_x.shape[0], 6, in_x.shape[2], dtype=torch.long)
+
+    class Dec:
+        def decode(self, tokens, causal):
+            return "x"
+
+    from contextlib import nullcontext
+    cases = []
+    for ctx, texts, lens in [(64, ["hello there"], [20]), (32, ["a much longer piece of text, truncated"], [40]), (48, ["ab", "cdefg"], [7, 12])]:
+        m = ref_inf.Model.__new__(ref_inf.Model)
+        m.tokenizer, m.model, m.decoder = Tok(), Rec(), Dec()
+        m.config = ref_inf.InferenceConfig(ckpt_path="", output_dir="", num_samples=1, device="cpu")
+        m._encodec_codes_pad_token, m._num_encodec_codebooks, m._encodec_ctx_window = 1024, 8, ctx
+        m.speaker_cond, m._ctx = True, nullcontext()
+        g = torch.Generator().manual_seed(ctx)
+        enc = [torch.randint(0, 1024, (1, 2, n), generator=g) for n in lens]
+        m.non_causal_sample(texts=texts, encodec_tokens=enc, batch_size=len(texts), top_k=200, temperature=1.0,
+                            speaker_embs=torch.zeros(len(texts), 1, 256))
+        cases.append(dict(ctx=ctx, texts=texts, text_ids=[Tok().encode(t) for t in texts], codebooks=[e[0].tolist() for e in enc],
+                          packed=m.model.seen[0].tolist()))
+    with open(os.path.join(HERE, "packing.json"), "w") as f:
+        json.dump(cases, f)
+    print(f"[packing] {len(cases)} second-stage packing cases pinned from fam/llm/inference.py")
+
+
 def stage2_case(name, **kw):
     args = synthetic.stage2_model_args(block_size=32, n_layer=2, n_head=2, n_embd=128, **kw)
     sd = synthetic.stage2_state_dict(args, speaker_emb_dim=256, seed=5)
@@ -234,6 +377,13 @@ def stage2_case(name, **kw):
 
 
 if __name__ == "__main__":
+    if "--extra" in sys.argv:  # cases added in round 2 (the round-1 files are reproduced bit for bit by the default run)
+        speaker_encoder_case()
+        packing_case()
+        sys.exit(0)
+    if "--full24" in sys.argv:  # ~5 min and ~12 GB of RAM: minted separately from the small cases
+        stage1_full_case()
+        sys.exit(0)
     small = dict(n_layer=2, n_head=2, dim=256, vocab_size=2562, block_size=64)
     wide = dict(n_layer=2, n_head=16, dim=2048, vocab_size=2562, block_size=2048)
     slow_vs_fast_selftest(small, 0)
@@ -244,4 +394,6 @@ if __name__ == "__main__":
     adapters_case()
     stage2_case("rms_swiglu")
     stage2_case("ln_gelu_bias", bias=True, norm_type="layernorm", nonlinearity_type="gelu")
+    speaker_encoder_case()
+    packing_case()
     print("golden vectors written to", HERE)

@@ -1,0 +1,106 @@
+"""BASELINE.json's own configuration against the REFERENCE: MetaVoice-1B shape (24 layers x 2048, 1.24 B synthetic parameters),
+the bench prompt (T = 128, seed 0), 64 greedy steps.
+
+`tests/golden/stage1_full24.npz` was minted by running the reference's `generate()` (fam/llm/fast_inference_utils.py:182-228)
+on CPU in fp32 on the bf16-rounded weights -- for bf16 weights, for the reference's int4 group-128 weights and for its int8
+per-channel weights (`tests/golden/make_golden.py --full24`) -- recording the logits of every forward call it makes.
+
+Checks per weight format (SURVEY.md 8c "parity criteria"):
+  (i)   teacher-forced along the reference's stream through the DECODE kernels (persistent kernel where supported): raw
+        logits of both CFG rows within the bf16 noise floor measured on the reference itself (|bf16 - fp32| up to
+        0.1 sigma on raw logits at 24 layers), and the argmax of the CFG mix equal to the reference's token at every step
+        whose reference top-2 margin exceeds twice the measured mix error of that step;
+  (ii)  free-running greedy stream (MFMA prefill + decode): identical to the reference's, or forked at a step whose reference
+        margin is inside that noise; the length of agreement is printed (the headline "bit-exact" number).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_pkg
+
+pytestmark = pytest.mark.gpu
+
+mv = load_pkg()
+synthetic = load_pkg("synthetic")
+fiu = load_pkg("fast_inference_utils")
+
+FULL = dict(n_layer=24, n_head=16, dim=2048, vocab_size=2562, block_size=2048)
+RAW_TOL_SIGMA = 0.15   # of the raw-logit std: two evaluations (bf16 engine, fp32 reference) through 24 layers
+MIX_TOL_SIGMA = 0.15   # of the CFG-mixed logit std (the 3*cond - 2*uncond mix amplifies the raw error ~3.5x, and the std ~3.2x)
+
+
+@pytest.fixture(scope="module")
+def golden():
+    g = np.load(os.path.join(GOLDEN, "stage1_full24.npz"))
+    assert json.loads(str(g["cfg"])) == FULL
+    return g
+
+
+@pytest.fixture(scope="module")
+def weights():
+    # the CPU generator: the same values the reference saw when the golden was minted
+    return fiu.remap_checkpoint_keys(synthetic.stage1_state_dict(seed=0, **FULL))
+
+
+def mix(lg):  # (n, 2, V) -> (n, V), fp32 (the reference's CFG formula, fast_inference_utils.py:113-117)
+    return 3.0 * lg[:, 0] + (1.0 - 3.0) * lg[:, 1]
+
+
+@pytest.mark.parametrize("mode", ["bf16", "int4", "int8"])
+def test_full_size_engine_follows_the_reference(golden, weights, mode):
+    T, n_new = int(golden["T"]), int(golden["n_new"])
+    gseq = golden[f"seq_{mode}"].tolist()
+    glog = torch.from_numpy(golden[f"logits_{mode}"].astype(np.float32))  # (n_new, 2, V): logits at input positions T-1 ..
+    prompt, spk = synthetic.prompt_tokens(T, seed=0), synthetic.speaker_embedding(0)
+    assert gseq[:T] == prompt.tolist()
+    engine = mv.Stage1Engine(mv.ModelArgs(**FULL), max_utterances=1, quantisation_mode=None if mode == "bf16" else mode)
+    engine.load_state_dict(weights)
+    engine.finalize()
+    engine.capture_logits(True)
+    sp = mv.SamplingParams(top_k=1, guidance_scale=3.0, seed=1)
+
+    # (i) teacher-forced through the decode kernels: the reference's stream is the "prompt"
+    engine.begin([gseq[:T + n_new - 1]], spk, sp, max_new_tokens=1, end_of_audio_token=9999, prefill_mode=0)
+    engine.run()
+    got = engine.captured_logits(T - 1, n_new)
+    raw_sigma, mix_sigma = float(glog.std()), float(mix(glog).std())
+    d_raw = (got - glog).abs().amax(dim=(1, 2))
+    gm, em = mix(glog), mix(got)
+    d_mix = (em - gm).abs().amax(dim=1)
+    top2 = gm.topk(2, dim=-1).values
+    margin = top2[:, 0] - top2[:, 1]
+    decided = margin > 2 * d_mix
+    same = em.argmax(-1) == torch.tensor(gseq[T:])
+    print(f"[full24 {mode}] teacher-forced {n_new} steps: max|draw| {float(d_raw.max()):.4f} ({float(d_raw.max()) / raw_sigma:.3f} sigma), "
+          f"max|dmix| {float(d_mix.max()):.4f} ({float(d_mix.max()) / mix_sigma:.3f} sigma); argmax equal at {int(same.sum())}/{n_new} steps, "
+          f"{int(decided.sum())} steps decided (margin > 2 dmix), reference margin min {float(margin.min()):.4f}")
+    assert float(d_raw.max()) <= RAW_TOL_SIGMA * raw_sigma
+    assert float(d_mix.max()) <= MIX_TOL_SIGMA * mix_sigma
+    assert bool(same[decided].all()), "argmax differs from the reference at a step the reference decides clearly"
+    assert int(decided.sum()) >= n_new // 2, "the measured error is too large to decide even half of the steps"
+
+    # (ii) free-running greedy: MFMA prefill + decode steps, the engine's own sampler
+    engine.begin([prompt], spk, sp, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
+    engine.run()
+    seq = engine.tokens(0)
+    assert len(seq) == T + n_new and seq[:T] == prompt.tolist()
+    fork = next((i for i, (a, b) in enumerate(zip(seq, gseq)) if a != b), None)
+    agree = n_new if fork is None else fork - T
+    first = engine.captured_logits(T - 1, 1)
+    d_pre = float((first - glog[:1]).abs().max())
+    print(f"[full24 {mode}] free-running greedy stream identical to the reference's for {agree}/{n_new} tokens; "
+          f"MFMA-prefill first-token max|draw| {d_pre:.4f}")
+    assert d_pre <= RAW_TOL_SIGMA * raw_sigma
+    if fork is not None:
+        # a fork is legitimate only where the reference's own margin is inside the engine-vs-reference noise
+        assert float(margin[fork - T]) <= 2 * MIX_TOL_SIGMA * mix_sigma, \
+            f"stream forks at generated token {fork - T} where the reference's top-2 margin is {float(margin[fork - T]):.4f}"
+        if fork - T < n_new and bool(decided[fork - T]):
+            # teacher-forced, this step agreed with the reference: then the free-running fork comes from the prefill path
+            # (different summation order), which must still be inside the same bound
+            assert float(margin[fork - T]) <= 4 * float(d_mix.max())
+    engine.close()

@@ -97,3 +97,35 @@ def test_bench_byte_accounting():
     assert bench.step_bytes(cfg, -1) == 2_476_945_408
     assert bench.step_bytes(cfg, 99) - bench.step_bytes(cfg, 98) == 393_216
     assert bench.TOKENS_PER_AUDIO_SECOND == 150 and (bench.T_PROMPT, bench.N_NEW) == (128, 1920)
+
+
+def test_second_stage_packing_matches_the_reference():
+    """a15: `pack_second_stage_input` against what the reference's own `Model.non_causal_sample` hands to `model.generate`
+    (tests/golden/packing.json, minted by executing fam/llm/inference.py:264-306 with audiocraft stubbed)."""
+    cases = json.load(open(os.path.join(GOLDEN, "packing.json")))
+    assert len(cases) >= 3
+    truncated = 0
+    for c in cases:
+        for ids, cbs, want in zip(c["text_ids"], c["codebooks"], c["packed"]):
+            got = inference.pack_second_stage_input(ids, cbs, c["ctx"])
+            assert got == want
+            truncated += int(len(ids) + len(cbs[0]) + 1 > c["ctx"])
+    assert truncated >= 1  # the truncating branch (:299-300) is covered
+
+
+def test_long_form_chunker():
+    longform = load_pkg("longform")
+    text = ("This is the first sentence. Here is a second one, with a clause; and another! Is this the third? " * 40).strip()
+    chunks = longform.split_text(text)
+    assert all(0 < len(c) <= 220 for c in chunks)
+    assert " ".join(chunks) == " ".join(text.split())  # nothing dropped, nothing reordered
+    assert all(c[-1] in ".!?" for c in chunks)           # sentences are kept whole when they fit
+    assert len(chunks) >= len(text) // 220
+    # a sentence longer than the limit falls back to clause / word boundaries, a giant "word" to hard cuts
+    monster = "word " * 100 + "x" * 500 + ", tail."
+    parts = longform.split_text(monster, max_chars=120)
+    assert all(0 < len(p) <= 120 for p in parts) and "".join(parts).replace(" ", "") == monster.replace(" ", "")
+    assert longform.split_text("   ") == [] and longform.split_text("Short.") == ["Short."]
+    ten_k = ("The quick brown fox jumps over the lazy dog near the quiet river bank. " * 150)[:10000]
+    n = len(longform.split_text(ten_k))
+    assert 46 <= n <= 60  # SURVEY 8d config 5: ~46-50 chunks for 10k characters

@@ -82,3 +82,104 @@ def test_multipart_upload(server):
     call = tts.calls[-1]
     assert call["text"] == "from upload" and call["guidance"] == 2.5 and call["top_p"] == 0.9
     assert call["ref_bytes"] == b"\x00\x01binary\xff\xfe"  # the uploaded bytes reached synthesise as a temp file
+
+
+class FakeBatchTTS:
+    """Stands in for `TTS.synthesise_batch`: the 'waveform' of a text is a RIFF-prefixed blob naming the rank that made it."""
+
+    def __init__(self, rank=0, max_utterances=2):
+        self.rank, self.max_utterances, self.batches = rank, max_utterances, []
+
+    def synthesise_batch(self, texts, spk_refs, top_p=0.95, guidance_scale=3.0, temperature=1.0):
+        if any("boom" in t for t in texts):
+            raise RuntimeError("synthetic failure")
+        self.batches.append(list(texts))
+        return [b"RIFF" + f"|{t}|{s}|{top_p}|{guidance_scale}|rank{self.rank}".encode() * (1 + len(t) % 3) for t, s in zip(texts, spk_refs)]
+
+
+def test_batching_dispatcher_groups_concurrent_requests(tmp_path):
+    tts = FakeBatchTTS()
+    disp = serving.BatchingDispatcher(tts, utterances_per_gpu=4, max_wait_ms=200.0).start()
+    srv = serving.make_server(tts, serving.ServingConfig(port=0), host="127.0.0.1", dispatcher=disp)
+    t = threading.Thread(target=srv.serve_forever, daemon=True)
+    t.start()
+    base = f"http://127.0.0.1:{srv.server_address[1]}"
+    results = {}
+
+    def call(i, extra=None):
+        form = {"text": f"request {i}", "speaker_ref_path": f"/refs/{i}.wav"}
+        form.update(extra or {})
+        results[i] = post(base + "/tts", urllib.parse.urlencode(form).encode())
+
+    threads = [threading.Thread(target=call, args=(i,)) for i in range(4)]
+    threads.append(threading.Thread(target=call, args=(9, {"guidance": "1.5"})))  # different controls: its own batch
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for i in (0, 1, 2, 3, 9):
+        code, ctype, body = results[i]
+        assert code == 200 and ctype == "audio/wav" and body.startswith(b"RIFF") and f"|request {i}|/refs/{i}.wav|".encode() in body
+    assert b"|1.5|" in results[9][2]
+    assert sum(disp.batches) == 5 and max(disp.batches) >= 2  # concurrent requests really were decoded together
+    assert all(len({"guid" for _ in b}) == 1 for b in tts.batches)
+    code, _, body = post(base + "/tts", urllib.parse.urlencode({"text": "boom", "speaker_ref_path": "x"}).encode())
+    assert code == 500 and body.decode() == serving.ERROR_TEXT
+    srv.shutdown()
+    disp.stop()
+
+
+def _dispatch_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    srv_mod = load_pkg("serving")
+    tts = FakeBatchTTS(rank=rank)
+    disp = srv_mod.BatchingDispatcher(tts, utterances_per_gpu=2, max_wait_ms=300.0)
+    if rank != 0:
+        disp.serve_worker()
+        q.put((rank, tts.batches))
+    else:
+        disp.start()
+        out = {}
+        ths = [threading.Thread(target=lambda i=i: out.__setitem__(i, disp.submit(f"utt {i}", f"/r/{i}.wav", 0.95, 3.0))) for i in range(4)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        disp.stop()
+        q.put((rank, tts.batches, {i: v.decode() for i, v in out.items()}, disp.batches))
+    dist.destroy_process_group()
+
+
+def test_dispatcher_shards_a_batch_over_two_ranks():
+    """world_size 2 over gloo: rank 0 queues four requests, both ranks decode their round-robin shard, one gather brings the
+    bytes back, results reach the right requesters."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dispatch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0 = next(g for g in got if g[0] == 0)
+    r1 = next(g for g in got if g[0] == 1)
+    out = r0[2]
+    assert set(out) == {0, 1, 2, 3}
+    for i in range(4):
+        assert out[i].startswith("RIFF") and f"|utt {i}|/r/{i}.wav|" in out[i]
+    by_rank = {i: ("rank0" in out[i], "rank1" in out[i]) for i in out}
+    assert sum(a for a, _ in by_rank.values()) + sum(b for _, b in by_rank.values()) == 4
+    assert any(b for _, b in by_rank.values()), "rank 1 never produced a result"
+    assert sum(len(b) for b in r0[1]) + sum(len(b) for b in r1[1]) == 4

@@ -1,0 +1,77 @@
+"""Speaker encoder, host side (no GPU): the oracle network against the golden minted from the reference's `SpeakerEncoder`
+class, the product's partial-utterance slicing against the reference's, and the restated librosa front end (parity unpinned:
+librosa is not in this image) against independent closed forms."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN, load_pkg
+from oracle import speaker_encoder as o_spk
+
+synthetic = load_pkg("synthetic")
+audio = load_pkg("speaker_encoder.audio")
+
+
+def test_oracle_forward_matches_the_reference_class():
+    g = np.load(os.path.join(GOLDEN, "speaker_encoder.npz"))
+    sd = synthetic.speaker_encoder_state_dict(seed=int(g["seed"]))
+    emb = o_spk.forward(sd, torch.from_numpy(g["mels"]))
+    assert emb.shape == (5, 256)
+    assert float((emb - torch.from_numpy(g["emb"])).abs().max()) < 1e-6
+    assert torch.allclose(emb.norm(dim=1), torch.ones(5), atol=1e-6)
+
+
+def test_partial_slices_match_the_reference():
+    import importlib
+    import re
+
+    # the slicing is a staticmethod with no device work; read it off the class without constructing an engine
+    model = importlib.import_module("metavoice-src_amd.speaker_encoder.model")
+    g = np.load(os.path.join(GOLDEN, "speaker_encoder.npz"))
+    for n, want in json.loads(str(g["slices"])).items():
+        wav_slices, mel_slices = model.SpeakerEncoder.compute_partial_slices(int(n), rate=1.3, min_coverage=0.75)
+        assert [[s.start, s.stop] for s in mel_slices] == want
+        assert all(w.start == m.start * 160 and w.stop == m.stop * 160 for w, m in zip(wav_slices, mel_slices))
+
+
+def test_mel_front_end_closed_forms():
+    sr, n_fft = 16000, 400
+    fb = audio.mel_filterbank(sr, n_fft, 40)
+    assert fb.shape == (40, 201) and float(fb.min()) >= 0
+    # Slaney area normalisation: every triangle integrates to ~1 over Hz (bin spacing sr / n_fft)
+    area = fb.sum(axis=1) * (sr / n_fft)
+    assert np.allclose(area, 1.0, atol=0.12)
+    # centre frequencies are increasing and the scale is linear below 1 kHz (200/3 Hz per mel)
+    peaks = fb.argmax(axis=1)
+    assert np.all(np.diff(peaks) > 0)
+    assert abs(float(audio._hz_to_mel(1000.0)) - 15.0) < 1e-9 and abs(float(audio._mel_to_hz(15.0)) - 1000.0) < 1e-6
+    # a pure tone lands in the band whose triangle covers it, frames = 1 + len // hop (centred STFT)
+    t = np.arange(sr, dtype=np.float32) / sr
+    mel = audio.wav_to_mel_spectrogram(np.sin(2 * np.pi * 1000.0 * t).astype(np.float32))
+    assert mel.shape == (101, 40) and mel.dtype == np.float32
+    band = int(mel[50].argmax())
+    assert fb[band, int(round(1000.0 / (sr / n_fft)))] > 0
+    # Parseval on one frame: total power through an all-pass bank equals the windowed frame energy (checks window + rfft usage)
+    x = np.random.default_rng(0).standard_normal(n_fft).astype(np.float32)
+    w = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)).astype(np.float32)
+    spec = np.abs(np.fft.rfft(x * w)) ** 2
+    assert np.isclose(spec[0] + 2 * spec[1:-1].sum() + spec[-1], n_fft * np.sum((x * w) ** 2), rtol=1e-4)
+
+
+def test_trim_and_wav_reader(tmp_path):
+    from scipy.io import wavfile
+
+    sr = 22050
+    t = np.arange(sr) / sr
+    tone = (0.5 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    y = np.concatenate([np.zeros(sr, np.float32), tone, np.zeros(sr // 2, np.float32)])
+    trimmed = audio.trim_silence(y, top_db=20)
+    assert abs(len(trimmed) - sr) <= 2 * 2048  # the tone survives, the silence goes (frame granularity)
+    path = str(tmp_path / "a.wav")
+    wavfile.write(path, sr, (y * 32767).astype(np.int16))
+    x = audio.load_audio(path, sr=16000)
+    assert abs(len(x) - int(len(y) * 16000 / sr)) <= 2 and x.dtype == np.float32
+    assert abs(float(np.abs(x).max()) - 0.5) < 0.02
+    assert audio.trim_silence(np.zeros(5000, np.float32)).size == 0
