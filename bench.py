@@ -14,6 +14,13 @@ before the timed region; the timed region is bracketed by barrier + torch.cuda.s
 over ranks is reported.  Utterances are independent, so N GPUs run N utterances with no data-path collective; the
 finished token streams are all-gathered over RCCL once per step (batched-serving path), inside the timed region.
 
+Other BASELINE.json configurations (not the default line; each prints the same JSON shape with its own `config.workload`):
+  --quantisation_mode int4|int8   configs[3]: the first stage decodes from weight-only quantised weights (reference numerics)
+  --utterances-per-gpu U          configs[2]: U utterances decoded TOGETHER per GPU (ragged prompts 96..160 tokens), the finished
+                                  fp32 waveforms all-gathered over RCCL (with --gpus 8 --utterances-per-gpu 4: batch 32)
+  --long-form [--long-form-chars C]  configs[4]: a C-character text (default 10 000) split at sentence boundaries into <= 220-char
+                                  chunks, each an independent generation on the same captured decode graph; a "step" is the whole text
+
 Extra objects on the JSON line:
   roofline      -- dominant kernel: the persistent decode-step kernel (one launch per token) where supported, else the
                    largest per-layer kernel of the decode step (fused RMSNorm + w1|w3 + SiLU-gate GEMV, 46 MB of weights per
@@ -40,13 +47,29 @@ TOKENS_PER_AUDIO_SECOND = 150.0
 T_PROMPT, N_NEW = 128, 1920
 
 
-def step_bytes(cfg, pos):
-    """algorithmic bytes of one decode step at input position `pos` (bf16, one utterance = 2 CFG rows).
-    The speaker projection is hoisted out of the step (it is step-invariant), so its 1 MB is not counted."""
-    per_layer = (3 * cfg.dim * cfg.dim + cfg.dim * cfg.dim + 3 * cfg.dim * cfg.intermediate_size + 2 * cfg.dim)
-    weights = 2 * (cfg.n_layer * per_layer + cfg.vocab_size * cfg.dim + cfg.dim)
-    kv = 2 * 2 * cfg.n_head * 128 * 2 * cfg.n_layer * (pos + 1)
-    return weights + kv
+def weight_bytes(cfg, fmt=None):
+    """bytes of weights one decode step must stream.  bf16: 2 B per parameter; int4 (group 128): half a byte per
+    weight + 4 B of (scale, zero) per 128 weights, LM head and norms stay bf16 (fast_quantize.py:225); int8: 1 B per weight + a
+    bf16 scale per output row, LM head included.  The speaker projection is hoisted out of the step (step-invariant)."""
+    lin = 3 * cfg.dim * cfg.dim + cfg.dim * cfg.dim + 3 * cfg.dim * cfg.intermediate_size   # weights per layer
+    rows = 3 * cfg.dim + cfg.dim + 2 * cfg.intermediate_size + cfg.dim                      # output rows per layer
+    norms = 2 * cfg.dim * 2
+    head = cfg.vocab_size * cfg.dim
+    if fmt == "int4":
+        return cfg.n_layer * (lin // 2 + lin // 128 * 4 + norms) + head * 2 + cfg.dim * 2
+    if fmt == "int8":
+        return cfg.n_layer * (lin + rows * 2 + norms) + head + cfg.vocab_size * 2 + cfg.dim * 2
+    return 2 * (cfg.n_layer * (lin + 2 * cfg.dim) + head + cfg.dim)
+
+
+def kv_bytes(cfg, pos):
+    """K and V rows [0, pos] of both CFG rows of ONE utterance, all layers (bf16)."""
+    return 2 * 2 * cfg.n_head * 128 * 2 * cfg.n_layer * (pos + 1)
+
+
+def step_bytes(cfg, pos, fmt=None):
+    """Algorithmic bytes of one decode step of one utterance at input position `pos`."""
+    return weight_bytes(cfg, fmt) + kv_bytes(cfg, pos)
 
 
 def cpu_baseline(mv, cfgk, sample_steps=8):
@@ -83,7 +106,14 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quantisation_mode", choices=["int4", "int8"], default=None)
+    ap.add_argument("--utterances-per-gpu", type=int, default=1)
+    ap.add_argument("--long-form", action="store_true")
+    ap.add_argument("--long-form-chars", type=int, default=10000)
     a = ap.parse_args()
+    U = a.utterances_per_gpu
+    if a.long_form and U != 1:
+        ap.error("--long-form runs one chunk at a time")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -102,14 +132,37 @@ def main():
     # ---- resident inputs: weights drawn on the GPU, copied into the engine's arena, then dropped -------------------
     fiu = importlib.import_module("metavoice-src_amd.fast_inference_utils")
     sd = fiu.remap_checkpoint_keys(mv.synthetic.stage1_state_dict(seed=rank, device="cuda", **cfgk))
-    engine = mv.Stage1Engine(args, max_utterances=1)
+    engine = mv.Stage1Engine(args, max_utterances=U, quantisation_mode=a.quantisation_mode)
     engine.load_state_dict(sd)
     del sd
     torch.cuda.empty_cache()
     engine.finalize()
-    prompt = mv.synthetic.prompt_tokens(T_PROMPT, seed=rank)
     spk = mv.synthetic.speaker_embedding(rank)
     sp = mv.SamplingParams(guidance_scale=3.0, temperature=1.0, top_p=0.95, seed=1337 + rank)  # TTS.synthesise defaults
+    # ---- the work list of one step: (prompt tokens, tokens to generate) per utterance ----------------------------------
+    if a.long_form:
+        # configs[4]: C characters -> sentence chunks of <= 220 characters (longform.split_text), tokenised with the synthetic
+        # 512-rank BPE table (the real ranks live in the unreachable checkpoint); every chunk speaks 7.5 tokens per character,
+        # the rate of configs[1] (256 characters -> 1920 tokens), end-of-audio unreachable
+        longform = importlib.import_module("metavoice-src_amd.longform")
+        tok_mod = importlib.import_module("metavoice-src_amd.tokenise")
+        tokenizer = tok_mod.TrainedBPETokeniser(**tok_mod.byte_level_tokenizer_info(offset=2049))
+        sentence = "The quick brown fox jumps over the lazy dog near the quiet river bank, while the old mill turns slowly. "
+        text = (sentence * (a.long_form_chars // len(sentence) + 1))[:a.long_form_chars]
+        chunks = longform.split_text(text)
+        work = []
+        for c in chunks:
+            ids = torch.tensor(tokenizer.encode(c), dtype=torch.int32)
+            work.append([(ids, min(args.block_size - len(ids), int(round(7.5 * len(c)))))])
+    elif U > 1:
+        # configs[2]: ragged prompts, lengths uniform in [96, 160] (seed 0 stream, offset by the rank), 12.8 s each unless the
+        # context window ends first (160 + 1920 > 2048)
+        g = torch.Generator().manual_seed(0)
+        lens = torch.randint(96, 161, (U * max(world, 1),), generator=g).tolist()[rank * U:(rank + 1) * U]
+        work = [[(mv.synthetic.prompt_tokens(t, seed=rank * 100 + u), min(N_NEW, args.block_size - t)) for u, t in enumerate(lens)]]
+    else:
+        work = [[(mv.synthetic.prompt_tokens(T_PROMPT, seed=rank), N_NEW)]]
+    prompt = work[0][0][0]
     dispatch = importlib.import_module("metavoice-src_amd.batch_dispatch")
 
     # second stage (fam/llm/inference.py Model + model.py GPT, non-causal): placeholder sizes, block_size 2048 so that the
@@ -121,36 +174,60 @@ def main():
     stage2.load_state_dict(mv.synthetic.stage2_state_dict(s2_args, speaker_emb_dim=256, seed=100 + rank))
     first_adapter = adapters.FlattenedInterleavedEncodec2Codebook(end_of_audio_token=1024)
     second_adapter = adapters.TiltedEncodec(end_of_audio_token=1024)
-    text2 = [int(t) - 1024 for t in prompt.tolist()]  # the same text in the second stage's id space (offset 1025)
+    stage1_only = a.quantisation_mode is not None  # configs[3] is "first-stage decode" only
     # codec stage: EnCodec's own decoder (8 codebooks -> 24 kHz waveform) in HIP; the reference's multi-band diffusion
     # refinement on top of it is not built yet and is NOT in this number
     codec_mod = importlib.import_module("metavoice-src_amd.codec")
     vocoder = codec_mod.EncodecDecoder.from_state_dict(mv.synthetic.encodec_state_dict(seed=rank))
     stage_ms = {"stage1_prefill+decode": 0.0, "stage1_decode_gpu": 0.0, "adapters+stage2": 0.0, "encodec_decode": 0.0}
 
+    def fold_onto_codebooks(toks, n_prompt):
+        """Random weights do not produce the cb0 / cb1 alternation a trained first stage does, and the adapter truncates both
+        codebooks to the shorter one (`flattened_encodec.py:25-31`: 654 of 960 frames survived in round 1).  For the stages
+        AFTER the first one the synthetic stream is folded onto strictly alternating codebooks so that they are timed on the
+        frame count the metric counts; the first stage's own arithmetic and timing are untouched."""
+        gen = toks[n_prompt:]
+        return toks[:n_prompt] + [(t % 1024) + 1024 * (i & 1) for i, t in enumerate(gen)]
+
     def one_step():
-        t0 = time.perf_counter()
-        engine.begin([prompt], spk, sp, max_new_tokens=N_NEW, end_of_audio_token=9999, prefill_mode=1)
-        engine.run(poll_every=1 << 20)
-        toks = engine.tokens(0)
-        t1 = time.perf_counter()
-        _, cbs = first_adapter.decode([toks])
-        grid = inference.pack_second_stage_input(text2, cbs, s2_args["block_size"])
-        in_x = torch.tensor([grid], dtype=torch.long)
-        y = stage2.generate(in_x, None, temperature=1.0, top_k=200, speaker_embs=spk, batch_size=1, seed=sp.seed)
-        _, audio_ids = second_adapter.decode(torch.cat([in_x, y], dim=1)[0].tolist())
-        t2 = time.perf_counter()
-        wav = vocoder.decode(torch.tensor(audio_ids, dtype=torch.long).unsqueeze(0))
-        t3 = time.perf_counter()
-        stage_ms["encodec_decode"] += (t3 - t2) * 1e3
-        stage_ms["stage1_prefill+decode"] += (t1 - t0) * 1e3
-        stage_ms["stage1_decode_gpu"] += engine.last_run_ms
-        stage_ms["adapters+stage2"] += (t2 - t1) * 1e3
-        if world > 1:  # batched-serving path: every rank ends up with every utterance's (8, f) token grid, in input order
-            mine = torch.tensor(audio_ids, dtype=torch.int32, device="cuda").flatten()
-            everyone = dispatch.gather_variable([mine], world, device=torch.device("cuda", local_rank))
-            assert len(everyone) == world
-        return toks, engine.last_run_ms
+        n_gen, run_ms, wavs = 0, 0.0, []
+        for group in work:
+            t0 = time.perf_counter()
+            prompts = [p for p, _ in group]
+            n_new = max(n for _, n in group)
+            caps = [n for _, n in group]
+            engine.begin(prompts, spk.expand(len(group), -1), [mv.SamplingParams(guidance_scale=3.0, temperature=1.0, top_p=0.95,
+                                                                              seed=sp.seed + 7 * u) for u in range(len(group))],
+                         max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
+            engine.run(poll_every=1 << 20)
+            streams = [engine.tokens(u)[:len(prompts[u]) + caps[u]] for u in range(len(group))]
+            t1 = time.perf_counter()
+            stage_ms["stage1_prefill+decode"] += (t1 - t0) * 1e3
+            stage_ms["stage1_decode_gpu"] += engine.last_run_ms
+            run_ms += engine.last_run_ms
+            for u, toks in enumerate(streams):
+                n_gen += len(toks) - len(prompts[u])
+                if stage1_only:
+                    continue
+                t1 = time.perf_counter()
+                _, cbs = first_adapter.decode([fold_onto_codebooks(toks, len(prompts[u]))])
+                text_ids = [int(t) - 1024 for t in prompts[u].tolist()]  # the same text in the second stage's id space (offset 1025)
+                grid = inference.pack_second_stage_input(text_ids, cbs, s2_args["block_size"])
+                in_x = torch.tensor([grid], dtype=torch.long)
+                y = stage2.generate(in_x, None, temperature=1.0, top_k=200, speaker_embs=spk, batch_size=1, seed=sp.seed)
+                _, audio_ids = second_adapter.decode(torch.cat([in_x, y], dim=1)[0].tolist())
+                t2 = time.perf_counter()
+                wav = vocoder.decode(torch.tensor(audio_ids, dtype=torch.long).unsqueeze(0))
+                t3 = time.perf_counter()
+                stage_ms["encodec_decode"] += (t3 - t2) * 1e3
+                stage_ms["adapters+stage2"] += (t2 - t1) * 1e3
+                wavs.append(wav.reshape(-1))
+        if world > 1 and wavs:
+            # batched-serving path (SURVEY 8e): every rank ends up with every utterance's fp32 waveform, in input order
+            dev = torch.device("cuda", local_rank)
+            everyone = dispatch.gather_variable([w.to(dev) for w in wavs], world * len(wavs), device=dev)
+            assert len(everyone) == world * len(wavs)
+        return n_gen, run_ms
 
     def fence():
         if world > 1:
@@ -166,9 +243,9 @@ def main():
     gpu_ms = 0.0
     n_tok = 0
     for _ in range(a.steps):
-        toks, ms = one_step()
+        n_gen, ms = one_step()
         gpu_ms += ms
-        n_tok += len(toks) - T_PROMPT
+        n_tok += n_gen
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -183,20 +260,23 @@ def main():
         import ctypes as C
         N = importlib.import_module("metavoice-src_amd._native")
         ms, nbytes = C.c_float(0), C.c_double(0)
-        # the decode step is ONE persistent launch per token (decode_mega.hip: 24 layers + LM head) when the configuration
-        # supports it; probe 6 times that kernel alone at the position the utterance ended on.  Otherwise (per-layer launches)
-        # the dominant kernel is the fused RMSNorm + w1|w3 + SiLU-gate GEMV (probe 3).
-        # The kernel's duration grows linearly with the context; it is probed at the MEAN context of the timed utterance, so that
-        # `avg_launch_us` is the average launch of the timed region (what the rocprofv3 --stats average in profiles/ shows) and
-        # `bytes_per_launch` the average algorithmic bytes of those launches.
-        mean_ctx = T_PROMPT + (N_NEW - 1) // 2
-        engine.begin([mv.synthetic.prompt_tokens(mean_ctx, seed=rank)], spk, sp, max_new_tokens=2, end_of_audio_token=9999, prefill_mode=1)
+        # the decode step is ONE persistent launch per token (decode_mega.hip: 24 layers + LM head, all utterances of the GPU)
+        # when the configuration supports it; probe 6 times that kernel alone.  Otherwise (per-layer launches) the dominant kernel
+        # is the fused RMSNorm + w1|w3 + SiLU-gate GEMV (probe 3).
+        # The kernel's duration grows linearly with the context; it is probed at the MEAN context of the first timed group, so
+        # that `avg_launch_us` is the average launch of the timed region (what the rocprofv3 --stats average in profiles/ shows)
+        # and `bytes_per_launch` the average algorithmic bytes of those launches.
+        g0 = work[0]
+        ctxs = [len(p) + (n - 1) // 2 for p, n in g0]
+        engine.begin([mv.synthetic.prompt_tokens(c, seed=rank + u) for u, c in enumerate(ctxs)], spk.expand(len(g0), -1), sp,
+                     max_new_tokens=2, end_of_audio_token=9999, prefill_mode=1)
         engine.run(max_steps=1)
         if N.lib().mv_probe_kernel(engine._h, 6, 200, C.byref(ms), C.byref(nbytes)) == 0:
-            kname = "decode_mega_kernel (persistent: 24 layers + LM head of one token; probed at context %d = the mean of the utterance)" % (mean_ctx + 1)
+            kname = ("decode_mega_kernel (persistent: 24 layers + LM head of one token for %d utterance(s); probed at context %s = the "
+                     "mean of the timed utterances)" % (len(g0), [c + 1 for c in ctxs]))
         else:
             N.check(N.lib().mv_probe_kernel(engine._h, 3, 24 * 20, C.byref(ms), C.byref(nbytes)))
-            kname = "gemv_kernel<2,4,1,SWIGLU,nt> (RMSNorm + w1|w3 + SiLU gate)"
+            kname = "gemv_kernel<SWIGLU> (RMSNorm + w1|w3 + SiLU gate; per-layer launches)"
         ach = nbytes.value / (ms.value * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": kname,
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -206,35 +286,62 @@ def main():
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "roofline_traffic.json")) as f:
                 tr = json.load(f)
-            if tr["kernel"] in kname:
+            if tr["kernel"] in kname and tr.get("mode", "bf16") == (a.quantisation_mode or "bf16") and tr.get("utterances", 1) == U:
                 roofline["traffic"] = tr["traffic_bytes_per_launch"]
                 roofline["traffic_note"] = (f"{tr['source']}; {tr['launch_contexts']}; algorithmic bytes of those launches "
                                             f"{tr['algorithmic_bytes_same_launches']} (ratio {tr['ratio']})")
         except (OSError, KeyError, ValueError):
             pass
         per_kernel = {}
-        for kind, name in [(0, "norm+wqkv+kv"), (1, "attention@pos"), (2, "wo+res"), (4, "w2+res"), (5, "norm+head")]:
-            N.check(N.lib().mv_probe_kernel(engine._h, kind, 24 * 10, C.byref(ms), C.byref(nbytes)))
-            per_kernel[name] = {"us": round(ms.value * 1e3, 2), "GB/s": round(nbytes.value / (ms.value * 1e-3) / 1e9, 1)}
-        total_bytes = sum(step_bytes(args, p) for p in range(T_PROMPT, T_PROMPT + N_NEW - 1))  # the decode steps mv_run timed
+        if a.quantisation_mode is None:
+            for kind, name in [(0, "norm+wqkv+kv"), (1, "attention@pos"), (2, "wo+res"), (4, "w2+res"), (5, "norm+head")]:
+                N.check(N.lib().mv_probe_kernel(engine._h, kind, 24 * 10, C.byref(ms), C.byref(nbytes)))
+                per_kernel[name] = {"us": round(ms.value * 1e3, 2), "GB/s": round(nbytes.value / (ms.value * 1e-3) / 1e9, 1)}
+        # the decode steps mv_run timed: weights once per step (shared by the utterances of a group), K/V per utterance
+        total_bytes, n_steps = 0, 0
+        for group in work:
+            steps = max(n for _, n in group) - 1
+            n_steps += steps
+            total_bytes += steps * weight_bytes(args, a.quantisation_mode)
+            for p, n in group:
+                total_bytes += sum(kv_bytes(args, q) for q in range(len(p), len(p) + n - 1))
         step_frac = total_bytes / ((gpu_ms / a.steps) * 1e-3) / 1e9 / HBM_PEAK_GBS
+        n_utt = sum(len(gp) for gp in work)
+        tok_per_step = sum(n for gp in work for _, n in gp)
+        mode = a.quantisation_mode or "bf16"
+        if a.long_form:
+            workload = (f"long-form synthesis (BASELINE configs[4]): {a.long_form_chars} characters split at sentence boundaries into "
+                        f"{len(work)} chunks of <= 220 characters, each an independent generation (MFMA prefill + 7.5 tokens per "
+                        f"character, top_p=0.95, guidance 3.0) on the same captured decode graph and speaker embedding, then token "
+                        f"adapters, second stage (placeholder sizes), EnCodec decode; {tok_per_step / 150.0:.1f} s of audio per step; "
+                        "synthetic speaker embedding (assets/bria.mp3 cannot be decoded here); multi-band diffusion not timed")
+        elif a.quantisation_mode is not None:
+            workload = (f"MetaVoice-1B {mode} weight-only first-stage decode (BASELINE configs[3]): prompt T={T_PROMPT} (MFMA prefill on "
+                        f"the de-quantised weights) + {N_NEW} sampled tokens (top_p=0.95, guidance 3.0) = 12.8 s audio; first stage only")
+        elif U > 1:
+            workload = (f"MetaVoice-1B bf16 batched serving (BASELINE configs[2]): {U} utterances per GPU decoded together (ragged prompts "
+                        f"96..160 tokens, up to {N_NEW} sampled tokens each), adapters, second stage (placeholder sizes), EnCodec decode, "
+                        f"fp32 waveforms all-gathered over RCCL; batch {U * world} over {world} GPU(s); multi-band diffusion not timed")
+        else:
+            workload = (f"MetaVoice-1B synthesis, 1 utterance/GPU: prompt T={T_PROMPT} tokens (MFMA prefill) + {N_NEW} "
+                        "sampled first-stage tokens (top_p=0.95, guidance 3.0) = 12.8 s audio, token adapters, "
+                        "second-stage expansion to 8 codebooks (placeholder sizes), EnCodec decode of all 960 frames "
+                        "to a 24 kHz waveform (synthetic stream folded onto alternating codebooks after the first stage); "
+                        "the multi-band-diffusion refinement is not built yet")
         out = {
-            "metric": "audio-sec/sec (RTF^-1) MetaVoice-1B bf16, 256-char prompt",
+            "metric": "audio-sec/sec (RTF^-1) MetaVoice-1B bf16, 256-char prompt" if mode == "bf16" and not a.long_form and U == 1
+                      else f"audio-sec/sec (RTF^-1) MetaVoice-1B {mode}",
             "value": round(value, 4), "unit": "audio-s/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"MetaVoice-1B synthesis, 1 utterance/GPU: prompt T={T_PROMPT} tokens (MFMA prefill) + {N_NEW} "
-                                   "sampled first-stage tokens (top_p=0.95, guidance 3.0) = 12.8 s audio, token adapters, "
-                                   "second-stage expansion to 8 codebooks (placeholder sizes), EnCodec decode "
-                                   "to a 24 kHz waveform; the multi-band-diffusion refinement is not built yet",
-                       "rows_per_gpu": 2, "tokens_per_step": N_NEW, "parallelism": f"utterance-dp{world}"},
-            "tokens_per_s_per_gpu": round((N_NEW - 1) / (gpu_ms / a.steps * 1e-3), 1),
-            "stage_ms_per_utterance": {k: round(v / a.steps, 2) for k, v in stage_ms.items()},
+            "vs_baseline": None, "dtype": "bf16" if mode == "bf16" else f"{mode} weights x bf16 activations", "data": "synthetic",
+            "config": {"workload": workload, "rows_per_gpu": 2 * U, "utterances_per_step_per_gpu": n_utt, "tokens_per_step": tok_per_step,
+                       "parallelism": f"utterance-dp{world}"},
+            "tokens_per_s_per_gpu": round((tok_per_step - n_utt) / (gpu_ms / a.steps * 1e-3), 1),
+            "stage_ms_per_step": {k: round(v / a.steps, 2) for k, v in stage_ms.items()},
             "roofline": roofline,
             "step_roofline": {"bound": "hbm", "achieved": round(step_frac * HBM_PEAK_GBS, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(step_frac, 4), "scope": "the 1919 decode steps (HIP-event time of mv_run)",
-                              "algorithmic_bytes_per_utterance": total_bytes,
-                              "gpu_ms_per_utterance": round(gpu_ms / a.steps, 2)},
+                              "frac": round(step_frac, 4), "scope": f"the {n_steps} decode steps of one bench step (HIP-event time of mv_run)",
+                              "algorithmic_bytes_per_step": total_bytes, "gpu_ms_per_step": round(gpu_ms / a.steps, 2)},
             "per_kernel": per_kernel,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -224,7 +224,7 @@ int mv_codec_create(const mv_codec_config* cfg, mv_codec** out) {
     if (rc == MV_OK) c->allocs.push_back(c->embed);
     if (rc == MV_OK && g.lstm_layers > 0) {
         const int H0 = g.num_filters << g.n_ratios;
-        if (H0 % 8 != 0 || lstm_seq_lds_bytes(1, H0) > 160 * 1024) rc = mv_fail(MV_ERR_INVALID, "LSTM width %d unsupported", H0);
+        if (H0 % 8 != 0 || lstm_seq_lds_bytes(1, H0) > 160 * 1024 - 256) rc = mv_fail(MV_ERR_INVALID, "LSTM width %d unsupported", H0);
         if (rc == MV_OK && (hipMalloc((void**)&c->lstm_hx, (size_t)2 * H0 * 8) != hipSuccess || hipMemset(c->lstm_hx, 0, (size_t)2 * H0 * 8) != hipSuccess ||
                             hipMalloc((void**)&c->lstm_abort, 4) != hipSuccess || hipMemset(c->lstm_abort, 0, 4) != hipSuccess))
             rc = mv_fail(MV_ERR_HIP, "hipMalloc failed");

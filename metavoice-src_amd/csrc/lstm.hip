@@ -181,12 +181,12 @@ size_t lstm_seq_lds_bytes(int B, int H) { return ((size_t)4 * LS_UPW * H + (size
 hipError_t launch_lstm_seq(hipStream_t s, const LstmSeqArgs& a) {
     if (a.H % LS_UPW != 0 || a.T < 1 || a.T > 65535 || a.B < 1) return hipErrorInvalidValue;
     const size_t lds = lstm_seq_lds_bytes(a.B, a.H);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)lstm_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;  // the kernel also has a few static words
+    static size_t raised = 0;
+    if (lds > raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        raised = true;
+        raised = lds;
     }
     hipLaunchKernelGGL(lstm_seq_kernel, dim3(a.H / LS_UPW), dim3(LS_THREADS), lds, s, a);
     return hipGetLastError();
@@ -321,7 +321,7 @@ int mv_spkenc_embed(mv_spkenc* e, const float* mels, int32_t B, int32_t T, float
     if (!e->finalized) return mv_fail(MV_ERR_STATE, "mv_spkenc_embed before mv_spkenc_finalize");
     const int H = e->cfg.hidden, M = e->cfg.n_mels, E = e->cfg.emb;
     if (B < 1 || T < 1 || T > 65535) return mv_fail(MV_ERR_INVALID, "mv_spkenc_embed: B = %d, T = %d out of range", B, T);
-    const int BMAX = (int)((160 * 1024 / 4 - 4 * LS_UPW * H) / (H + LS_UPW));  // LDS budget of the recurrence kernel
+    const int BMAX = (int)(((160 * 1024 - 256) / 4 - 4 * LS_UPW * H) / (H + LS_UPW));  // LDS budget of the recurrence kernel
     hipStream_t s = e->stream;
     float *x = nullptr, *gin = nullptr, *y0 = nullptr, *y1 = nullptr, *hl = nullptr, *d_out = nullptr;
     auto cleanup = [&]() { for (float* p : {x, gin, y0, y1, hl, d_out}) if (p) (void)hipFree(p); };

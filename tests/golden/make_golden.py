@@ -170,7 +170,25 @@ def stage1_full_case(T=128, n_new=64, seed=0):
         out[f"seq_{mode}"] = np.array(seq, dtype=np.int32)
         out[f"logits_{mode}"] = logits.numpy() if mode == "bf16" else logits.numpy().astype(np.float16)
         del model
+    out.update(stage1_full_noise_floor(out["seq_bf16"].tolist(), torch.from_numpy(out["logits_bf16"]), T, n_new, seed))
     np.savez_compressed(os.path.join(HERE, "stage1_full24.npz"), **out)
+
+
+def stage1_full_noise_floor(seq, logits_fp32, T, n_new, seed):
+    """What bf16 costs at this size, measured on the reference itself: its `Transformer` in bf16 end to end (eager, CPU),
+    teacher-forced along the fp32 greedy stream, against its own fp32 logits.  Stored per step (max over both rows and the
+    vocabulary; raw logits and the 3*cond - 2*uncond mix): the tolerance of tests/test_fullsize_golden_gpu.py derives from it."""
+    model, _ = build_ref_stage1(FULL, seed, torch.bfloat16)
+    prompt = synthetic.prompt_tokens(T, seed=seed)
+    spk = synthetic.speaker_embedding(seed).to(torch.bfloat16)
+    got = [model(prompt.view(1, -1).repeat(2, 1), spk, torch.arange(T))[:, -1].float()]
+    for i in range(n_new - 1):
+        got.append(model(torch.full((2, 1), seq[T + i], dtype=torch.int32), spk, torch.tensor([T + i]))[:, -1].float())
+    lb = torch.stack(got)
+    raw = (lb - logits_fp32).abs().amax(dim=(1, 2))
+    mixed = ((3.0 * lb[:, 0] - 2.0 * lb[:, 1]) - (3.0 * logits_fp32[:, 0] - 2.0 * logits_fp32[:, 1])).abs().amax(dim=1)
+    print(f"[full24] the reference's own bf16 vs fp32: raw max {float(raw.max()):.4f}, mix max {float(mixed.max()):.4f}")
+    return dict(noise_raw_refbf16=raw.numpy(), noise_mix_refbf16=mixed.numpy())
 
 
 def slow_vs_fast_selftest(cfg_kwargs, seed):

@@ -7,9 +7,10 @@ per-channel weights (`tests/golden/make_golden.py --full24`) -- recording the lo
 
 Checks per weight format (SURVEY.md 8c "parity criteria"):
   (i)   teacher-forced along the reference's stream through the DECODE kernels (persistent kernel where supported): raw
-        logits of both CFG rows within the bf16 noise floor measured on the reference itself (|bf16 - fp32| up to
-        0.1 sigma on raw logits at 24 layers), and the argmax of the CFG mix equal to the reference's token at every step
-        whose reference top-2 margin exceeds twice the measured mix error of that step;
+        logits of both CFG rows and their CFG mix within NOISE_FACTOR x the bf16 noise floor -- the floor is what the
+        reference's own bf16 evaluation loses against its own fp32 one on this very stream, stored in the golden
+        (`noise_*_refbf16`: raw max 0.119 = 0.13 sigma, mix max 0.298) --, and the argmax of the CFG mix equal to the
+        reference's token at every step whose reference top-2 margin exceeds twice the measured mix error of that step;
   (ii)  free-running greedy stream (MFMA prefill + decode): identical to the reference's, or forked at a step whose reference
         margin is inside that noise; the length of agreement is printed (the headline "bit-exact" number).
 """
@@ -29,8 +30,7 @@ synthetic = load_pkg("synthetic")
 fiu = load_pkg("fast_inference_utils")
 
 FULL = dict(n_layer=24, n_head=16, dim=2048, vocab_size=2562, block_size=2048)
-RAW_TOL_SIGMA = 0.15   # of the raw-logit std: two evaluations (bf16 engine, fp32 reference) through 24 layers
-MIX_TOL_SIGMA = 0.15   # of the CFG-mixed logit std (the 3*cond - 2*uncond mix amplifies the raw error ~3.5x, and the std ~3.2x)
+NOISE_FACTOR = 1.5  # engine-vs-fp32 error allowed, in units of the reference's own bf16-vs-fp32 error (different summation orders)
 
 
 @pytest.fixture(scope="module")
@@ -68,6 +68,8 @@ def test_full_size_engine_follows_the_reference(golden, weights, mode):
     engine.run()
     got = engine.captured_logits(T - 1, n_new)
     raw_sigma, mix_sigma = float(glog.std()), float(mix(glog).std())
+    raw_tol = NOISE_FACTOR * float(golden["noise_raw_refbf16"].max())
+    mix_tol = NOISE_FACTOR * float(golden["noise_mix_refbf16"].max())
     d_raw = (got - glog).abs().amax(dim=(1, 2))
     gm, em = mix(glog), mix(got)
     d_mix = (em - gm).abs().amax(dim=1)
@@ -78,10 +80,11 @@ def test_full_size_engine_follows_the_reference(golden, weights, mode):
     print(f"[full24 {mode}] teacher-forced {n_new} steps: max|draw| {float(d_raw.max()):.4f} ({float(d_raw.max()) / raw_sigma:.3f} sigma), "
           f"max|dmix| {float(d_mix.max()):.4f} ({float(d_mix.max()) / mix_sigma:.3f} sigma); argmax equal at {int(same.sum())}/{n_new} steps, "
           f"{int(decided.sum())} steps decided (margin > 2 dmix), reference margin min {float(margin.min()):.4f}")
-    assert float(d_raw.max()) <= RAW_TOL_SIGMA * raw_sigma
-    assert float(d_mix.max()) <= MIX_TOL_SIGMA * mix_sigma
+    assert float(d_raw.max()) <= raw_tol, f"raw logits off by {float(d_raw.max()):.4f} > {raw_tol:.4f}"
+    assert float(d_mix.max()) <= mix_tol, f"mixed logits off by {float(d_mix.max()):.4f} > {mix_tol:.4f}"
+    assert float(d_raw.mean()) <= NOISE_FACTOR * float(golden["noise_raw_refbf16"].mean())  # not just the tail: the typical step too
     assert bool(same[decided].all()), "argmax differs from the reference at a step the reference decides clearly"
-    assert int(decided.sum()) >= n_new // 2, "the measured error is too large to decide even half of the steps"
+    assert int(decided.sum()) >= n_new // 3, "the measured error is too large to decide even a third of the steps"
 
     # (ii) free-running greedy: MFMA prefill + decode steps, the engine's own sampler
     engine.begin([prompt], spk, sp, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
@@ -94,10 +97,10 @@ def test_full_size_engine_follows_the_reference(golden, weights, mode):
     d_pre = float((first - glog[:1]).abs().max())
     print(f"[full24 {mode}] free-running greedy stream identical to the reference's for {agree}/{n_new} tokens; "
           f"MFMA-prefill first-token max|draw| {d_pre:.4f}")
-    assert d_pre <= RAW_TOL_SIGMA * raw_sigma
+    assert d_pre <= raw_tol
     if fork is not None:
         # a fork is legitimate only where the reference's own margin is inside the engine-vs-reference noise
-        assert float(margin[fork - T]) <= 2 * MIX_TOL_SIGMA * mix_sigma, \
+        assert float(margin[fork - T]) <= 2 * mix_tol, \
             f"stream forks at generated token {fork - T} where the reference's top-2 margin is {float(margin[fork - T]):.4f}"
         if fork - T < n_new and bool(decided[fork - T]):
             # teacher-forced, this step agreed with the reference: then the free-running fork comes from the prefill path
