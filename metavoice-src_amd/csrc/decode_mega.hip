@@ -1,5 +1,6 @@
-// Persistent decode-step kernel: all 24 layers + the LM head of one token in ONE launch (MetaVoice-1B shape, one utterance
-// = 2 CFG rows).  Same arithmetic, in the same order, as the per-layer launches (gemv.hip / attention.hip share
+// Persistent decode-step kernel: all 24 layers + the LM head of one token in ONE launch (MetaVoice-1B shape; NU = 1, 2 or 4
+// utterances = 2 NU CFG rows decoded together: the weight rows a wave holds in registers are applied to every utterance, so
+// the weight stream and the six hand-offs of a layer are shared by all of them).  Same arithmetic, in the same order, as the per-layer launches (gemv.hip / attention.hip share
 // gemv_core.h / attn_core.h with this file): the two paths produce identical bits (tests/test_engine_gpu.py).
 //
 // Why (profiles/r01b_attn_sampler/NOTES.md): with one launch per op a decode step is 122 dependent launches of 1.5-9 us
@@ -13,28 +14,33 @@
 #include "gemv_i4_core.h"
 #include "gemv_i8_core.h"
 
-// RMSNorm of raw[2][2048] into xs[2][2048], bit-identical to gemv.hip's prologue (threads 0..255 own 8 columns each).
+// RMSNorm of the NU row pairs xs[u][2][2048], IN PLACE, bit-identical to gemv.hip's prologue (threads 0..255 own 8 columns
+// each, of both rows of every utterance; every thread holds its columns in registers across the two barriers).
 // The norm weights `nw` (columns 8 tid .. 8 tid + 7) are requested by the caller a phase ahead: loaded here, their load would
 // return in order behind the K/V and weight requests already in flight and the norm would wait ~2 us for data it does not need.
-__device__ __forceinline__ void mega_norm(const bf16_t* raw, const u32x4& nw, bf16_t* xs, float* red, float eps) {
+template <int NU>
+__device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x4& nw, float* red, float eps) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = tid * 8;
     const bool in_k = c < MG_DIM;
-    u32x4 xv[2];
+    u32x4 xv[NU][2];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        xv[r] = in_k ? *(const u32x4*)(raw + r * MG_DIM + c) : u32x4{0, 0, 0, 0};
-        const float s = wave_sum(sumsq8(xv[r]));
-        if (lane == 0) red[wave * 2 + r] = s;
-    }
-    __syncthreads();
-    float tots[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) tots[r] = block_total(red + r, 2, MG_WAVES, lane);
-    if (in_k) {
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            *(u32x4*)(xs + r * MG_DIM + c) = rms_apply8(xv[r], rms_rstd(tots[r], MG_DIM, eps), nw);
+            xv[u][r] = in_k ? *(const u32x4*)(xs[u] + r * MG_DIM + c) : u32x4{0, 0, 0, 0};
+            const float s = wave_sum(sumsq8(xv[u][r]));
+            if (lane == 0) red[u * 2 * MG_WAVES + wave * 2 + r] = s;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        float tots[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) tots[r] = block_total(red + u * 2 * MG_WAVES + r, 2, MG_WAVES, lane);
+        if (in_k) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) *(u32x4*)(xs[u] + r * MG_DIM + c) = rms_apply8(xv[u][r], rms_rstd(tots[r], MG_DIM, eps), nw);
         }
     }
     __syncthreads();
@@ -108,14 +114,28 @@ __device__ __forceinline__ void mega_dots_i8(const u32x4* cq, const bf16_t* xs, 
 }
 __device__ __forceinline__ float i8_out(float wave_total, float scale) { return round_bf(round_bf(wave_total) * scale); }
 
-template <int WF>  // MV_W_BF16, MV_W_INT4_G128 (LM head bf16) or MV_W_INT8 (LM head int8 too)
-__global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16_t raw_x[2 * MG_DIM];   // residual stream entering the layer (P0 in, P2 residual)
-    __shared__ __attribute__((aligned(16))) bf16_t raw_h[2 * MG_DIM];   // residual stream after attention (P3 in, P4 residual)
-    __shared__ __attribute__((aligned(16))) bf16_t xs[2 * MG_INTER];    // the GEMV operand of the current phase
-    __shared__ __attribute__((aligned(16))) bf16_t qkv_s[3 * 2 * 128];  // q, k_new, v_new of this block's head, both rows
-    __shared__ __attribute__((aligned(16))) float sm[ATTN_WAVES][16][12];
-    __shared__ float red[MG_WAVES * 2];
+// 16-byte polls of a row-paired 2048-column vector of every utterance ([NU][2048] granules): pair n = granules 2n, 2n+1 =
+// columns 2n, 2n+1 of both rows.  ONE poll loop for all utterances: a loop per utterance would pay a round trip each.
+template <int NU>
+__device__ __forceinline__ void mega_poll_rowpairs(const gran_t* g, uint32_t tag, bf16_t (*xs)[2 * MG_INTER], uint32_t* abort_flag, int* s_abort,
+                                                   int tid) {
+    wave_poll16<2 * NU>(g, tag, abort_flag, s_abort, [&](int k) { return (k >> 1) * (MG_DIM / 2) + tid + (k & 1) * MG_THREADS; },
+                        [&](int n, uint32_t p0, uint32_t p1) {
+                            const int u = n / (MG_DIM / 2), c = n % (MG_DIM / 2);
+                            *(uint32_t*)(xs[u] + 2 * c) = (p0 & 0xFFFFu) | (p1 << 16);
+                            *(uint32_t*)(xs[u] + MG_DIM + 2 * c) = (p0 >> 16) | (p1 & 0xFFFF0000u);
+                        });
+}
+
+template <int WF, int NU>  // WF: MV_W_BF16, MV_W_INT4_G128 (LM head bf16) or MV_W_INT8 (LM head int8 too); NU utterances
+__global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_kernel(const MegaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mg_lds[];
+    // the GEMV operand of the current phase, per utterance; the residual stream is NOT kept here: a wave produces exactly the
+    // columns (8 b + wave) whose residual it needs two phases later, so those ride in registers (xres / hres)
+    bf16_t (*xs)[2 * MG_INTER] = (bf16_t(*)[2 * MG_INTER])mg_lds;
+    bf16_t (*qkv_s)[3 * 2 * 128] = (bf16_t(*)[3 * 2 * 128])(mg_lds + (size_t)NU * 2 * MG_INTER * 2);  // q, k_new, v_new of this block's head
+    float (*sm)[16][12] = (float(*)[16][12])(mg_lds + (size_t)NU * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2));
+    float* red = (float*)(sm + ATTN_WAVES);  // [NU][MG_WAVES * 2]
     __shared__ int s_abort;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
@@ -123,15 +143,21 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
     __syncthreads();
 #define MG_ABORTED() (*(volatile int*)&s_abort != 0)
     const uint32_t epoch = a.step_counter[0] * 256u;
-    const int P = a.pos[0] + 1;  // keys [0, P): the cache holds [0, P-1), key P-1 is produced by this step's QKV phase
 
-    // attention geometry: block (r, h, s) = one of the (up to) 8 even key ranges of (row r, head h); 8 waves x 32 keys
+    // attention geometry: block (r, h, s) = one of the (up to) 8 even key ranges of (row r, head h) of EVERY utterance; 8 waves x 32 keys
     const int at_r = b >> 7, at_h = (b >> 3) & 15, at_s = b & 7, at_w = wave;
     const int g = lane >> 4, dl = lane & 15;
-    const int cs = attn_keys_per_split(P);
-    const int nact = (P + cs - 1) / cs;
-    const int kw = attn_keys_per_wave(cs);
-    const int at_s0 = at_s * cs + at_w * kw, at_s1 = min(min(P, at_s * cs + cs), at_s0 + kw);
+    int P[NU], cs[NU], nact[NU], kw[NU];
+    bool any_att = false;
+    int first_att = -1;
+#pragma unroll
+    for (int u = NU - 1; u >= 0; --u) {
+        P[u] = a.pos[u] + 1;  // keys [0, P): the cache holds [0, P-1), key P-1 is produced by this step's QKV phase
+        cs[u] = attn_keys_per_split(P[u]);
+        nact[u] = (P[u] + cs[u] - 1) / cs[u];
+        kw[u] = attn_keys_per_wave(cs[u]);
+        if (at_s < nact[u]) { any_att = true; first_att = u; }
+    }
 
     // optional phase stamps (blocks 0 and 255, wave 0): poll-wait vs compute per phase, for profiles/
     const bool stamping = a.stamps != nullptr && (b == 0 || b == 255) && wave == 0;
@@ -155,7 +181,17 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
     }
     // RMSNorm weights of the next norm, requested together with the weight rows of its phase (threads 0..255 own 8 columns each)
     u32x4 nw_attn = load16(a.layers[0].attn_norm + min(tid * 8, MG_DIM - 8)), nw_ffn = u32x4{0u, 0u, 0u, 0u};
+    // residual values of this wave's own column n = 8 b + wave, both rows packed (row 0 | row 1 << 16): x entering the layer
+    // (layer 0: the sampler's / prefill's output; later: what this wave published in P4) and h (published in P2)
+    uint32_t xres[NU], hres[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const bf16_t* xi = a.x_in + (size_t)u * 2 * MG_DIM + 8 * b + wave;
+        xres[u] = (uint32_t)xi[0] | ((uint32_t)xi[MG_DIM] << 16);
+        hres[u] = 0u;
+    }
 
+    u32x4 kv[ATTN_U], vv[ATTN_U];
     for (int l = 0; l < a.n_layer; ++l) {
         // Address arithmetic below is a function of (lane, wave): left alone, the compiler hoists ~60 loop-invariant 64-bit
         // addresses out of the layer loop and spills them.  Making the two ids opaque once per layer keeps every address
@@ -167,51 +203,60 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
         const uint32_t tag0 = epoch + (uint32_t)l * 8u + 1u;  // + phase index
         bf16_t* kc = a.kcache + (size_t)l * a.kv_layer_elems;
         bf16_t* vc = a.vcache + (size_t)l * a.kv_layer_elems;
+        // This block's K/V slice of utterance u (rows of EARLIER steps: independent of this step), into the kv / vv registers.
+        // Addresses are clamped to the newest row an EARLIER launch wrote (P-2): row P-1 is being written by this launch and
+        // is taken from the hand-off -- it must not even be touched here (a line fetched before its producer's store could be
+        // served stale to the next launch).
+        auto issue_kv = [&](int u) {
+#pragma unroll
+            for (int q = 0; q < ATTN_U; ++q) kv[q] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int q = 0; q < ATTN_U; ++q) vv[q] = u32x4{0u, 0u, 0u, 0u};
+            const int go = lane_o >> 4, dlo = lane_o & 15, s0o = at_s * cs[u] + wave_o * kw[u];
+            const size_t head_base = ((size_t)(2 * u + at_r) * MG_HEADS + at_h) * (size_t)a.cache_len * 128 + dlo * 8;
+            const int last_old = max(P[u] - 2, 0);
+            if (P[u] > 1 && at_s < nact[u]) {
+#pragma unroll
+                for (int q = 0; q < ATTN_U; ++q)
+                    if (q * 4 < kw[u]) kv[q] = load_stream16(kc + head_base + (size_t)min(s0o + q * 4 + go, last_old) * 128);
+#pragma unroll
+                for (int q = 0; q < ATTN_U; ++q)
+                    if (q * 4 < kw[u]) vv[q] = load_stream16(vc + head_base + (size_t)min(s0o + q * 4 + go, last_old) * 128);
+            }
+        };
 
         // ================= P0: RMSNorm + wqkv (+ KV-cache write)        fast_model.py:179,209,218 ====================
         __syncthreads();
         MG_STAMP(l, 0);
         if (l == 0) {
-            *(u32x4*)(raw_x + tid * 8) = load16(a.x_in + tid * 8);  // written by the sampler in the previous launch
-        } else wave_poll_rowpair16(a.g_x, tag0 - 8u + 4u, raw_x, a.abort_flag, &s_abort, tid_o);
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+                *(u32x4*)(xs[u] + tid * 8) = load16(a.x_in + (size_t)u * 2 * MG_DIM + tid * 8);  // written by the sampler in the previous launch
+        } else mega_poll_rowpairs<NU>(a.g_x, tag0 - 8u + 4u, xs, a.abort_flag, &s_abort, tid_o);
         __syncthreads();
         if (MG_ABORTED()) return;
         MG_STAMP(l, 1);
-        // The K/V stream of this block's attention slice (rows of EARLIER steps: independent of this step) is requested here,
-        // before the norm and the wqkv dots: it lands while they run.  (Requested after the q/k/v publish instead it sits in
-        // front of the q/k/v poll: 831 vs 794 us/step.)
-        u32x4 kv[ATTN_U], vv[ATTN_U];
+        // The K/V stream of the first attention slice is requested here, before the norm and the wqkv dots: it lands while they
+        // run.  (Requested after the q/k/v publish instead it sits in front of the q/k/v poll: 831 vs 794 us/step.)
 #pragma unroll
-        for (int u = 0; u < ATTN_U; ++u) kv[u] = u32x4{0u, 0u, 0u, 0u};
+        for (int q = 0; q < ATTN_U; ++q) kv[q] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int u = 0; u < ATTN_U; ++u) vv[u] = u32x4{0u, 0u, 0u, 0u};
-        {
-            const int go = lane_o >> 4, dlo = lane_o & 15, s0o = at_s * cs + wave_o * kw;
-            const size_t head_base = ((size_t)at_r * MG_HEADS + at_h) * (size_t)a.cache_len * 128 + dlo * 8;
-            // Addresses are clamped to the newest row an EARLIER launch wrote (P-2): row P-1 is being written by this launch and
-            // is taken from the hand-off below -- it must not even be touched here (a line fetched before its producer's store
-            // could be served stale to the next launch).
-            const int last_old = max(P - 2, 0);
-            if (P > 1 && at_s < nact) {
+        for (int q = 0; q < ATTN_U; ++q) vv[q] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-                for (int u = 0; u < ATTN_U; ++u)
-                    if (u * 4 < kw) kv[u] = load_stream16(kc + head_base + (size_t)min(s0o + u * 4 + go, last_old) * 128);
-#pragma unroll
-                for (int u = 0; u < ATTN_U; ++u)
-                    if (u * 4 < kw) vv[u] = load_stream16(vc + head_base + (size_t)min(s0o + u * 4 + go, last_old) * 128);
-            }
-        }
+        for (int u = 0; u < NU; ++u)
+            if (u == first_att) issue_kv(u);
         __builtin_amdgcn_sched_barrier(0);
         MG_STAMP(l, 11);  // K/V requested
-        mega_norm(raw_x, nw_attn, xs, red, a.eps);
+        mega_norm<NU>(xs, nw_attn, red, a.eps);
         MG_STAMP(l, 12);  // norm done
-        {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
             float acc[3][2];
-            if (I4) mega_dots_i4<1, 3, MG_DIM>(cq, cz, xs, MG_DIM, lane, acc);
-            else if (I8) mega_dots_i8<2, 3, MG_DIM>(cq, xs, MG_DIM, lane, acc);
-            else mega_dots<4, 3, MG_DIM>(wv, xs, lane, acc);
+            if (I4) mega_dots_i4<1, 3, MG_DIM>(cq, cz, xs[u], MG_DIM, lane, acc);
+            else if (I8) mega_dots_i8<2, 3, MG_DIM>(cq, xs[u], MG_DIM, lane, acc);
+            else mega_dots<4, 3, MG_DIM>(wv, xs[u], lane, acc);
             __builtin_amdgcn_sched_barrier(0);
-            MG_STAMP(l, 13);  // wqkv dots done
+            if (u == 0) MG_STAMP(l, 13);  // wqkv dots done
             float v0 = 0.f, v1 = 0.f;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -222,12 +267,12 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             if (lane < 3) {
                 const int n = 24 * b + 3 * wave + lane;
                 const bf16_t y0 = f2bf(v0), y1 = f2bf(v1);
-                gran_store(a.g_qkv + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 0u);
-                if (a.dbg && n < MG_DIM) { bf16_t* d = a.dbg + ((size_t)l * 5 + 0) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
+                gran_store(a.g_qkv + (size_t)u * 3 * MG_DIM + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 0u);
+                if (a.dbg && u == 0 && n < MG_DIM) { bf16_t* d = a.dbg + ((size_t)l * 5 + 0) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
                 if (n >= MG_DIM) {  // K / V rows also go to the cache for the FUTURE steps (this step reads them from the granules)
                     const int which = (n - MG_DIM) / MG_DIM, hd = (n - MG_DIM) % MG_DIM;
-                    bf16_t* cache = which ? vc : kc;
-                    const size_t off = ((size_t)(hd / 128) * a.cache_len + (P - 1)) * 128 + hd % 128;
+                    bf16_t* cache = (which ? vc : kc) + (size_t)2 * u * MG_HEADS * a.cache_len * 128;
+                    const size_t off = ((size_t)(hd / 128) * a.cache_len + (P[u] - 1)) * 128 + hd % 128;
                     cache[off] = y0;
                     cache[(size_t)MG_HEADS * a.cache_len * 128 + off] = y1;
                 }
@@ -236,41 +281,9 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
         __builtin_amdgcn_sched_barrier(0);
         MG_STAMP(l, 2);
 
-        // ================= P1: attention over keys [0, P)               fast_model.py:218-222 =========================
-        if (at_s < nact) {
-            __syncthreads();
-            {   // q, k_new, v_new of head at_h: 3 x 128 row-paired granules
-                const bool mine = tid_o < 384;
-                const int sec = tid_o >> 7, c = tid_o & 127;
-                const gran_t* gp = a.g_qkv + sec * MG_DIM + at_h * 128 + c;
-                wave_poll<1>(tag0 + 0u, a.abort_flag, &s_abort, [&](int, u64& v) { if (!mine) return false; v = gran_load(gp); return true; },
-                             [&](int, uint32_t p) { qkv_s[(sec * 2 + 0) * 128 + c] = (bf16_t)p; qkv_s[(sec * 2 + 1) * 128 + c] = (bf16_t)(p >> 16); });
-            }
-            __syncthreads();
-            if (MG_ABORTED()) return;
-            MG_STAMP(l, 3);
-            const u32x4 qv = *(const u32x4*)(qkv_s + (0 * 2 + at_r) * 128 + dl * 8);
-#pragma unroll
-            for (int u = 0; u < ATTN_U; ++u) {
-                if (at_s0 + u * 4 + g == P - 1) {  // the key produced by this step: not in the cache yet for this launch
-                    kv[u] = *(const u32x4*)(qkv_s + (1 * 2 + at_r) * 128 + dl * 8);
-                    vv[u] = *(const u32x4*)(qkv_s + (2 * 2 + at_r) * 128 + dl * 8);
-                }
-            }
-            const AttnAcc w = attn_wave_partial(kv, vv, qv, at_s0, at_s1, g);
-            MG_STAMP(l, 14);  // wave partial done
-            if (g == 0) {
-                sm[at_w][dl][0] = w.m;
-                sm[at_w][dl][1] = w.l;
-#pragma unroll
-                for (int d = 0; d < 8; ++d) sm[at_w][dl][2 + d] = w.o[d];
-            }
-            __syncthreads();
-        }
         // next: wo row 8 b + wave.  Publish-before-prefetch (profiles/r01g_handoff/NOTES.md): a wave that still has something to
         // publish does so BEFORE it queues its next weight loads -- the memory pipeline accepts loads only as fast as it
         // drains them, so a publish behind 100-200 KB of requests reaches its consumers microseconds late.
-        __builtin_amdgcn_sched_barrier(0);
         // wo goes to wv[12..15]; the w1 rows of P3 ride along in wv[0..11] (the w3 rows follow after P2's dots into wv[12..23]):
         // w1|w3 is 45 % of a layer's bytes, asked for in one go it made P2 -> P3 the one stream-bound hand-off (8 us).
         const int rb13 = 22 * b + (wave_o < 6 ? 3 * wave_o : 18 + 2 * (wave_o - 6));
@@ -294,41 +307,101 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
             }
             nw_ffn = load16(L.ffn_norm + min(tid_o * 8, MG_DIM - 8));
         };
+
+        // ================= P1: attention over keys [0, P)               fast_model.py:218-222 =========================
         // Publish-before-prefetch holds for the WORKGROUP here, not just per wave: wave 0 still has the block's partial (and, in
         // the workgroup of split 0, the combined output) to publish, and a store queued behind 112 KB of the other waves' bulk
         // requests in this CU's memory pipeline reaches the combiner -- on everybody's critical path -- microseconds late.  So the
-        // other waves of an attending workgroup hold their requests until wave 0 is through.
-        const bool attending = at_s < nact;
-        if (!attending) request_wo_w1();
-        __builtin_amdgcn_sched_barrier(0);
-        if (at_s < nact && at_w == 0) {
-            AttnAcc bb = attn_merge_waves(sm, g, dl);
-            bool last = true;
-            if (nact > 1) {
-                // split partials as tagged granules: every split publishes, the workgroup of split 0 polls all of them and
-                // combines (attn_core.h) -- one hand-off instead of store + vmcnt(0) + ticket round trip + load round trip
-                u64* slots = (u64*)a.partial + ((size_t)at_r * MG_HEADS + at_h) * ATTN_NSPLIT * ATTN_TPART_STRIDE;
-                attn_publish_tagged(bb, slots + (size_t)at_s * ATTN_TPART_STRIDE, tag0 + 5u, lane);
-                last = at_s == 0;
-                if (last && !attn_combine_tagged(bb, slots, tag0 + 5u, nact, lane, MG_SPIN_LIMIT)) {
-                    __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    *(volatile int*)&s_abort = 1;
-                    last = false;
+        // other waves of an attending workgroup hold their requests (the next utterance's K/V, then wo | w1) until wave 0 is through.
+        if (!any_att) request_wo_w1();
+        if (any_att) {
+            __syncthreads();
+            {   // q, k_new, v_new of head at_h of every utterance this block attends for: 3 x 128 row-paired granules each
+                const int sec = tid_o >> 7, c = tid_o & 127;
+                wave_poll<NU>(tag0 + 0u, a.abort_flag, &s_abort,
+                              [&](int k, u64& v) {
+                                  if (tid_o >= 384 || !(at_s < nact[k])) return false;
+                                  v = gran_load(a.g_qkv + (size_t)k * 3 * MG_DIM + sec * MG_DIM + at_h * 128 + c);
+                                  return true;
+                              },
+                              [&](int k, uint32_t p) { qkv_s[k][(sec * 2 + 0) * 128 + c] = (bf16_t)p; qkv_s[k][(sec * 2 + 1) * 128 + c] = (bf16_t)(p >> 16); });
+            }
+            __syncthreads();
+            if (MG_ABORTED()) return;
+            MG_STAMP(l, 3);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                if (!(at_s < nact[u])) continue;  // block-uniform
+                int next_att = -1;
+#pragma unroll
+                for (int v = NU - 1; v > u; --v)
+                    if (at_s < nact[v]) next_att = v;
+                const int at_s0 = at_s * cs[u] + at_w * kw[u], at_s1 = min(min(P[u], at_s * cs[u] + cs[u]), at_s0 + kw[u]);
+                const u32x4 qv = *(const u32x4*)(qkv_s[u] + (0 * 2 + at_r) * 128 + dl * 8);
+#pragma unroll
+                for (int q = 0; q < ATTN_U; ++q) {
+                    if (at_s0 + q * 4 + g == P[u] - 1) {  // the key produced by this step: not in the cache yet for this launch
+                        kv[q] = *(const u32x4*)(qkv_s[u] + (1 * 2 + at_r) * 128 + dl * 8);
+                        vv[q] = *(const u32x4*)(qkv_s[u] + (2 * 2 + at_r) * 128 + dl * 8);
+                    }
                 }
+                const AttnAcc w = attn_wave_partial(kv, vv, qv, at_s0, at_s1, g);
+                if (u == 0) MG_STAMP(l, 14);  // wave partial done
+                if (g == 0) {
+                    sm[at_w][dl][0] = w.m;
+                    sm[at_w][dl][1] = w.l;
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) sm[at_w][dl][2 + d] = w.o[d];
+                }
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+                AttnAcc bb;
+                u64* slots = (u64*)a.partial + ((size_t)(2 * u + at_r) * MG_HEADS + at_h) * ATTN_NSPLIT * ATTN_TPART_STRIDE;
+                if (at_w == 0) {
+                    bb = attn_merge_waves(sm, g, dl);
+                    // split partials as tagged granules: every split publishes, the workgroup of split 0 polls all of them and
+                    // combines (attn_core.h) -- one hand-off instead of store + vmcnt(0) + ticket round trip + load round trip
+                    if (nact[u] > 1) attn_publish_tagged(bb, slots + (size_t)at_s * ATTN_TPART_STRIDE, tag0 + 5u, lane);
+                }
+                if (next_att >= 0) {
+                    // more utterances to attend for: the block's partial has left (workgroup-wide publish-before-prefetch), the
+                    // wave partials in `sm` have been consumed; now the next slice's K/V may be requested -- by wave 0 only after
+                    // its combine below, whose polls would otherwise queue behind its own requests
+                    __syncthreads();
+                    if (at_w != 0) {
+#pragma unroll
+                        for (int v = 0; v < NU; ++v)
+                            if (v == next_att) issue_kv(v);
+                    }
+                }
+                if (at_w == 0) {
+                    bool last = true;
+                    if (nact[u] > 1) {
+                        last = at_s == 0;
+                        if (last && !attn_combine_tagged(bb, slots, tag0 + 5u, nact[u], lane, MG_SPIN_LIMIT)) {
+                            __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            *(volatile int*)&s_abort = 1;
+                            last = false;
+                        }
+                    }
+                    if (last && g == 0) {  // 8 dims per lane = 4 column-paired granules
+                        const u32x4 y = attn_normalise(bb);
+                        gran_t* gp = a.g_attn + (size_t)u * MG_DIM + at_r * (MG_DIM / 2) + (at_h * 128 + dl * 8) / 2;
+                        gran_store(gp + 0, y.x, tag0 + 1u);
+                        gran_store(gp + 1, y.y, tag0 + 1u);
+                        gran_store(gp + 2, y.z, tag0 + 1u);
+                        gran_store(gp + 3, y.w, tag0 + 1u);
+                        if (a.dbg && u == 0) *(u32x4*)(a.dbg + ((size_t)l * 5 + 1) * 2 * MG_INTER + at_r * MG_INTER + at_h * 128 + dl * 8) = y;
+                    }
+                    if (next_att >= 0) {
+#pragma unroll
+                        for (int v = 0; v < NU; ++v)
+                            if (v == next_att) issue_kv(v);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (last && g == 0) {  // 8 dims per lane = 4 column-paired granules
-                const u32x4 y = attn_normalise(bb);
-                gran_t* gp = a.g_attn + at_r * (MG_DIM / 2) + (at_h * 128 + dl * 8) / 2;
-                gran_store(gp + 0, y.x, tag0 + 1u);
-                gran_store(gp + 1, y.y, tag0 + 1u);
-                gran_store(gp + 2, y.z, tag0 + 1u);
-                gran_store(gp + 3, y.w, tag0 + 1u);
-                if (a.dbg) *(u32x4*)(a.dbg + ((size_t)l * 5 + 1) * 2 * MG_INTER + at_r * MG_INTER + at_h * 128 + dl * 8) = y;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        MG_STAMP(l, 15);  // wave 0: attention output (or partial) published
-        if (attending) {
+            MG_STAMP(l, 15);  // wave 0: attention output (or partial) published
             __syncthreads();
             request_wo_w1();
         }
@@ -338,26 +411,31 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
         __syncthreads();
         MG_STAMP(l, 4);
         {
-            wave_poll16<2>(a.g_attn, tag0 + 1u, a.abort_flag, &s_abort, [&](int k) { return tid_o + k * MG_THREADS; },
-                           [&](int n, uint32_t p0, uint32_t p1) { ((uint2*)xs)[n] = make_uint2(p0, p1); });  // granule i = elements 2i, 2i+1 of [2][2048]
+            // granule i of utterance u = elements 2i, 2i+1 of its [2][2048] attention output
+            wave_poll16<2 * NU>(a.g_attn, tag0 + 1u, a.abort_flag, &s_abort, [&](int k) { return (k >> 1) * (MG_DIM / 2) * 2 / 2 + tid_o + (k & 1) * MG_THREADS; },
+                                [&](int n, uint32_t p0, uint32_t p1) { ((uint2*)xs[n / (MG_DIM / 2)])[n % (MG_DIM / 2)] = make_uint2(p0, p1); });
             __syncthreads();
             if (MG_ABORTED()) return;
             MG_STAMP(l, 5);
-            float acc[1][2];
-            if (I4) mega_dots_i4<1, 1, MG_DIM>(cq + 6, cz + 6, xs, MG_DIM, lane, acc);
-            else if (I8) mega_dots_i8<2, 1, MG_DIM>(cq + 12, xs, MG_DIM, lane, acc);
-            else mega_dots<4, 1, MG_DIM>(wv + 12, xs, lane, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            MG_STAMP(l, 16);  // wo dots done
-            float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
-            if (I8) { t0 = i8_out(t0, sc_c); t1 = i8_out(t1, sc_c); }
-            // test hook (mv_tune "mega_fault"): one workgroup withholds this publish -> every peer's wait has to time out, raise the
-            // abort flag and leave the kernel; mv_run then reports the error (tests/test_engine_gpu.py)
-            if (lane == 0 && !(a.fault != 0 && b == ((a.fault - 1) & 255) && l == 1)) {
-                const int n = 8 * b + wave;
-                const bf16_t y0 = epi_resid(raw_x[n], t0), y1 = epi_resid(raw_x[MG_DIM + n], t1);
-                gran_store(a.g_h + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 2u);
-                if (a.dbg) { bf16_t* d = a.dbg + ((size_t)l * 5 + 2) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                float acc[1][2];
+                if (I4) mega_dots_i4<1, 1, MG_DIM>(cq + 6, cz + 6, xs[u], MG_DIM, lane, acc);
+                else if (I8) mega_dots_i8<2, 1, MG_DIM>(cq + 12, xs[u], MG_DIM, lane, acc);
+                else mega_dots<4, 1, MG_DIM>(wv + 12, xs[u], lane, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u == 0) MG_STAMP(l, 16);  // wo dots done
+                float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
+                if (I8) { t0 = i8_out(t0, sc_c); t1 = i8_out(t1, sc_c); }
+                const bf16_t y0 = epi_resid((bf16_t)xres[u], t0), y1 = epi_resid((bf16_t)(xres[u] >> 16), t1);
+                hres[u] = (uint32_t)y0 | ((uint32_t)y1 << 16);
+                // test hook (mv_tune "mega_fault"): one workgroup withholds this publish -> every peer's wait has to time out, raise the
+                // abort flag and leave the kernel; mv_run then reports the error (tests/test_engine_gpu.py)
+                if (lane == 0 && !(a.fault != 0 && b == ((a.fault - 1) & 255) && l == 1)) {
+                    const int n = 8 * b + wave;
+                    gran_store(a.g_h + (size_t)u * MG_DIM + n, hres[u], tag0 + 2u);
+                    if (a.dbg && u == 0) { bf16_t* d = a.dbg + ((size_t)l * 5 + 2) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 17);  // h published
@@ -376,38 +454,41 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
         __syncthreads();
         MG_STAMP(l, 6);
         {
-            wave_poll_rowpair16(a.g_h, tag0 + 2u, raw_h, a.abort_flag, &s_abort, tid_o);
+            mega_poll_rowpairs<NU>(a.g_h, tag0 + 2u, xs, a.abort_flag, &s_abort, tid_o);
             __syncthreads();
             if (MG_ABORTED()) return;
             MG_STAMP(l, 7);
-            mega_norm(raw_h, nw_ffn, xs, red, a.eps);
+            mega_norm<NU>(xs, nw_ffn, red, a.eps);
             MG_STAMP(l, 18);  // norm done
-            float acc1[3][2], acc3[3][2];
-            if (I4) {
-                mega_dots_i4<1, 3, MG_DIM>(cq, cz, xs, MG_DIM, lane, acc1);
-                mega_dots_i4<1, 3, MG_DIM>(cq + 3, cz + 3, xs, MG_DIM, lane, acc3);
-            } else if (I8) {
-                mega_dots_i8<2, 3, MG_DIM>(cq, xs, MG_DIM, lane, acc1);
-                mega_dots_i8<2, 3, MG_DIM>(cq + 6, xs, MG_DIM, lane, acc3);
-            } else {
-                mega_dots<4, 3, MG_DIM>(wv, xs, lane, acc1);
-                mega_dots<4, 3, MG_DIM>(wv + 12, xs, lane, acc3);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            MG_STAMP(l, 19);  // w1|w3 dots done
             const int nrows = wave < 6 ? 3 : 2;
             const int rb = 22 * b + (wave < 6 ? 3 * wave : 18 + 2 * (wave - 6));
-            float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                float a0 = wave_sum(acc1[i][0]), a1 = wave_sum(acc1[i][1]), c0 = wave_sum(acc3[i][0]), c1 = wave_sum(acc3[i][1]);
-                if (I8) { a0 = i8_out(a0, sc_a[i]); a1 = i8_out(a1, sc_a[i]); c0 = i8_out(c0, sc_b[i]); c1 = i8_out(c1, sc_b[i]); }
-                if (lane == i) { g0 = a0; g1 = a1; u0 = c0; u1 = c1; }
-            }
-            if (lane < nrows) {
-                const bf16_t y0 = epi_swiglu(g0, u0), y1 = epi_swiglu(g1, u1);
-                gran_store(a.g_act + rb + lane, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 3u);
-                if (a.dbg) { bf16_t* d = a.dbg + ((size_t)l * 5 + 3) * 2 * MG_INTER; d[rb + lane] = y0; d[MG_INTER + rb + lane] = y1; }
+            for (int u = 0; u < NU; ++u) {
+                float acc1[3][2], acc3[3][2];
+                if (I4) {
+                    mega_dots_i4<1, 3, MG_DIM>(cq, cz, xs[u], MG_DIM, lane, acc1);
+                    mega_dots_i4<1, 3, MG_DIM>(cq + 3, cz + 3, xs[u], MG_DIM, lane, acc3);
+                } else if (I8) {
+                    mega_dots_i8<2, 3, MG_DIM>(cq, xs[u], MG_DIM, lane, acc1);
+                    mega_dots_i8<2, 3, MG_DIM>(cq + 6, xs[u], MG_DIM, lane, acc3);
+                } else {
+                    mega_dots<4, 3, MG_DIM>(wv, xs[u], lane, acc1);
+                    mega_dots<4, 3, MG_DIM>(wv + 12, xs[u], lane, acc3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (u == 0) MG_STAMP(l, 19);  // w1|w3 dots done
+                float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    float a0 = wave_sum(acc1[i][0]), a1 = wave_sum(acc1[i][1]), c0 = wave_sum(acc3[i][0]), c1 = wave_sum(acc3[i][1]);
+                    if (I8) { a0 = i8_out(a0, sc_a[i]); a1 = i8_out(a1, sc_a[i]); c0 = i8_out(c0, sc_b[i]); c1 = i8_out(c1, sc_b[i]); }
+                    if (lane == i) { g0 = a0; g1 = a1; u0 = c0; u1 = c1; }
+                }
+                if (lane < nrows) {
+                    const bf16_t y0 = epi_swiglu(g0, u0), y1 = epi_swiglu(g1, u1);
+                    gran_store(a.g_act + (size_t)u * MG_INTER + rb + lane, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 3u);
+                    if (a.dbg && u == 0) { bf16_t* d = a.dbg + ((size_t)l * 5 + 3) * 2 * MG_INTER; d[rb + lane] = y0; d[MG_INTER + rb + lane] = y1; }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 20);  // act published
@@ -422,24 +503,44 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
         __syncthreads();
         MG_STAMP(l, 8);
         {
-            wave_poll_rowpair<MG_INTER>(a.g_act, tag0 + 3u, xs, a.abort_flag, &s_abort, tid_o);
+            // 8-byte polls, 11 per thread and utterance; at most two utterances per poll loop (registers)
+            constexpr int UPP = NU < 2 ? NU : 2;
+#pragma unroll
+            for (int u0 = 0; u0 < NU; u0 += UPP) {
+                wave_poll<11 * UPP>(tag0 + 3u, a.abort_flag, &s_abort,
+                                    [&](int k, u64& v) {
+                                        const int n = tid_o + (k % 11) * MG_THREADS;
+                                        if (n >= MG_INTER) return false;
+                                        v = gran_load(a.g_act + (size_t)(u0 + k / 11) * MG_INTER + n);
+                                        return true;
+                                    },
+                                    [&](int k, uint32_t p) {
+                                        const int n = tid_o + (k % 11) * MG_THREADS;
+                                        xs[u0 + k / 11][n] = (bf16_t)p;
+                                        xs[u0 + k / 11][MG_INTER + n] = (bf16_t)(p >> 16);
+                                    });
+            }
             __syncthreads();
             if (MG_ABORTED()) return;
             MG_STAMP(l, 9);
-            float acc[1][2];
-            if (I4) mega_dots_i4<3, 1, MG_INTER>(cq + 6, cz + 6, xs, MG_INTER, lane, acc);
-            else if (I8) mega_dots_i8<6, 1, MG_INTER>(cq, xs, MG_INTER, lane, acc);
-            else mega_dots<11, 1, MG_INTER>(wv, xs, lane, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            MG_STAMP(l, 21);  // w2 dots done
-            float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
-            if (I8) { t0 = i8_out(t0, sc_c); t1 = i8_out(t1, sc_c); }
-            if (lane == 0) {
-                const int n = 8 * b + wave;
-                const bf16_t y0 = epi_resid(raw_h[n], t0), y1 = epi_resid(raw_h[MG_DIM + n], t1);
-                gran_store(a.g_x + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 4u);
-                MG_STAMP(l, 10);
-                if (a.dbg) { bf16_t* d = a.dbg + ((size_t)l * 5 + 4) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                float acc[1][2];
+                if (I4) mega_dots_i4<3, 1, MG_INTER>(cq + 6, cz + 6, xs[u], MG_INTER, lane, acc);
+                else if (I8) mega_dots_i8<6, 1, MG_INTER>(cq, xs[u], MG_INTER, lane, acc);
+                else mega_dots<11, 1, MG_INTER>(wv, xs[u], lane, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u == 0) MG_STAMP(l, 21);  // w2 dots done
+                float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
+                if (I8) { t0 = i8_out(t0, sc_c); t1 = i8_out(t1, sc_c); }
+                const bf16_t y0 = epi_resid((bf16_t)hres[u], t0), y1 = epi_resid((bf16_t)(hres[u] >> 16), t1);
+                xres[u] = (uint32_t)y0 | ((uint32_t)y1 << 16);
+                if (lane == 0) {
+                    const int n = 8 * b + wave;
+                    gran_store(a.g_x + (size_t)u * MG_DIM + n, xres[u], tag0 + 4u);
+                    if (u == 0) MG_STAMP(l, 10);
+                    if (a.dbg && u == 0) { bf16_t* d = a.dbg + ((size_t)l * 5 + 4) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             // next: the following layer's wqkv rows, or the LM-head rows 11 b + wave + 8 i
@@ -466,14 +567,15 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
 
     // ================= LM head on the last position: logits = head(norm(x))     fast_model.py:161-162 =================
     __syncthreads();
-    wave_poll_rowpair16(a.g_x, epoch + (uint32_t)(a.n_layer - 1) * 8u + 1u + 4u, raw_x, a.abort_flag, &s_abort, tid);
+    mega_poll_rowpairs<NU>(a.g_x, epoch + (uint32_t)(a.n_layer - 1) * 8u + 1u + 4u, xs, a.abort_flag, &s_abort, tid);
     __syncthreads();
     if (MG_ABORTED()) return;
-    mega_norm(raw_x, nw_attn, xs, red, a.eps);
-    {
+    mega_norm<NU>(xs, nw_attn, red, a.eps);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
         float acc[2][2];
-        if (I8) mega_dots_i8<2, 2, MG_DIM>(cq, xs, MG_DIM, lane, acc);
-        else mega_dots<4, 2, MG_DIM>(wv, xs, lane, acc);
+        if (I8) mega_dots_i8<2, 2, MG_DIM>(cq, xs[u], MG_DIM, lane, acc);
+        else mega_dots<4, 2, MG_DIM>(wv, xs[u], lane, acc);
         float v0 = 0.f, v1 = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -484,15 +586,16 @@ __global__ void __launch_bounds__(MG_THREADS, 2) decode_mega_kernel(const MegaAr
         if (lane < 2) {
             const int slot = wave + 8 * lane, n = 11 * b + slot;
             if (slot < 11 && n < a.vocab) {
-                a.logits[n] = f2bf(v0);
-                a.logits[a.vocab + n] = f2bf(v1);
+                a.logits[(size_t)(2 * u) * a.vocab + n] = f2bf(v0);
+                a.logits[(size_t)(2 * u + 1) * a.vocab + n] = f2bf(v1);
             }
         }
     }
 }
 
+
 bool mega_supported(const mv_config& c, int rows, int n_cus) {
-    return rows == 2 && c.dim == MG_DIM && c.intermediate == MG_INTER && c.n_head == MG_HEADS && c.vocab <= 256 * 11 && n_cus >= 256 &&
+    return (rows == 2 || rows == 4 || rows == 8) && c.dim == MG_DIM && c.intermediate == MG_INTER && c.n_head == MG_HEADS && c.vocab <= 256 * 11 && n_cus >= 256 &&
            c.block_size <= ATTN_NSPLIT * 256 &&
            c.n_layer <= 31;  // hand-off tag = step * 256 + layer * 8 + phase + 1: layer * 8 + 6 must stay below 256
 }
@@ -503,9 +606,33 @@ hipError_t launch_bump_counter(hipStream_t s, uint32_t* c) {
     return hipGetLastError();
 }
 
-hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a, int weight_format) {
-    if (weight_format == MV_W_INT4_G128) hipLaunchKernelGGL(decode_mega_kernel<MV_W_INT4_G128>, dim3(256), dim3(MG_THREADS), 0, s, a);
-    else if (weight_format == MV_W_INT8) hipLaunchKernelGGL(decode_mega_kernel<MV_W_INT8>, dim3(256), dim3(MG_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(decode_mega_kernel<MV_W_BF16>, dim3(256), dim3(MG_THREADS), 0, s, a);
+size_t mega_lds_bytes(int n_utt) {
+    return (size_t)n_utt * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2) + ATTN_WAVES * 16 * 12 * 4 + (size_t)n_utt * MG_WAVES * 2 * 4;
+}
+
+template <int WF, int NU>
+static hipError_t launch_mega_instance(hipStream_t s, const MegaArgs& a) {
+    static bool raised = false;  // > 64 KB of LDS for more than one utterance: dynamic, raised once per instance
+    const size_t lds = mega_lds_bytes(NU);
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)decode_mega_kernel<WF, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL((decode_mega_kernel<WF, NU>), dim3(256), dim3(MG_THREADS), lds, s, a);
     return hipGetLastError();
+}
+template <int WF>
+static hipError_t launch_mega_format(hipStream_t s, const MegaArgs& a) {
+    switch (a.n_utt) {
+        case 1: return launch_mega_instance<WF, 1>(s, a);
+        case 2: return launch_mega_instance<WF, 2>(s, a);
+        case 4: return launch_mega_instance<WF, 4>(s, a);
+        default: return hipErrorInvalidValue;
+    }
+}
+hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a, int weight_format) {
+    if (weight_format == MV_W_INT4_G128) return launch_mega_format<MV_W_INT4_G128>(s, a);
+    if (weight_format == MV_W_INT8) return launch_mega_format<MV_W_INT8>(s, a);
+    return launch_mega_format<MV_W_BF16>(s, a);
 }

@@ -162,7 +162,9 @@ static MegaArgs mega_args(mv_engine* e) {
     m.x_in = e->x; m.layers = e->mega_layers; m.n_layer = c.n_layer; m.vocab = c.vocab; m.cache_len = c.block_size;
     m.final_norm = e->final_norm; m.head = e->head; m.head_q8 = e->head_q8; m.head_s8 = e->head_s8; m.logits = e->logits; m.kcache = e->kcache; m.vcache = e->vcache;
     m.kv_layer_elems = e->kv_layer_elems; m.pos = e->pos_arr; m.step_counter = e->step_counter;
-    m.g_x = e->granules; m.g_qkv = m.g_x + c.dim; m.g_attn = m.g_qkv + 3 * c.dim; m.g_h = m.g_attn + c.dim; m.g_act = m.g_h + c.dim;
+    const size_t U = (size_t)c.max_utterances;
+    m.n_utt = c.max_utterances;
+    m.g_x = e->granules; m.g_qkv = m.g_x + U * c.dim; m.g_attn = m.g_qkv + U * 3 * c.dim; m.g_h = m.g_attn + U * c.dim; m.g_act = m.g_h + U * c.dim;
     m.partial = e->partial; m.counters = e->counters; m.abort_flag = e->abort_flag; m.eps = c.norm_eps; m.dbg = e->dbg; m.stamps = e->stamps;
     m.ablate = g_tune.gemv_ablate;
     m.fault = g_tune.mega_fault;
@@ -643,7 +645,7 @@ int mv_finalize(mv_engine* e) {
             }
             HIP_TRY(hipMalloc((void**)&e->mega_layers, ml.size() * sizeof(MegaLayer)));
             HIP_TRY(hipMemcpy(e->mega_layers, ml.data(), ml.size() * sizeof(MegaLayer), hipMemcpyHostToDevice));
-            const size_t ngran = (size_t)c.dim * 6 + c.intermediate;  // x, qkv (3), attn, h, act
+            const size_t ngran = ((size_t)c.dim * 6 + c.intermediate) * c.max_utterances;  // per utterance: x, qkv (3), attn, h, act
             HIP_TRY(hipMalloc((void**)&e->granules, ngran * 8));
             HIP_TRY(hipMemset(e->granules, 0, ngran * 8));
         }

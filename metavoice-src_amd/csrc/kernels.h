@@ -213,20 +213,22 @@ struct MegaLayer {
     const bf16_t* s8[5];
 };
 struct MegaArgs {
-    const bf16_t* x_in = nullptr;          // [2][2048]: input rows of layer 0 (written by the sampler / prefill)
+    const bf16_t* x_in = nullptr;          // [2 n_utt][2048]: input rows of layer 0 (written by the sampler / prefill)
     const MegaLayer* layers = nullptr;     // device array [n_layer]
     int32_t n_layer = 0, vocab = 0, cache_len = 0;
+    int32_t n_utt = 1;                     // utterances decoded together (1, 2 or 4): rows 2u, 2u+1 belong to utterance u
     const bf16_t* final_norm = nullptr;
     const bf16_t* head = nullptr;
     const signed char* head_q8 = nullptr;  // int8 engines: the LM head is quantised too
     const bf16_t* head_s8 = nullptr;
-    bf16_t* logits = nullptr;              // [2][vocab]
+    bf16_t* logits = nullptr;              // [2 n_utt][vocab]
     bf16_t* kcache = nullptr;
     bf16_t* vcache = nullptr;
     size_t kv_layer_elems = 0;
-    const int32_t* pos = nullptr;          // [1]
+    const int32_t* pos = nullptr;          // [n_utt]
     const uint32_t* step_counter = nullptr;
-    unsigned long long *g_x = nullptr, *g_qkv = nullptr, *g_attn = nullptr, *g_h = nullptr, *g_act = nullptr;  // granule buffers
+    // granule buffers, each [n_utt][columns]: x 2048, qkv 6144, attn 2048, h 2048, act 5632
+    unsigned long long *g_x = nullptr, *g_qkv = nullptr, *g_attn = nullptr, *g_h = nullptr, *g_act = nullptr;
     float* partial = nullptr;
     uint32_t* counters = nullptr;
     uint32_t* abort_flag = nullptr;

@@ -287,6 +287,45 @@ def test_persistent_decode_kernel_is_bit_identical_to_per_layer_launches(n_layer
     engine.close()
 
 
+@pytest.mark.parametrize("n_utt,n_layer,lens,n_new,combo", [
+    (2, 3, [40, 23], 30, dict(top_p=0.95)),
+    (2, 2, [250, 700], 20, dict(top_k=1)),                    # one utterance crosses 256 keys (1 -> 8 key ranges), the other is beyond
+    (4, 3, [96, 160, 131, 17], 40, dict(top_p=0.95)),
+    (4, 2, [300, 12, 2000, 255], 24, dict(top_p=0.9, temperature=0.8)),  # every attention regime at once
+])
+def test_persistent_kernel_with_several_utterances_is_bit_identical_to_launches(n_utt, n_layer, lens, n_new, combo):
+    """The persistent kernel decoding 2 or 4 utterances together (the weight rows a wave holds are applied to every utterance;
+    per-utterance positions, key ranges, seeds and end-of-audio) against the per-layer launches on the same batch, and against
+    each utterance decoded ALONE: identical tokens and logits."""
+    cfgk = dict(WIDE2, n_layer=n_layer)
+    engine, sd, cfg = build(cfgk, 13, max_utterances=n_utt)
+    prompts = [synthetic.prompt_tokens(t, seed=30 + u) for u, t in enumerate(lens)]
+    spks = torch.cat([synthetic.speaker_embedding(40 + u) for u in range(n_utt)])
+    sps = [mv.SamplingParams(guidance_scale=3.0, seed=50 + u, **combo) for u in range(n_utt)]
+    engine.capture_logits(True)
+    out = {}
+    for mega in (1, 0):
+        engine.tune(mega=mega)
+        engine.begin(prompts, spks, sps, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
+        engine.run()
+        toks = [engine.tokens(u) for u in range(n_utt)]
+        first = min(lens) - 1
+        out[mega] = (toks, engine.captured_logits(max(lens) - 1, n_new - 1))  # steps every utterance is decoding in
+    engine.tune(mega=1)
+    for u in range(n_utt):
+        assert len(out[1][0][u]) == lens[u] + n_new
+        assert out[1][0][u] == out[0][0][u], f"utterance {u}: token streams differ between the persistent kernel and the launches"
+    assert torch.equal(out[1][1], out[0][1]), f"logits differ: max {float((out[1][1] - out[0][1]).abs().max())}"
+    engine.close()
+    # each utterance on its own (single-utterance persistent kernel): same stream as inside the batch
+    single, _, _ = build(cfgk, 13, max_utterances=1)
+    for u in (0, n_utt - 1):
+        single.begin([prompts[u]], spks[u:u + 1], sps[u], max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
+        single.run()
+        assert single.tokens(0) == out[1][0][u], f"utterance {u} decodes differently alone and in a batch of {n_utt}"
+    single.close()
+
+
 def test_persistent_kernel_times_out_cleanly_and_the_run_falls_back_to_launches():
     """A persistent kernel whose grid is not co-resident (or whose peer dies) must not hang and must not fail the run: every
     wait is bounded, the first workgroup to give up raises a device flag, the rest leave within a polling interval, and mv_run
