@@ -14,15 +14,15 @@ __device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((uint3
 __device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xFFFF0000u); }
 
-// fp32 -> bf16, round to nearest even (the rounding torch's .to(bfloat16) applies).
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (bf16_t)((u >> 16) | 0x40u);  // quiet NaN
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// fp32 -> bf16, round to nearest even (the rounding torch's .to(bfloat16) applies): gfx950 converts in hardware
+// (v_cvt_pk_bf16_f32, two values per instruction) -- the integer add-and-shift form cost ~8 VALU ops per value, which made the
+// RMSNorm apply and the epilogues of the decode kernels VALU-bound (1.6 us per norm in the persistent kernel).
+typedef __bf16 mv_bf16pair_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, mv_bf16pair_t{(__bf16)lo, (__bf16)hi});
 }
-__device__ __forceinline__ float round_bf(float f) { return bf2f(f2bf(f)); }
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)pack_bf2(f, 0.f); }
+__device__ __forceinline__ float round_bf(float f) { return __uint_as_float(pack_bf2(0.f, f) & 0xFFFF0000u); }
 
 // acc += w.lo*x.lo + w.hi*x.hi  (v_dot2c_f32_bf16; products of two bf16 are exact in fp32)
 __device__ __forceinline__ float dot2_bf16(uint32_t w, uint32_t x, float acc) {

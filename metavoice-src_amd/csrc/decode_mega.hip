@@ -21,27 +21,25 @@
 template <int NU>
 __device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x4& nw, float* red, float eps) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = tid * 8;
-    const bool in_k = c < MG_DIM;
-    u32x4 xv[NU][2];
+    // statistics: threads 0..255 own 8 columns each, of both rows (the summation order of gemv.hip's prologue)
+    if (tid < MG_DIM / 8) {
+#pragma unroll 1
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
-    for (int u = 0; u < NU; ++u)
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            xv[u][r] = in_k ? *(const u32x4*)(xs[u] + r * MG_DIM + c) : u32x4{0, 0, 0, 0};
-            const float s = wave_sum(sumsq8(xv[u][r]));
-            if (lane == 0) red[u * 2 * MG_WAVES + wave * 2 + r] = s;
-        }
+            for (int r = 0; r < 2; ++r) {
+                const float s = wave_sum(sumsq8(*(const u32x4*)(xs[u] + r * MG_DIM + tid * 8)));
+                if (lane == 0) red[u * 2 * MG_WAVES + wave * 2 + r] = s;
+            }
+    }
     __syncthreads();
-#pragma unroll
+    // apply (element-wise, any partition gives the same bits): ALL 512 threads, waves 0..3 row 0, waves 4..7 row 1 -- the apply is
+    // ~150 VALU ops per 8 columns and was the longer half of the norm when only half of the waves did it
+    const int r = tid >> 8, c = (tid & 255) * 8;
+#pragma unroll 1
     for (int u = 0; u < NU; ++u) {
-        float tots[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) tots[r] = block_total(red + u * 2 * MG_WAVES + r, 2, MG_WAVES, lane);
-        if (in_k) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) *(u32x4*)(xs[u] + r * MG_DIM + c) = rms_apply8(xv[u][r], rms_rstd(tots[r], MG_DIM, eps), nw);
-        }
+        const float tot = wave_sum(lane < MG_DIM / 8 / 64 ? red[u * 2 * MG_WAVES + lane * 2 + r] : 0.f);  // == block_total over the 4 waves that hold columns
+        const u32x4 xv = *(const u32x4*)(xs[u] + r * MG_DIM + c);
+        *(u32x4*)(xs[u] + r * MG_DIM + c) = rms_apply8(xv, rms_rstd(tot, MG_DIM, eps), nw);
     }
     __syncthreads();
 }
@@ -137,6 +135,11 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     float (*sm)[16][12] = (float(*)[16][12])(mg_lds + (size_t)NU * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2));
     float* red = (float*)(sm + ATTN_WAVES);  // [NU][MG_WAVES * 2]
     __shared__ int s_abort;
+    // per-utterance attention geometry and the residual values of each wave's own column: in LDS so that the loops over the
+    // utterances stay ROLLED (unrolled they interleave the utterances' temporaries: 60-190 spilled VGPRs, and a scratch
+    // reload waits, in order, for every weight request in flight)
+    __shared__ int geo[4][NU];                 // P, cs, nact, kw
+    __shared__ uint32_t res_s[2][NU][MG_WAVES];  // x and h residuals of column 8 b + wave, rows packed
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     if (tid == 0) s_abort = 0;
@@ -147,17 +150,17 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     // attention geometry: block (r, h, s) = one of the (up to) 8 even key ranges of (row r, head h) of EVERY utterance; 8 waves x 32 keys
     const int at_r = b >> 7, at_h = (b >> 3) & 15, at_s = b & 7, at_w = wave;
     const int g = lane >> 4, dl = lane & 15;
-    int P[NU], cs[NU], nact[NU], kw[NU];
     bool any_att = false;
     int first_att = -1;
 #pragma unroll
     for (int u = NU - 1; u >= 0; --u) {
-        P[u] = a.pos[u] + 1;  // keys [0, P): the cache holds [0, P-1), key P-1 is produced by this step's QKV phase
-        cs[u] = attn_keys_per_split(P[u]);
-        nact[u] = (P[u] + cs[u] - 1) / cs[u];
-        kw[u] = attn_keys_per_wave(cs[u]);
-        if (at_s < nact[u]) { any_att = true; first_att = u; }
+        const int Pu = a.pos[u] + 1;  // keys [0, P): the cache holds [0, P-1), key P-1 is produced by this step's QKV phase
+        const int csu = attn_keys_per_split(Pu), nactu = (Pu + csu - 1) / csu;
+        if (tid == 0) { geo[0][u] = Pu; geo[1][u] = csu; geo[2][u] = nactu; geo[3][u] = attn_keys_per_wave(csu); }
+        if (at_s < nactu) { any_att = true; first_att = u; }
     }
+    __syncthreads();
+#define GEO(k, u) __builtin_amdgcn_readfirstlane(geo[k][u])
 
     // optional phase stamps (blocks 0 and 255, wave 0): poll-wait vs compute per phase, for profiles/
     const bool stamping = a.stamps != nullptr && (b == 0 || b == 255) && wave == 0;
@@ -179,16 +182,14 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave + i, MG_DIM, lane, a.ablate);
         }
     }
-    // RMSNorm weights of the next norm, requested together with the weight rows of its phase (threads 0..255 own 8 columns each)
-    u32x4 nw_attn = load16(a.layers[0].attn_norm + min(tid * 8, MG_DIM - 8)), nw_ffn = u32x4{0u, 0u, 0u, 0u};
+    // RMSNorm weights of the next norm, requested together with the weight rows of its phase (thread t: columns 8 (t & 255) ..)
+    u32x4 nw_attn = load16(a.layers[0].attn_norm + (tid & 255) * 8), nw_ffn = u32x4{0u, 0u, 0u, 0u};
     // residual values of this wave's own column n = 8 b + wave, both rows packed (row 0 | row 1 << 16): x entering the layer
     // (layer 0: the sampler's / prefill's output; later: what this wave published in P4) and h (published in P2)
-    uint32_t xres[NU], hres[NU];
-#pragma unroll
+#pragma unroll 1
     for (int u = 0; u < NU; ++u) {
         const bf16_t* xi = a.x_in + (size_t)u * 2 * MG_DIM + 8 * b + wave;
-        xres[u] = (uint32_t)xi[0] | ((uint32_t)xi[MG_DIM] << 16);
-        hres[u] = 0u;
+        if (lane == 0) res_s[0][u][wave] = (uint32_t)xi[0] | ((uint32_t)xi[MG_DIM] << 16);
     }
 
     u32x4 kv[ATTN_U], vv[ATTN_U];
@@ -207,21 +208,22 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         // Addresses are clamped to the newest row an EARLIER launch wrote (P-2): row P-1 is being written by this launch and
         // is taken from the hand-off -- it must not even be touched here (a line fetched before its producer's store could be
         // served stale to the next launch).
-        auto issue_kv = [&](int u) {
+        auto issue_kv = [&](int u) {  // u: runtime, block-uniform
 #pragma unroll
             for (int q = 0; q < ATTN_U; ++q) kv[q] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
             for (int q = 0; q < ATTN_U; ++q) vv[q] = u32x4{0u, 0u, 0u, 0u};
-            const int go = lane_o >> 4, dlo = lane_o & 15, s0o = at_s * cs[u] + wave_o * kw[u];
+            const int Pu = GEO(0, u), csu = GEO(1, u), nactu = GEO(2, u), kwu = GEO(3, u);
+            const int go = lane_o >> 4, dlo = lane_o & 15, s0o = at_s * csu + wave_o * kwu;
             const size_t head_base = ((size_t)(2 * u + at_r) * MG_HEADS + at_h) * (size_t)a.cache_len * 128 + dlo * 8;
-            const int last_old = max(P[u] - 2, 0);
-            if (P[u] > 1 && at_s < nact[u]) {
+            const int last_old = max(Pu - 2, 0);
+            if (Pu > 1 && at_s < nactu) {
 #pragma unroll
                 for (int q = 0; q < ATTN_U; ++q)
-                    if (q * 4 < kw[u]) kv[q] = load_stream16(kc + head_base + (size_t)min(s0o + q * 4 + go, last_old) * 128);
+                    if (q * 4 < kwu) kv[q] = load_stream16(kc + head_base + (size_t)min(s0o + q * 4 + go, last_old) * 128);
 #pragma unroll
                 for (int q = 0; q < ATTN_U; ++q)
-                    if (q * 4 < kw[u]) vv[q] = load_stream16(vc + head_base + (size_t)min(s0o + q * 4 + go, last_old) * 128);
+                    if (q * 4 < kwu) vv[q] = load_stream16(vc + head_base + (size_t)min(s0o + q * 4 + go, last_old) * 128);
             }
         };
 
@@ -242,14 +244,12 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         for (int q = 0; q < ATTN_U; ++q) kv[q] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int q = 0; q < ATTN_U; ++q) vv[q] = u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-            if (u == first_att) issue_kv(u);
+        if (first_att >= 0) issue_kv(first_att);
         __builtin_amdgcn_sched_barrier(0);
         MG_STAMP(l, 11);  // K/V requested
         mega_norm<NU>(xs, nw_attn, red, a.eps);
         MG_STAMP(l, 12);  // norm done
-#pragma unroll
+#pragma unroll 1
         for (int u = 0; u < NU; ++u) {
             float acc[3][2];
             if (I4) mega_dots_i4<1, 3, MG_DIM>(cq, cz, xs[u], MG_DIM, lane, acc);
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 if (n >= MG_DIM) {  // K / V rows also go to the cache for the FUTURE steps (this step reads them from the granules)
                     const int which = (n - MG_DIM) / MG_DIM, hd = (n - MG_DIM) % MG_DIM;
                     bf16_t* cache = (which ? vc : kc) + (size_t)2 * u * MG_HEADS * a.cache_len * 128;
-                    const size_t off = ((size_t)(hd / 128) * a.cache_len + (P[u] - 1)) * 128 + hd % 128;
+                    const size_t off = ((size_t)(hd / 128) * a.cache_len + (GEO(0, u) - 1)) * 128 + hd % 128;
                     cache[off] = y0;
                     cache[(size_t)MG_HEADS * a.cache_len * 128 + off] = y1;
                 }
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
 #pragma unroll
                 for (int i = 0; i < 3; ++i) mega_issue_row<4>(wv + 4 * i, L.w1, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o, a.ablate);
             }
-            nw_ffn = load16(L.ffn_norm + min(tid_o * 8, MG_DIM - 8));
+            nw_ffn = load16(L.ffn_norm + (tid_o & 255) * 8);
         };
 
         // ================= P1: attention over keys [0, P)               fast_model.py:218-222 =========================
@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 const int sec = tid_o >> 7, c = tid_o & 127;
                 wave_poll<NU>(tag0 + 0u, a.abort_flag, &s_abort,
                               [&](int k, u64& v) {
-                                  if (tid_o >= 384 || !(at_s < nact[k])) return false;
+                                  if (tid_o >= 384 || !(at_s < GEO(2, k))) return false;
                                   v = gran_load(a.g_qkv + (size_t)k * 3 * MG_DIM + sec * MG_DIM + at_h * 128 + c);
                                   return true;
                               },
@@ -329,18 +329,23 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             __syncthreads();
             if (MG_ABORTED()) return;
             MG_STAMP(l, 3);
-#pragma unroll
+            // One K/V register set.  After an utterance's partial has been merged and published (workgroup-wide
+            // publish-before-prefetch) EVERY wave requests its slice of the next attending utterance -- wave 0 too, before the
+            // combine polls it may owe.  The split partials of utterance u are combined by the workgroup of split u % nact (not
+            // all by split 0, which would then wait for a combine once per utterance).
+#pragma unroll 1
             for (int u = 0; u < NU; ++u) {
-                if (!(at_s < nact[u])) continue;  // block-uniform
+                const int Pu = GEO(0, u), csu = GEO(1, u), nactu = GEO(2, u), kwu = GEO(3, u);
+                if (!(at_s < nactu)) continue;  // block-uniform
                 int next_att = -1;
-#pragma unroll
+#pragma unroll 1
                 for (int v = NU - 1; v > u; --v)
-                    if (at_s < nact[v]) next_att = v;
-                const int at_s0 = at_s * cs[u] + at_w * kw[u], at_s1 = min(min(P[u], at_s * cs[u] + cs[u]), at_s0 + kw[u]);
+                    if (at_s < GEO(2, v)) next_att = v;
+                const int at_s0 = at_s * csu + at_w * kwu, at_s1 = min(min(Pu, at_s * csu + csu), at_s0 + kwu);
                 const u32x4 qv = *(const u32x4*)(qkv_s[u] + (0 * 2 + at_r) * 128 + dl * 8);
 #pragma unroll
                 for (int q = 0; q < ATTN_U; ++q) {
-                    if (at_s0 + q * 4 + g == P[u] - 1) {  // the key produced by this step: not in the cache yet for this launch
+                    if (at_s0 + q * 4 + g == Pu - 1) {  // the key produced by this step: not in the cache yet for this launch
                         kv[q] = *(const u32x4*)(qkv_s[u] + (1 * 2 + at_r) * 128 + dl * 8);
                         vv[q] = *(const u32x4*)(qkv_s[u] + (2 * 2 + at_r) * 128 + dl * 8);
                     }
@@ -359,26 +364,19 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 u64* slots = (u64*)a.partial + ((size_t)(2 * u + at_r) * MG_HEADS + at_h) * ATTN_NSPLIT * ATTN_TPART_STRIDE;
                 if (at_w == 0) {
                     bb = attn_merge_waves(sm, g, dl);
-                    // split partials as tagged granules: every split publishes, the workgroup of split 0 polls all of them and
+                    // split partials as tagged granules: every split publishes, one workgroup polls all of them and
                     // combines (attn_core.h) -- one hand-off instead of store + vmcnt(0) + ticket round trip + load round trip
-                    if (nact[u] > 1) attn_publish_tagged(bb, slots + (size_t)at_s * ATTN_TPART_STRIDE, tag0 + 5u, lane);
+                    if (nactu > 1) attn_publish_tagged(bb, slots + (size_t)at_s * ATTN_TPART_STRIDE, tag0 + 5u, lane);
                 }
                 if (next_att >= 0) {
-                    // more utterances to attend for: the block's partial has left (workgroup-wide publish-before-prefetch), the
-                    // wave partials in `sm` have been consumed; now the next slice's K/V may be requested -- by wave 0 only after
-                    // its combine below, whose polls would otherwise queue behind its own requests
-                    __syncthreads();
-                    if (at_w != 0) {
-#pragma unroll
-                        for (int v = 0; v < NU; ++v)
-                            if (v == next_att) issue_kv(v);
-                    }
+                    __syncthreads();  // the partial has left, `sm` has been consumed
+                    issue_kv(next_att);
                 }
                 if (at_w == 0) {
                     bool last = true;
-                    if (nact[u] > 1) {
-                        last = at_s == 0;
-                        if (last && !attn_combine_tagged(bb, slots, tag0 + 5u, nact[u], lane, MG_SPIN_LIMIT)) {
+                    if (nactu > 1) {
+                        last = at_s == (NU == 1 ? 0 : u % nactu);
+                        if (last && !attn_combine_tagged(bb, slots, tag0 + 5u, nactu, lane, MG_SPIN_LIMIT)) {
                             __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             *(volatile int*)&s_abort = 1;
                             last = false;
@@ -392,11 +390,6 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                         gran_store(gp + 2, y.z, tag0 + 1u);
                         gran_store(gp + 3, y.w, tag0 + 1u);
                         if (a.dbg && u == 0) *(u32x4*)(a.dbg + ((size_t)l * 5 + 1) * 2 * MG_INTER + at_r * MG_INTER + at_h * 128 + dl * 8) = y;
-                    }
-                    if (next_att >= 0) {
-#pragma unroll
-                        for (int v = 0; v < NU; ++v)
-                            if (v == next_att) issue_kv(v);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -417,7 +410,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             __syncthreads();
             if (MG_ABORTED()) return;
             MG_STAMP(l, 5);
-#pragma unroll
+#pragma unroll 1
             for (int u = 0; u < NU; ++u) {
                 float acc[1][2];
                 if (I4) mega_dots_i4<1, 1, MG_DIM>(cq + 6, cz + 6, xs[u], MG_DIM, lane, acc);
@@ -427,13 +420,15 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 if (u == 0) MG_STAMP(l, 16);  // wo dots done
                 float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
                 if (I8) { t0 = i8_out(t0, sc_c); t1 = i8_out(t1, sc_c); }
-                const bf16_t y0 = epi_resid((bf16_t)xres[u], t0), y1 = epi_resid((bf16_t)(xres[u] >> 16), t1);
-                hres[u] = (uint32_t)y0 | ((uint32_t)y1 << 16);
+                const uint32_t xr = res_s[0][u][wave];
+                const bf16_t y0 = epi_resid((bf16_t)xr, t0), y1 = epi_resid((bf16_t)(xr >> 16), t1);
+                const uint32_t hr = (uint32_t)y0 | ((uint32_t)y1 << 16);
+                if (lane == 0) res_s[1][u][wave] = hr;
                 // test hook (mv_tune "mega_fault"): one workgroup withholds this publish -> every peer's wait has to time out, raise the
                 // abort flag and leave the kernel; mv_run then reports the error (tests/test_engine_gpu.py)
                 if (lane == 0 && !(a.fault != 0 && b == ((a.fault - 1) & 255) && l == 1)) {
                     const int n = 8 * b + wave;
-                    gran_store(a.g_h + (size_t)u * MG_DIM + n, hres[u], tag0 + 2u);
+                    gran_store(a.g_h + (size_t)u * MG_DIM + n, hr, tag0 + 2u);
                     if (a.dbg && u == 0) { bf16_t* d = a.dbg + ((size_t)l * 5 + 2) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
                 }
             }
@@ -462,7 +457,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             MG_STAMP(l, 18);  // norm done
             const int nrows = wave < 6 ? 3 : 2;
             const int rb = 22 * b + (wave < 6 ? 3 * wave : 18 + 2 * (wave - 6));
-#pragma unroll
+#pragma unroll 1
             for (int u = 0; u < NU; ++u) {
                 float acc1[3][2], acc3[3][2];
                 if (I4) {
@@ -523,7 +518,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             __syncthreads();
             if (MG_ABORTED()) return;
             MG_STAMP(l, 9);
-#pragma unroll
+#pragma unroll 1
             for (int u = 0; u < NU; ++u) {
                 float acc[1][2];
                 if (I4) mega_dots_i4<3, 1, MG_INTER>(cq + 6, cz + 6, xs[u], MG_INTER, lane, acc);
@@ -533,11 +528,13 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 if (u == 0) MG_STAMP(l, 21);  // w2 dots done
                 float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
                 if (I8) { t0 = i8_out(t0, sc_c); t1 = i8_out(t1, sc_c); }
-                const bf16_t y0 = epi_resid((bf16_t)hres[u], t0), y1 = epi_resid((bf16_t)(hres[u] >> 16), t1);
-                xres[u] = (uint32_t)y0 | ((uint32_t)y1 << 16);
+                const uint32_t hr = res_s[1][u][wave];
+                const bf16_t y0 = epi_resid((bf16_t)hr, t0), y1 = epi_resid((bf16_t)(hr >> 16), t1);
+                const uint32_t xr = (uint32_t)y0 | ((uint32_t)y1 << 16);
                 if (lane == 0) {
                     const int n = 8 * b + wave;
-                    gran_store(a.g_x + (size_t)u * MG_DIM + n, xres[u], tag0 + 4u);
+                    res_s[0][u][wave] = xr;
+                    gran_store(a.g_x + (size_t)u * MG_DIM + n, xr, tag0 + 4u);
                     if (u == 0) MG_STAMP(l, 10);
                     if (a.dbg && u == 0) { bf16_t* d = a.dbg + ((size_t)l * 5 + 4) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
                 }
@@ -560,7 +557,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                     else mega_issue_row<4>(wv + 4 * i, a.head, hn, MG_DIM, lane_o, a.ablate);
                 }
             }
-            nw_attn = load16((l + 1 < a.n_layer ? a.layers[l + 1].attn_norm : a.final_norm) + min(tid_o * 8, MG_DIM - 8));
+            nw_attn = load16((l + 1 < a.n_layer ? a.layers[l + 1].attn_norm : a.final_norm) + (tid_o & 255) * 8);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -571,7 +568,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     __syncthreads();
     if (MG_ABORTED()) return;
     mega_norm<NU>(xs, nw_attn, red, a.eps);
-#pragma unroll
+#pragma unroll 1
     for (int u = 0; u < NU; ++u) {
         float acc[2][2];
         if (I8) mega_dots_i8<2, 2, MG_DIM>(cq, xs[u], MG_DIM, lane, acc);

@@ -14,11 +14,12 @@ pos = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 args = mv.ModelArgs.from_name("metavoice-1B")
 cfgk = dict(n_layer=args.n_layer, n_head=args.n_head, dim=args.dim, vocab_size=args.vocab_size, block_size=args.block_size)
 sd = fiu.remap_checkpoint_keys(mv.synthetic.stage1_state_dict(seed=0, device="cuda", **cfgk))
-e = mv.Stage1Engine(args, max_utterances=1, quantisation_mode=os.environ.get("MV_QUANT") or None)
+NU = int(os.environ.get("MV_UTT", "1"))
+e = mv.Stage1Engine(args, max_utterances=NU, quantisation_mode=os.environ.get("MV_QUANT") or None)
 e.load_state_dict(sd); del sd
 e.finalize()
 e.tune(mega=int(os.environ.get("MV_MEGA", "1")))
-e.begin([mv.synthetic.prompt_tokens(pos, seed=0)], mv.synthetic.speaker_embedding(0), mv.SamplingParams(top_p=0.95), max_new_tokens=64,
+e.begin([mv.synthetic.prompt_tokens(pos, seed=u) for u in range(NU)], mv.synthetic.speaker_embedding(0).expand(NU, -1), mv.SamplingParams(top_p=0.95), max_new_tokens=64,
         end_of_audio_token=9999, prefill_mode=1)
 e.run(max_steps=32)
 print(f"32 steps at pos~{pos}: {e.last_run_ms / 32 * 1e3:.1f} us/step")
