@@ -189,6 +189,49 @@ int64_t mv_codec_samples(const mv_codec* c, int32_t frames);   /* frames x prod(
  * [hidden][frames], the summed codebook vectors (`decode_latent`, the diffusion decoder's conditioning). */
 int mv_codec_decode(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t frames, float* wav_out, float* latent_out);
 
+/* ---- multi-band diffusion vocoder: replaces `mbd.tokens_to_wav` after the codec decode (fam/llm/decoders.py:13,84-85 ->
+ * audiocraft==1.2.0 MultiBandDiffusion.generate / re_eq, third party): n_models DiffusionUnets (one per frequency band), n_eval
+ * evaluations each under the sub-sampled DDPM sampler, MultiBandProcessor.return_sample, sum, 32-band re-equalisation against the
+ * EnCodec decode.  Sizes come from the checkpoint's own cfg entries (host shim: metavoice-src_amd/mbd.py); tensor names are those of
+ * audiocraft's DiffusionUnet state dict ("encoders.0.conv.weight", "decoders.3.res_blocks.0.conv1.bias", "embeddings.1.weight", ...). */
+typedef struct mv_mbd mv_mbd;
+typedef struct mv_mbd_config {
+    int32_t n_models;        /* 4 bands                                               */
+    int32_t chin;            /* 1 (mono)                                              */
+    int32_t depth;           /* 4                                                     */
+    int32_t channels[8];     /* hidden * growth^i: 48, 192, 768, 3072                 */
+    int32_t kernel, stride;  /* 8, 4 (kernel must be 2 x stride)                      */
+    int32_t norm_groups;     /* 4                                                     */
+    int32_t res_blocks;      /* 1                                                     */
+    int32_t act;             /* 0 relu, 1 gelu, 2 silu                                */
+    int32_t codec_dim;       /* 128, or 0: unconditioned                              */
+    int32_t emb_all_layers;  /* step embedding on every encoder level                 */
+    int32_t bilstm;          /* BiLSTM bottleneck (without one the bottleneck is zeroed, as in audiocraft's forward) */
+    int32_t num_steps;       /* 1000 diffusion steps in the embedding tables          */
+    int32_t n_eval;          /* 20 evaluations (step_list 999, 949, ..., 49)          */
+    int32_t proc_bands;      /* 8  mel bands of MultiBandProcessor, 1 = no processor  */
+    int32_t eq_bands;        /* 32 mel bands of re_eq, 1 = no re-equalisation         */
+    int32_t precision;       /* MFMA terms per product: 1 bf16, 3 bf16 hi/lo split (~fp32) */
+} mv_mbd_config;
+int mv_mbd_create(const mv_mbd_config* cfg, mv_mbd** out);
+int mv_mbd_destroy(mv_mbd* m);
+int mv_mbd_load_weight(mv_mbd* m, int32_t band, const char* name, const float* data, int64_t numel);   /* host fp32, torch layouts */
+/* the scalars of NoiseSchedule.generate_subsampled for the n_eval evaluations: previous = (current - est_c * estimate) * inv_sqrt_alpha
+ * + sigma * noise, clamped to +-clip (0: none), times `rescale` after step 0 */
+int mv_mbd_set_schedule(mv_mbd* m, int32_t band, const int32_t* steps, const float* est_c, const float* inv_sqrt_alpha, const float* sigma,
+                        float clip, float rescale, float noise_scale);
+/* MultiBandProcessor.return_sample: band b of the model output times scale[b] plus mean[b] */
+int mv_mbd_set_processor(mv_mbd* m, int32_t band, int32_t n_bands, const float* scale, const float* mean);
+/* julius.LowPassFilters bank of SplitBands: which 0 = processor (proc_bands - 1 filters), 1 = re_eq (eq_bands - 1); taps odd */
+int mv_mbd_set_filterbank(mv_mbd* m, int32_t which, int32_t n_filters, int32_t taps, const float* coeffs);
+int mv_mbd_finalize(mv_mbd* m);
+/* latent: host fp32 [codec_dim][frames] (mv_codec_decode's latent_out); wav_ref: host fp32 [samples], the EnCodec decode (NULL: no
+ * re_eq); noise: host fp32 [n_models][n_eval + 1][samples] injected Gaussian draws (parity tests) or NULL = Philox stream of `seed` */
+int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float* wav_ref, int32_t samples, const float* noise, uint64_t seed,
+                    float* wav_out);
+/* parity hook: one DiffusionUnet evaluation of band `band` at diffusion step `step` on x host fp32 [samples] */
+int mv_mbd_unet_forward(mv_mbd* m, int32_t band, const float* x, int32_t samples, int32_t step, const float* latent, int32_t frames, float* out);
+
 /* ---- speaker encoder: replaces SpeakerEncoder.forward (fam/quantiser/audio/speaker_encoder/model.py:21-59): 3-layer LSTM over
  * 40-bin mel frames of the partial utterances, relu(Linear(h_T)), L2-normalised per partial.  Tensor names are those of
  * `checkpoint["model_state"]`: lstm.weight_ih_l0 ... lstm.bias_hh_l2, linear.weight, linear.bias (host fp32).  The mel front

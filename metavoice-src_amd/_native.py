@@ -48,6 +48,13 @@ class mv_codec_config(C.Structure):
     ]
 
 
+class mv_mbd_config(C.Structure):
+    _fields_ = [("n_models", C.c_int32), ("chin", C.c_int32), ("depth", C.c_int32), ("channels", C.c_int32 * 8), ("kernel", C.c_int32),
+                ("stride", C.c_int32), ("norm_groups", C.c_int32), ("res_blocks", C.c_int32), ("act", C.c_int32), ("codec_dim", C.c_int32),
+                ("emb_all_layers", C.c_int32), ("bilstm", C.c_int32), ("num_steps", C.c_int32), ("n_eval", C.c_int32), ("proc_bands", C.c_int32),
+                ("eq_bands", C.c_int32), ("precision", C.c_int32)]
+
+
 class mv_spkenc_config(C.Structure):
     _fields_ = [("n_mels", C.c_int32), ("hidden", C.c_int32), ("n_layers", C.c_int32), ("emb", C.c_int32)]
 
@@ -96,6 +103,18 @@ SYMBOLS = [
     ("mv_codec_finalize", C.c_int, [_P]),
     ("mv_codec_samples", C.c_int64, [_P, C.c_int32]),
     ("mv_codec_decode", C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("mv_mbd_create", C.c_int, [C.POINTER(mv_mbd_config), C.POINTER(_P)]),
+    ("mv_mbd_destroy", C.c_int, [_P]),
+    ("mv_mbd_load_weight", C.c_int, [_P, C.c_int32, C.c_char_p, C.POINTER(C.c_float), C.c_int64]),
+    ("mv_mbd_set_schedule", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                      C.c_float, C.c_float, C.c_float]),
+    ("mv_mbd_set_processor", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("mv_mbd_set_filterbank", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
+    ("mv_mbd_finalize", C.c_int, [_P]),
+    ("mv_mbd_generate", C.c_int, [_P, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.c_uint64,
+                                  C.POINTER(C.c_float)]),
+    ("mv_mbd_unet_forward", C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32,
+                                      C.POINTER(C.c_float)]),
     ("mv_spkenc_create", C.c_int, [C.POINTER(mv_spkenc_config), C.POINTER(_P)]),
     ("mv_spkenc_destroy", C.c_int, [_P]),
     ("mv_spkenc_load_weight", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_float), C.c_int64]),

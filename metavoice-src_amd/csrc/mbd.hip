@@ -1,0 +1,1052 @@
+// Multi-band diffusion vocoder on gfx950: the waveform stage the reference reaches through `mbd.tokens_to_wav`
+// (`fam/llm/decoders.py:13,84-85` -> audiocraft==1.2.0 `MultiBandDiffusion`, third party, not vendored, not installed here).
+// What is restated (oracle/mbd.py cites the published module graph): per band a `DiffusionUnet` -- depth x [strided Conv1d ->
+// GroupNorm -> act -> ResBlock] encoder, optional BiLSTM bottleneck, mirrored [ResBlock -> GroupNorm -> act -> ConvTranspose1d]
+// decoder with skip connections, step embeddings on the encoder layers, codec latent added at the bottleneck -- evaluated 20
+// times by the sub-sampled DDPM sampler; then the per-band affine of `MultiBandProcessor.return_sample`, the sum over the bands and
+// the 32-band re-equalisation against the EnCodec decode (`re_eq`).
+//
+// Mapping to the hardware.  Activations are CHANNELS-LAST fp32 [T][C]: a Conv1d(k, stride s) output row m is then the dot
+// product of the weight row with ONE CONTIGUOUS WINDOW of the input starting at row m s - pad (k rows x Cin channels), so every
+// convolution is a plain GEMM  C[M][N] = A[M][K] W[N][K]^T  whose A rows OVERLAP (lda = s Cin < K = k Cin) -- no im2col buffer.
+// A ConvTranspose1d with k = 2 s is the same with K = 2 Cin (rows q-1, q) and N = s Cout (the s output phases of step q).
+// 75 % of the FLOPs sit in the 3072-channel layers (M = 1200, N = 3072, K = 9216 at 12.8 s of audio): MFMA-bound, so the GEMM is
+// v_mfma_f32_16x16x32_bf16 on 128x128x64 tiles.  The reference asks for fp32 here (`autocast(dtype=float32)`, decoders.py:84);
+// bf16 operands alone would leave 8 mantissa bits, so operands are split hi + lo and the product is evaluated as
+// a_hi w_hi + a_hi w_lo + a_lo w_hi (three K-segments of one GEMM, fp32 accumulate): ~16 mantissa bits, past the TF32 that
+// cuDNN uses for the reference's convolutions by default.  `precision = 1` keeps only the first segment (bf16, 3x faster).
+// GroupNorm needs whole-layer statistics: a deterministic two-stage reduction, then one pass that normalises, applies the
+// activation and emits the bf16 hi / lo operands of the next convolution (padded with zero rows: the conv padding).
+// The thin ends (1 -> C first conv, C -> 1 last transposed conv), the DDPM update, the FIR band splits (julius.SplitBands:
+// windowed-sinc low-pass bank, replicate padding) and the band statistics are HBM-bound elementwise / stencil kernels.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+int mv_fail(int code, const char* fmt, ...);  // engine.hip
+
+#define MB_TRY(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess) return mv_fail(MV_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                             __FILE__, __LINE__);                                             \
+    } while (0)
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int MB_MAX_SEG = 12;   // K-segments of one GEMM: (conv taps when dilated) x (precision terms)
+constexpr int BM = 128, BN = 128, BK = 64;
+
+struct GemmSeg {
+    const bf16_t* a;   // first row of the A window of output row 0 for this segment
+    const bf16_t* w;   // [N][ldw] slice start
+    int K;             // multiple of 8
+};
+struct MbdGemmArgs {
+    GemmSeg seg[MB_MAX_SEG];
+    int n_seg = 0;
+    int M = 0, N = 0;
+    int64_t lda = 0;       // elements between the windows of consecutive output rows
+    int64_t ldw = 0;       // elements between weight rows
+    float* out = nullptr;  // [M][ldc]
+    int64_t ldc = 0;
+    const float* bias = nullptr;      // [N] or null
+    const float* residual = nullptr;  // [M][ldr] or null
+    int64_t ldr = 0;
+    const float* col_add = nullptr;   // [N] or null (step embedding)
+};
+
+// C = A W^T on 128 x 128 x 64 tiles, 256 threads = 4 waves (2 x 2), each wave 64 x 64 = 4 x 4 MFMA 16x16x32 tiles.
+// Staging as in gemm.hip: 16-byte chunks, XOR-swizzled by row, global -> registers -> LDS with the next K-tile's loads in flight
+// under the current tile's MFMAs.  Rows past M / N are clamped (duplicates) and dropped in the epilogue.
+__global__ void __launch_bounds__(256) mbd_gemm_kernel(const MbdGemmArgs a) {
+    __shared__ __attribute__((aligned(16))) u32x4 lds[2][BM * 8];  // A tile, W tile: [row][8 chunks of 16 B], chunk ^= row & 7
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile_m = blockIdx.y * BM, tile_n = blockIdx.x * BN;
+    const int M = a.M, N = a.N;
+    const int sr = tid >> 3, sc = tid & 7;  // thread stages chunk sc of rows sr + 32 i, i < 4
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+
+    for (int s = 0; s < a.n_seg; ++s) {
+        const GemmSeg sg = a.seg[s];
+        const bf16_t* ga[4];
+        const bf16_t* gw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ga[i] = sg.a + (size_t)min(tile_m + sr + 32 * i, M - 1) * a.lda + sc * 8;
+            gw[i] = sg.w + (size_t)min(tile_n + sr + 32 * i, N - 1) * a.ldw + sc * 8;
+        }
+        u32x4 ra[4], rw[4];
+        const bool in0 = sc * 8 < sg.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ra[i] = in0 ? load16(ga[i]) : zero; rw[i] = in0 ? load16(gw[i]) : zero; }
+        for (int k0 = 0; k0 < sg.K; k0 += BK) {
+            __syncthreads();  // everyone is done reading the previous tile
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = sr + 32 * i;
+                lds[0][r * 8 + (sc ^ (r & 7))] = ra[i];
+                lds[1][r * 8 + (sc ^ (r & 7))] = rw[i];
+            }
+            __syncthreads();
+            if (k0 + BK < sg.K) {
+                const bool in = k0 + BK + sc * 8 < sg.K;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ra[i] = in ? load16(ga[i] + k0 + BK) : zero; rw[i] = in ? load16(gw[i] + k0 + BK) : zero; }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t af[4], bf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = wm * 64 + i * 16 + (lane & 15);
+                    af[i] = __builtin_bit_cast(bf16x8_t, lds[0][r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = wn * 64 + j * 16 + (lane & 15);
+                    bf[j] = __builtin_bit_cast(bf16x8_t, lds[1][r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: C fragment (i, j): column lane & 15, rows (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = tile_n + wn * 64 + j * 16 + (lane & 15);
+            if (n >= N) continue;
+            const float add = (a.bias ? a.bias[n] : 0.f) + (a.col_add ? a.col_add[n] : 0.f);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int m = tile_m + wm * 64 + i * 16 + (lane >> 4) * 4 + reg;
+                if (m >= M) continue;
+                float y = acc[i][j][reg] + add;
+                if (a.residual) y += a.residual[(size_t)m * a.ldr + n];
+                a.out[(size_t)m * a.ldc + n] = y;
+            }
+        }
+}
+
+// ---- GroupNorm statistics: deterministic two stages ------------------------------------------------------------------------
+// stage 1: block (chunk c, group g) sums x and x^2 over rows [c * rows_per, ...) x channels of group g -> part[c][g][2] (double)
+__global__ void __launch_bounds__(256) gn_partial_kernel(const float* __restrict__ x, int T, int C, int G, int rows_per, double* __restrict__ part) {
+    __shared__ double red[2][4];
+    const int c = blockIdx.x, g = blockIdx.y, cg = C / G;
+    const int t0 = c * rows_per, t1 = min(T, t0 + rows_per);
+    double s = 0.0, s2 = 0.0;
+    const int n = (t1 - t0) * cg;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int t = t0 + i / cg, ch = g * cg + i % cg;
+        const float v = x[(size_t)t * C + ch];
+        s += v;
+        s2 += (double)v * v;
+    }
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); s2 += __shfl_down(s2, off, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((size_t)c * G + g) * 2 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        part[((size_t)c * G + g) * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+// stage 2: stats[g] = (mean, rstd) with the biased variance torch.nn.GroupNorm uses
+__global__ void gn_final_kernel(const double* __restrict__ part, int n_chunks, int G, double count, float eps, float* __restrict__ stats) {
+    const int g = threadIdx.x;
+    if (g >= G) return;
+    double s = 0.0, s2 = 0.0;
+    for (int c = 0; c < n_chunks; ++c) { s += part[((size_t)c * G + g) * 2]; s2 += part[((size_t)c * G + g) * 2 + 1]; }
+    const double mean = s / count;
+    const double var = fmax(s2 / count - mean * mean, 0.0);
+    stats[2 * g] = (float)mean;
+    stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__device__ __forceinline__ float mb_act(float v, int act) {
+    if (act == 0) return fmaxf(v, 0.f);                                            // relu
+    if (act == 1) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));      // gelu (exact)
+    return v / (1.0f + expf(-v));                                                  // silu
+}
+
+// y = act(gn(x)) (stats == null: y = x), written as fp32 [T][C] (optional) and as the bf16 hi / lo operands of the next
+// convolution, rows shifted by `row0` inside a zero-margined buffer
+__global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__ x, size_t n, int C, int G, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                       float* __restrict__ y32, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, size_t row0) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = x[i];
+    if (stats) {
+        const int ch = (int)(i % C), g = ch / (C / G);
+        v = (v - stats[2 * g]) * stats[2 * g + 1] * gamma[ch] + beta[ch];
+        v = mb_act(v, act);
+    }
+    if (y32) y32[i] = v;
+    if (hi) {
+        const bf16_t h = f2bf(v);
+        hi[row0 * C + i] = h;
+        if (lo) lo[row0 * C + i] = f2bf(v - bf2f(h));
+    }
+}
+
+// first encoder convolution, 1 -> C channels: out[m][c] = sum_k w[c][k] x[m s + k - pad]   (zero padding, no bias)
+__global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ x, int T, const float* __restrict__ w, int C, int k, int s, int pad,
+                                                      float* __restrict__ out, int M) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * C) return;
+    const int m = (int)(i / C), c = (int)(i % C);
+    float acc = 0.f;
+    for (int j = 0; j < k; ++j) {
+        const int t = m * s + j - pad;
+        if (t >= 0 && t < T) acc = fmaf(w[c * k + j], x[t], acc);
+    }
+    out[i] = acc;
+}
+// last decoder transposed convolution, C -> 1 channel: out[t'] = sum_c sum_{(t, j): t s + j - pad = t'} x[t][c] w[c][j]
+__global__ void __launch_bounds__(256) convtr_out_kernel(const float* __restrict__ x, int Tin, int C, const float* __restrict__ w, int k, int s,
+                                                         int pad, float* __restrict__ out, int Tout) {
+    const int tp = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tp >= Tout) return;
+    float acc = 0.f;
+    for (int j = (tp + pad) % s; j < k; j += s) {
+        const int t = (tp + pad - j) / s;
+        if (t < 0 || t >= Tin) continue;
+        for (int c = lane; c < C; c += 64) acc = fmaf(x[(size_t)t * C + c], w[c * k + j], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[tp] = acc;
+}
+
+// z[t][c] = skip[t][c] (+ add[t][c])                      (decoder: z = z[:, :, :skip.T] + skip; the first z is zero or the LSTM's)
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] + (b ? b[i] : 0.f);
+}
+// bottleneck conditioning: z[t][c] += cond[nearest(t)][c], cond = conv_codec(latent) evaluated here (1x1 conv, codec_dim -> C):
+// one block per bottleneck row
+__global__ void __launch_bounds__(256) cond_add_kernel(float* __restrict__ z, int Tz, int C, const float* __restrict__ latent, int frames, int D,
+                                                       const float* __restrict__ w, const float* __restrict__ bias) {
+    extern __shared__ float lat[];
+    const int t = blockIdx.x;
+    const int f = min((int)floorf((float)t * ((float)frames / (float)Tz)), frames - 1);  // F.interpolate(mode="nearest")
+    for (int d = threadIdx.x; d < D; d += 256) lat[d] = latent[(size_t)d * frames + f];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = bias[c];
+        for (int d = 0; d < D; ++d) acc = fmaf(w[(size_t)c * D + d], lat[d], acc);
+        z[(size_t)t * C + c] += acc;
+    }
+}
+
+// DDPM step: cur = clamp((cur - est_c * estimate) * inv_sqrt_alpha + sigma * noise, -clip, clip) [* rescale on the last step]
+__device__ __forceinline__ uint32_t mb_philox(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t* second) {
+    uint32_t x0 = c0, x1 = c1, x2 = 0x6d626421u, x3 = 0u;
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * x0, p1 = (uint64_t)0xCD9E8D57u * x2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1, n3 = (uint32_t)p0;
+        x0 = n0; x1 = n1; x2 = n2; x3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    *second = x1;
+    return x0;
+}
+__device__ __forceinline__ float mb_gauss(uint64_t seed, uint32_t stream, uint32_t i) {
+    uint32_t b;
+    const uint32_t a = mb_philox(i, stream, (uint32_t)seed, (uint32_t)(seed >> 32), &b);
+    const float u1 = ((a >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = ((b >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+__global__ void ddpm_kernel(float* __restrict__ cur, const float* __restrict__ est, const float* __restrict__ noise, int T, float est_c,
+                            float inv_sqrt_alpha, float sigma, float noise_scale, float clip, float rescale, uint64_t seed, uint32_t stream) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T) return;
+    float v = (cur[i] - est_c * (est[i] * noise_scale)) * inv_sqrt_alpha;
+    if (sigma > 0.f) v += sigma * (noise ? noise[i] : mb_gauss(seed, stream, (uint32_t)i)) * noise_scale;
+    if (clip > 0.f) v = fminf(fmaxf(v, -clip), clip);
+    cur[i] = v * rescale;
+}
+__global__ void init_noise_kernel(float* __restrict__ cur, const float* __restrict__ noise, int T, float noise_scale, uint64_t seed, uint32_t stream) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < T) cur[i] = (noise ? noise[i] : mb_gauss(seed, stream, (uint32_t)i)) * noise_scale;
+}
+
+// julius.LowPassFilters: low[f][t] = sum_j bank[f][j] x[clamp(t + j - half)]  (replicate padding).  Block = 256 outputs of one
+// filter; the input tile with its halo and the taps sit in LDS (the taps are a broadcast read).
+__global__ void __launch_bounds__(256) fir_bank_kernel(const float* __restrict__ x, int T, const float* __restrict__ bank, int taps,
+                                                       float* __restrict__ low) {
+    extern __shared__ float sh[];  // [256 + taps - 1] input, then [taps] filter
+    const int f = blockIdx.y, t0 = blockIdx.x * 256, half = (taps - 1) / 2;
+    float* xs = sh;
+    float* fs = sh + 256 + taps - 1;
+    for (int i = threadIdx.x; i < 256 + taps - 1; i += 256) xs[i] = x[min(max(t0 + i - half, 0), T - 1)];
+    for (int i = threadIdx.x; i < taps; i += 256) fs[i] = bank[(size_t)f * taps + i];
+    __syncthreads();
+    const int t = t0 + threadIdx.x;
+    if (t >= T) return;
+    float acc = 0.f;
+    for (int j = 0; j < taps; ++j) acc = fmaf(fs[j], xs[threadIdx.x + j], acc);
+    low[(size_t)f * T + t] = acc;
+}
+// bands from the low-passes in place: band[0] = low[0], band[i] = low[i] - low[i-1], band[n-1] = x - low[n-2]   (SplitBands.forward)
+__global__ void bands_kernel(const float* __restrict__ x, const float* __restrict__ low, int T, int n_bands, float* __restrict__ bands) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    float prev = 0.f;
+    for (int b = 0; b < n_bands - 1; ++b) {
+        const float l = low[(size_t)b * T + t];
+        bands[(size_t)b * T + t] = l - prev;
+        prev = l;
+    }
+    bands[(size_t)(n_bands - 1) * T + t] = x[t] - prev;
+}
+// per-band sum and sum of squares (double), one block per band
+__global__ void __launch_bounds__(1024) band_stats_kernel(const float* __restrict__ bands, int T, double* __restrict__ out) {
+    __shared__ double red[2][16];
+    const int b = blockIdx.x;
+    double s = 0.0, s2 = 0.0;
+    for (int t = threadIdx.x; t < T; t += 1024) {
+        const float v = bands[(size_t)b * T + t];
+        s += v;
+        s2 += (double)v * v;
+    }
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); s2 += __shfl_down(s2, off, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, c = 0.0;
+        for (int w = 0; w < 16; ++w) { a += red[0][w]; c += red[1][w]; }
+        out[2 * b] = a;
+        out[2 * b + 1] = c;
+    }
+}
+// out[t] (+)= sum_b bands[b][t] * scale[b] + shift[b]
+__global__ void band_mix_kernel(const float* __restrict__ bands, int T, int n_bands, const float* __restrict__ scale, const float* __restrict__ shift,
+                                float* __restrict__ out, int accumulate) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    float acc = accumulate ? out[t] : 0.f;
+    for (int b = 0; b < n_bands; ++b) acc += bands[(size_t)b * T + t] * scale[b] + (shift ? shift[b] : 0.f);
+    out[t] = acc;
+}
+// re_eq scales: scale[b] = std_ref[b] / std_wav[b] with the unbiased std torch.Tensor.std() uses
+__global__ void eq_scale_kernel(const double* __restrict__ st_wav, const double* __restrict__ st_ref, int n_bands, double T, float* __restrict__ scale) {
+    const int b = threadIdx.x;
+    if (b >= n_bands) return;
+    auto sd = [&](const double* st) { const double m = st[2 * b] / T; return sqrt(fmax((st[2 * b + 1] - T * m * m) / (T - 1.0), 0.0)); };
+    scale[b] = (float)(sd(st_ref) / sd(st_wav));
+}
+
+struct ConvW {   // one convolution as a GEMM: bf16 hi / lo weights [N][Ktot] (tap-major K), fp32 bias
+    bf16_t *hi = nullptr, *lo = nullptr;
+    float* bias = nullptr;
+    int N = 0, Ktot = 0;
+    bool loaded_w = false, loaded_b = false, has_bias = false;
+};
+struct NormW { float *g = nullptr, *b = nullptr; bool lg = false, lb = false; };
+struct ResW { NormW n1, n2; ConvW c1, c2; };
+struct EncW { float* conv_in_w = nullptr; bool conv_in_loaded = false; ConvW conv; NormW norm; std::vector<ResW> res; float* emb = nullptr; bool emb_loaded = false; };
+struct DecW { std::vector<ResW> res; NormW norm; ConvW convtr; float* convtr_out_w = nullptr; bool convtr_out_loaded = false; };
+struct LstmW { std::vector<float*> w_ih, w_hh, bias; std::vector<std::vector<float>> bias_host; std::vector<int> loaded; float *lin_w = nullptr, *lin_b = nullptr; int lin_loaded = 0; };
+struct BandW {
+    std::vector<EncW> enc;
+    std::vector<DecW> dec;
+    float *codec_w = nullptr, *codec_b = nullptr;
+    int codec_loaded = 0;
+    LstmW lstm;
+    // schedule (host): per evaluation step id, est coefficient, 1/sqrt(alpha), sigma
+    std::vector<int> steps;
+    std::vector<float> est_c, inv_sqrt_alpha, sigma;
+    float clip = 5.f, rescale = 1.f, noise_scale = 1.f;
+    // MultiBandProcessor.return_sample: band * scale + mean over proc_bands mel bands (scale empty: no processor)
+    std::vector<float> proc_scale, proc_mean;
+};
+
+}  // namespace
+
+struct mv_mbd {
+    mv_mbd_config cfg{};
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;
+    std::vector<BandW> band;
+    std::vector<int> ch;                     // channels per encoder level
+    float *proc_bank = nullptr, *eq_bank = nullptr;  // device FIR banks [n-1][taps]
+    int proc_taps = 0, eq_taps = 0;
+    bool finalized = false;
+    // LSTM scratch (bottleneck BiLSTM)
+    unsigned long long* lstm_hx = nullptr;
+    uint32_t* lstm_abort = nullptr;
+    uint32_t lstm_serial = 0;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(mv_mbd* m, T** p, size_t count) {
+    if (hipMalloc((void**)p, count * sizeof(T) + 64) != hipSuccess) return mv_fail(MV_ERR_HIP, "hipMalloc of %zu bytes failed", count * sizeof(T));
+    m->allocs.push_back(*p);
+    return MV_OK;
+}
+
+int upload_f32(mv_mbd* m, float** dst, const float* src, size_t n) {
+    if (!*dst) { const int rc = dev_alloc(m, dst, n); if (rc != MV_OK) return rc; }
+    MB_TRY(hipMemcpy(*dst, src, n * 4, hipMemcpyHostToDevice));
+    return MV_OK;
+}
+
+inline bf16_t host_f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+inline float host_bf2f(bf16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+
+// host re-layout of a convolution weight into [N][Ktot] rows + hi / lo split, then upload
+int upload_gemm_weight(mv_mbd* m, ConvW& cw, const std::vector<float>& rows, int N, int Ktot) {
+    std::vector<bf16_t> hi(rows.size()), lo(rows.size());
+    for (size_t i = 0; i < rows.size(); ++i) {
+        hi[i] = host_f2bf(rows[i]);
+        lo[i] = host_f2bf(rows[i] - host_bf2f(hi[i]));
+    }
+    cw.N = N; cw.Ktot = Ktot;
+    if (!cw.hi) { int rc = dev_alloc(m, &cw.hi, rows.size()); if (rc != MV_OK) return rc; rc = dev_alloc(m, &cw.lo, rows.size()); if (rc != MV_OK) return rc; }
+    MB_TRY(hipMemcpy(cw.hi, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
+    MB_TRY(hipMemcpy(cw.lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+    cw.loaded_w = true;
+    return MV_OK;
+}
+
+// per-run device workspace
+struct Work {
+    std::vector<void*> allocs;
+    ~Work() { for (void* p : allocs) (void)hipFree(p); }
+    template <typename T> hipError_t get(T** p, size_t count, bool zero) {
+        hipError_t e = hipMalloc((void**)p, count * sizeof(T) + 64);
+        if (e != hipSuccess) return e;
+        allocs.push_back(*p);
+        return zero ? hipMemset(*p, 0, count * sizeof(T) + 64) : hipSuccess;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int mv_mbd_create(const mv_mbd_config* cfg, mv_mbd** out) {
+    if (!cfg || !out) return mv_fail(MV_ERR_INVALID, "mv_mbd_create: null argument");
+    const mv_mbd_config& g = *cfg;
+    if (g.n_models < 1 || g.n_models > 8 || g.depth < 1 || g.depth > 8 || g.kernel != 2 * g.stride || g.stride < 2 || g.norm_groups < 1 ||
+        g.res_blocks < 0 || g.res_blocks > 4 || g.chin != 1 || g.act < 0 || g.act > 2 || g.n_eval < 1 || g.n_eval > 1000 || g.precision < 1 || g.precision > 3)
+        return mv_fail(MV_ERR_INVALID, "mv_mbd_create: unsupported configuration (kernel must be 2 x stride, chin 1)");
+    for (int i = 0; i < g.depth; ++i)
+        if (g.channels[i] < 8 || g.channels[i] % 8 || g.channels[i] % g.norm_groups)
+            return mv_fail(MV_ERR_INVALID, "mv_mbd_create: channel count %d must be a multiple of 8 and of norm_groups", g.channels[i]);
+    if (g.bilstm && (g.channels[g.depth - 1] % 8 || lstm_seq_lds_bytes(1, g.channels[g.depth - 1]) > 160 * 1024 - 256))
+        return mv_fail(MV_ERR_INVALID, "mv_mbd_create: BiLSTM width %d not supported", g.channels[g.depth - 1]);
+    mv_mbd* m = new mv_mbd();
+    m->cfg = g;
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return mv_fail(MV_ERR_HIP, "stream creation failed"); }
+    m->ch.assign(g.channels, g.channels + g.depth);
+    m->band.resize(g.n_models);
+    for (auto& b : m->band) {
+        b.enc.resize(g.depth);
+        b.dec.resize(g.depth);
+        for (auto& e : b.enc) e.res.resize(g.res_blocks);
+        for (auto& d : b.dec) d.res.resize(g.res_blocks);
+        if (g.bilstm) {
+            b.lstm.w_ih.assign(4, nullptr); b.lstm.w_hh.assign(4, nullptr); b.lstm.bias.assign(4, nullptr);   // (layer, direction) = l * 2 + d
+            b.lstm.bias_host.assign(4, std::vector<float>());
+            b.lstm.loaded.assign(4, 0);
+        }
+    }
+    *out = m;
+    return MV_OK;
+}
+
+int mv_mbd_destroy(mv_mbd* m) {
+    if (!m) return MV_OK;
+    for (void* p : m->allocs) (void)hipFree(p);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+    return MV_OK;
+}
+
+// Tensor names are those of audiocraft's DiffusionUnet state dict:
+//   encoders.{i}.conv.weight [Cout][Cin][k] | encoders.{i}.norm.{weight,bias} | encoders.{i}.res_blocks.{r}.{norm1,norm2}.{weight,bias} |
+//   encoders.{i}.res_blocks.{r}.{conv1,conv2}.{weight,bias} | decoders.{i}.res_blocks... | decoders.{i}.norm.* | decoders.{i}.convtr.weight
+//   [Cin][Cout][k] | embedding.weight, embeddings.{i}.weight [num_steps][C] | conv_codec.{weight,bias} |
+//   bilstm.lstm.{weight,bias}_{ih,hh}_l{0,1}[_reverse], bilstm.linear.{weight,bias}
+int mv_mbd_load_weight(mv_mbd* m, int32_t band_idx, const char* name, const float* data, int64_t numel) {
+    if (!m || !name || !data) return mv_fail(MV_ERR_INVALID, "mv_mbd_load_weight: null argument");
+    if (band_idx < 0 || band_idx >= m->cfg.n_models) return mv_fail(MV_ERR_INVALID, "band %d out of range", band_idx);
+    const mv_mbd_config& g = m->cfg;
+    BandW& B = m->band[band_idx];
+    const int k = g.kernel, s = g.stride;
+    int i = -1, r = -1;
+    char leaf[64];
+    auto chan_in = [&](int lvl) { return lvl == 0 ? g.chin : m->ch[lvl - 1]; };
+    auto want = [&](int64_t n) -> int { return numel == n ? MV_OK : mv_fail(MV_ERR_INVALID, "%s: expected %lld elements, got %lld", name, (long long)n, (long long)numel); };
+    auto load_norm = [&](NormW& nw, bool is_w, int C) -> int {
+        int rc = want(C);
+        if (rc != MV_OK) return rc;
+        rc = upload_f32(m, is_w ? &nw.g : &nw.b, data, C);
+        if (rc == MV_OK) (is_w ? nw.lg : nw.lb) = true;
+        return rc;
+    };
+    auto load_res = [&](ResW& rw, const char* lf, int C) -> int {
+        if (!strcmp(lf, "norm1.weight")) return load_norm(rw.n1, true, C);
+        if (!strcmp(lf, "norm1.bias")) return load_norm(rw.n1, false, C);
+        if (!strcmp(lf, "norm2.weight")) return load_norm(rw.n2, true, C);
+        if (!strcmp(lf, "norm2.bias")) return load_norm(rw.n2, false, C);
+        const bool c1 = !strncmp(lf, "conv1.", 6);
+        ConvW& cw = c1 ? rw.c1 : rw.c2;
+        if (!strcmp(lf + 6, "weight")) {  // [C][C][3] -> [C][3 C] tap-major
+            int rc = want((int64_t)C * C * 3);
+            if (rc != MV_OK) return rc;
+            std::vector<float> rows((size_t)C * 3 * C);
+            for (int co = 0; co < C; ++co)
+                for (int ci = 0; ci < C; ++ci)
+                    for (int j = 0; j < 3; ++j) rows[(size_t)co * 3 * C + (size_t)j * C + ci] = data[((size_t)co * C + ci) * 3 + j];
+            return upload_gemm_weight(m, cw, rows, C, 3 * C);
+        }
+        if (!strcmp(lf + 6, "bias")) {
+            int rc = want(C);
+            if (rc != MV_OK) return rc;
+            rc = upload_f32(m, &cw.bias, data, C);
+            if (rc == MV_OK) { cw.loaded_b = true; cw.has_bias = true; }
+            return rc;
+        }
+        return mv_fail(MV_ERR_INVALID, "unknown tensor %s", name);
+    };
+    if (sscanf(name, "encoders.%d.res_blocks.%d.%63s", &i, &r, leaf) == 3) {
+        if (i < 0 || i >= g.depth || r < 0 || r >= g.res_blocks) return mv_fail(MV_ERR_INVALID, "%s: index out of range", name);
+        return load_res(B.enc[i].res[r], leaf, m->ch[i]);
+    }
+    if (sscanf(name, "decoders.%d.res_blocks.%d.%63s", &i, &r, leaf) == 3) {
+        if (i < 0 || i >= g.depth || r < 0 || r >= g.res_blocks) return mv_fail(MV_ERR_INVALID, "%s: index out of range", name);
+        return load_res(B.dec[i].res[r], leaf, m->ch[g.depth - 1 - i]);  // decoders run from the bottleneck outwards
+    }
+    if (sscanf(name, "encoders.%d.%63s", &i, leaf) == 2) {
+        if (i < 0 || i >= g.depth) return mv_fail(MV_ERR_INVALID, "%s: index out of range", name);
+        EncW& e = B.enc[i];
+        const int Cin = chan_in(i), Cout = m->ch[i];
+        if (!strcmp(leaf, "norm.weight")) return load_norm(e.norm, true, Cout);
+        if (!strcmp(leaf, "norm.bias")) return load_norm(e.norm, false, Cout);
+        if (!strcmp(leaf, "conv.weight")) {
+            int rc = want((int64_t)Cout * Cin * k);
+            if (rc != MV_OK) return rc;
+            if (i == 0) { rc = upload_f32(m, &e.conv_in_w, data, (size_t)numel); if (rc == MV_OK) e.conv_in_loaded = true; return rc; }
+            std::vector<float> rows((size_t)Cout * k * Cin);
+            for (int co = 0; co < Cout; ++co)
+                for (int ci = 0; ci < Cin; ++ci)
+                    for (int j = 0; j < k; ++j) rows[(size_t)co * k * Cin + (size_t)j * Cin + ci] = data[((size_t)co * Cin + ci) * k + j];
+            return upload_gemm_weight(m, e.conv, rows, Cout, k * Cin);
+        }
+        return mv_fail(MV_ERR_INVALID, "unknown tensor %s", name);
+    }
+    if (sscanf(name, "decoders.%d.%63s", &i, leaf) == 2) {
+        if (i < 0 || i >= g.depth) return mv_fail(MV_ERR_INVALID, "%s: index out of range", name);
+        DecW& d = B.dec[i];
+        const int lvl = g.depth - 1 - i, Cin = m->ch[lvl], Cout = chan_in(lvl);
+        if (!strcmp(leaf, "norm.weight")) return load_norm(d.norm, true, Cin);
+        if (!strcmp(leaf, "norm.bias")) return load_norm(d.norm, false, Cin);
+        if (!strcmp(leaf, "convtr.weight")) {  // [Cin][Cout][k]
+            int rc = want((int64_t)Cin * Cout * k);
+            if (rc != MV_OK) return rc;
+            if (lvl == 0) { rc = upload_f32(m, &d.convtr_out_w, data, (size_t)numel); if (rc == MV_OK) d.convtr_out_loaded = true; return rc; }
+            // GEMM row (p, co), K = [tap x[q-1] : kernel index p + s | tap x[q] : kernel index p]
+            std::vector<float> rows((size_t)s * Cout * 2 * Cin);
+            for (int p = 0; p < s; ++p)
+                for (int co = 0; co < Cout; ++co)
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        const size_t row = (size_t)p * Cout + co;
+                        rows[row * 2 * Cin + ci] = data[((size_t)ci * Cout + co) * k + p + s];
+                        rows[row * 2 * Cin + Cin + ci] = data[((size_t)ci * Cout + co) * k + p];
+                    }
+            return upload_gemm_weight(m, d.convtr, rows, s * Cout, 2 * Cin);
+        }
+        return mv_fail(MV_ERR_INVALID, "unknown tensor %s", name);
+    }
+    if (!strcmp(name, "embedding.weight") || sscanf(name, "embeddings.%d.weight", &i) == 1) {
+        const int lvl = !strcmp(name, "embedding.weight") ? 0 : i + 1;
+        if (lvl < 0 || lvl >= g.depth) return mv_fail(MV_ERR_INVALID, "%s: level out of range", name);
+        int rc = want((int64_t)g.num_steps * m->ch[lvl]);
+        if (rc != MV_OK) return rc;
+        rc = upload_f32(m, &B.enc[lvl].emb, data, (size_t)numel);
+        if (rc == MV_OK) B.enc[lvl].emb_loaded = true;
+        return rc;
+    }
+    if (!strcmp(name, "conv_codec.weight") || !strcmp(name, "conv_codec.bias")) {
+        if (g.codec_dim <= 0) return MV_OK;
+        const bool w = name[11] == 'w';
+        const int Cb = m->ch[g.depth - 1];
+        int rc = want(w ? (int64_t)Cb * g.codec_dim : Cb);
+        if (rc != MV_OK) return rc;
+        rc = upload_f32(m, w ? &B.codec_w : &B.codec_b, data, (size_t)numel);
+        if (rc == MV_OK) B.codec_loaded |= w ? 1 : 2;
+        return rc;
+    }
+    if (!strncmp(name, "bilstm.", 7)) {
+        if (!g.bilstm) return mv_fail(MV_ERR_INVALID, "%s: this configuration has no BiLSTM", name);
+        const int H = m->ch[g.depth - 1];
+        char kind[8], lf[4], rev[16] = "";
+        int l = -1;
+        if (!strcmp(name, "bilstm.linear.weight")) { int rc = want((int64_t)H * 2 * H); if (rc == MV_OK) rc = upload_f32(m, &B.lstm.lin_w, data, (size_t)numel); if (rc == MV_OK) B.lstm.lin_loaded |= 1; return rc; }
+        if (!strcmp(name, "bilstm.linear.bias")) { int rc = want(H); if (rc == MV_OK) rc = upload_f32(m, &B.lstm.lin_b, data, (size_t)numel); if (rc == MV_OK) B.lstm.lin_loaded |= 2; return rc; }
+        const int nf = sscanf(name, "bilstm.lstm.%7[a-z]_%2[a-z]_l%d%15s", kind, lf, &l, rev);
+        if (nf < 3 || l < 0 || l > 1) return mv_fail(MV_ERR_INVALID, "unknown tensor %s", name);
+        const int d = (nf == 4 && !strcmp(rev, "_reverse")) ? 1 : 0, slot = l * 2 + d;
+        const bool ih = !strcmp(lf, "ih");
+        const int I = l == 0 ? H : 2 * H;
+        if (!strcmp(kind, "weight")) {
+            int rc = want((int64_t)4 * H * (ih ? I : H));
+            if (rc != MV_OK) return rc;
+            rc = upload_f32(m, ih ? &B.lstm.w_ih[slot] : &B.lstm.w_hh[slot], data, (size_t)numel);
+            if (rc == MV_OK) B.lstm.loaded[slot] |= ih ? 1 : 2;
+            return rc;
+        }
+        int rc = want(4 * H);
+        if (rc != MV_OK) return rc;
+        if (B.lstm.bias_host[slot].empty()) B.lstm.bias_host[slot].assign((size_t)4 * H, 0.f);
+        for (int q = 0; q < 4 * H; ++q) B.lstm.bias_host[slot][q] += data[q];
+        B.lstm.loaded[slot] |= ih ? 4 : 8;
+        return MV_OK;
+    }
+    return mv_fail(MV_ERR_INVALID, "unknown multi-band-diffusion tensor %s", name);
+}
+
+int mv_mbd_set_schedule(mv_mbd* m, int32_t band_idx, const int32_t* steps, const float* est_c, const float* inv_sqrt_alpha, const float* sigma,
+                        float clip, float rescale, float noise_scale) {
+    if (!m || band_idx < 0 || band_idx >= m->cfg.n_models || !steps || !est_c || !inv_sqrt_alpha || !sigma) return mv_fail(MV_ERR_INVALID, "mv_mbd_set_schedule: bad argument");
+    BandW& B = m->band[band_idx];
+    const int n = m->cfg.n_eval;
+    B.steps.assign(steps, steps + n); B.est_c.assign(est_c, est_c + n); B.inv_sqrt_alpha.assign(inv_sqrt_alpha, inv_sqrt_alpha + n); B.sigma.assign(sigma, sigma + n);
+    for (int i = 0; i < n; ++i)
+        if (steps[i] < 0 || steps[i] >= m->cfg.num_steps) return mv_fail(MV_ERR_INVALID, "mv_mbd_set_schedule: step %d out of range", steps[i]);
+    B.clip = clip; B.rescale = rescale; B.noise_scale = noise_scale;
+    return MV_OK;
+}
+
+int mv_mbd_set_processor(mv_mbd* m, int32_t band_idx, int32_t n_bands, const float* scale, const float* mean) {
+    if (!m || band_idx < 0 || band_idx >= m->cfg.n_models || n_bands != m->cfg.proc_bands || !scale || !mean) return mv_fail(MV_ERR_INVALID, "mv_mbd_set_processor: bad argument");
+    m->band[band_idx].proc_scale.assign(scale, scale + n_bands);
+    m->band[band_idx].proc_mean.assign(mean, mean + n_bands);
+    return MV_OK;
+}
+
+int mv_mbd_set_filterbank(mv_mbd* m, int32_t which, int32_t n_filters, int32_t taps, const float* coeffs) {
+    if (!m || !coeffs || taps < 1 || taps % 2 == 0 || taps > 8191) return mv_fail(MV_ERR_INVALID, "mv_mbd_set_filterbank: bad argument");
+    const int want = (which == 0 ? m->cfg.proc_bands : m->cfg.eq_bands) - 1;
+    if (n_filters != want) return mv_fail(MV_ERR_INVALID, "mv_mbd_set_filterbank: expected %d filters, got %d", want, n_filters);
+    float** dst = which == 0 ? &m->proc_bank : &m->eq_bank;
+    *dst = nullptr;
+    const int rc = upload_f32(m, dst, coeffs, (size_t)n_filters * taps);
+    if (rc != MV_OK) return rc;
+    (which == 0 ? m->proc_taps : m->eq_taps) = taps;
+    return MV_OK;
+}
+
+int mv_mbd_finalize(mv_mbd* m) {
+    if (!m) return mv_fail(MV_ERR_INVALID, "mv_mbd_finalize: null");
+    const mv_mbd_config& g = m->cfg;
+    for (int bi = 0; bi < g.n_models; ++bi) {
+        BandW& B = m->band[bi];
+        auto norm_ok = [](const NormW& n) { return n.lg && n.lb; };
+        auto res_ok = [&](const ResW& r) { return norm_ok(r.n1) && norm_ok(r.n2) && r.c1.loaded_w && r.c1.loaded_b && r.c2.loaded_w && r.c2.loaded_b; };
+        for (int i = 0; i < g.depth; ++i) {
+            const EncW& e = B.enc[i];
+            bool ok = (i == 0 ? e.conv_in_loaded : e.conv.loaded_w) && norm_ok(e.norm);
+            for (const auto& r : e.res) ok = ok && res_ok(r);
+            if (i == 0 || g.emb_all_layers) ok = ok && e.emb_loaded;
+            const DecW& d = B.dec[i];
+            const int lvl = g.depth - 1 - i;
+            ok = ok && (lvl == 0 ? d.convtr_out_loaded : d.convtr.loaded_w) && norm_ok(d.norm);
+            for (const auto& r : d.res) ok = ok && res_ok(r);
+            if (!ok) return mv_fail(MV_ERR_MISSING_WEIGHT, "multi-band diffusion: band %d level %d has missing tensors", bi, i);
+        }
+        if (g.codec_dim > 0 && g.bilstm && B.codec_loaded != 3) return mv_fail(MV_ERR_MISSING_WEIGHT, "band %d: conv_codec missing", bi);
+        if (g.bilstm) {
+            const int H = m->ch[g.depth - 1];
+            for (int sl = 0; sl < 4; ++sl) {
+                if (B.lstm.loaded[sl] != 15) return mv_fail(MV_ERR_MISSING_WEIGHT, "band %d: BiLSTM tensors incomplete", bi);
+                B.lstm.bias[sl] = nullptr;
+                const int rc = upload_f32(m, &B.lstm.bias[sl], B.lstm.bias_host[sl].data(), (size_t)4 * H);
+                if (rc != MV_OK) return rc;
+            }
+            if (B.lstm.lin_loaded != 3) return mv_fail(MV_ERR_MISSING_WEIGHT, "band %d: bilstm.linear missing", bi);
+        }
+        if ((int)B.steps.size() != g.n_eval) return mv_fail(MV_ERR_STATE, "band %d: mv_mbd_set_schedule not called", bi);
+        if (g.proc_bands > 1 && (int)B.proc_scale.size() != g.proc_bands) return mv_fail(MV_ERR_STATE, "band %d: mv_mbd_set_processor not called", bi);
+    }
+    if (g.proc_bands > 1 && !m->proc_bank) return mv_fail(MV_ERR_STATE, "processor filter bank not set");
+    if (g.eq_bands > 1 && !m->eq_bank) return mv_fail(MV_ERR_STATE, "re-equalisation filter bank not set");
+    if (g.bilstm) {
+        const int H = m->ch[g.depth - 1];
+        int rc = dev_alloc(m, &m->lstm_hx, (size_t)2 * H);
+        if (rc != MV_OK) return rc;
+        MB_TRY(hipMemset(m->lstm_hx, 0, (size_t)2 * H * 8));
+        rc = dev_alloc(m, &m->lstm_abort, 1);
+        if (rc != MV_OK) return rc;
+        MB_TRY(hipMemset(m->lstm_abort, 0, 4));
+    }
+    m->finalized = true;
+    return MV_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// everything one band's 20 evaluations need, allocated once per mv_mbd_generate call
+struct UnetBuffers {
+    std::vector<int> T;                    // length at every encoder level (after the strided conv)
+    std::vector<int> Tpad;                 // input length of level i padded to a multiple of the stride
+    std::vector<float*> skip;              // encoder outputs [T_i][C_i]
+    float *a32 = nullptr, *b32 = nullptr, *c32 = nullptr;   // fp32 scratch, widest layer
+    bf16_t *hi = nullptr, *lo = nullptr;   // bf16 conv operand with zero margins, widest layer
+    double* part = nullptr;
+    float* stats = nullptr;
+    float* dec_out = nullptr;              // transposed-conv output with s/2 margin rows on both sides
+    size_t widest = 0;
+};
+
+hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, MbdGemmArgs& g, const bf16_t* a_hi, const bf16_t* a_lo, const ConvW& w, int taps, int64_t tap_stride,
+                       int k_per_tap) {
+    // segments: precision terms x taps (a tap per segment only when the taps are not contiguous in memory)
+    g.n_seg = 0;
+    g.ldw = w.Ktot;
+    const int prec = m->cfg.precision;
+    for (int term = 0; term < prec; ++term) {
+        const bf16_t* ab = term == 2 ? a_lo : a_hi;          // a_hi w_hi, a_hi w_lo, a_lo w_hi
+        const bf16_t* wb = term == 1 ? w.lo : w.hi;
+        for (int t = 0; t < taps; ++t) {
+            if (g.n_seg >= MB_MAX_SEG) return hipErrorInvalidValue;
+            g.seg[g.n_seg++] = GemmSeg{ab + t * tap_stride, wb + (size_t)t * k_per_tap, k_per_tap};
+        }
+    }
+    hipLaunchKernelGGL(mbd_gemm_kernel, dim3((g.N + BN - 1) / BN, (g.M + BM - 1) / BM), dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
+hipError_t group_stats(hipStream_t s, const float* x, int T, int C, int G, UnetBuffers& ub) {
+    const int rows_per = 64;
+    const int chunks = (T + rows_per - 1) / rows_per;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, G), dim3(256), 0, s, x, T, C, G, rows_per, ub.part);
+    hipLaunchKernelGGL(gn_final_kernel, dim3(1), dim3(64), 0, s, ub.part, chunks, G, (double)T * (C / G), 1e-5f, ub.stats);
+    return hipGetLastError();
+}
+
+// x [T][C] fp32 -> ResBlock(x) into `out` (may alias x): x + conv2(act(gn2(conv1(act(gn1(x))))))  (+ col_add)
+hipError_t res_block(hipStream_t s, const mv_mbd* m, const ResW& rw, const float* x, float* out, int T, int C, int dilation, const float* col_add,
+                     UnetBuffers& ub) {
+    const int G = m->cfg.norm_groups, act = m->cfg.act;
+    const size_t n = (size_t)T * C;
+    const int pad = dilation;  // kernel 3
+    hipError_t e;
+    // zero margins of the operand buffer: `pad` rows before and after (the interior is overwritten)
+    if ((e = hipMemsetAsync(ub.hi, 0, (size_t)pad * C * 2, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(ub.lo, 0, (size_t)pad * C * 2, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(ub.hi + ((size_t)T + pad) * C, 0, (size_t)pad * C * 2, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(ub.lo + ((size_t)T + pad) * C, 0, (size_t)pad * C * 2, s)) != hipSuccess) return e;
+    for (int half = 0; half < 2; ++half) {
+        const float* in = half == 0 ? x : ub.b32;
+        const NormW& nw = half == 0 ? rw.n1 : rw.n2;
+        const ConvW& cw = half == 0 ? rw.c1 : rw.c2;
+        if ((e = group_stats(s, in, T, C, G, ub)) != hipSuccess) return e;
+        hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, C, G, ub.stats, nw.g, nw.b, act, (float*)nullptr, ub.hi,
+                           m->cfg.precision > 2 ? ub.lo : nullptr, (size_t)pad);
+        MbdGemmArgs g;
+        g.M = T; g.N = C; g.lda = C; g.out = half == 0 ? ub.b32 : out; g.ldc = C; g.bias = cw.bias;
+        if (half == 1) { g.residual = x; g.ldr = C; g.col_add = col_add; }
+        // window of output row t: rows t - pad + j * dilation, j = 0..2; contiguous (one segment per term) when dilation == 1
+        if (dilation == 1) e = launch_gemm(s, m, g, ub.hi, ub.lo, cw, 1, 0, 3 * C);
+        else e = launch_gemm(s, m, g, ub.hi, ub.lo, cw, 3, (int64_t)dilation * C, C);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace
+
+extern "C" {
+
+// latent: host fp32 [codec_dim][frames] (mv_codec_decode's latent_out) or NULL when codec_dim == 0; wav_ref: host fp32 [T], the
+// EnCodec decode the result is re-equalised against (NULL: no re_eq); noise: host fp32 [n_models][n_eval + 1][T] (initial noise,
+// then one draw per evaluation; parity tests) or NULL = the engine's Philox stream keyed by `seed`; wav_out: host fp32 [T].
+int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float* wav_ref, int32_t T, const float* noise, uint64_t seed,
+                    float* wav_out) {
+    if (!m || !wav_out) return mv_fail(MV_ERR_INVALID, "mv_mbd_generate: null argument");
+    if (!m->finalized) return mv_fail(MV_ERR_STATE, "mv_mbd_generate before mv_mbd_finalize");
+    const mv_mbd_config& g = m->cfg;
+    if (T < g.kernel * 4 || (g.codec_dim > 0 && (!latent || frames < 1))) return mv_fail(MV_ERR_INVALID, "mv_mbd_generate: bad sizes (T = %d, frames = %d)", T, frames);
+    hipStream_t s = m->stream;
+    const int k = g.kernel, st = g.stride, pad = (k - st) / 2, D = g.depth, G = g.norm_groups;
+    Work wk;
+    UnetBuffers ub;
+    // geometry
+    ub.T.resize(D); ub.Tpad.resize(D);
+    {
+        int t = T;
+        for (int i = 0; i < D; ++i) {
+            ub.Tpad[i] = (t + st - 1) / st * st;
+            ub.T[i] = (ub.Tpad[i] + 2 * pad - k) / st + 1;
+            t = ub.T[i];
+            ub.widest = std::max(ub.widest, (size_t)(ub.T[i] + 2 * st + 8) * m->ch[i]);
+        }
+        if (ub.T[D - 1] < 2) return mv_fail(MV_ERR_INVALID, "mv_mbd_generate: %d samples are too few for depth %d", T, D);
+        if (g.codec_dim > 0 && frames > 2 * ub.T[D - 1]) return mv_fail(MV_ERR_INVALID, "conditioning would be downsampled by more than 2");
+    }
+#define MG_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return mv_fail(MV_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+    ub.skip.resize(D);
+    for (int i = 0; i < D; ++i) MG_TRY(wk.get(&ub.skip[i], (size_t)ub.T[i] * m->ch[i], false));
+    MG_TRY(wk.get(&ub.a32, ub.widest, false));
+    MG_TRY(wk.get(&ub.b32, ub.widest, false));
+    MG_TRY(wk.get(&ub.c32, ub.widest, false));
+    MG_TRY(wk.get(&ub.hi, ub.widest + (size_t)k * 3072, true));
+    MG_TRY(wk.get(&ub.lo, ub.widest + (size_t)k * 3072, true));
+    MG_TRY(wk.get(&ub.dec_out, ub.widest + (size_t)4 * st * 3072, false));
+    MG_TRY(wk.get(&ub.part, (size_t)((T / st + 64) / 64 + 2) * G * 2, false));
+    MG_TRY(wk.get(&ub.stats, (size_t)2 * G, false));
+    float *cur = nullptr, *est = nullptr, *total = nullptr, *d_lat = nullptr, *d_noise = nullptr, *d_ref = nullptr;
+    MG_TRY(wk.get(&cur, (size_t)T, false));
+    MG_TRY(wk.get(&est, (size_t)T + 4 * st, false));
+    MG_TRY(wk.get(&total, (size_t)T, true));
+    if (g.codec_dim > 0) {
+        MG_TRY(wk.get(&d_lat, (size_t)g.codec_dim * frames, false));
+        MG_TRY(hipMemcpyAsync(d_lat, latent, (size_t)g.codec_dim * frames * 4, hipMemcpyHostToDevice, s));
+    }
+    if (noise) MG_TRY(wk.get(&d_noise, (size_t)T, false));
+    const int max_bands = std::max(g.proc_bands, g.eq_bands);
+    float *bands = nullptr, *bands2 = nullptr, *d_scale = nullptr, *d_shift = nullptr;
+    double *st_a = nullptr, *st_b = nullptr;
+    if (max_bands > 1) {
+        MG_TRY(wk.get(&bands, (size_t)max_bands * T, false));
+        MG_TRY(wk.get(&bands2, (size_t)max_bands * T, false));
+        MG_TRY(wk.get(&d_scale, (size_t)max_bands, false));
+        MG_TRY(wk.get(&d_shift, (size_t)max_bands, false));
+        MG_TRY(wk.get(&st_a, (size_t)2 * max_bands, false));
+        MG_TRY(wk.get(&st_b, (size_t)2 * max_bands, false));
+    }
+    float *lstm_gin = nullptr, *lstm_y0 = nullptr, *lstm_y1 = nullptr, *lstm_rev = nullptr;
+    const int Cb = m->ch[D - 1], Tb = ub.T[D - 1];
+    if (g.bilstm) {
+        MG_TRY(wk.get(&lstm_gin, (size_t)Tb * 4 * Cb, false));
+        MG_TRY(wk.get(&lstm_y0, (size_t)Tb * 2 * Cb, false));
+        MG_TRY(wk.get(&lstm_y1, (size_t)Tb * 2 * Cb, false));
+        MG_TRY(wk.get(&lstm_rev, (size_t)Tb * 2 * Cb, false));
+    }
+    auto split = [&](const float* x, int n_bands, const float* bank, int taps, float* lowbuf, float* out_bands) -> hipError_t {
+        hipLaunchKernelGGL(fir_bank_kernel, dim3((T + 255) / 256, n_bands - 1), dim3(256), (size_t)(256 + 2 * taps) * 4, s, x, T, bank, taps, lowbuf);
+        hipLaunchKernelGGL(bands_kernel, dim3((T + 255) / 256), dim3(256), 0, s, x, lowbuf, T, n_bands, out_bands);
+        return hipGetLastError();
+    };
+
+    for (int bi = 0; bi < g.n_models; ++bi) {
+        const BandW& B = m->band[bi];
+        const float* nz = noise ? noise + (size_t)bi * (g.n_eval + 1) * T : nullptr;
+        if (nz) MG_TRY(hipMemcpyAsync(d_noise, nz, (size_t)T * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(init_noise_kernel, dim3((T + 255) / 256), dim3(256), 0, s, cur, nz ? d_noise : nullptr, T, B.noise_scale, seed, (uint32_t)(bi * 4096));
+        for (int ev = 0; ev < g.n_eval; ++ev) {
+            const int step = B.steps[ev];
+            // ---------------- encoder -----------------------------------------------------------------------------------------
+            const float* zin = cur;   // [Tin][Cin]
+            int Tin = T;
+            for (int i = 0; i < D; ++i) {
+                const EncW& E = B.enc[i];
+                const int Cin = i == 0 ? 1 : m->ch[i - 1], Cout = m->ch[i], To = ub.T[i];
+                if (i == 0) {
+                    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)(((size_t)To * Cout + 255) / 256)), dim3(256), 0, s, zin, Tin, E.conv_in_w, Cout, k, st, pad, ub.a32, To);
+                } else {
+                    // operand: zin with `pad` zero rows in front and (Tpad - Tin) + (k - st - pad) behind
+                    const size_t back = (size_t)(ub.Tpad[i] - Tin + k) * Cin;
+                    MG_TRY(hipMemsetAsync(ub.hi, 0, (size_t)pad * Cin * 2, s));
+                    MG_TRY(hipMemsetAsync(ub.hi + ((size_t)pad + Tin) * Cin, 0, back * 2, s));
+                    if (g.precision > 2) {
+                        MG_TRY(hipMemsetAsync(ub.lo, 0, (size_t)pad * Cin * 2, s));
+                        MG_TRY(hipMemsetAsync(ub.lo + ((size_t)pad + Tin) * Cin, 0, back * 2, s));
+                    }
+                    const size_t n = (size_t)Tin * Cin;
+                    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, zin, n, Cin, G, (const float*)nullptr, (const float*)nullptr,
+                                       (const float*)nullptr, 0, (float*)nullptr, ub.hi, g.precision > 2 ? ub.lo : nullptr, (size_t)pad);
+                    MbdGemmArgs ga;
+                    ga.M = To; ga.N = Cout; ga.lda = (int64_t)st * Cin; ga.out = ub.a32; ga.ldc = Cout;
+                    MG_TRY(launch_gemm(s, m, ga, ub.hi, ub.lo, E.conv, 1, 0, k * Cin));
+                }
+                MG_TRY(group_stats(s, ub.a32, To, Cout, G, ub));
+                const size_t no = (size_t)To * Cout;
+                const float* emb = (i == 0 || g.emb_all_layers) ? E.emb + (size_t)step * Cout : nullptr;
+                float* dst = g.res_blocks > 0 ? ub.c32 : ub.skip[i];
+                hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, s, ub.a32, no, Cout, G, ub.stats, E.norm.g, E.norm.b, g.act, dst,
+                                   (bf16_t*)nullptr, (bf16_t*)nullptr, (size_t)0);
+                for (int r = 0; r < g.res_blocks; ++r) {
+                    const bool lastr = r == g.res_blocks - 1;
+                    MG_TRY(res_block(s, m, E.res[r], ub.c32, lastr ? ub.skip[i] : ub.c32, To, Cout, 1 << r, lastr ? emb : nullptr, ub));
+                }
+                if (g.res_blocks == 0 && emb) return mv_fail(MV_ERR_INVALID, "res_blocks = 0 is not supported");
+                zin = ub.skip[i];
+                Tin = To;
+            }
+            // ---------------- bottleneck --------------------------------------------------------------------------------------
+            // z = encoder output (+ codec conditioning); without a BiLSTM audiocraft's forward replaces z by zeros (unet.py), so the
+            // decoder starts from the last skip alone
+            const float* zb = nullptr;  // [Tb][Cb] added to the last skip, or null (zeros)
+            if (g.bilstm) {
+                MG_TRY(hipMemcpyAsync(ub.c32, ub.skip[D - 1], (size_t)Tb * Cb * 4, hipMemcpyDeviceToDevice, s));
+                if (g.codec_dim > 0)
+                    hipLaunchKernelGGL(cond_add_kernel, dim3(Tb), dim3(256), (size_t)g.codec_dim * 4, s, ub.c32, Tb, Cb, d_lat, frames, g.codec_dim, B.codec_w, B.codec_b);
+                // BLSTM: 2 layers, both directions (the reverse direction runs on the time-reversed view through negative strides), then
+                // Linear(2 C -> C)
+                const float* in = ub.c32;
+                int I = Cb;
+                float* ys[2] = {lstm_y0, lstm_y1};
+                for (int l = 0; l < 2; ++l) {
+                    for (int d = 0; d < 2; ++d) {
+                        const int sl = l * 2 + d;
+                        MG_TRY(launch_lstm_inproj(s, in, B.lstm.w_ih[sl], B.lstm.bias[sl], lstm_gin, Tb, I, 4 * Cb));
+                        if (++m->lstm_serial >= 65535u) { MG_TRY(hipMemsetAsync(m->lstm_hx, 0, (size_t)2 * Cb * 8, s)); m->lstm_serial = 1; }
+                        LstmSeqArgs la{};
+                        // direction 1 walks the sequence backwards: step t reads gin[Tb-1-t] and writes y[Tb-1-t]
+                        la.gin = d == 0 ? lstm_gin : lstm_gin + (size_t)(Tb - 1) * 4 * Cb; la.gs_b = 0; la.gs_t = d == 0 ? 4 * Cb : -(int64_t)4 * Cb; la.gs_r = 1;
+                        la.whh = B.lstm.w_hh[sl];
+                        la.y = ys[l] + (d == 0 ? 0 : (size_t)(Tb - 1) * 2 * Cb) + (size_t)d * Cb; la.ys_b = 0; la.ys_t = d == 0 ? 2 * Cb : -(int64_t)2 * Cb; la.ys_u = 1;
+                        la.hx = m->lstm_hx; la.tag_base = m->lstm_serial << 16; la.abort_flag = m->lstm_abort;
+                        la.B = 1; la.H = Cb; la.T = Tb;
+                        MG_TRY(launch_lstm_seq(s, la));
+                    }
+                    in = ys[l];
+                    I = 2 * Cb;
+                }
+                MG_TRY(launch_lstm_inproj(s, lstm_y1, B.lstm.lin_w, B.lstm.lin_b, lstm_rev, Tb, 2 * Cb, Cb));  // Linear(2C -> C): the same batched product
+                zb = lstm_rev;
+            }
+            // ---------------- decoder -----------------------------------------------------------------------------------------
+            const float* z = zb;
+            int Tz = Tb;
+            for (int i = 0; i < D; ++i) {
+                const DecW& Dw = B.dec[i];
+                const int lvl = D - 1 - i, C = m->ch[lvl], Cout = lvl == 0 ? 1 : m->ch[lvl - 1], Ts = ub.T[lvl];
+                // z = z[:, :, :skip.T] + skip   (z rows beyond skip.T are dropped; z never is shorter)
+                const size_t n = (size_t)Ts * C;
+                hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ub.skip[lvl], z, ub.c32, n);
+                (void)Tz;
+                for (int r = 0; r < g.res_blocks; ++r) MG_TRY(res_block(s, m, Dw.res[r], ub.c32, ub.c32, Ts, C, 1 << r, nullptr, ub));
+                MG_TRY(group_stats(s, ub.c32, Ts, C, G, ub));
+                if (lvl == 0) {
+                    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ub.c32, n, C, G, ub.stats, Dw.norm.g, Dw.norm.b, g.act, ub.a32,
+                                       (bf16_t*)nullptr, (bf16_t*)nullptr, (size_t)0);
+                    hipLaunchKernelGGL(convtr_out_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ub.a32, Ts, C, Dw.convtr_out_w, k, st, pad, est, T);
+                } else {
+                    // operand rows: [zero row | z rows 0..Ts-1 | zero row]; GEMM row q = (x[q-1], x[q]), q = 0..Ts
+                    MG_TRY(hipMemsetAsync(ub.hi, 0, (size_t)C * 2, s));
+                    MG_TRY(hipMemsetAsync(ub.hi + ((size_t)Ts + 1) * C, 0, (size_t)C * 2, s));
+                    if (g.precision > 2) {
+                        MG_TRY(hipMemsetAsync(ub.lo, 0, (size_t)C * 2, s));
+                        MG_TRY(hipMemsetAsync(ub.lo + ((size_t)Ts + 1) * C, 0, (size_t)C * 2, s));
+                    }
+                    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ub.c32, n, C, G, ub.stats, Dw.norm.g, Dw.norm.b, g.act, (float*)nullptr,
+                                       ub.hi, g.precision > 2 ? ub.lo : nullptr, (size_t)1);
+                    MbdGemmArgs ga;
+                    ga.M = Ts + 1; ga.N = st * Cout; ga.lda = C; ga.out = ub.dec_out; ga.ldc = (int64_t)st * Cout;
+                    MG_TRY(launch_gemm(s, m, ga, ub.hi, ub.lo, Dw.convtr, 1, 0, 2 * C));
+                    // row q holds output times q st - pad + p: the valid signal starts `pad` rows into the buffer
+                    z = ub.dec_out + (size_t)pad * Cout;
+                    Tz = Ts * st;
+                }
+            }
+            MG_TRY(hipGetLastError());
+            // ---------------- DDPM update -------------------------------------------------------------------------------------
+            const float* stepnoise = nullptr;
+            if (nz && B.sigma[ev] > 0.f) {
+                MG_TRY(hipMemcpyAsync(d_noise, nz + (size_t)(ev + 1) * T, (size_t)T * 4, hipMemcpyHostToDevice, s));
+                stepnoise = d_noise;
+            }
+            hipLaunchKernelGGL(ddpm_kernel, dim3((T + 255) / 256), dim3(256), 0, s, cur, est, stepnoise, T, B.est_c[ev], B.inv_sqrt_alpha[ev], B.sigma[ev], B.noise_scale,
+                               B.clip, step == 0 ? B.rescale : 1.0f, seed, (uint32_t)(bi * 4096 + ev + 1));
+        }
+        // ---------------- MultiBandProcessor.return_sample, summed into the total ---------------------------------------------------
+        if (g.proc_bands > 1) {
+            MG_TRY(split(cur, g.proc_bands, m->proc_bank, m->proc_taps, bands2, bands));
+            MG_TRY(hipMemcpyAsync(d_scale, B.proc_scale.data(), (size_t)g.proc_bands * 4, hipMemcpyHostToDevice, s));
+            MG_TRY(hipMemcpyAsync(d_shift, B.proc_mean.data(), (size_t)g.proc_bands * 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(band_mix_kernel, dim3((T + 255) / 256), dim3(256), 0, s, bands, T, g.proc_bands, d_scale, d_shift, total, 1);
+        } else {
+            hipLaunchKernelGGL(add_kernel, dim3((T + 255) / 256), dim3(256), 0, s, total, cur, total, (size_t)T);
+        }
+        MG_TRY(hipStreamSynchronize(s));  // host vectors above must outlive the copies
+    }
+    // ---------------- re_eq against the EnCodec decode ---------------------------------------------------------------------------------
+    float* result = total;
+    if (wav_ref && g.eq_bands > 1) {
+        MG_TRY(wk.get(&d_ref, (size_t)T, false));
+        MG_TRY(hipMemcpyAsync(d_ref, wav_ref, (size_t)T * 4, hipMemcpyHostToDevice, s));
+        float* low = nullptr;
+        MG_TRY(wk.get(&low, (size_t)g.eq_bands * T, false));
+        MG_TRY(split(d_ref, g.eq_bands, m->eq_bank, m->eq_taps, low, bands2));
+        hipLaunchKernelGGL(band_stats_kernel, dim3(g.eq_bands), dim3(1024), 0, s, bands2, T, st_b);
+        MG_TRY(split(total, g.eq_bands, m->eq_bank, m->eq_taps, low, bands));
+        hipLaunchKernelGGL(band_stats_kernel, dim3(g.eq_bands), dim3(1024), 0, s, bands, T, st_a);
+        hipLaunchKernelGGL(eq_scale_kernel, dim3(1), dim3(64), 0, s, st_a, st_b, g.eq_bands, (double)T, d_scale);
+        hipLaunchKernelGGL(band_mix_kernel, dim3((T + 255) / 256), dim3(256), 0, s, bands, T, g.eq_bands, d_scale, (const float*)nullptr, cur, 0);
+        result = cur;
+    }
+    MG_TRY(hipGetLastError());
+    uint32_t aborted = 0;
+    MG_TRY(hipMemcpyAsync(wav_out, result, (size_t)T * 4, hipMemcpyDeviceToHost, s));
+    if (m->lstm_abort) MG_TRY(hipMemcpyAsync(&aborted, m->lstm_abort, 4, hipMemcpyDeviceToHost, s));
+    MG_TRY(hipStreamSynchronize(s));
+#undef MG_TRY
+    if (aborted) {
+        (void)hipMemset(m->lstm_abort, 0, 4);
+        return mv_fail(MV_ERR_HIP, "mv_mbd_generate: the BiLSTM workgroups timed out waiting for each other");
+    }
+    return MV_OK;
+}
+
+// One UNet evaluation (parity hook): x host fp32 [T] -> estimate host fp32 [T] for band `band_idx` at diffusion step `step`.
+int mv_mbd_unet_forward(mv_mbd* m, int32_t band_idx, const float* x, int32_t T, int32_t step, const float* latent, int32_t frames, float* out) {
+    if (!m || !x || !out || band_idx < 0 || band_idx >= m->cfg.n_models) return mv_fail(MV_ERR_INVALID, "mv_mbd_unet_forward: bad argument");
+    // run the generator for ONE evaluation with a schedule that makes the update the identity on the estimate: cur' = -est * 1
+    mv_mbd_config saved = m->cfg;
+    BandW& B = m->band[band_idx];
+    BandW keep = B;
+    std::vector<BandW> all = m->band;
+    // isolate the band: a one-model, one-evaluation view
+    m->cfg.n_models = 1; m->cfg.n_eval = 1; m->cfg.proc_bands = 1; m->cfg.eq_bands = 1;
+    m->band.assign(1, keep);
+    BandW& V = m->band[0];
+    V.steps = {step}; V.est_c = {1.0f}; V.inv_sqrt_alpha = {-1.0f}; V.sigma = {0.f}; V.clip = 0.f; V.rescale = 1.f; V.noise_scale = 1.f;
+    // with cur = x: cur' = (x - est) * -1 = est - x  -> add x back on the host
+    std::vector<float> nz((size_t)2 * T);
+    memcpy(nz.data(), x, (size_t)T * 4);
+    const int rc = mv_mbd_generate(m, latent, frames, nullptr, T, nz.data(), 0, out);
+    m->cfg = saved;
+    m->band = all;
+    if (rc != MV_OK) return rc;
+    for (int i = 0; i < T; ++i) out[i] += x[i];
+    return MV_OK;
+}
+
+}  // extern "C"

@@ -227,3 +227,77 @@ def encodec_state_dict(seed: int = 0, *, hidden: int = 128, num_filters: int = 3
     sd[f"decoder.layers.{idx + 1}.conv.weight"] = uni((1, ch, last_kernel_size), ch * last_kernel_size)
     sd[f"decoder.layers.{idx + 1}.conv.bias"] = uni((1,), ch * last_kernel_size)
     return sd
+
+
+def mbd_package(seed: int = 0, *, n_bands: int = 4, hidden: int = 48, depth: int = 4, growth: float = 4.0, kernel: int = 8, stride: int = 4,
+                norm_groups: int = 4, res_blocks: int = 1, codec_dim: Optional[int] = 128, emb_all_layers: bool = True, bilstm: bool = False,
+                activation: str = "relu", num_steps: int = 1000, proc_bands: int = 8, sample_rate: int = 24_000) -> dict:
+    """A multi-band diffusion package with audiocraft's layout (`load_diffusion_models`: {i: {"model_state", "processor_state", "cfg"},
+    "n_bands", "sample_rate"}) and synthetic weights: torch's default Conv / Linear / LSTM initialisation (uniform +-1/sqrt(fan_in)),
+    GroupNorm weights 1 + 0.1 N(0,1), step embeddings N(0, 1).  The defaults are the sizes of audiocraft's
+    `config/model/score/basic.yaml` as recalled (hidden 48, depth 4, growth 4, kernel 8, stride 4): the released `mbd_comp_8.pt` is
+    not reachable offline, the engine reads whatever the package's cfg says."""
+    pkg: dict = {"n_bands": n_bands, "sample_rate": sample_rate}
+    for b in range(n_bands):
+        g = torch.Generator().manual_seed(11000 + 97 * seed + b)
+
+        def uni(shape, fan_in):
+            return (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+
+        def norm(sd, name, c):
+            sd[name + ".weight"] = 1.0 + 0.1 * torch.randn(c, generator=g)
+            sd[name + ".bias"] = 0.1 * torch.randn(c, generator=g)
+
+        def res(sd, prefix, c):
+            for j in (1, 2):
+                norm(sd, f"{prefix}norm{j}", c)
+                sd[f"{prefix}conv{j}.weight"] = uni((c, c, 3), c * 3)
+                sd[f"{prefix}conv{j}.bias"] = uni((c,), c * 3)
+
+        sd: Dict[str, torch.Tensor] = {}
+        chans, cin, h = [], 1, hidden
+        for i in range(depth):
+            chans.append((cin, h))
+            sd[f"encoders.{i}.conv.weight"] = uni((h, cin, kernel), cin * kernel)
+            norm(sd, f"encoders.{i}.norm", h)
+            for r in range(res_blocks):
+                res(sd, f"encoders.{i}.res_blocks.{r}.", h)
+            if i == 0:
+                sd["embedding.weight"] = torch.randn(num_steps, h, generator=g)
+            elif emb_all_layers:
+                sd[f"embeddings.{i - 1}.weight"] = torch.randn(num_steps, h, generator=g)
+            cin, h = h, int(h * growth)
+        for i in range(depth):  # decoders[0] is the innermost layer
+            ci, co = chans[depth - 1 - i][1], chans[depth - 1 - i][0]
+            for r in range(res_blocks):
+                res(sd, f"decoders.{i}.res_blocks.{r}.", ci)
+            norm(sd, f"decoders.{i}.norm", ci)
+            sd[f"decoders.{i}.convtr.weight"] = uni((ci, co, kernel), ci * kernel / stride)
+        cb = chans[-1][1]
+        if codec_dim is not None:
+            sd["conv_codec.weight"] = uni((cb, codec_dim, 1), codec_dim)
+            sd["conv_codec.bias"] = uni((cb,), codec_dim)
+        if bilstm:
+            for l in range(2):
+                for suffix in ("", "_reverse"):
+                    i_sz = cb if l == 0 else 2 * cb
+                    sd[f"bilstm.lstm.weight_ih_l{l}{suffix}"] = uni((4 * cb, i_sz), cb)
+                    sd[f"bilstm.lstm.weight_hh_l{l}{suffix}"] = uni((4 * cb, cb), cb)
+                    sd[f"bilstm.lstm.bias_ih_l{l}{suffix}"] = uni((4 * cb,), cb)
+                    sd[f"bilstm.lstm.bias_hh_l{l}{suffix}"] = uni((4 * cb,), cb)
+            sd["bilstm.linear.weight"] = uni((cb, 2 * cb), 2 * cb)
+            sd["bilstm.linear.bias"] = uni((cb,), 2 * cb)
+        counts = torch.tensor([10_000.0])
+        mean = 0.01 * torch.randn(proc_bands, generator=g)
+        std = 0.5 + torch.rand(proc_bands, generator=g)
+        proc = {"counts": counts, "sum_x": mean * counts, "sum_x2": (std ** 2 + mean ** 2) * counts,
+                "sum_target_x2": (0.5 + torch.rand(proc_bands, generator=g)) * counts}
+        pkg[b] = {
+            "model_state": sd, "processor_state": proc if proc_bands > 1 else None,
+            "cfg": {"diffusion_unet": dict(hidden=hidden, depth=depth, growth=growth, kernel=kernel, stride=stride, norm_groups=norm_groups,
+                                           res_blocks=res_blocks, codec_dim=codec_dim, emb_all_layers=emb_all_layers, bilstm=bilstm,
+                                           transformer=False, cross_attention=False, max_channels=10_000, activation=activation),
+                    "schedule": dict(beta_t0=1e-4, beta_t1=0.02, num_steps=num_steps, beta_exp=1.0, clip=5.0, rescale=1.0, noise_scale=1.0),
+                    "processor": dict(use=proc_bands > 1, n_bands=proc_bands, power_std=1.0)},
+        }
+    return pkg

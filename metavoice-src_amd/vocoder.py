@@ -77,14 +77,13 @@ class MultiBandDiffusion:
                           "multi-band diffusion refinement of the reference")
         return MultiBandDiffusion(codec, diffusion)
 
-    def tokens_to_wav(self, tokens: torch.Tensor, noise: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
+    def tokens_to_wav(self, tokens: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
         """(1, n_q, frames) int -> (1, 1, frames * 320) fp32 at 24 kHz.  `noise`: injected Gaussian tensors for the diffusion
         bands (parity tests); default = the engine's own Philox stream."""
         if self.diffusion is None:
             return self.codec_model.decode(tokens)
         wav_encodec, latent = self.codec_model.decode(tokens, return_latent=True)
-        wav_diffusion = self.diffusion.generate(latent, noise=noise)
-        return self.diffusion.re_eq(wav_diffusion, wav_encodec)
+        return self.diffusion.tokens_to_wav(latent, wav_encodec, noise=noise)  # band processes, sum, re_eq against wav_encodec
 
     __call__ = tokens_to_wav
 
