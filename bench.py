@@ -8,8 +8,9 @@ A "step" is one pass of the hot path over one utterance per GPU: BASELINE.json c
 utterance, synthetic 256-char-equivalent prompt (T = 128 text tokens), batched MFMA prefill, N = 1920 generated
 first-stage tokens forced (end-of-audio unreachable) = 12.8 s of audio at 150 tokens/s, token adapter,
 second-stage expansion to 8 codebooks (placeholder second-stage sizes: the real model_args are not reachable offline),
-EnCodec decode (8 codebooks -> 24 kHz waveform), random-init weights of the exact MetaVoice-1B first-stage and EnCodec
-shapes.  The reference's multi-band-diffusion refinement (audiocraft, third party) is not built yet and not timed.  Inputs (weights, prompt, speaker embedding) are resident
+vocoder = EnCodec decode (8 codebooks -> 24 kHz waveform) + the multi-band diffusion refinement (4 band UNets x 20 DDPM
+evaluations, processor, 32-band re_eq: what `mbd.tokens_to_wav` does in the reference), random-init weights of the exact
+MetaVoice-1B first-stage and EnCodec shapes and of the recalled audiocraft MBD sizes.  Inputs (weights, prompt, speaker embedding) are resident
 before the timed region; the timed region is bracketed by barrier + torch.cuda.synchronize on both sides and the MAX
 over ranks is reported.  Utterances are independent, so N GPUs run N utterances with no data-path collective; the
 finished token streams are all-gathered over RCCL once per step (batched-serving path), inside the timed region.
@@ -110,6 +111,8 @@ def main():
     ap.add_argument("--utterances-per-gpu", type=int, default=1)
     ap.add_argument("--long-form", action="store_true")
     ap.add_argument("--long-form-chars", type=int, default=10000)
+    ap.add_argument("--mbd-precision", type=int, default=3, choices=[0, 1, 3],
+                    help="multi-band diffusion vocoder: MFMA terms per product (3 = bf16 hi/lo split, ~fp32; 1 = bf16 operands; 0 = EnCodec decode only)")
     a = ap.parse_args()
     U = a.utterances_per_gpu
     if a.long_form and U != 1:
@@ -179,7 +182,14 @@ def main():
     # refinement on top of it is not built yet and is NOT in this number
     codec_mod = importlib.import_module("metavoice-src_amd.codec")
     vocoder = codec_mod.EncodecDecoder.from_state_dict(mv.synthetic.encodec_state_dict(seed=rank))
-    stage_ms = {"stage1_prefill+decode": 0.0, "stage1_decode_gpu": 0.0, "adapters+stage2": 0.0, "encodec_decode": 0.0}
+    # multi-band diffusion on top of it (fam/llm/decoders.py:13,84-85): 4 band models x 20 evaluations + processor + 32-band re_eq.
+    # The released mbd_comp_8.pt is not reachable offline: the sizes are audiocraft's config/model/score/basic.yaml as recalled
+    # (hidden 48, depth 4, growth 4, kernel 8, stride 4: 166 M parameters per band), synthetic weights.
+    diffusion = None
+    if a.mbd_precision and a.quantisation_mode is None:
+        mbd_mod = importlib.import_module("metavoice-src_amd.mbd")
+        diffusion = mbd_mod.MultiBandDiffusionBands.from_package(mv.synthetic.mbd_package(seed=rank), seed=1234 + rank, precision=a.mbd_precision)
+    stage_ms = {"stage1_prefill+decode": 0.0, "stage1_decode_gpu": 0.0, "adapters+stage2": 0.0, "encodec_decode": 0.0, "multiband_diffusion": 0.0}
 
     def fold_onto_codebooks(toks, n_prompt):
         """Random weights do not produce the cb0 / cb1 alternation a trained first stage does, and the adapter truncates both
@@ -217,8 +227,15 @@ def main():
                 y = stage2.generate(in_x, None, temperature=1.0, top_k=200, speaker_embs=spk, batch_size=1, seed=sp.seed)
                 _, audio_ids = second_adapter.decode(torch.cat([in_x, y], dim=1)[0].tolist())
                 t2 = time.perf_counter()
-                wav = vocoder.decode(torch.tensor(audio_ids, dtype=torch.long).unsqueeze(0))
-                t3 = time.perf_counter()
+                grid8 = torch.tensor(audio_ids, dtype=torch.long).unsqueeze(0)
+                if diffusion is not None:
+                    wav, latent = vocoder.decode(grid8, return_latent=True)
+                    t3 = time.perf_counter()
+                    wav = diffusion.tokens_to_wav(latent, wav)
+                    stage_ms["multiband_diffusion"] += (time.perf_counter() - t3) * 1e3
+                else:
+                    wav = vocoder.decode(grid8)
+                    t3 = time.perf_counter()
                 stage_ms["encodec_decode"] += (t3 - t2) * 1e3
                 stage_ms["adapters+stage2"] += (t2 - t1) * 1e3
                 wavs.append(wav.reshape(-1))
@@ -309,25 +326,27 @@ def main():
         n_utt = sum(len(gp) for gp in work)
         tok_per_step = sum(n for gp in work for _, n in gp)
         mode = a.quantisation_mode or "bf16"
+        voc = ("EnCodec decode + multi-band diffusion (4 bands x 20 evaluations of a 166 M-parameter UNet at the recalled audiocraft basic.yaml "
+               f"sizes, {'bf16 hi/lo-split (fp32-class)' if a.mbd_precision == 3 else 'bf16'} MFMA convolutions, processor, 32-band re_eq)"
+               if diffusion is not None else "EnCodec decode (multi-band diffusion switched off)")
         if a.long_form:
             workload = (f"long-form synthesis (BASELINE configs[4]): {a.long_form_chars} characters split at sentence boundaries into "
                         f"{len(work)} chunks of <= 220 characters, each an independent generation (MFMA prefill + 7.5 tokens per "
                         f"character, top_p=0.95, guidance 3.0) on the same captured decode graph and speaker embedding, then token "
-                        f"adapters, second stage (placeholder sizes), EnCodec decode; {tok_per_step / 150.0:.1f} s of audio per step; "
-                        "synthetic speaker embedding (assets/bria.mp3 cannot be decoded here); multi-band diffusion not timed")
+                        f"adapters, second stage (placeholder sizes), {voc}; {tok_per_step / 150.0:.1f} s of audio per step; "
+                        "synthetic speaker embedding (assets/bria.mp3 cannot be decoded here)")
         elif a.quantisation_mode is not None:
             workload = (f"MetaVoice-1B {mode} weight-only first-stage decode (BASELINE configs[3]): prompt T={T_PROMPT} (MFMA prefill on "
                         f"the de-quantised weights) + {N_NEW} sampled tokens (top_p=0.95, guidance 3.0) = 12.8 s audio; first stage only")
         elif U > 1:
             workload = (f"MetaVoice-1B bf16 batched serving (BASELINE configs[2]): {U} utterances per GPU decoded together (ragged prompts "
-                        f"96..160 tokens, up to {N_NEW} sampled tokens each), adapters, second stage (placeholder sizes), EnCodec decode, "
-                        f"fp32 waveforms all-gathered over RCCL; batch {U * world} over {world} GPU(s); multi-band diffusion not timed")
+                        f"96..160 tokens, up to {N_NEW} sampled tokens each), adapters, second stage (placeholder sizes), {voc}, "
+                        f"fp32 waveforms all-gathered over RCCL; batch {U * world} over {world} GPU(s)")
         else:
             workload = (f"MetaVoice-1B synthesis, 1 utterance/GPU: prompt T={T_PROMPT} tokens (MFMA prefill) + {N_NEW} "
                         "sampled first-stage tokens (top_p=0.95, guidance 3.0) = 12.8 s audio, token adapters, "
-                        "second-stage expansion to 8 codebooks (placeholder sizes), EnCodec decode of all 960 frames "
-                        "to a 24 kHz waveform (synthetic stream folded onto alternating codebooks after the first stage); "
-                        "the multi-band-diffusion refinement is not built yet")
+                        f"second-stage expansion to 8 codebooks (placeholder sizes), vocoder on all 960 frames -> 24 kHz waveform: {voc} "
+                        "(synthetic stream folded onto alternating codebooks after the first stage)")
         out = {
             "metric": "audio-sec/sec (RTF^-1) MetaVoice-1B bf16, 256-char prompt" if mode == "bf16" and not a.long_form and U == 1
                       else f"audio-sec/sec (RTF^-1) MetaVoice-1B {mode}",

@@ -45,7 +45,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int MB_MAX_SEG = 12;   // K-segments of one GEMM: (conv taps when dilated) x (precision terms)
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BN = 128, BK = 64;   // BM = 128 or 64 (template): the 3072-channel layers have M = 1200, 64-row tiles give 456 blocks
 
 struct GemmSeg {
     const bf16_t* a;   // first row of the A window of output row 0 for this segment
@@ -66,66 +66,72 @@ struct MbdGemmArgs {
     const float* col_add = nullptr;   // [N] or null (step embedding)
 };
 
-// C = A W^T on 128 x 128 x 64 tiles, 256 threads = 4 waves (2 x 2), each wave 64 x 64 = 4 x 4 MFMA 16x16x32 tiles.
-// Staging as in gemm.hip: 16-byte chunks, XOR-swizzled by row, global -> registers -> LDS with the next K-tile's loads in flight
-// under the current tile's MFMAs.  Rows past M / N are clamped (duplicates) and dropped in the epilogue.
-__global__ void __launch_bounds__(256) mbd_gemm_kernel(const MbdGemmArgs a) {
-    __shared__ __attribute__((aligned(16))) u32x4 lds[2][BM * 8];  // A tile, W tile: [row][8 chunks of 16 B], chunk ^= row & 7
+// C = A W^T on BM x 128 x 64 tiles (BM = 128 or 64), 256 threads = 4 waves (2 x 2), each wave (BM / 2) x 64 = MI x 4 MFMA 16x16x32
+// tiles.  Staging as in gemm.hip: 16-byte chunks, XOR-swizzled by row, global -> registers -> LDS with the next K-tile's loads in
+// flight under the current tile's MFMAs; two blocks per CU overlap one block's staging with the other's MFMAs.  Rows past M / N
+// are clamped (duplicates) and dropped in the epilogue.
+template <int BM>
+__global__ void __launch_bounds__(256, 2) mbd_gemm_kernel(const MbdGemmArgs a) {
+    constexpr int MI = BM / 32;   // MFMA row tiles per wave
+    constexpr int AR = BM / 32;   // A rows staged per thread
+    __shared__ __attribute__((aligned(16))) u32x4 lds_a[BM * 8];  // [row][8 chunks of 16 B], chunk ^= row & 7
+    __shared__ __attribute__((aligned(16))) u32x4 lds_w[BN * 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tile_m = blockIdx.y * BM, tile_n = blockIdx.x * BN;
     const int M = a.M, N = a.N;
-    const int sr = tid >> 3, sc = tid & 7;  // thread stages chunk sc of rows sr + 32 i, i < 4
+    const int sr = tid >> 3, sc = tid & 7;  // thread stages chunk sc of rows sr + 32 i
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
     const u32x4 zero = {0u, 0u, 0u, 0u};
 
     for (int s = 0; s < a.n_seg; ++s) {
         const GemmSeg sg = a.seg[s];
-        const bf16_t* ga[4];
+        const bf16_t* ga[AR];
         const bf16_t* gw[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ga[i] = sg.a + (size_t)min(tile_m + sr + 32 * i, M - 1) * a.lda + sc * 8;
-            gw[i] = sg.w + (size_t)min(tile_n + sr + 32 * i, N - 1) * a.ldw + sc * 8;
-        }
-        u32x4 ra[4], rw[4];
+        for (int i = 0; i < AR; ++i) ga[i] = sg.a + (size_t)min(tile_m + sr + 32 * i, M - 1) * a.lda + sc * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gw[i] = sg.w + (size_t)min(tile_n + sr + 32 * i, N - 1) * a.ldw + sc * 8;
+        u32x4 ra[AR], rw[4];
         const bool in0 = sc * 8 < sg.K;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { ra[i] = in0 ? load16(ga[i]) : zero; rw[i] = in0 ? load16(gw[i]) : zero; }
+        for (int i = 0; i < AR; ++i) ra[i] = in0 ? load16(ga[i]) : zero;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rw[i] = in0 ? load16(gw[i]) : zero;
         for (int k0 = 0; k0 < sg.K; k0 += BK) {
             __syncthreads();  // everyone is done reading the previous tile
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = sr + 32 * i;
-                lds[0][r * 8 + (sc ^ (r & 7))] = ra[i];
-                lds[1][r * 8 + (sc ^ (r & 7))] = rw[i];
-            }
+            for (int i = 0; i < AR; ++i) { const int r = sr + 32 * i; lds_a[r * 8 + (sc ^ (r & 7))] = ra[i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int r = sr + 32 * i; lds_w[r * 8 + (sc ^ (r & 7))] = rw[i]; }
             __syncthreads();
             if (k0 + BK < sg.K) {
                 const bool in = k0 + BK + sc * 8 < sg.K;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { ra[i] = in ? load16(ga[i] + k0 + BK) : zero; rw[i] = in ? load16(gw[i] + k0 + BK) : zero; }
+                for (int i = 0; i < AR; ++i) ra[i] = in ? load16(ga[i] + k0 + BK) : zero;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rw[i] = in ? load16(gw[i] + k0 + BK) : zero;
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                bf16x8_t af[4], bf[4];
+                bf16x8_t af[MI], bf[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = wm * 64 + i * 16 + (lane & 15);
-                    af[i] = __builtin_bit_cast(bf16x8_t, lds[0][r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
+                for (int i = 0; i < MI; ++i) {
+                    const int r = wm * (BM / 2) + i * 16 + (lane & 15);
+                    af[i] = __builtin_bit_cast(bf16x8_t, lds_a[r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = wn * 64 + j * 16 + (lane & 15);
-                    bf[j] = __builtin_bit_cast(bf16x8_t, lds[1][r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
+                    bf[j] = __builtin_bit_cast(bf16x8_t, lds_w[r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
@@ -133,7 +139,7 @@ __global__ void __launch_bounds__(256) mbd_gemm_kernel(const MbdGemmArgs a) {
     }
     // epilogue: C fragment (i, j): column lane & 15, rows (lane >> 4) * 4 + reg
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = tile_n + wn * 64 + j * 16 + (lane & 15);
@@ -141,7 +147,7 @@ __global__ void __launch_bounds__(256) mbd_gemm_kernel(const MbdGemmArgs a) {
             const float add = (a.bias ? a.bias[n] : 0.f) + (a.col_add ? a.col_add[n] : 0.f);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int m = tile_m + wm * 64 + i * 16 + (lane >> 4) * 4 + reg;
+                const int m = tile_m + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + reg;
                 if (m >= M) continue;
                 float y = acc[i][j][reg] + add;
                 if (a.residual) y += a.residual[(size_t)m * a.ldr + n];
@@ -151,37 +157,60 @@ __global__ void __launch_bounds__(256) mbd_gemm_kernel(const MbdGemmArgs a) {
 }
 
 // ---- GroupNorm statistics: deterministic two stages ------------------------------------------------------------------------
-// stage 1: block (chunk c, group g) sums x and x^2 over rows [c * rows_per, ...) x channels of group g -> part[c][g][2] (double)
-__global__ void __launch_bounds__(256) gn_partial_kernel(const float* __restrict__ x, int T, int C, int G, int rows_per, double* __restrict__ part) {
-    __shared__ double red[2][4];
-    const int c = blockIdx.x, g = blockIdx.y, cg = C / G;
-    const int t0 = c * rows_per, t1 = min(T, t0 + rows_per);
-    double s = 0.0, s2 = 0.0;
-    const int n = (t1 - t0) * cg;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int t = t0 + i / cg, ch = g * cg + i % cg;
-        const float v = x[(size_t)t * C + ch];
-        s += v;
-        s2 += (double)v * v;
+// stage 1: block c sums x and x^2 of elements [c * GN_CHUNK, ...) per group -> part[c][g][2] (double).  A thread walks the chunk
+// in float4 steps; the group is resolved per element (G <= 8 accumulators in registers).
+constexpr int GN_CHUNK = 16384, GN_MAXG = 8;   // elements per block: the grid does not depend on the [T][C] aspect ratio
+__global__ void __launch_bounds__(256) gn_partial_kernel(const float* __restrict__ x, int T, int C, int G, double* __restrict__ part) {
+    __shared__ double red[4][GN_MAXG][2];
+    const int c = blockIdx.x, cg = C / G;
+    const size_t e0 = (size_t)c * GN_CHUNK, e1 = min((size_t)T * C, e0 + (size_t)GN_CHUNK);
+    float s[GN_MAXG], s2[GN_MAXG];
+#pragma unroll
+    for (int g = 0; g < GN_MAXG; ++g) { s[g] = 0.f; s2[g] = 0.f; }
+    for (size_t i = e0 + (size_t)threadIdx.x * 4; i < e1; i += 1024) {
+        const float4 v = *(const float4*)(x + i);
+        const int ch = (int)(i % C);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int g = (ch + q) / cg;
+#pragma unroll
+            for (int k = 0; k < GN_MAXG; ++k)
+                if (k == g) { s[k] += vv[q]; s2[k] = fmaf(vv[q], vv[q], s2[k]); }
+        }
     }
-    for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); s2 += __shfl_down(s2, off, 64); }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = s2; }
+    for (int g = 0; g < G; ++g) {
+        double a = s[g], b = s2[g];
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][g][0] = a; red[threadIdx.x >> 6][g][1] = b; }
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        part[((size_t)c * G + g) * 2 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        part[((size_t)c * G + g) * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (threadIdx.x < 2 * G) {
+        const int g = threadIdx.x >> 1, w = threadIdx.x & 1;
+        part[((size_t)c * G + g) * 2 + w] = red[0][g][w] + red[1][g][w] + red[2][g][w] + red[3][g][w];
     }
 }
-// stage 2: stats[g] = (mean, rstd) with the biased variance torch.nn.GroupNorm uses
-__global__ void gn_final_kernel(const double* __restrict__ part, int n_chunks, int G, double count, float eps, float* __restrict__ stats) {
-    const int g = threadIdx.x;
-    if (g >= G) return;
-    double s = 0.0, s2 = 0.0;
-    for (int c = 0; c < n_chunks; ++c) { s += part[((size_t)c * G + g) * 2]; s2 += part[((size_t)c * G + g) * 2 + 1]; }
-    const double mean = s / count;
-    const double var = fmax(s2 / count - mean * mean, 0.0);
-    stats[2 * g] = (float)mean;
-    stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+// stage 2 (one block): stats[g] = (mean, rstd) with the biased variance torch.nn.GroupNorm uses; fixed-order tree over the chunks
+__global__ void __launch_bounds__(256) gn_final_kernel(const double* __restrict__ part, int n_chunks, int G, double count, float eps, float* __restrict__ stats) {
+    __shared__ double red[256];
+    __shared__ double s_mean;
+    for (int q = 0; q < 2 * G; ++q) {   // q = g * 2 + {sum, sum of squares}
+        double a = 0.0;
+        for (int c = threadIdx.x; c < n_chunks; c += 256) a += part[(size_t)c * 2 * G + q];
+        red[threadIdx.x] = a;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        const double tot = red[0];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if ((q & 1) == 0) { s_mean = tot / count; stats[q] = (float)s_mean; }
+            else stats[q] = (float)(1.0 / sqrt(fmax(tot / count - s_mean * s_mean, 0.0) + (double)eps));
+        }
+        __syncthreads();
+    }
 }
 
 __device__ __forceinline__ float mb_act(float v, int act) {
@@ -191,23 +220,36 @@ __device__ __forceinline__ float mb_act(float v, int act) {
 }
 
 // y = act(gn(x)) (stats == null: y = x), written as fp32 [T][C] (optional) and as the bf16 hi / lo operands of the next
-// convolution, rows shifted by `row0` inside a zero-margined buffer
-__global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__ x, size_t n, int C, int G, const float* __restrict__ stats,
+// convolution: rows [0, front) and [front + T, front + T + back) of the operand buffers are the convolution's zero padding and are
+// written here too (no separate memsets).  Four elements per thread (C is a multiple of 8).
+__global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__ x, int T, int C, int G, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-                                                       float* __restrict__ y32, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, size_t row0) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float v = x[i];
-    if (stats) {
-        const int ch = (int)(i % C), g = ch / (C / G);
-        v = (v - stats[2 * g]) * stats[2 * g + 1] * gamma[ch] + beta[ch];
-        v = mb_act(v, act);
+                                                       float* __restrict__ y32, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int front, int back) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;   // element index inside the operand buffer
+    const size_t total = (size_t)(front + T + back) * C;
+    if (i >= total) return;
+    const size_t row = i / C;
+    if (row < (size_t)front || row >= (size_t)front + T) {
+        if (hi) *(uint2*)(hi + i) = make_uint2(0u, 0u);
+        if (lo) *(uint2*)(lo + i) = make_uint2(0u, 0u);
+        return;
     }
-    if (y32) y32[i] = v;
+    const size_t j = i - (size_t)front * C;   // element index inside x
+    const float4 xv = *(const float4*)(x + j);
+    float v[4] = {xv.x, xv.y, xv.z, xv.w};
+    if (stats) {
+        const int ch = (int)(j % C), cg = C / G;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int g = (ch + q) / cg;
+            v[q] = mb_act((v[q] - stats[2 * g]) * stats[2 * g + 1] * gamma[ch + q] + beta[ch + q], act);
+        }
+    }
+    if (y32) *(float4*)(y32 + j) = make_float4(v[0], v[1], v[2], v[3]);
     if (hi) {
-        const bf16_t h = f2bf(v);
-        hi[row0 * C + i] = h;
-        if (lo) lo[row0 * C + i] = f2bf(v - bf2f(h));
+        const uint32_t h0 = pack_bf2(v[0], v[1]), h1 = pack_bf2(v[2], v[3]);
+        *(uint2*)(hi + i) = make_uint2(h0, h1);
+        if (lo) *(uint2*)(lo + i) = make_uint2(pack_bf2(v[0] - bf_lo(h0), v[1] - bf_hi(h0)), pack_bf2(v[2] - bf_lo(h1), v[3] - bf_hi(h1)));
     }
 }
 
@@ -459,7 +501,7 @@ int mv_mbd_create(const mv_mbd_config* cfg, mv_mbd** out) {
     if (!cfg || !out) return mv_fail(MV_ERR_INVALID, "mv_mbd_create: null argument");
     const mv_mbd_config& g = *cfg;
     if (g.n_models < 1 || g.n_models > 8 || g.depth < 1 || g.depth > 8 || g.kernel != 2 * g.stride || g.stride < 2 || g.norm_groups < 1 ||
-        g.res_blocks < 0 || g.res_blocks > 4 || g.chin != 1 || g.act < 0 || g.act > 2 || g.n_eval < 1 || g.n_eval > 1000 || g.precision < 1 || g.precision > 3)
+        g.norm_groups > 8 || g.res_blocks < 0 || g.res_blocks > 4 || g.chin != 1 || g.act < 0 || g.act > 2 || g.n_eval < 1 || g.n_eval > 1000 || g.precision < 1 || g.precision > 3)
         return mv_fail(MV_ERR_INVALID, "mv_mbd_create: unsupported configuration (kernel must be 2 x stride, chin 1)");
     for (int i = 0; i < g.depth; ++i)
         if (g.channels[i] < 8 || g.channels[i] % 8 || g.channels[i] % g.norm_groups)
@@ -747,15 +789,16 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, MbdGemmArgs& g, const bf1
             g.seg[g.n_seg++] = GemmSeg{ab + t * tap_stride, wb + (size_t)t * k_per_tap, k_per_tap};
         }
     }
-    hipLaunchKernelGGL(mbd_gemm_kernel, dim3((g.N + BN - 1) / BN, (g.M + BM - 1) / BM), dim3(256), 0, s, g);
+    const int nt = (g.N + BN - 1) / BN;
+    if (nt * ((g.M + 127) / 128) >= 400) hipLaunchKernelGGL(mbd_gemm_kernel<128>, dim3(nt, (g.M + 127) / 128), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(mbd_gemm_kernel<64>, dim3(nt, (g.M + 63) / 64), dim3(256), 0, s, g);
     return hipGetLastError();
 }
 
 hipError_t group_stats(hipStream_t s, const float* x, int T, int C, int G, UnetBuffers& ub) {
-    const int rows_per = 64;
-    const int chunks = (T + rows_per - 1) / rows_per;
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, G), dim3(256), 0, s, x, T, C, G, rows_per, ub.part);
-    hipLaunchKernelGGL(gn_final_kernel, dim3(1), dim3(64), 0, s, ub.part, chunks, G, (double)T * (C / G), 1e-5f, ub.stats);
+    const int chunks = (int)(((size_t)T * C + GN_CHUNK - 1) / GN_CHUNK);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks), dim3(256), 0, s, x, T, C, G, ub.part);
+    hipLaunchKernelGGL(gn_final_kernel, dim3(1), dim3(256), 0, s, ub.part, chunks, G, (double)T * (C / G), 1e-5f, ub.stats);
     return hipGetLastError();
 }
 
@@ -763,21 +806,15 @@ hipError_t group_stats(hipStream_t s, const float* x, int T, int C, int G, UnetB
 hipError_t res_block(hipStream_t s, const mv_mbd* m, const ResW& rw, const float* x, float* out, int T, int C, int dilation, const float* col_add,
                      UnetBuffers& ub) {
     const int G = m->cfg.norm_groups, act = m->cfg.act;
-    const size_t n = (size_t)T * C;
     const int pad = dilation;  // kernel 3
     hipError_t e;
-    // zero margins of the operand buffer: `pad` rows before and after (the interior is overwritten)
-    if ((e = hipMemsetAsync(ub.hi, 0, (size_t)pad * C * 2, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(ub.lo, 0, (size_t)pad * C * 2, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(ub.hi + ((size_t)T + pad) * C, 0, (size_t)pad * C * 2, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(ub.lo + ((size_t)T + pad) * C, 0, (size_t)pad * C * 2, s)) != hipSuccess) return e;
     for (int half = 0; half < 2; ++half) {
         const float* in = half == 0 ? x : ub.b32;
         const NormW& nw = half == 0 ? rw.n1 : rw.n2;
         const ConvW& cw = half == 0 ? rw.c1 : rw.c2;
         if ((e = group_stats(s, in, T, C, G, ub)) != hipSuccess) return e;
-        hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, C, G, ub.stats, nw.g, nw.b, act, (float*)nullptr, ub.hi,
-                           m->cfg.precision > 2 ? ub.lo : nullptr, (size_t)pad);
+        hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)(((size_t)(T + 2 * pad) * C / 4 + 255) / 256)), dim3(256), 0, s, in, T, C, G, ub.stats, nw.g, nw.b, act,
+                           (float*)nullptr, ub.hi, m->cfg.precision > 2 ? ub.lo : nullptr, pad, pad);
         MbdGemmArgs g;
         g.M = T; g.N = C; g.lda = C; g.out = half == 0 ? ub.b32 : out; g.ldc = C; g.bias = cw.bias;
         if (half == 1) { g.residual = x; g.ldr = C; g.col_add = col_add; }
@@ -828,7 +865,7 @@ int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float*
     MG_TRY(wk.get(&ub.hi, ub.widest + (size_t)k * 3072, true));
     MG_TRY(wk.get(&ub.lo, ub.widest + (size_t)k * 3072, true));
     MG_TRY(wk.get(&ub.dec_out, ub.widest + (size_t)4 * st * 3072, false));
-    MG_TRY(wk.get(&ub.part, (size_t)((T / st + 64) / 64 + 2) * G * 2, false));
+    MG_TRY(wk.get(&ub.part, (ub.widest / GN_CHUNK + 2) * G * 2, false));
     MG_TRY(wk.get(&ub.stats, (size_t)2 * G, false));
     float *cur = nullptr, *est = nullptr, *total = nullptr, *d_lat = nullptr, *d_noise = nullptr, *d_ref = nullptr;
     MG_TRY(wk.get(&cur, (size_t)T, false));
@@ -880,17 +917,10 @@ int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float*
                 if (i == 0) {
                     hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)(((size_t)To * Cout + 255) / 256)), dim3(256), 0, s, zin, Tin, E.conv_in_w, Cout, k, st, pad, ub.a32, To);
                 } else {
-                    // operand: zin with `pad` zero rows in front and (Tpad - Tin) + (k - st - pad) behind
-                    const size_t back = (size_t)(ub.Tpad[i] - Tin + k) * Cin;
-                    MG_TRY(hipMemsetAsync(ub.hi, 0, (size_t)pad * Cin * 2, s));
-                    MG_TRY(hipMemsetAsync(ub.hi + ((size_t)pad + Tin) * Cin, 0, back * 2, s));
-                    if (g.precision > 2) {
-                        MG_TRY(hipMemsetAsync(ub.lo, 0, (size_t)pad * Cin * 2, s));
-                        MG_TRY(hipMemsetAsync(ub.lo + ((size_t)pad + Tin) * Cin, 0, back * 2, s));
-                    }
-                    const size_t n = (size_t)Tin * Cin;
-                    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, zin, n, Cin, G, (const float*)nullptr, (const float*)nullptr,
-                                       (const float*)nullptr, 0, (float*)nullptr, ub.hi, g.precision > 2 ? ub.lo : nullptr, (size_t)pad);
+                    // operand: zin with `pad` zero rows in front and (Tpad - Tin) + k behind
+                    const int back = ub.Tpad[i] - Tin + k;
+                    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)(((size_t)(pad + Tin + back) * Cin / 4 + 255) / 256)), dim3(256), 0, s, zin, Tin, Cin, G,
+                                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, ub.hi, g.precision > 2 ? ub.lo : nullptr, pad, back);
                     MbdGemmArgs ga;
                     ga.M = To; ga.N = Cout; ga.lda = (int64_t)st * Cin; ga.out = ub.a32; ga.ldc = Cout;
                     MG_TRY(launch_gemm(s, m, ga, ub.hi, ub.lo, E.conv, 1, 0, k * Cin));
@@ -899,8 +929,8 @@ int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float*
                 const size_t no = (size_t)To * Cout;
                 const float* emb = (i == 0 || g.emb_all_layers) ? E.emb + (size_t)step * Cout : nullptr;
                 float* dst = g.res_blocks > 0 ? ub.c32 : ub.skip[i];
-                hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, s, ub.a32, no, Cout, G, ub.stats, E.norm.g, E.norm.b, g.act, dst,
-                                   (bf16_t*)nullptr, (bf16_t*)nullptr, (size_t)0);
+                hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)((no / 4 + 255) / 256)), dim3(256), 0, s, ub.a32, To, Cout, G, ub.stats, E.norm.g, E.norm.b, g.act, dst,
+                                   (bf16_t*)nullptr, (bf16_t*)nullptr, 0, 0);
                 for (int r = 0; r < g.res_blocks; ++r) {
                     const bool lastr = r == g.res_blocks - 1;
                     MG_TRY(res_block(s, m, E.res[r], ub.c32, lastr ? ub.skip[i] : ub.c32, To, Cout, 1 << r, lastr ? emb : nullptr, ub));
@@ -955,19 +985,13 @@ int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float*
                 for (int r = 0; r < g.res_blocks; ++r) MG_TRY(res_block(s, m, Dw.res[r], ub.c32, ub.c32, Ts, C, 1 << r, nullptr, ub));
                 MG_TRY(group_stats(s, ub.c32, Ts, C, G, ub));
                 if (lvl == 0) {
-                    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ub.c32, n, C, G, ub.stats, Dw.norm.g, Dw.norm.b, g.act, ub.a32,
-                                       (bf16_t*)nullptr, (bf16_t*)nullptr, (size_t)0);
+                    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, ub.c32, Ts, C, G, ub.stats, Dw.norm.g, Dw.norm.b, g.act, ub.a32,
+                                       (bf16_t*)nullptr, (bf16_t*)nullptr, 0, 0);
                     hipLaunchKernelGGL(convtr_out_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ub.a32, Ts, C, Dw.convtr_out_w, k, st, pad, est, T);
                 } else {
                     // operand rows: [zero row | z rows 0..Ts-1 | zero row]; GEMM row q = (x[q-1], x[q]), q = 0..Ts
-                    MG_TRY(hipMemsetAsync(ub.hi, 0, (size_t)C * 2, s));
-                    MG_TRY(hipMemsetAsync(ub.hi + ((size_t)Ts + 1) * C, 0, (size_t)C * 2, s));
-                    if (g.precision > 2) {
-                        MG_TRY(hipMemsetAsync(ub.lo, 0, (size_t)C * 2, s));
-                        MG_TRY(hipMemsetAsync(ub.lo + ((size_t)Ts + 1) * C, 0, (size_t)C * 2, s));
-                    }
-                    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ub.c32, n, C, G, ub.stats, Dw.norm.g, Dw.norm.b, g.act, (float*)nullptr,
-                                       ub.hi, g.precision > 2 ? ub.lo : nullptr, (size_t)1);
+                    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)(((size_t)(Ts + 2) * C / 4 + 255) / 256)), dim3(256), 0, s, ub.c32, Ts, C, G, ub.stats, Dw.norm.g,
+                                       Dw.norm.b, g.act, (float*)nullptr, ub.hi, g.precision > 2 ? ub.lo : nullptr, 1, 1);
                     MbdGemmArgs ga;
                     ga.M = Ts + 1; ga.N = st * Cout; ga.lda = C; ga.out = ub.dec_out; ga.ldc = (int64_t)st * Cout;
                     MG_TRY(launch_gemm(s, m, ga, ub.hi, ub.lo, Dw.convtr, 1, 0, 2 * C));
