@@ -45,7 +45,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int MB_MAX_SEG = 12;   // K-segments of one GEMM: (conv taps when dilated) x (precision terms)
-constexpr int BN = 128, BK = 64;   // BM = 128 or 64 (template): the 3072-channel layers have M = 1200, 64-row tiles give 456 blocks
+constexpr int BN = 128, BK = 128;   // BM = 128 or 64 (template): the 3072-channel layers have M = 1200, 64-row tiles give 456 blocks
 
 struct GemmSeg {
     const bf16_t* a;   // first row of the A window of output row 0 for this segment
@@ -66,21 +66,23 @@ struct MbdGemmArgs {
     const float* col_add = nullptr;   // [N] or null (step embedding)
 };
 
-// C = A W^T on BM x 128 x 64 tiles (BM = 128 or 64), 256 threads = 4 waves (2 x 2), each wave (BM / 2) x 64 = MI x 4 MFMA 16x16x32
-// tiles.  Staging as in gemm.hip: 16-byte chunks, XOR-swizzled by row, global -> registers -> LDS with the next K-tile's loads in
-// flight under the current tile's MFMAs; two blocks per CU overlap one block's staging with the other's MFMAs.  Rows past M / N
-// are clamped (duplicates) and dropped in the epilogue.
+// C = A W^T on BM x 128 x 128 tiles (BM = 128 or 64), 256 threads = 4 waves (2 x 2), each wave (BM / 2) x 64 = MI x 4 MFMA 16x16x32
+// tiles.  Staging: 16-byte chunks, XOR-swizzled by row, global -> registers -> LDS with the NEXT K-tile's loads in flight under the
+// current tile's MFMAs.  The K-tile is 128 deep: with one tile of prefetch distance a 64-deep tile left ~0.15 us of MFMA work to
+// cover ~0.4 us of load latency (the first version ran at 19 % of the MFMA peak, one iteration per load round trip); two blocks
+// per CU overlap one block's staging with the other's MFMAs.  Rows past M / N are clamped (duplicates) and dropped in the epilogue.
 template <int BM>
 __global__ void __launch_bounds__(256, 2) mbd_gemm_kernel(const MbdGemmArgs a) {
     constexpr int MI = BM / 32;   // MFMA row tiles per wave
-    constexpr int AR = BM / 32;   // A rows staged per thread
-    __shared__ __attribute__((aligned(16))) u32x4 lds_a[BM * 8];  // [row][8 chunks of 16 B], chunk ^= row & 7
-    __shared__ __attribute__((aligned(16))) u32x4 lds_w[BN * 8];
+    constexpr int AR = BM / 16;   // A rows staged per thread
+    constexpr int CH = BK / 8;    // 16-byte chunks per row
+    __shared__ __attribute__((aligned(16))) u32x4 lds_a[BM * CH];  // [row][16 chunks of 16 B], chunk ^= row & 15
+    __shared__ __attribute__((aligned(16))) u32x4 lds_w[BN * CH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tile_m = blockIdx.y * BM, tile_n = blockIdx.x * BN;
     const int M = a.M, N = a.N;
-    const int sr = tid >> 3, sc = tid & 7;  // thread stages chunk sc of rows sr + 32 i
+    const int sr = tid >> 4, sc = tid & 15;  // thread stages chunk sc of rows sr + 16 i
 
     f32x4_t acc[MI][4];
 #pragma unroll
@@ -92,43 +94,43 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_kernel(const MbdGemmArgs a) {
     for (int s = 0; s < a.n_seg; ++s) {
         const GemmSeg sg = a.seg[s];
         const bf16_t* ga[AR];
-        const bf16_t* gw[4];
+        const bf16_t* gw[8];
 #pragma unroll
-        for (int i = 0; i < AR; ++i) ga[i] = sg.a + (size_t)min(tile_m + sr + 32 * i, M - 1) * a.lda + sc * 8;
+        for (int i = 0; i < AR; ++i) ga[i] = sg.a + (size_t)min(tile_m + sr + 16 * i, M - 1) * a.lda + sc * 8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gw[i] = sg.w + (size_t)min(tile_n + sr + 32 * i, N - 1) * a.ldw + sc * 8;
-        u32x4 ra[AR], rw[4];
+        for (int i = 0; i < 8; ++i) gw[i] = sg.w + (size_t)min(tile_n + sr + 16 * i, N - 1) * a.ldw + sc * 8;
+        u32x4 ra[AR], rw[8];
         const bool in0 = sc * 8 < sg.K;
 #pragma unroll
         for (int i = 0; i < AR; ++i) ra[i] = in0 ? load16(ga[i]) : zero;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rw[i] = in0 ? load16(gw[i]) : zero;
+        for (int i = 0; i < 8; ++i) rw[i] = in0 ? load16(gw[i]) : zero;
         for (int k0 = 0; k0 < sg.K; k0 += BK) {
             __syncthreads();  // everyone is done reading the previous tile
 #pragma unroll
-            for (int i = 0; i < AR; ++i) { const int r = sr + 32 * i; lds_a[r * 8 + (sc ^ (r & 7))] = ra[i]; }
+            for (int i = 0; i < AR; ++i) { const int r = sr + 16 * i; lds_a[r * CH + (sc ^ (r & 15))] = ra[i]; }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const int r = sr + 32 * i; lds_w[r * 8 + (sc ^ (r & 7))] = rw[i]; }
+            for (int i = 0; i < 8; ++i) { const int r = sr + 16 * i; lds_w[r * CH + (sc ^ (r & 15))] = rw[i]; }
             __syncthreads();
             if (k0 + BK < sg.K) {
                 const bool in = k0 + BK + sc * 8 < sg.K;
 #pragma unroll
                 for (int i = 0; i < AR; ++i) ra[i] = in ? load16(ga[i] + k0 + BK) : zero;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rw[i] = in ? load16(gw[i] + k0 + BK) : zero;
+                for (int i = 0; i < 8; ++i) rw[i] = in ? load16(gw[i] + k0 + BK) : zero;
             }
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < BK / 32; ++kk) {
                 bf16x8_t af[MI], bf[4];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     const int r = wm * (BM / 2) + i * 16 + (lane & 15);
-                    af[i] = __builtin_bit_cast(bf16x8_t, lds_a[r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
+                    af[i] = __builtin_bit_cast(bf16x8_t, lds_a[r * CH + ((kk * 4 + (lane >> 4)) ^ (r & 15))]);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = wn * 64 + j * 16 + (lane & 15);
-                    bf[j] = __builtin_bit_cast(bf16x8_t, lds_w[r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
+                    bf[j] = __builtin_bit_cast(bf16x8_t, lds_w[r * CH + ((kk * 4 + (lane >> 4)) ^ (r & 15))]);
                 }
 #pragma unroll
                 for (int i = 0; i < MI; ++i)

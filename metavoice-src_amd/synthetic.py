@@ -134,7 +134,8 @@ def prompt_tokens(n: int = 128, seed: int = 0, text_offset: int = 2049, n_text: 
     return torch.cat([body, torch.tensor([text_offset + n_text])]).to(torch.int32)
 
 
-def write_model_dir(path: str, *, stage1: Optional[dict] = None, stage2_args: Optional[dict] = None, seed: int = 0) -> str:
+def write_model_dir(path: str, *, stage1: Optional[dict] = None, stage2_args: Optional[dict] = None, seed: int = 0,
+                    mbd: Optional[dict] = None) -> str:
     """Write `first_stage.pt` / `second_stage.pt` / `speaker_encoder.pt` (+ `encodec_24khz.pt`, which the reference fetches from
     the hub) with the reference's checkpoint layout (`fam/llm/finetune.py:300-313`:
     {"model", "model_args", "config", "meta"}) and synthetic weights + a synthetic 512-rank BPE table, so that the whole
@@ -164,6 +165,8 @@ def write_model_dir(path: str, *, stage1: Optional[dict] = None, stage2_args: Op
     }, os.path.join(path, "second_stage.pt"))
     torch.save({"model_state": speaker_encoder_state_dict(seed=seed + 2)}, os.path.join(path, "speaker_encoder.pt"))
     torch.save(encodec_state_dict(seed=seed + 3), os.path.join(path, "encodec_24khz.pt"))
+    if mbd is not None:  # kwargs of mbd_package: the multi-band diffusion package the reference fetches from the hub
+        torch.save(mbd_package(seed=seed + 4, **mbd), os.path.join(path, "mbd_comp_8.pt"))
     return path
 
 

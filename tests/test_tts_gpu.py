@@ -108,3 +108,40 @@ def test_tts_without_codec_weights_fails_at_construction(tmp_path):
     os.unlink(os.path.join(model_dir, "encodec_24khz.pt"))
     with pytest.raises(FileNotFoundError, match="encodec_24khz.pt"):
         fast_inference.TTS(model_dir, output_dir=str(tmp_path / "out"))
+
+
+def test_tts_with_multiband_diffusion_in_the_model_dir(tmp_path):
+    """`mbd_comp_8.pt` next to the checkpoints: the default vocoder becomes EnCodec decode + multi-band diffusion + re_eq, as
+    `fam/llm/decoders.py:13,84-85` has it.  `synthesise` runs end to end on the engine's own noise; with injected noise the
+    vocoder's waveform is compared with the oracle chain (oracle/codec.py -> oracle/mbd.py)."""
+    import math
+
+    from oracle import mbd as o_mbd
+
+    small = dict(n_bands=2, hidden=16, depth=3, growth=2.0, codec_dim=128, proc_bands=4)
+    model_dir = synthetic.write_model_dir(str(tmp_path / "model"), seed=6, mbd=small)
+    t = fast_inference.TTS(model_dir, seed=2, output_dir=str(tmp_path / "out"))
+    assert t.vocoder.diffusion is not None
+    path = t.synthesise("Multi band diffusion in the loop.", synthetic.speaker_embedding(2))
+    pcm, rate = read_pcm16(path)
+    assert rate == 24000 and pcm.size >= 9600 and int(np.abs(pcm).max()) > 100
+    # parity of the vocoder call with injected noise
+    g = torch.Generator().manual_seed(4)
+    grid = torch.randint(0, 1024, (1, 8, 40), generator=g)
+    T = 40 * 320
+    noise = torch.randn(2, 21, T, generator=g)
+    got = t.vocoder.tokens_to_wav(grid, noise=noise).reshape(-1)
+    sd = {k: v.float() for k, v in codec.fold_weight_norm(torch.load(os.path.join(model_dir, "encodec_24khz.pt"))).items()}
+    owav, olat = o_codec.decode(sd, grid[0])
+    pkg = torch.load(os.path.join(model_dir, "mbd_comp_8.pt"), weights_only=False)
+    bands = []
+    for b in range(2):
+        u = pkg[b]["cfg"]["diffusion_unet"]
+        bands.append(o_mbd.BandModel(sd=pkg[b]["model_state"], processor=pkg[b]["processor_state"],
+                                     cfg=o_mbd.UnetConfig(hidden=u["hidden"], depth=u["depth"], growth=u["growth"], codec_dim=u["codec_dim"])))
+    ref = o_mbd.tokens_to_wav(bands, owav.view(1, 1, -1), olat.view(1, 128, -1), [noise[b, 0].view(1, 1, -1) for b in range(2)],
+                              [[noise[b, 1 + i].view(1, 1, -1) for i in range(20)] for b in range(2)]).reshape(-1)
+    err = float(((got - ref) ** 2).mean())
+    snr = 10 * math.log10(float((ref ** 2).mean()) / max(err, 1e-30))
+    print(f"[tts + mbd] vocoder waveform vs oracle chain: SNR {snr:.1f} dB, MSE {err:.3e}")
+    assert snr >= 40.0
