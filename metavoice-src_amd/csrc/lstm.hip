@@ -61,12 +61,25 @@ __global__ void __launch_bounds__(LS_THREADS) lstm_seq_kernel(const LstmSeqArgs 
             // h_{t-1} of every unit and batch row: granules tagged with this launch's serial and t
             const gran_t* src = a.hx + (size_t)(t & 1) * B * H;
             const uint32_t tag = a.tag_base + (uint32_t)t;
-            for (int n = tid; n < B * H; n += LS_THREADS) {
-                unsigned long long v = 0;
-                int tries = 0;
-                for (;; ++tries) {
-                    v = __hip_atomic_load(src + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((uint32_t)(v >> 32) == tag) break;
+            // all of a thread's granules are requested before the first is examined (one round trip, not one per granule);
+            // only the ones still carrying an old tag are re-read
+            for (int n0 = tid; n0 < B * H; n0 += 4 * LS_THREADS) {
+                unsigned long long v[4];
+                bool need[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { need[k] = n0 + k * LS_THREADS < B * H; v[k] = 0; }
+                for (int tries = 0;; ++tries) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (need[k]) v[k] = __hip_atomic_load(src + n0 + k * LS_THREADS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bool pending = false;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (need[k]) {
+                            if ((uint32_t)(v[k] >> 32) == tag) { h_s[n0 + k * LS_THREADS] = __uint_as_float((uint32_t)v[k]); need[k] = false; }
+                            else pending = true;
+                        }
+                    if (!pending) break;
                     if ((tries & 1023) == 1023) {
                         const bool peer = __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
                         if (peer || tries >= LS_SPIN_LIMIT) {
@@ -77,7 +90,6 @@ __global__ void __launch_bounds__(LS_THREADS) lstm_seq_kernel(const LstmSeqArgs 
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                h_s[n] = __uint_as_float((uint32_t)v);
             }
             __syncthreads();
             if (s_abort) return;
@@ -86,33 +98,41 @@ __global__ void __launch_bounds__(LS_THREADS) lstm_seq_kernel(const LstmSeqArgs 
         gran_t* dst = a.hx + (size_t)((t + 1) & 1) * B * H;
         for (int b = 0; b < B; ++b) {
             const float* hb = h_s + (size_t)b * H;
+            // the wave's 8 gate rows (2 units x i, f, g, o): row totals are wave-uniform after wave_sum; lane l < 8 keeps the total of
+            // (unit l >> 2, gate l & 3) and evaluates that gate's non-linearity -- the eight expf / tanhf run in parallel lanes
+            // instead of one after the other in lane 0 (they were ~0.5 us of every step's serial chain)
+            float mine = 0.f;
 #pragma unroll
-            for (int uu = 0; uu < 2; ++uu) {
-                const int u = wave * 2 + uu;
-                float g[4];
+            for (int uu = 0; uu < 2; ++uu)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float* w = w_s + (size_t)(q * LS_UPW + u) * H;
+                    const float* w = w_s + (size_t)(q * LS_UPW + wave * 2 + uu) * H;
                     float s = 0.f;
                     for (int k = lane; k < H; k += 64) s = fmaf(w[k], hb[k], s);
-                    g[q] = wave_sum(s);
+                    s = wave_sum(s);
+                    if (lane == uu * 4 + q) mine = s;
                 }
-                if (lane == 0) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) g[q] += a.gin[(size_t)b * a.gs_b + (size_t)t * a.gs_t + (size_t)(q * H + u0 + u) * a.gs_r];
-                    const float ig = sigmoidf_(g[0]), fg = sigmoidf_(g[1]), gg = tanhf(g[2]), og = sigmoidf_(g[3]);
-                    const float c = fmaf(fg, c_s[b * LS_UPW + u], ig * gg);
-                    const float h = og * tanhf(c);
-                    c_s[b * LS_UPW + u] = c;
-                    if (t + 1 < a.T)
-                        __hip_atomic_store(dst + (size_t)b * H + u0 + u, ((unsigned long long)(a.tag_base + (uint32_t)t + 1u) << 32) | __float_as_uint(h),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (a.y) {
-                        const size_t o = (size_t)b * a.ys_b + (size_t)t * a.ys_t + (size_t)(u0 + u) * a.ys_u;
-                        a.y[o] = h + (a.skip ? a.skip[o] : 0.f);
-                    }
-                    if (a.h_last && t == a.T - 1) a.h_last[(size_t)b * H + u0 + u] = h;
+            float act = 0.f;
+            if (lane < 8) {
+                const int u = wave * 2 + (lane >> 2), q = lane & 3;
+                const float g = mine + a.gin[(size_t)b * a.gs_b + (size_t)t * a.gs_t + (size_t)(q * H + u0 + u) * a.gs_r];
+                act = q == 2 ? tanhf(g) : sigmoidf_(g);
+            }
+            const int base = lane & 4;  // lanes 0 and 4 gather their unit's i, f, g, o
+            const float ig = __shfl(act, base + 0, 64), fg = __shfl(act, base + 1, 64), gg = __shfl(act, base + 2, 64), og = __shfl(act, base + 3, 64);
+            if (lane == 0 || lane == 4) {
+                const int u = wave * 2 + (lane >> 2);
+                const float c = fmaf(fg, c_s[b * LS_UPW + u], ig * gg);
+                const float h = og * tanhf(c);
+                c_s[b * LS_UPW + u] = c;
+                if (t + 1 < a.T)
+                    __hip_atomic_store(dst + (size_t)b * H + u0 + u, ((unsigned long long)(a.tag_base + (uint32_t)t + 1u) << 32) | __float_as_uint(h),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.y) {
+                    const size_t o = (size_t)b * a.ys_b + (size_t)t * a.ys_t + (size_t)(u0 + u) * a.ys_u;
+                    a.y[o] = h + (a.skip ? a.skip[o] : 0.f);
                 }
+                if (a.h_last && t == a.T - 1) a.h_last[(size_t)b * H + u0 + u] = h;
             }
         }
         __syncthreads();  // h_s is overwritten by the next poll
