@@ -159,59 +159,53 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_kernel(const MbdGemmArgs a) {
 }
 
 // ---- GroupNorm statistics: deterministic two stages ------------------------------------------------------------------------
-// stage 1: block c sums x and x^2 of elements [c * GN_CHUNK, ...) per group -> part[c][g][2] (double).  A thread walks the chunk
-// in float4 steps; the group is resolved per element (G <= 8 accumulators in registers).
-constexpr int GN_CHUNK = 16384, GN_MAXG = 8;   // elements per block: the grid does not depend on the [T][C] aspect ratio
-__global__ void __launch_bounds__(256) gn_partial_kernel(const float* __restrict__ x, int T, int C, int G, double* __restrict__ part) {
-    __shared__ double red[4][GN_MAXG][2];
-    const int c = blockIdx.x, cg = C / G;
-    const size_t e0 = (size_t)c * GN_CHUNK, e1 = min((size_t)T * C, e0 + (size_t)GN_CHUNK);
-    float s[GN_MAXG], s2[GN_MAXG];
-#pragma unroll
-    for (int g = 0; g < GN_MAXG; ++g) { s[g] = 0.f; s2[g] = 0.f; }
-    for (size_t i = e0 + (size_t)threadIdx.x * 4; i < e1; i += 1024) {
-        const float4 v = *(const float4*)(x + i);
-        const int ch = (int)(i % C);
-        const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int g = (ch + q) / cg;
-#pragma unroll
-            for (int k = 0; k < GN_MAXG; ++k)
-                if (k == g) { s[k] += vv[q]; s2[k] = fmaf(vv[q], vv[q], s2[k]); }
+// stage 1: block (c, g) sums x and x^2 of group g over rows [c * rows_per, ...) -> part[c][g][2] (double).  A thread walks the
+// (rows x C / G) sub-matrix in float4 steps (C / G is a multiple of 4 whenever C is a multiple of 16; otherwise scalar steps).
+__global__ void __launch_bounds__(256) gn_partial_kernel(const float* __restrict__ x, int T, int C, int G, int rows_per, double* __restrict__ part) {
+    __shared__ double red[4][2];
+    const int c = blockIdx.x, g = blockIdx.y, cg = C / G;
+    const int t0 = c * rows_per, t1 = min(T, t0 + rows_per);
+    const float* base = x + (size_t)t0 * C + (size_t)g * cg;
+    float s = 0.f, s2 = 0.f;
+    if ((cg & 3) == 0) {
+        const int q4 = cg >> 2, n = (t1 - t0) * q4;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int r = i / q4, k = i - r * q4;
+            const float4 v = *(const float4*)(base + (size_t)r * C + 4 * k);
+            s += (v.x + v.y) + (v.z + v.w);
+            s2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, s2))));
+        }
+    } else {
+        const int n = (t1 - t0) * cg;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int r = i / cg, k = i - r * cg;
+            const float v = base[(size_t)r * C + k];
+            s += v;
+            s2 = fmaf(v, v, s2);
         }
     }
-    for (int g = 0; g < G; ++g) {
-        double a = s[g], b = s2[g];
-        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
-        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][g][0] = a; red[threadIdx.x >> 6][g][1] = b; }
-    }
+    double a = s, b = s2;
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a; red[threadIdx.x >> 6][1] = b; }
     __syncthreads();
-    if (threadIdx.x < 2 * G) {
-        const int g = threadIdx.x >> 1, w = threadIdx.x & 1;
-        part[((size_t)c * G + g) * 2 + w] = red[0][g][w] + red[1][g][w] + red[2][g][w] + red[3][g][w];
-    }
+    if (threadIdx.x < 2) part[((size_t)c * G + g) * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
-// stage 2 (one block): stats[g] = (mean, rstd) with the biased variance torch.nn.GroupNorm uses; fixed-order tree over the chunks
+// stage 2 (one block): stats[g] = (mean, rstd) with the biased variance torch.nn.GroupNorm uses.  Thread t sums entry q = t % (2 G)
+// of chunks t / (2 G), t / (2 G) + 256 / (2 G), ...; the 256 / (2 G) per-q partials are then added in index order.
 __global__ void __launch_bounds__(256) gn_final_kernel(const double* __restrict__ part, int n_chunks, int G, double count, float eps, float* __restrict__ stats) {
     __shared__ double red[256];
-    __shared__ double s_mean;
-    for (int q = 0; q < 2 * G; ++q) {   // q = g * 2 + {sum, sum of squares}
-        double a = 0.0;
-        for (int c = threadIdx.x; c < n_chunks; c += 256) a += part[(size_t)c * 2 * G + q];
-        red[threadIdx.x] = a;
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-            __syncthreads();
-        }
-        const double tot = red[0];
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            if ((q & 1) == 0) { s_mean = tot / count; stats[q] = (float)s_mean; }
-            else stats[q] = (float)(1.0 / sqrt(fmax(tot / count - s_mean * s_mean, 0.0) + (double)eps));
-        }
-        __syncthreads();
+    const int nq = 2 * G, lanes = 256 / nq, q = threadIdx.x % nq, j = threadIdx.x / nq;
+    double a = 0.0;
+    if (j < lanes)
+        for (int c = j; c < n_chunks; c += lanes) a += part[(size_t)c * nq + q];
+    red[threadIdx.x] = j < lanes ? a : 0.0;
+    __syncthreads();
+    if (threadIdx.x < G) {
+        double sum = 0.0, sq = 0.0;
+        for (int k = 0; k < lanes; ++k) { sum += red[k * nq + 2 * threadIdx.x]; sq += red[k * nq + 2 * threadIdx.x + 1]; }
+        const double mean = sum / count;
+        stats[2 * threadIdx.x] = (float)mean;
+        stats[2 * threadIdx.x + 1] = (float)(1.0 / sqrt(fmax(sq / count - mean * mean, 0.0) + (double)eps));
     }
 }
 
@@ -240,11 +234,20 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__
     const float4 xv = *(const float4*)(x + j);
     float v[4] = {xv.x, xv.y, xv.z, xv.w};
     if (stats) {
-        const int ch = (int)(j % C), cg = C / G;
+        const int ch = (int)(j - (row - front) * (size_t)C), cg = C / G;
+        const float4 gm = *(const float4*)(gamma + ch), bt = *(const float4*)(beta + ch);
+        const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+        if ((cg & 3) == 0) {  // the four channels share a group
+            const int g = ch / cg;
+            const float mean = stats[2 * g], rstd = stats[2 * g + 1];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int g = (ch + q) / cg;
-            v[q] = mb_act((v[q] - stats[2 * g]) * stats[2 * g + 1] * gamma[ch + q] + beta[ch + q], act);
+            for (int q = 0; q < 4; ++q) v[q] = mb_act((v[q] - mean) * rstd * gmv[q] + btv[q], act);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int g = (ch + q) / cg;
+                v[q] = mb_act((v[q] - stats[2 * g]) * stats[2 * g + 1] * gmv[q] + btv[q], act);
+            }
         }
     }
     if (y32) *(float4*)(y32 + j) = make_float4(v[0], v[1], v[2], v[3]);
@@ -702,7 +705,7 @@ int mv_mbd_set_processor(mv_mbd* m, int32_t band_idx, int32_t n_bands, const flo
 }
 
 int mv_mbd_set_filterbank(mv_mbd* m, int32_t which, int32_t n_filters, int32_t taps, const float* coeffs) {
-    if (!m || !coeffs || taps < 1 || taps % 2 == 0 || taps > 8191) return mv_fail(MV_ERR_INVALID, "mv_mbd_set_filterbank: bad argument");
+    if (!m || !coeffs || taps < 1 || taps % 2 == 0 || taps > 7679)  /* (256 + 2 taps) floats of LDS <= 64 KB */ return mv_fail(MV_ERR_INVALID, "mv_mbd_set_filterbank: bad argument");
     const int want = (which == 0 ? m->cfg.proc_bands : m->cfg.eq_bands) - 1;
     if (n_filters != want) return mv_fail(MV_ERR_INVALID, "mv_mbd_set_filterbank: expected %d filters, got %d", want, n_filters);
     float** dst = which == 0 ? &m->proc_bank : &m->eq_bank;
@@ -798,8 +801,10 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, MbdGemmArgs& g, const bf1
 }
 
 hipError_t group_stats(hipStream_t s, const float* x, int T, int C, int G, UnetBuffers& ub) {
-    const int chunks = (int)(((size_t)T * C + GN_CHUNK - 1) / GN_CHUNK);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks), dim3(256), 0, s, x, T, C, G, ub.part);
+    // ~16 K elements per block whatever the [T][C] aspect ratio: rows_per rows of one group
+    const int rows_per = std::max(1, (int)((size_t)16384 * G / C));
+    const int chunks = (T + rows_per - 1) / rows_per;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, G), dim3(256), 0, s, x, T, C, G, rows_per, ub.part);
     hipLaunchKernelGGL(gn_final_kernel, dim3(1), dim3(256), 0, s, ub.part, chunks, G, (double)T * (C / G), 1e-5f, ub.stats);
     return hipGetLastError();
 }
@@ -864,10 +869,20 @@ int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float*
     MG_TRY(wk.get(&ub.a32, ub.widest, false));
     MG_TRY(wk.get(&ub.b32, ub.widest, false));
     MG_TRY(wk.get(&ub.c32, ub.widest, false));
-    MG_TRY(wk.get(&ub.hi, ub.widest + (size_t)k * 3072, true));
-    MG_TRY(wk.get(&ub.lo, ub.widest + (size_t)k * 3072, true));
-    MG_TRY(wk.get(&ub.dec_out, ub.widest + (size_t)4 * st * 3072, false));
-    MG_TRY(wk.get(&ub.part, (ub.widest / GN_CHUNK + 2) * G * 2, false));
+    size_t max_c = 8;
+    for (int i = 0; i < D; ++i) max_c = std::max(max_c, (size_t)m->ch[i]);
+    const size_t margin = (size_t)(2 * k + 2 * st + 8) * max_c;   // zero rows around a convolution operand / transposed-conv overhang
+    MG_TRY(wk.get(&ub.hi, ub.widest + margin, true));
+    MG_TRY(wk.get(&ub.lo, ub.widest + margin, true));
+    MG_TRY(wk.get(&ub.dec_out, ub.widest + margin, false));
+    {
+        size_t max_blocks = 1;   // gn_partial_kernel's grid (chunks x G), largest level: see group_stats
+        for (int i = 0; i < D; ++i) {
+            const int rows_per = std::max(1, (int)((size_t)16384 * G / m->ch[i]));
+            max_blocks = std::max(max_blocks, (size_t)((ub.T[i] + rows_per - 1) / rows_per + 1) * G);
+        }
+        MG_TRY(wk.get(&ub.part, max_blocks * 2, false));
+    }
     MG_TRY(wk.get(&ub.stats, (size_t)2 * G, false));
     float *cur = nullptr, *est = nullptr, *total = nullptr, *d_lat = nullptr, *d_noise = nullptr, *d_ref = nullptr;
     MG_TRY(wk.get(&cur, (size_t)T, false));

@@ -62,6 +62,31 @@ def test_full_size_path_equivalences(full):
     assert run(engine, prompt, spk, mv.SamplingParams(top_p=0.95, seed=7), n_new, prefill_mode=1) != a  # the seed matters
 
 
+def test_full_size_two_utterances_in_the_persistent_kernel():
+    """BASELINE configs[2] at the real depth: two utterances with ragged prompts decoded together by the persistent kernel (24
+    layers, 256 workgroups) against the per-layer launches on the same batch -- identical tokens and logits."""
+    sd = fiu.remap_checkpoint_keys(synthetic.stage1_state_dict(seed=1, device="cuda", **FULL))
+    engine = mv.Stage1Engine(mv.ModelArgs(**FULL), max_utterances=2)
+    engine.load_state_dict(sd)
+    del sd
+    engine.finalize()
+    lens, n_new = [141, 96], 40
+    prompts = [synthetic.prompt_tokens(t, seed=60 + u) for u, t in enumerate(lens)]
+    spks = torch.cat([synthetic.speaker_embedding(70 + u) for u in range(2)])
+    sps = [mv.SamplingParams(top_p=0.95, guidance_scale=3.0, seed=80 + u) for u in range(2)]
+    engine.capture_logits(True)
+    out = {}
+    for mega in (1, 0):
+        engine.tune(mega=mega)
+        engine.begin(prompts, spks, sps, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
+        engine.run()
+        out[mega] = ([engine.tokens(u) for u in range(2)], engine.captured_logits(max(lens) - 1, n_new - 1))
+    engine.tune(mega=1)
+    assert out[1][0] == out[0][0] and torch.equal(out[1][1], out[0][1])
+    assert [len(t) for t in out[1][0]] == [lens[0] + n_new, lens[1] + n_new]
+    engine.close()
+
+
 def test_full_size_first_positions_against_the_oracle(full):
     """Two decode positions of the 24-layer model against the oracle (bf16 rounding points), ~20 s of CPU."""
     engine, sd = full
