@@ -47,23 +47,30 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int MB_MAX_SEG = 12;   // K-segments of one GEMM: (conv taps when dilated) x (precision terms)
 constexpr int BN = 128, BK = 128;   // BM = 128 or 64 (template): the 3072-channel layers have M = 1200, 64-row tiles give 456 blocks
 
+constexpr int MB_MAX_BANDS = 8;
+struct PF { const float* p[MB_MAX_BANDS]; };     // one pointer per band model (weights differ per band; activations are band-strided)
+struct PH { const bf16_t* p[MB_MAX_BANDS]; };
+
 struct GemmSeg {
-    const bf16_t* a;   // first row of the A window of output row 0 for this segment
-    const bf16_t* w;   // [N][ldw] slice start
+    const bf16_t* a;   // band 0: first row of the A window of output row 0 for this segment
+    int w_lo;          // 0: the hi half of the weights, 1: the lo half
+    int64_t w_off;     // element offset of the slice inside a weight row
     int K;             // multiple of 8
 };
-struct MbdGemmArgs {
+struct MbdGemmArgs {   // the band models run the same shapes: grid.z = band
     GemmSeg seg[MB_MAX_SEG];
     int n_seg = 0;
     int M = 0, N = 0;
     int64_t lda = 0;       // elements between the windows of consecutive output rows
+    int64_t a_band = 0;    // elements between the operand buffers of consecutive bands
     int64_t ldw = 0;       // elements between weight rows
-    float* out = nullptr;  // [M][ldc]
-    int64_t ldc = 0;
-    const float* bias = nullptr;      // [N] or null
-    const float* residual = nullptr;  // [M][ldr] or null
-    int64_t ldr = 0;
-    const float* col_add = nullptr;   // [N] or null (step embedding)
+    PH w_hi, w_lo;         // [N][ldw] per band
+    float* out = nullptr;  // band 0: [M][ldc]
+    int64_t ldc = 0, out_band = 0;
+    PF bias;               // [N] per band or null
+    const float* residual = nullptr;  // band 0: [M][ldr] or null
+    int64_t ldr = 0, res_band = 0;
+    PF col_add;            // [N] per band or null (step embedding row)
 };
 
 // C = A W^T on BM x 128 x 128 tiles (BM = 128 or 64), 256 threads = 4 waves (2 x 2), each wave (BM / 2) x 64 = MI x 4 MFMA 16x16x32
@@ -80,7 +87,7 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_kernel(const MbdGemmArgs a) {
     __shared__ __attribute__((aligned(16))) u32x4 lds_w[BN * CH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile_m = blockIdx.y * BM, tile_n = blockIdx.x * BN;
+    const int tile_m = blockIdx.y * BM, tile_n = blockIdx.x * BN, band = blockIdx.z;
     const int M = a.M, N = a.N;
     const int sr = tid >> 4, sc = tid & 15;  // thread stages chunk sc of rows sr + 16 i
 
@@ -96,9 +103,10 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_kernel(const MbdGemmArgs a) {
         const bf16_t* ga[AR];
         const bf16_t* gw[8];
 #pragma unroll
-        for (int i = 0; i < AR; ++i) ga[i] = sg.a + (size_t)min(tile_m + sr + 16 * i, M - 1) * a.lda + sc * 8;
+        for (int i = 0; i < AR; ++i) ga[i] = sg.a + (size_t)band * a.a_band + (size_t)min(tile_m + sr + 16 * i, M - 1) * a.lda + sc * 8;
+        const bf16_t* wbase = (sg.w_lo ? a.w_lo.p[band] : a.w_hi.p[band]) + sg.w_off;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) gw[i] = sg.w + (size_t)min(tile_n + sr + 16 * i, N - 1) * a.ldw + sc * 8;
+        for (int i = 0; i < 8; ++i) gw[i] = wbase + (size_t)min(tile_n + sr + 16 * i, N - 1) * a.ldw + sc * 8;
         u32x4 ra[AR], rw[8];
         const bool in0 = sc * 8 < sg.K;
 #pragma unroll
@@ -146,14 +154,14 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_kernel(const MbdGemmArgs a) {
         for (int j = 0; j < 4; ++j) {
             const int n = tile_n + wn * 64 + j * 16 + (lane & 15);
             if (n >= N) continue;
-            const float add = (a.bias ? a.bias[n] : 0.f) + (a.col_add ? a.col_add[n] : 0.f);
+            const float add = (a.bias.p[band] ? a.bias.p[band][n] : 0.f) + (a.col_add.p[band] ? a.col_add.p[band][n] : 0.f);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int m = tile_m + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + reg;
                 if (m >= M) continue;
                 float y = acc[i][j][reg] + add;
-                if (a.residual) y += a.residual[(size_t)m * a.ldr + n];
-                a.out[(size_t)m * a.ldc + n] = y;
+                if (a.residual) y += a.residual[(size_t)band * a.res_band + (size_t)m * a.ldr + n];
+                a.out[(size_t)band * a.out_band + (size_t)m * a.ldc + n] = y;
             }
         }
 }
@@ -161,11 +169,13 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_kernel(const MbdGemmArgs a) {
 // ---- GroupNorm statistics: deterministic two stages ------------------------------------------------------------------------
 // stage 1: block (c, g) sums x and x^2 of group g over rows [c * rows_per, ...) -> part[c][g][2] (double).  A thread walks the
 // (rows x C / G) sub-matrix in float4 steps (C / G is a multiple of 4 whenever C is a multiple of 16; otherwise scalar steps).
-__global__ void __launch_bounds__(256) gn_partial_kernel(const float* __restrict__ x, int T, int C, int G, int rows_per, double* __restrict__ part) {
+__global__ void __launch_bounds__(256) gn_partial_kernel(const float* __restrict__ x, int64_t x_band, int T, int C, int G, int rows_per,
+                                                         double* __restrict__ part) {
     __shared__ double red[4][2];
     const int c = blockIdx.x, g = blockIdx.y, cg = C / G;
     const int t0 = c * rows_per, t1 = min(T, t0 + rows_per);
-    const float* base = x + (size_t)t0 * C + (size_t)g * cg;
+    const float* base = x + (size_t)blockIdx.z * x_band + (size_t)t0 * C + (size_t)g * cg;
+    part += (size_t)blockIdx.z * gridDim.x * G * 2;
     float s = 0.f, s2 = 0.f;
     if ((cg & 3) == 0) {
         const int q4 = cg >> 2, n = (t1 - t0) * q4;
@@ -194,6 +204,8 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const float* __restrict
 // of chunks t / (2 G), t / (2 G) + 256 / (2 G), ...; the 256 / (2 G) per-q partials are then added in index order.
 __global__ void __launch_bounds__(256) gn_final_kernel(const double* __restrict__ part, int n_chunks, int G, double count, float eps, float* __restrict__ stats) {
     __shared__ double red[256];
+    part += (size_t)blockIdx.x * n_chunks * G * 2;   // one block per band
+    stats += (size_t)blockIdx.x * 2 * G;
     const int nq = 2 * G, lanes = 256 / nq, q = threadIdx.x % nq, j = threadIdx.x / nq;
     double a = 0.0;
     if (j < lanes)
@@ -218,12 +230,20 @@ __device__ __forceinline__ float mb_act(float v, int act) {
 // y = act(gn(x)) (stats == null: y = x), written as fp32 [T][C] (optional) and as the bf16 hi / lo operands of the next
 // convolution: rows [0, front) and [front + T, front + T + back) of the operand buffers are the convolution's zero padding and are
 // written here too (no separate memsets).  Four elements per thread (C is a multiple of 8).
-__global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__ x, int T, int C, int G, const float* __restrict__ stats,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-                                                       float* __restrict__ y32, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int front, int back) {
+__global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__ x, int64_t x_band, int T, int C, int G, const float* __restrict__ stats,
+                                                       const PF gammas, const PF betas, int act, float* __restrict__ y32, int64_t y_band,
+                                                       bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int64_t op_band, int front, int back) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;   // element index inside the operand buffer
     const size_t total = (size_t)(front + T + back) * C;
     if (i >= total) return;
+    const int band = blockIdx.y;
+    x += (size_t)band * x_band;
+    if (y32) y32 += (size_t)band * y_band;
+    if (hi) hi += (size_t)band * op_band;
+    if (lo) lo += (size_t)band * op_band;
+    if (stats) stats += (size_t)band * 2 * G;
+    const float* gamma = gammas.p[band];
+    const float* beta = betas.p[band];
     const size_t row = i / C;
     if (row < (size_t)front || row >= (size_t)front + T) {
         if (hi) *(uint2*)(hi + i) = make_uint2(0u, 0u);
@@ -259,10 +279,13 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__
 }
 
 // first encoder convolution, 1 -> C channels: out[m][c] = sum_k w[c][k] x[m s + k - pad]   (zero padding, no bias)
-__global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ x, int T, const float* __restrict__ w, int C, int k, int s, int pad,
-                                                      float* __restrict__ out, int M) {
+__global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ x, int T, const PF ws, int C, int k, int s, int pad,
+                                                      float* __restrict__ out, int64_t out_band, int M) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)M * C) return;
+    x += (size_t)blockIdx.y * T;
+    out += (size_t)blockIdx.y * out_band;
+    const float* w = ws.p[blockIdx.y];
     const int m = (int)(i / C), c = (int)(i % C);
     float acc = 0.f;
     for (int j = 0; j < k; ++j) {
@@ -272,10 +295,13 @@ __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ 
     out[i] = acc;
 }
 // last decoder transposed convolution, C -> 1 channel: out[t'] = sum_c sum_{(t, j): t s + j - pad = t'} x[t][c] w[c][j]
-__global__ void __launch_bounds__(256) convtr_out_kernel(const float* __restrict__ x, int Tin, int C, const float* __restrict__ w, int k, int s,
-                                                         int pad, float* __restrict__ out, int Tout) {
+__global__ void __launch_bounds__(256) convtr_out_kernel(const float* __restrict__ x, int64_t x_band, int Tin, int C, const PF ws, int k, int s,
+                                                         int pad, float* __restrict__ out, int64_t out_band, int Tout) {
     const int tp = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (tp >= Tout) return;
+    x += (size_t)blockIdx.y * x_band;
+    out += (size_t)blockIdx.y * out_band;
+    const float* w = ws.p[blockIdx.y];
     float acc = 0.f;
     for (int j = (tp + pad) % s; j < k; j += s) {
         const int t = (tp + pad - j) / s;
@@ -287,9 +313,10 @@ __global__ void __launch_bounds__(256) convtr_out_kernel(const float* __restrict
 }
 
 // z[t][c] = skip[t][c] (+ add[t][c])                      (decoder: z = z[:, :, :skip.T] + skip; the first z is zero or the LSTM's)
-__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = a[i] + (b ? b[i] : 0.f);
+__global__ void add_kernel(const float* __restrict__ a, int64_t a_band, const float* __restrict__ b, int64_t b_band, float* __restrict__ out,
+                           int64_t out_band, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, band = blockIdx.y;
+    if (i < n) out[band * out_band + i] = a[band * a_band + i] + (b ? b[band * b_band + i] : 0.f);
 }
 // bottleneck conditioning: z[t][c] += cond[nearest(t)][c], cond = conv_codec(latent) evaluated here (1x1 conv, codec_dim -> C):
 // one block per bottleneck row
@@ -325,18 +352,20 @@ __device__ __forceinline__ float mb_gauss(uint64_t seed, uint32_t stream, uint32
     const float u1 = ((a >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = ((b >> 8) + 0.5f) * (1.0f / 16777216.0f);
     return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
 }
-__global__ void ddpm_kernel(float* __restrict__ cur, const float* __restrict__ est, const float* __restrict__ noise, int T, float est_c,
-                            float inv_sqrt_alpha, float sigma, float noise_scale, float clip, float rescale, uint64_t seed, uint32_t stream) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+struct DdpmCoef { float est_c[MB_MAX_BANDS], inv_sqrt_alpha[MB_MAX_BANDS], sigma[MB_MAX_BANDS], noise_scale[MB_MAX_BANDS], clip[MB_MAX_BANDS], rescale[MB_MAX_BANDS]; };
+__global__ void ddpm_kernel(float* __restrict__ cur, const float* __restrict__ est, int64_t est_band, const float* __restrict__ noise, int T,
+                            const DdpmCoef c, uint64_t seed, uint32_t stream) {
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
     if (i >= T) return;
-    float v = (cur[i] - est_c * (est[i] * noise_scale)) * inv_sqrt_alpha;
-    if (sigma > 0.f) v += sigma * (noise ? noise[i] : mb_gauss(seed, stream, (uint32_t)i)) * noise_scale;
-    if (clip > 0.f) v = fminf(fmaxf(v, -clip), clip);
-    cur[i] = v * rescale;
+    cur += (size_t)b * T;
+    float v = (cur[i] - c.est_c[b] * (est[(size_t)b * est_band + i] * c.noise_scale[b])) * c.inv_sqrt_alpha[b];
+    if (c.sigma[b] > 0.f) v += c.sigma[b] * (noise ? noise[(size_t)b * T + i] : mb_gauss(seed, stream + (uint32_t)b * 4096u, (uint32_t)i)) * c.noise_scale[b];
+    if (c.clip[b] > 0.f) v = fminf(fmaxf(v, -c.clip[b]), c.clip[b]);
+    cur[i] = v * c.rescale[b];
 }
-__global__ void init_noise_kernel(float* __restrict__ cur, const float* __restrict__ noise, int T, float noise_scale, uint64_t seed, uint32_t stream) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < T) cur[i] = (noise ? noise[i] : mb_gauss(seed, stream, (uint32_t)i)) * noise_scale;
+__global__ void init_noise_kernel(float* __restrict__ cur, const float* __restrict__ noise, int T, const DdpmCoef c, uint64_t seed) {
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i < T) cur[(size_t)b * T + i] = (noise ? noise[(size_t)b * T + i] : mb_gauss(seed, (uint32_t)b * 4096u, (uint32_t)i)) * c.noise_scale[b];
 }
 
 // julius.LowPassFilters: low[f][t] = sum_j bank[f][j] x[clamp(t + j - half)]  (replicate padding).  Block = 256 outputs of one
@@ -767,67 +796,92 @@ int mv_mbd_finalize(mv_mbd* m) {
 
 namespace {
 
-// everything one band's 20 evaluations need, allocated once per mv_mbd_generate call
+// everything the 20 evaluations need, allocated once per mv_mbd_generate call.  The band models have identical shapes and are
+// independent, so every launch covers ALL of them (grid.z / grid.y = band): four times the blocks per launch -- the 3072-channel
+// GEMMs alone had 456 -- and a quarter of the launches.  Buffers are [band][...] with the strides below.
 struct UnetBuffers {
+    int NB = 1;
     std::vector<int> T;                    // length at every encoder level (after the strided conv)
     std::vector<int> Tpad;                 // input length of level i padded to a multiple of the stride
-    std::vector<float*> skip;              // encoder outputs [T_i][C_i]
-    float *a32 = nullptr, *b32 = nullptr, *c32 = nullptr;   // fp32 scratch, widest layer
-    bf16_t *hi = nullptr, *lo = nullptr;   // bf16 conv operand with zero margins, widest layer
-    double* part = nullptr;
-    float* stats = nullptr;
-    float* dec_out = nullptr;              // transposed-conv output with s/2 margin rows on both sides
-    size_t widest = 0;
+    std::vector<float*> skip;              // encoder outputs [band][T_i][C_i]
+    std::vector<size_t> skip_band;
+    float *a32 = nullptr, *b32 = nullptr, *c32 = nullptr;   // fp32 scratch [band][widest]
+    bf16_t *hi = nullptr, *lo = nullptr;   // bf16 conv operand with zero margins [band][op_band]
+    double* part = nullptr;                // [band][part_band]
+    float* stats = nullptr;                // [band][2 G]
+    float* dec_out = nullptr;              // transposed-conv output [band][op_band]
+    size_t widest = 0, op_band = 0;
 };
 
-hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, MbdGemmArgs& g, const bf16_t* a_hi, const bf16_t* a_lo, const ConvW& w, int taps, int64_t tap_stride,
+template <typename F> PF pf_of(int nb, F f) { PF r{}; for (int b = 0; b < nb; ++b) r.p[b] = f(b); return r; }
+template <typename F> PH ph_of(int nb, F f) { PH r{}; for (int b = 0; b < nb; ++b) r.p[b] = f(b); return r; }
+
+// cw(b): the band's ConvW.  taps > 1 only when the taps are not contiguous in memory (dilation).
+template <typename CW>
+hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, const bf16_t* a_hi, const bf16_t* a_lo, CW cw, int taps, int64_t tap_stride,
                        int k_per_tap) {
-    // segments: precision terms x taps (a tap per segment only when the taps are not contiguous in memory)
     g.n_seg = 0;
-    g.ldw = w.Ktot;
+    g.ldw = cw(0).Ktot;
+    g.w_hi = ph_of(nb, [&](int b) { return (const bf16_t*)cw(b).hi; });
+    g.w_lo = ph_of(nb, [&](int b) { return (const bf16_t*)cw(b).lo; });
     const int prec = m->cfg.precision;
-    for (int term = 0; term < prec; ++term) {
-        const bf16_t* ab = term == 2 ? a_lo : a_hi;          // a_hi w_hi, a_hi w_lo, a_lo w_hi
-        const bf16_t* wb = term == 1 ? w.lo : w.hi;
+    for (int term = 0; term < prec; ++term) {      // a_hi w_hi, a_hi w_lo, a_lo w_hi
+        const bf16_t* ab = term == 2 ? a_lo : a_hi;
         for (int t = 0; t < taps; ++t) {
             if (g.n_seg >= MB_MAX_SEG) return hipErrorInvalidValue;
-            g.seg[g.n_seg++] = GemmSeg{ab + t * tap_stride, wb + (size_t)t * k_per_tap, k_per_tap};
+            g.seg[g.n_seg++] = GemmSeg{ab + t * tap_stride, term == 1 ? 1 : 0, (int64_t)t * k_per_tap, k_per_tap};
         }
     }
     const int nt = (g.N + BN - 1) / BN;
-    if (nt * ((g.M + 127) / 128) >= 400) hipLaunchKernelGGL(mbd_gemm_kernel<128>, dim3(nt, (g.M + 127) / 128), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL(mbd_gemm_kernel<64>, dim3(nt, (g.M + 63) / 64), dim3(256), 0, s, g);
+    if ((size_t)nt * ((g.M + 127) / 128) * nb >= 400) hipLaunchKernelGGL(mbd_gemm_kernel<128>, dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(mbd_gemm_kernel<64>, dim3(nt, (g.M + 63) / 64, nb), dim3(256), 0, s, g);
     return hipGetLastError();
 }
 
-hipError_t group_stats(hipStream_t s, const float* x, int T, int C, int G, UnetBuffers& ub) {
+size_t gn_blocks(int T, int C, int G) {
+    const int rows_per = std::max(1, (int)((size_t)16384 * G / C));
+    return (size_t)((T + rows_per - 1) / rows_per) * G;
+}
+hipError_t group_stats(hipStream_t s, const float* x, int64_t x_band, int T, int C, int G, UnetBuffers& ub) {
     // ~16 K elements per block whatever the [T][C] aspect ratio: rows_per rows of one group
     const int rows_per = std::max(1, (int)((size_t)16384 * G / C));
     const int chunks = (T + rows_per - 1) / rows_per;
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, G), dim3(256), 0, s, x, T, C, G, rows_per, ub.part);
-    hipLaunchKernelGGL(gn_final_kernel, dim3(1), dim3(256), 0, s, ub.part, chunks, G, (double)T * (C / G), 1e-5f, ub.stats);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, G, ub.NB), dim3(256), 0, s, x, x_band, T, C, G, rows_per, ub.part);
+    hipLaunchKernelGGL(gn_final_kernel, dim3(ub.NB), dim3(256), 0, s, ub.part, chunks, G, (double)T * (C / G), 1e-5f, ub.stats);
     return hipGetLastError();
 }
 
-// x [T][C] fp32 -> ResBlock(x) into `out` (may alias x): x + conv2(act(gn2(conv1(act(gn1(x))))))  (+ col_add)
-hipError_t res_block(hipStream_t s, const mv_mbd* m, const ResW& rw, const float* x, float* out, int T, int C, int dilation, const float* col_add,
+void launch_norm_act(hipStream_t s, const UnetBuffers& ub, const float* x, int64_t x_band, int T, int C, int G, const float* stats, PF gamma, PF beta, int act,
+                     float* y32, int64_t y_band, bf16_t* hi, bf16_t* lo, int front, int back) {
+    const size_t vec = (size_t)(front + T + back) * C / 4;
+    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)((vec + 255) / 256), ub.NB), dim3(256), 0, s, x, x_band, T, C, G, stats, gamma, beta, act, y32, y_band, hi, lo,
+                       (int64_t)ub.op_band, front, back);
+}
+
+// x [band][T][C] fp32 -> ResBlock(x) into `out` (may alias x): x + conv2(act(gn2(conv1(act(gn1(x))))))  (+ col_add); rw(b) = band b's weights
+template <typename RW>
+hipError_t res_block(hipStream_t s, const mv_mbd* m, RW rw, const float* x, int64_t x_band, float* out, int64_t out_band, int T, int C, int dilation, PF col_add,
                      UnetBuffers& ub) {
-    const int G = m->cfg.norm_groups, act = m->cfg.act;
+    const int G = m->cfg.norm_groups, act = m->cfg.act, nb = ub.NB;
     const int pad = dilation;  // kernel 3
     hipError_t e;
     for (int half = 0; half < 2; ++half) {
         const float* in = half == 0 ? x : ub.b32;
-        const NormW& nw = half == 0 ? rw.n1 : rw.n2;
-        const ConvW& cw = half == 0 ? rw.c1 : rw.c2;
-        if ((e = group_stats(s, in, T, C, G, ub)) != hipSuccess) return e;
-        hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)(((size_t)(T + 2 * pad) * C / 4 + 255) / 256)), dim3(256), 0, s, in, T, C, G, ub.stats, nw.g, nw.b, act,
-                           (float*)nullptr, ub.hi, m->cfg.precision > 2 ? ub.lo : nullptr, pad, pad);
+        const int64_t in_band = half == 0 ? x_band : (int64_t)ub.widest;
+        if ((e = group_stats(s, in, in_band, T, C, G, ub)) != hipSuccess) return e;
+        launch_norm_act(s, ub, in, in_band, T, C, G, ub.stats, pf_of(nb, [&](int b) { return (const float*)(half == 0 ? rw(b).n1.g : rw(b).n2.g); }),
+                        pf_of(nb, [&](int b) { return (const float*)(half == 0 ? rw(b).n1.b : rw(b).n2.b); }), act, nullptr, 0, ub.hi,
+                        m->cfg.precision > 2 ? ub.lo : nullptr, pad, pad);
         MbdGemmArgs g;
-        g.M = T; g.N = C; g.lda = C; g.out = half == 0 ? ub.b32 : out; g.ldc = C; g.bias = cw.bias;
-        if (half == 1) { g.residual = x; g.ldr = C; g.col_add = col_add; }
+        g.M = T; g.N = C; g.lda = C; g.a_band = (int64_t)ub.op_band; g.ldc = C;
+        g.out = half == 0 ? ub.b32 : out; g.out_band = half == 0 ? (int64_t)ub.widest : out_band;
+        g.bias = pf_of(nb, [&](int b) { return (const float*)(half == 0 ? rw(b).c1.bias : rw(b).c2.bias); });
+        g.col_add = PF{};
+        if (half == 1) { g.residual = x; g.ldr = C; g.res_band = x_band; g.col_add = col_add; }
+        auto cw = [&](int b) -> const ConvW& { return half == 0 ? rw(b).c1 : rw(b).c2; };
         // window of output row t: rows t - pad + j * dilation, j = 0..2; contiguous (one segment per term) when dilation == 1
-        if (dilation == 1) e = launch_gemm(s, m, g, ub.hi, ub.lo, cw, 1, 0, 3 * C);
-        else e = launch_gemm(s, m, g, ub.hi, ub.lo, cw, 3, (int64_t)dilation * C, C);
+        if (dilation == 1) e = launch_gemm(s, m, nb, g, ub.hi, ub.lo, cw, 1, 0, 3 * C);
+        else e = launch_gemm(s, m, nb, g, ub.hi, ub.lo, cw, 3, (int64_t)dilation * C, C);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -847,11 +901,13 @@ int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float*
     const mv_mbd_config& g = m->cfg;
     if (T < g.kernel * 4 || (g.codec_dim > 0 && (!latent || frames < 1))) return mv_fail(MV_ERR_INVALID, "mv_mbd_generate: bad sizes (T = %d, frames = %d)", T, frames);
     hipStream_t s = m->stream;
-    const int k = g.kernel, st = g.stride, pad = (k - st) / 2, D = g.depth, G = g.norm_groups;
+    const int k = g.kernel, st = g.stride, pad = (k - st) / 2, D = g.depth, G = g.norm_groups, NB = g.n_models;
     Work wk;
     UnetBuffers ub;
+    ub.NB = NB;
     // geometry
     ub.T.resize(D); ub.Tpad.resize(D);
+    size_t max_c = 8, max_gn = 1;
     {
         int t = T;
         for (int i = 0; i < D; ++i) {
@@ -859,40 +915,39 @@ int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float*
             ub.T[i] = (ub.Tpad[i] + 2 * pad - k) / st + 1;
             t = ub.T[i];
             ub.widest = std::max(ub.widest, (size_t)(ub.T[i] + 2 * st + 8) * m->ch[i]);
+            max_c = std::max(max_c, (size_t)m->ch[i]);
+            max_gn = std::max(max_gn, gn_blocks(ub.T[i], m->ch[i], G) + G);
         }
         if (ub.T[D - 1] < 2) return mv_fail(MV_ERR_INVALID, "mv_mbd_generate: %d samples are too few for depth %d", T, D);
         if (g.codec_dim > 0 && frames > 2 * ub.T[D - 1]) return mv_fail(MV_ERR_INVALID, "conditioning would be downsampled by more than 2");
     }
+    ub.widest = (ub.widest + 7) & ~(size_t)7;
+    ub.op_band = (ub.widest + (size_t)(2 * k + 2 * st + 8) * max_c + 7) & ~(size_t)7;   // operand rows + zero margins / transposed-conv overhang
 #define MG_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return mv_fail(MV_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
-    ub.skip.resize(D);
-    for (int i = 0; i < D; ++i) MG_TRY(wk.get(&ub.skip[i], (size_t)ub.T[i] * m->ch[i], false));
-    MG_TRY(wk.get(&ub.a32, ub.widest, false));
-    MG_TRY(wk.get(&ub.b32, ub.widest, false));
-    MG_TRY(wk.get(&ub.c32, ub.widest, false));
-    size_t max_c = 8;
-    for (int i = 0; i < D; ++i) max_c = std::max(max_c, (size_t)m->ch[i]);
-    const size_t margin = (size_t)(2 * k + 2 * st + 8) * max_c;   // zero rows around a convolution operand / transposed-conv overhang
-    MG_TRY(wk.get(&ub.hi, ub.widest + margin, true));
-    MG_TRY(wk.get(&ub.lo, ub.widest + margin, true));
-    MG_TRY(wk.get(&ub.dec_out, ub.widest + margin, false));
-    {
-        size_t max_blocks = 1;   // gn_partial_kernel's grid (chunks x G), largest level: see group_stats
-        for (int i = 0; i < D; ++i) {
-            const int rows_per = std::max(1, (int)((size_t)16384 * G / m->ch[i]));
-            max_blocks = std::max(max_blocks, (size_t)((ub.T[i] + rows_per - 1) / rows_per + 1) * G);
-        }
-        MG_TRY(wk.get(&ub.part, max_blocks * 2, false));
+    ub.skip.resize(D); ub.skip_band.resize(D);
+    for (int i = 0; i < D; ++i) {
+        ub.skip_band[i] = ((size_t)ub.T[i] * m->ch[i] + 7) & ~(size_t)7;
+        MG_TRY(wk.get(&ub.skip[i], ub.skip_band[i] * NB, false));
     }
-    MG_TRY(wk.get(&ub.stats, (size_t)2 * G, false));
+    MG_TRY(wk.get(&ub.a32, ub.widest * NB, false));
+    MG_TRY(wk.get(&ub.b32, ub.widest * NB, false));
+    MG_TRY(wk.get(&ub.c32, ub.widest * NB, false));
+    MG_TRY(wk.get(&ub.hi, ub.op_band * NB, true));
+    MG_TRY(wk.get(&ub.lo, ub.op_band * NB, true));
+    MG_TRY(wk.get(&ub.dec_out, ub.op_band * NB, false));
+    MG_TRY(wk.get(&ub.part, max_gn * 2 * NB, false));
+    MG_TRY(wk.get(&ub.stats, (size_t)2 * G * NB, false));
+    const int64_t WB = (int64_t)ub.widest, OB = (int64_t)ub.op_band;
     float *cur = nullptr, *est = nullptr, *total = nullptr, *d_lat = nullptr, *d_noise = nullptr, *d_ref = nullptr;
-    MG_TRY(wk.get(&cur, (size_t)T, false));
-    MG_TRY(wk.get(&est, (size_t)T + 4 * st, false));
+    const int64_t est_band = (int64_t)T + 4 * st;
+    MG_TRY(wk.get(&cur, (size_t)T * NB, false));
+    MG_TRY(wk.get(&est, (size_t)est_band * NB, false));
     MG_TRY(wk.get(&total, (size_t)T, true));
     if (g.codec_dim > 0) {
         MG_TRY(wk.get(&d_lat, (size_t)g.codec_dim * frames, false));
         MG_TRY(hipMemcpyAsync(d_lat, latent, (size_t)g.codec_dim * frames * 4, hipMemcpyHostToDevice, s));
     }
-    if (noise) MG_TRY(wk.get(&d_noise, (size_t)T, false));
+    if (noise) MG_TRY(wk.get(&d_noise, (size_t)T * NB, false));
     const int max_bands = std::max(g.proc_bands, g.eq_bands);
     float *bands = nullptr, *bands2 = nullptr, *d_scale = nullptr, *d_shift = nullptr;
     double *st_a = nullptr, *st_b = nullptr;
@@ -906,66 +961,83 @@ int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float*
     }
     float *lstm_gin = nullptr, *lstm_y0 = nullptr, *lstm_y1 = nullptr, *lstm_rev = nullptr;
     const int Cb = m->ch[D - 1], Tb = ub.T[D - 1];
+    const int64_t lstm_band = (int64_t)Tb * Cb;
     if (g.bilstm) {
         MG_TRY(wk.get(&lstm_gin, (size_t)Tb * 4 * Cb, false));
         MG_TRY(wk.get(&lstm_y0, (size_t)Tb * 2 * Cb, false));
         MG_TRY(wk.get(&lstm_y1, (size_t)Tb * 2 * Cb, false));
-        MG_TRY(wk.get(&lstm_rev, (size_t)Tb * 2 * Cb, false));
+        MG_TRY(wk.get(&lstm_rev, (size_t)lstm_band * NB, false));
     }
     auto split = [&](const float* x, int n_bands, const float* bank, int taps, float* lowbuf, float* out_bands) -> hipError_t {
         hipLaunchKernelGGL(fir_bank_kernel, dim3((T + 255) / 256, n_bands - 1), dim3(256), (size_t)(256 + 2 * taps) * 4, s, x, T, bank, taps, lowbuf);
         hipLaunchKernelGGL(bands_kernel, dim3((T + 255) / 256), dim3(256), 0, s, x, lowbuf, T, n_bands, out_bands);
         return hipGetLastError();
     };
+    auto coef = [&](int ev) {
+        DdpmCoef c{};
+        for (int b = 0; b < NB; ++b) {
+            const BandW& B = m->band[b];
+            c.noise_scale[b] = B.noise_scale; c.clip[b] = B.clip;
+            if (ev >= 0) { c.est_c[b] = B.est_c[ev]; c.inv_sqrt_alpha[b] = B.inv_sqrt_alpha[ev]; c.sigma[b] = B.sigma[ev]; c.rescale[b] = B.steps[ev] == 0 ? B.rescale : 1.0f; }
+        }
+        return c;
+    };
+    auto upload_noise = [&](int slot) -> hipError_t {   // draw `slot` of every band -> d_noise [band][T]
+        for (int b = 0; b < NB; ++b) {
+            hipError_t e = hipMemcpyAsync(d_noise + (size_t)b * T, noise + ((size_t)b * (g.n_eval + 1) + slot) * T, (size_t)T * 4, hipMemcpyHostToDevice, s);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    };
 
-    for (int bi = 0; bi < g.n_models; ++bi) {
-        const BandW& B = m->band[bi];
-        const float* nz = noise ? noise + (size_t)bi * (g.n_eval + 1) * T : nullptr;
-        if (nz) MG_TRY(hipMemcpyAsync(d_noise, nz, (size_t)T * 4, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(init_noise_kernel, dim3((T + 255) / 256), dim3(256), 0, s, cur, nz ? d_noise : nullptr, T, B.noise_scale, seed, (uint32_t)(bi * 4096));
-        for (int ev = 0; ev < g.n_eval; ++ev) {
-            const int step = B.steps[ev];
-            // ---------------- encoder -----------------------------------------------------------------------------------------
-            const float* zin = cur;   // [Tin][Cin]
-            int Tin = T;
-            for (int i = 0; i < D; ++i) {
-                const EncW& E = B.enc[i];
-                const int Cin = i == 0 ? 1 : m->ch[i - 1], Cout = m->ch[i], To = ub.T[i];
-                if (i == 0) {
-                    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)(((size_t)To * Cout + 255) / 256)), dim3(256), 0, s, zin, Tin, E.conv_in_w, Cout, k, st, pad, ub.a32, To);
-                } else {
-                    // operand: zin with `pad` zero rows in front and (Tpad - Tin) + k behind
-                    const int back = ub.Tpad[i] - Tin + k;
-                    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)(((size_t)(pad + Tin + back) * Cin / 4 + 255) / 256)), dim3(256), 0, s, zin, Tin, Cin, G,
-                                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, ub.hi, g.precision > 2 ? ub.lo : nullptr, pad, back);
-                    MbdGemmArgs ga;
-                    ga.M = To; ga.N = Cout; ga.lda = (int64_t)st * Cin; ga.out = ub.a32; ga.ldc = Cout;
-                    MG_TRY(launch_gemm(s, m, ga, ub.hi, ub.lo, E.conv, 1, 0, k * Cin));
-                }
-                MG_TRY(group_stats(s, ub.a32, To, Cout, G, ub));
-                const size_t no = (size_t)To * Cout;
-                const float* emb = (i == 0 || g.emb_all_layers) ? E.emb + (size_t)step * Cout : nullptr;
-                float* dst = g.res_blocks > 0 ? ub.c32 : ub.skip[i];
-                hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)((no / 4 + 255) / 256)), dim3(256), 0, s, ub.a32, To, Cout, G, ub.stats, E.norm.g, E.norm.b, g.act, dst,
-                                   (bf16_t*)nullptr, (bf16_t*)nullptr, 0, 0);
-                for (int r = 0; r < g.res_blocks; ++r) {
-                    const bool lastr = r == g.res_blocks - 1;
-                    MG_TRY(res_block(s, m, E.res[r], ub.c32, lastr ? ub.skip[i] : ub.c32, To, Cout, 1 << r, lastr ? emb : nullptr, ub));
-                }
-                if (g.res_blocks == 0 && emb) return mv_fail(MV_ERR_INVALID, "res_blocks = 0 is not supported");
-                zin = ub.skip[i];
-                Tin = To;
+    if (noise) MG_TRY(upload_noise(0));
+    hipLaunchKernelGGL(init_noise_kernel, dim3((T + 255) / 256, NB), dim3(256), 0, s, cur, noise ? d_noise : nullptr, T, coef(-1), seed);
+    for (int ev = 0; ev < g.n_eval; ++ev) {
+        // ---------------- encoder ---------------------------------------------------------------------------------------------
+        const float* zin = cur;   // [band][Tin][Cin]
+        int64_t zin_band = T;
+        int Tin = T;
+        for (int i = 0; i < D; ++i) {
+            const int Cin = i == 0 ? 1 : m->ch[i - 1], Cout = m->ch[i], To = ub.T[i];
+            auto E = [&](int b) -> const EncW& { return m->band[b].enc[i]; };
+            if (i == 0) {
+                hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)(((size_t)To * Cout + 255) / 256), NB), dim3(256), 0, s, zin, Tin,
+                                   pf_of(NB, [&](int b) { return (const float*)E(b).conv_in_w; }), Cout, k, st, pad, ub.a32, WB, To);
+            } else {
+                // operand: zin with `pad` zero rows in front and (Tpad - Tin) + k behind
+                const int back = ub.Tpad[i] - Tin + k;
+                launch_norm_act(s, ub, zin, zin_band, Tin, Cin, G, nullptr, PF{}, PF{}, 0, nullptr, 0, ub.hi, g.precision > 2 ? ub.lo : nullptr, pad, back);
+                MbdGemmArgs ga;
+                ga.M = To; ga.N = Cout; ga.lda = (int64_t)st * Cin; ga.a_band = OB; ga.out = ub.a32; ga.ldc = Cout; ga.out_band = WB;
+                ga.bias = PF{}; ga.col_add = PF{};
+                MG_TRY(launch_gemm(s, m, NB, ga, ub.hi, ub.lo, [&](int b) -> const ConvW& { return E(b).conv; }, 1, 0, k * Cin));
             }
-            // ---------------- bottleneck --------------------------------------------------------------------------------------
-            // z = encoder output (+ codec conditioning); without a BiLSTM audiocraft's forward replaces z by zeros (unet.py), so the
-            // decoder starts from the last skip alone
-            const float* zb = nullptr;  // [Tb][Cb] added to the last skip, or null (zeros)
-            if (g.bilstm) {
-                MG_TRY(hipMemcpyAsync(ub.c32, ub.skip[D - 1], (size_t)Tb * Cb * 4, hipMemcpyDeviceToDevice, s));
+            MG_TRY(group_stats(s, ub.a32, WB, To, Cout, G, ub));
+            const bool has_emb = i == 0 || g.emb_all_layers;
+            const PF emb = has_emb ? pf_of(NB, [&](int b) { return (const float*)(E(b).emb + (size_t)m->band[b].steps[ev] * Cout); }) : PF{};
+            if (g.res_blocks == 0) return mv_fail(MV_ERR_INVALID, "res_blocks = 0 is not supported");
+            launch_norm_act(s, ub, ub.a32, WB, To, Cout, G, ub.stats, pf_of(NB, [&](int b) { return (const float*)E(b).norm.g; }),
+                            pf_of(NB, [&](int b) { return (const float*)E(b).norm.b; }), g.act, ub.c32, WB, nullptr, nullptr, 0, 0);
+            for (int r = 0; r < g.res_blocks; ++r) {
+                const bool lastr = r == g.res_blocks - 1;
+                MG_TRY(res_block(s, m, [&](int b) -> const ResW& { return E(b).res[r]; }, ub.c32, WB, lastr ? ub.skip[i] : ub.c32,
+                                 lastr ? (int64_t)ub.skip_band[i] : WB, To, Cout, 1 << r, lastr ? emb : PF{}, ub));
+            }
+            zin = ub.skip[i];
+            zin_band = (int64_t)ub.skip_band[i];
+            Tin = To;
+        }
+        // ---------------- bottleneck ------------------------------------------------------------------------------------------
+        // z = encoder output (+ codec conditioning); without a BiLSTM audiocraft's forward replaces z by zeros (unet.py), so the
+        // decoder starts from the last skip alone
+        const float* zb = nullptr;  // [band][Tb][Cb] added to the last skip, or null (zeros)
+        if (g.bilstm) {
+            for (int b = 0; b < NB; ++b) {   // the recurrences run band after band (latency-bound chains, 64 workgroups each)
+                const BandW& B = m->band[b];
+                MG_TRY(hipMemcpyAsync(ub.c32, ub.skip[D - 1] + (size_t)b * ub.skip_band[D - 1], (size_t)Tb * Cb * 4, hipMemcpyDeviceToDevice, s));
                 if (g.codec_dim > 0)
                     hipLaunchKernelGGL(cond_add_kernel, dim3(Tb), dim3(256), (size_t)g.codec_dim * 4, s, ub.c32, Tb, Cb, d_lat, frames, g.codec_dim, B.codec_w, B.codec_b);
-                // BLSTM: 2 layers, both directions (the reverse direction runs on the time-reversed view through negative strides), then
-                // Linear(2 C -> C)
+                // BLSTM: 2 layers, both directions (the reverse direction walks the sequence through negative strides), then Linear(2 C -> C)
                 const float* in = ub.c32;
                 int I = Cb;
                 float* ys[2] = {lstm_y0, lstm_y1};
@@ -986,57 +1058,59 @@ int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float*
                     in = ys[l];
                     I = 2 * Cb;
                 }
-                MG_TRY(launch_lstm_inproj(s, lstm_y1, B.lstm.lin_w, B.lstm.lin_b, lstm_rev, Tb, 2 * Cb, Cb));  // Linear(2C -> C): the same batched product
-                zb = lstm_rev;
+                MG_TRY(launch_lstm_inproj(s, lstm_y1, B.lstm.lin_w, B.lstm.lin_b, lstm_rev + (size_t)b * lstm_band, Tb, 2 * Cb, Cb));  // Linear(2C -> C)
             }
-            // ---------------- decoder -----------------------------------------------------------------------------------------
-            const float* z = zb;
-            int Tz = Tb;
-            for (int i = 0; i < D; ++i) {
-                const DecW& Dw = B.dec[i];
-                const int lvl = D - 1 - i, C = m->ch[lvl], Cout = lvl == 0 ? 1 : m->ch[lvl - 1], Ts = ub.T[lvl];
-                // z = z[:, :, :skip.T] + skip   (z rows beyond skip.T are dropped; z never is shorter)
-                const size_t n = (size_t)Ts * C;
-                hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ub.skip[lvl], z, ub.c32, n);
-                (void)Tz;
-                for (int r = 0; r < g.res_blocks; ++r) MG_TRY(res_block(s, m, Dw.res[r], ub.c32, ub.c32, Ts, C, 1 << r, nullptr, ub));
-                MG_TRY(group_stats(s, ub.c32, Ts, C, G, ub));
-                if (lvl == 0) {
-                    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, ub.c32, Ts, C, G, ub.stats, Dw.norm.g, Dw.norm.b, g.act, ub.a32,
-                                       (bf16_t*)nullptr, (bf16_t*)nullptr, 0, 0);
-                    hipLaunchKernelGGL(convtr_out_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ub.a32, Ts, C, Dw.convtr_out_w, k, st, pad, est, T);
-                } else {
-                    // operand rows: [zero row | z rows 0..Ts-1 | zero row]; GEMM row q = (x[q-1], x[q]), q = 0..Ts
-                    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)(((size_t)(Ts + 2) * C / 4 + 255) / 256)), dim3(256), 0, s, ub.c32, Ts, C, G, ub.stats, Dw.norm.g,
-                                       Dw.norm.b, g.act, (float*)nullptr, ub.hi, g.precision > 2 ? ub.lo : nullptr, 1, 1);
-                    MbdGemmArgs ga;
-                    ga.M = Ts + 1; ga.N = st * Cout; ga.lda = C; ga.out = ub.dec_out; ga.ldc = (int64_t)st * Cout;
-                    MG_TRY(launch_gemm(s, m, ga, ub.hi, ub.lo, Dw.convtr, 1, 0, 2 * C));
-                    // row q holds output times q st - pad + p: the valid signal starts `pad` rows into the buffer
-                    z = ub.dec_out + (size_t)pad * Cout;
-                    Tz = Ts * st;
-                }
-            }
-            MG_TRY(hipGetLastError());
-            // ---------------- DDPM update -------------------------------------------------------------------------------------
-            const float* stepnoise = nullptr;
-            if (nz && B.sigma[ev] > 0.f) {
-                MG_TRY(hipMemcpyAsync(d_noise, nz + (size_t)(ev + 1) * T, (size_t)T * 4, hipMemcpyHostToDevice, s));
-                stepnoise = d_noise;
-            }
-            hipLaunchKernelGGL(ddpm_kernel, dim3((T + 255) / 256), dim3(256), 0, s, cur, est, stepnoise, T, B.est_c[ev], B.inv_sqrt_alpha[ev], B.sigma[ev], B.noise_scale,
-                               B.clip, step == 0 ? B.rescale : 1.0f, seed, (uint32_t)(bi * 4096 + ev + 1));
+            zb = lstm_rev;
         }
-        // ---------------- MultiBandProcessor.return_sample, summed into the total ---------------------------------------------------
+        // ---------------- decoder ---------------------------------------------------------------------------------------------
+        const float* z = zb;
+        int64_t z_band = lstm_band;
+        for (int i = 0; i < D; ++i) {
+            const int lvl = D - 1 - i, C = m->ch[lvl], Cout = lvl == 0 ? 1 : m->ch[lvl - 1], Ts = ub.T[lvl];
+            auto Dw = [&](int b) -> const DecW& { return m->band[b].dec[i]; };
+            // z = z[:, :, :skip.T] + skip   (z rows beyond skip.T are dropped; z never is shorter)
+            const size_t n = (size_t)Ts * C;
+            hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256), NB), dim3(256), 0, s, ub.skip[lvl], (int64_t)ub.skip_band[lvl], z, z_band, ub.c32, WB, n);
+            for (int r = 0; r < g.res_blocks; ++r)
+                MG_TRY(res_block(s, m, [&](int b) -> const ResW& { return Dw(b).res[r]; }, ub.c32, WB, ub.c32, WB, Ts, C, 1 << r, PF{}, ub));
+            MG_TRY(group_stats(s, ub.c32, WB, Ts, C, G, ub));
+            const PF ng = pf_of(NB, [&](int b) { return (const float*)Dw(b).norm.g; }), nbias = pf_of(NB, [&](int b) { return (const float*)Dw(b).norm.b; });
+            if (lvl == 0) {
+                launch_norm_act(s, ub, ub.c32, WB, Ts, C, G, ub.stats, ng, nbias, g.act, ub.a32, WB, nullptr, nullptr, 0, 0);
+                hipLaunchKernelGGL(convtr_out_kernel, dim3((T + 3) / 4, NB), dim3(256), 0, s, ub.a32, WB, Ts, C,
+                                   pf_of(NB, [&](int b) { return (const float*)Dw(b).convtr_out_w; }), k, st, pad, est, est_band, T);
+            } else {
+                // operand rows: [zero row | z rows 0..Ts-1 | zero row]; GEMM row q = (x[q-1], x[q]), q = 0..Ts
+                launch_norm_act(s, ub, ub.c32, WB, Ts, C, G, ub.stats, ng, nbias, g.act, nullptr, 0, ub.hi, g.precision > 2 ? ub.lo : nullptr, 1, 1);
+                MbdGemmArgs ga;
+                ga.M = Ts + 1; ga.N = st * Cout; ga.lda = C; ga.a_band = OB; ga.out = ub.dec_out; ga.ldc = (int64_t)st * Cout; ga.out_band = OB;
+                ga.bias = PF{}; ga.col_add = PF{};
+                MG_TRY(launch_gemm(s, m, NB, ga, ub.hi, ub.lo, [&](int b) -> const ConvW& { return Dw(b).convtr; }, 1, 0, 2 * C));
+                // row q holds output times q st - pad + p: the valid signal starts `pad` rows into the buffer
+                z = ub.dec_out + (size_t)pad * Cout;
+                z_band = OB;
+            }
+        }
+        MG_TRY(hipGetLastError());
+        // ---------------- DDPM update -----------------------------------------------------------------------------------------
+        bool any_sigma = false;
+        for (int b = 0; b < NB; ++b) any_sigma = any_sigma || m->band[b].sigma[ev] > 0.f;
+        if (noise && any_sigma) MG_TRY(upload_noise(ev + 1));
+        hipLaunchKernelGGL(ddpm_kernel, dim3((T + 255) / 256, NB), dim3(256), 0, s, cur, est, est_band, noise ? d_noise : nullptr, T, coef(ev), seed, (uint32_t)(ev + 1));
+    }
+    // ---------------- MultiBandProcessor.return_sample of every band, summed in band order into the total ---------------------------
+    for (int bi = 0; bi < NB; ++bi) {
+        const BandW& B = m->band[bi];
+        const float* x = cur + (size_t)bi * T;
         if (g.proc_bands > 1) {
-            MG_TRY(split(cur, g.proc_bands, m->proc_bank, m->proc_taps, bands2, bands));
+            MG_TRY(split(x, g.proc_bands, m->proc_bank, m->proc_taps, bands2, bands));
             MG_TRY(hipMemcpyAsync(d_scale, B.proc_scale.data(), (size_t)g.proc_bands * 4, hipMemcpyHostToDevice, s));
             MG_TRY(hipMemcpyAsync(d_shift, B.proc_mean.data(), (size_t)g.proc_bands * 4, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(band_mix_kernel, dim3((T + 255) / 256), dim3(256), 0, s, bands, T, g.proc_bands, d_scale, d_shift, total, 1);
+            MG_TRY(hipStreamSynchronize(s));  // d_scale / d_shift are reused by the next band
         } else {
-            hipLaunchKernelGGL(add_kernel, dim3((T + 255) / 256), dim3(256), 0, s, total, cur, total, (size_t)T);
+            hipLaunchKernelGGL(add_kernel, dim3((T + 255) / 256, 1), dim3(256), 0, s, total, (int64_t)0, x, (int64_t)0, total, (int64_t)0, (size_t)T);
         }
-        MG_TRY(hipStreamSynchronize(s));  // host vectors above must outlive the copies
     }
     // ---------------- re_eq against the EnCodec decode ---------------------------------------------------------------------------------
     float* result = total;
