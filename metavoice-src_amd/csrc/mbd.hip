@@ -100,19 +100,20 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_kernel(const MbdGemmArgs a) {
 
     for (int s = 0; s < a.n_seg; ++s) {
         const GemmSeg sg = a.seg[s];
-        const bf16_t* ga[AR];
-        const bf16_t* gw[8];
+        // row offsets as 32-bit element indices off two base pointers (16 64-bit row pointers cost 32 VGPRs and spilled)
+        const bf16_t* abase = sg.a + (size_t)band * a.a_band + sc * 8;
+        const bf16_t* wbase = (sg.w_lo ? a.w_lo.p[band] : a.w_hi.p[band]) + sg.w_off + sc * 8;
+        uint32_t oa[AR], ow[8];
 #pragma unroll
-        for (int i = 0; i < AR; ++i) ga[i] = sg.a + (size_t)band * a.a_band + (size_t)min(tile_m + sr + 16 * i, M - 1) * a.lda + sc * 8;
-        const bf16_t* wbase = (sg.w_lo ? a.w_lo.p[band] : a.w_hi.p[band]) + sg.w_off;
+        for (int i = 0; i < AR; ++i) oa[i] = (uint32_t)((size_t)min(tile_m + sr + 16 * i, M - 1) * a.lda);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) gw[i] = wbase + (size_t)min(tile_n + sr + 16 * i, N - 1) * a.ldw + sc * 8;
+        for (int i = 0; i < 8; ++i) ow[i] = (uint32_t)((size_t)min(tile_n + sr + 16 * i, N - 1) * a.ldw);
         u32x4 ra[AR], rw[8];
         const bool in0 = sc * 8 < sg.K;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) ra[i] = in0 ? load16(ga[i]) : zero;
+        for (int i = 0; i < AR; ++i) ra[i] = in0 ? load16(abase + oa[i]) : zero;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) rw[i] = in0 ? load16(gw[i]) : zero;
+        for (int i = 0; i < 8; ++i) rw[i] = in0 ? load16(wbase + ow[i]) : zero;
         for (int k0 = 0; k0 < sg.K; k0 += BK) {
             __syncthreads();  // everyone is done reading the previous tile
 #pragma unroll
@@ -123,11 +124,11 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_kernel(const MbdGemmArgs a) {
             if (k0 + BK < sg.K) {
                 const bool in = k0 + BK + sc * 8 < sg.K;
 #pragma unroll
-                for (int i = 0; i < AR; ++i) ra[i] = in ? load16(ga[i] + k0 + BK) : zero;
+                for (int i = 0; i < AR; ++i) ra[i] = in ? load16(abase + oa[i] + k0 + BK) : zero;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) rw[i] = in ? load16(gw[i] + k0 + BK) : zero;
+                for (int i = 0; i < 8; ++i) rw[i] = in ? load16(wbase + ow[i] + k0 + BK) : zero;
             }
-#pragma unroll
+#pragma unroll 2
             for (int kk = 0; kk < BK / 32; ++kk) {
                 bf16x8_t af[MI], bf[4];
 #pragma unroll
