@@ -18,7 +18,7 @@ NU = int(os.environ.get("MV_UTT", "1"))
 e = mv.Stage1Engine(args, max_utterances=NU, quantisation_mode=os.environ.get("MV_QUANT") or None)
 e.load_state_dict(sd); del sd
 e.finalize()
-e.tune(mega=int(os.environ.get("MV_MEGA", "1")))
+e.tune(mega=int(os.environ.get("MV_MEGA", "1")), gemv_ablate=int(os.environ.get("MV_ABLATE", "0")))
 e.begin([mv.synthetic.prompt_tokens(pos, seed=u) for u in range(NU)], mv.synthetic.speaker_embedding(0).expand(NU, -1), mv.SamplingParams(top_p=0.95), max_new_tokens=64,
         end_of_audio_token=9999, prefill_mode=1)
 e.run(max_steps=32)
