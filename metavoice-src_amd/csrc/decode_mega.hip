@@ -498,22 +498,23 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         __syncthreads();
         MG_STAMP(l, 8);
         {
-            // 8-byte polls, 11 per thread and utterance; at most two utterances per poll loop (registers)
+            // 16-byte polls carrying two granules (each half validated by its own tag): 5632 / 2 = 2816 pairs per utterance, 6 per
+            // thread (was eleven 8-byte loads per thread); at most two utterances per poll loop (registers)
             constexpr int UPP = NU < 2 ? NU : 2;
+            constexpr int PPT = (MG_INTER / 2 + MG_THREADS - 1) / MG_THREADS;  // pairs per thread and utterance
 #pragma unroll
             for (int u0 = 0; u0 < NU; u0 += UPP) {
-                wave_poll<11 * UPP>(tag0 + 3u, a.abort_flag, &s_abort,
-                                    [&](int k, u64& v) {
-                                        const int n = tid_o + (k % 11) * MG_THREADS;
-                                        if (n >= MG_INTER) return false;
-                                        v = gran_load(a.g_act + (size_t)(u0 + k / 11) * MG_INTER + n);
-                                        return true;
-                                    },
-                                    [&](int k, uint32_t p) {
-                                        const int n = tid_o + (k % 11) * MG_THREADS;
-                                        xs[u0 + k / 11][n] = (bf16_t)p;
-                                        xs[u0 + k / 11][MG_INTER + n] = (bf16_t)(p >> 16);
-                                    });
+                wave_poll16<PPT * UPP>(a.g_act + (size_t)u0 * MG_INTER, tag0 + 3u, a.abort_flag, &s_abort,
+                                       [&](int k) {
+                                           const int n = tid_o + (k % PPT) * MG_THREADS;
+                                           return n < MG_INTER / 2 ? (k / PPT) * (MG_INTER / 2) + n : -1;
+                                       },
+                                       [&](int n, uint32_t p0, uint32_t p1) {
+                                           bf16_t* row = xs[u0 + n / (MG_INTER / 2)];
+                                           const int c = n % (MG_INTER / 2);
+                                           *(uint32_t*)(row + 2 * c) = (p0 & 0xFFFFu) | (p1 << 16);
+                                           *(uint32_t*)(row + MG_INTER + 2 * c) = (p0 >> 16) | (p1 & 0xFFFF0000u);
+                                       });
             }
             __syncthreads();
             if (MG_ABORTED()) return;
