@@ -287,26 +287,21 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         // wo goes to wv[12..15]; the w1 rows of P3 ride along in wv[0..11] (the w3 rows follow after P2's dots into wv[12..23]):
         // w1|w3 is 45 % of a layer's bytes, asked for in one go it made P2 -> P3 the one stream-bound hand-off (8 us).
         const int rb13 = 22 * b + (wave_o < 6 ? 3 * wave_o : 18 + 2 * (wave_o - 6));
-        auto request_wo_w1 = [&]() {
-            if (I4) {
-                mega_issue_row_i4<1>(cq + 6, cz + 6, L.q[1], L.sz[1], 8 * b + wave_o, MG_DIM, lane_o);
+        auto request_wo = [&]() {
+            if (I4) mega_issue_row_i4<1>(cq + 6, cz + 6, L.q[1], L.sz[1], 8 * b + wave_o, MG_DIM, lane_o);
+            else if (I8) { mega_issue_row_i8<2>(cq + 12, L.q8[1], 8 * b + wave_o, MG_DIM, lane_o); sc_c = bf2f(L.s8[1][8 * b + wave_o]); }
+            else mega_issue_row<4>(wv + 12, L.wo, 8 * b + wave_o, MG_DIM, lane_o, a.ablate);
+        };
+        auto request_w1 = [&]() {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) mega_issue_row_i4<1>(cq + i, cz + i, L.q[2], L.sz[2], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
-            } else if (I8) {
-                mega_issue_row_i8<2>(cq + 12, L.q8[1], 8 * b + wave_o, MG_DIM, lane_o);
-                sc_c = bf2f(L.s8[1][8 * b + wave_o]);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    mega_issue_row_i8<2>(cq + 2 * i, L.q8[2], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
-                    sc_a[i] = bf2f(L.s8[2][min(rb13 + i, MG_INTER - 1)]);
-                }
-            } else {
-                mega_issue_row<4>(wv + 12, L.wo, 8 * b + wave_o, MG_DIM, lane_o, a.ablate);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) mega_issue_row<4>(wv + 4 * i, L.w1, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o, a.ablate);
+            for (int i = 0; i < 3; ++i) {
+                if (I4) mega_issue_row_i4<1>(cq + i, cz + i, L.q[2], L.sz[2], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
+                else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, L.q8[2], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o); sc_a[i] = bf2f(L.s8[2][min(rb13 + i, MG_INTER - 1)]); }
+                else mega_issue_row<4>(wv + 4 * i, L.w1, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o, a.ablate);
             }
             nw_ffn = load16(L.ffn_norm + (tid_o & 255) * 8);
         };
+        auto request_wo_w1 = [&]() { request_wo(); request_w1(); };
 
         // ================= P1: attention over keys [0, P)               fast_model.py:218-222 =========================
         // Publish-before-prefetch holds for the WORKGROUP here, not just per wave: wave 0 still has the block's partial (and, in
@@ -316,6 +311,9 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         if (!any_att) request_wo_w1();
         if (any_att) {
             __syncthreads();
+            // every wave of the block has published its q/k/v rows: the wo row (8 MB chip-wide, ~1 us of stream) is requested HERE, under
+            // the q/k/v hand-off, which costs its ~1.7 us of latency whatever is queued behind it; w1 follows after the attention
+            request_wo();
             {   // q, k_new, v_new of head at_h of every utterance this block attends for: 3 x 128 row-paired granules each
                 const int sec = tid_o >> 7, c = tid_o & 127;
                 wave_poll<NU>(tag0 + 0u, a.abort_flag, &s_abort,
@@ -396,7 +394,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }
             MG_STAMP(l, 15);  // wave 0: attention output (or partial) published
             __syncthreads();
-            request_wo_w1();
+            request_w1();
         }
         __builtin_amdgcn_sched_barrier(0);
 
