@@ -45,7 +45,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int MB_MAX_SEG = 12;   // K-segments of one GEMM: (conv taps when dilated) x (precision terms)
-constexpr int BN = 128, BK = 128;   // BM = 128 or 64 (template): the 3072-channel layers have M = 1200, 64-row tiles give 456 blocks
+constexpr int BN = 128, BK = 64;   // BM = 128 or 64 (template): the 3072-channel layers have M = 1200, 64-row tiles give 456 blocks
 
 constexpr int MB_MAX_BANDS = 8;
 struct PF { const float* p[MB_MAX_BANDS]; };     // one pointer per band model (weights differ per band; activations are band-strided)
@@ -79,17 +79,19 @@ struct MbdGemmArgs {   // the band models run the same shapes: grid.z = band
 // cover ~0.4 us of load latency (the first version ran at 19 % of the MFMA peak, one iteration per load round trip); two blocks
 // per CU overlap one block's staging with the other's MFMAs.  Rows past M / N are clamped (duplicates) and dropped in the epilogue.
 template <int BM>
-__global__ void __launch_bounds__(256, 2) mbd_gemm_kernel(const MbdGemmArgs a) {
+__global__ void __launch_bounds__(256, 3) mbd_gemm_kernel(const MbdGemmArgs a) {
     constexpr int MI = BM / 32;   // MFMA row tiles per wave
-    constexpr int AR = BM / 16;   // A rows staged per thread
     constexpr int CH = BK / 8;    // 16-byte chunks per row
+    constexpr int RP = 256 / CH;  // rows staged per pass of the 256 threads
+    constexpr int AR = BM / RP;   // A rows staged per thread
+    constexpr int WR = BN / RP;   // W rows staged per thread
     __shared__ __attribute__((aligned(16))) u32x4 lds_a[BM * CH];  // [row][16 chunks of 16 B], chunk ^= row & 15
     __shared__ __attribute__((aligned(16))) u32x4 lds_w[BN * CH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tile_m = blockIdx.y * BM, tile_n = blockIdx.x * BN, band = blockIdx.z;
     const int M = a.M, N = a.N;
-    const int sr = tid >> 4, sc = tid & 15;  // thread stages chunk sc of rows sr + 16 i
+    const int sr = tid / CH, sc = tid % CH;  // thread stages chunk sc of rows sr + RP i
 
     f32x4_t acc[MI][4];
 #pragma unroll
@@ -103,43 +105,43 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_kernel(const MbdGemmArgs a) {
         // row offsets as 32-bit element indices off two base pointers (16 64-bit row pointers cost 32 VGPRs and spilled)
         const bf16_t* abase = sg.a + (size_t)band * a.a_band + sc * 8;
         const bf16_t* wbase = (sg.w_lo ? a.w_lo.p[band] : a.w_hi.p[band]) + sg.w_off + sc * 8;
-        uint32_t oa[AR], ow[8];
+        uint32_t oa[AR], ow[WR];
 #pragma unroll
-        for (int i = 0; i < AR; ++i) oa[i] = (uint32_t)((size_t)min(tile_m + sr + 16 * i, M - 1) * a.lda);
+        for (int i = 0; i < AR; ++i) oa[i] = (uint32_t)((size_t)min(tile_m + sr + RP * i, M - 1) * a.lda);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ow[i] = (uint32_t)((size_t)min(tile_n + sr + 16 * i, N - 1) * a.ldw);
-        u32x4 ra[AR], rw[8];
+        for (int i = 0; i < WR; ++i) ow[i] = (uint32_t)((size_t)min(tile_n + sr + RP * i, N - 1) * a.ldw);
+        u32x4 ra[AR], rw[WR];
         const bool in0 = sc * 8 < sg.K;
 #pragma unroll
         for (int i = 0; i < AR; ++i) ra[i] = in0 ? load16(abase + oa[i]) : zero;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) rw[i] = in0 ? load16(wbase + ow[i]) : zero;
+        for (int i = 0; i < WR; ++i) rw[i] = in0 ? load16(wbase + ow[i]) : zero;
         for (int k0 = 0; k0 < sg.K; k0 += BK) {
             __syncthreads();  // everyone is done reading the previous tile
 #pragma unroll
-            for (int i = 0; i < AR; ++i) { const int r = sr + 16 * i; lds_a[r * CH + (sc ^ (r & 15))] = ra[i]; }
+            for (int i = 0; i < AR; ++i) { const int r = sr + RP * i; lds_a[r * CH + (sc ^ (r & (CH - 1)))] = ra[i]; }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { const int r = sr + 16 * i; lds_w[r * CH + (sc ^ (r & 15))] = rw[i]; }
+            for (int i = 0; i < WR; ++i) { const int r = sr + RP * i; lds_w[r * CH + (sc ^ (r & (CH - 1)))] = rw[i]; }
             __syncthreads();
             if (k0 + BK < sg.K) {
                 const bool in = k0 + BK + sc * 8 < sg.K;
 #pragma unroll
                 for (int i = 0; i < AR; ++i) ra[i] = in ? load16(abase + oa[i] + k0 + BK) : zero;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) rw[i] = in ? load16(wbase + ow[i] + k0 + BK) : zero;
+                for (int i = 0; i < WR; ++i) rw[i] = in ? load16(wbase + ow[i] + k0 + BK) : zero;
             }
-#pragma unroll 2
+#pragma unroll 1
             for (int kk = 0; kk < BK / 32; ++kk) {
                 bf16x8_t af[MI], bf[4];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     const int r = wm * (BM / 2) + i * 16 + (lane & 15);
-                    af[i] = __builtin_bit_cast(bf16x8_t, lds_a[r * CH + ((kk * 4 + (lane >> 4)) ^ (r & 15))]);
+                    af[i] = __builtin_bit_cast(bf16x8_t, lds_a[r * CH + ((kk * 4 + (lane >> 4)) ^ (r & (CH - 1)))]);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = wn * 64 + j * 16 + (lane & 15);
-                    bf[j] = __builtin_bit_cast(bf16x8_t, lds_w[r * CH + ((kk * 4 + (lane >> 4)) ^ (r & 15))]);
+                    bf[j] = __builtin_bit_cast(bf16x8_t, lds_w[r * CH + ((kk * 4 + (lane >> 4)) ^ (r & (CH - 1)))]);
                 }
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
