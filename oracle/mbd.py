@@ -134,10 +134,38 @@ def _res_block(sd, p, x, cfg: UnetConfig, dilation: int):
     return x + h
 
 
+def _lstm_direction(x: torch.Tensor, w_ih, w_hh, bias, reverse: bool) -> torch.Tensor:
+    """One direction of one nn.LSTM layer on (T, I) -> (T, H), explicit gates (order i, f, g, o)."""
+    T, H = x.shape[0], w_hh.shape[1]
+    h, c = torch.zeros(H), torch.zeros(H)
+    gin = x @ w_ih.T + bias
+    out = torch.zeros(T, H)
+    for t in (range(T - 1, -1, -1) if reverse else range(T)):
+        g = gin[t] + w_hh @ h
+        i, f, gg, o = g[:H], g[H:2 * H], g[2 * H:3 * H], g[3 * H:]
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        out[t] = h
+    return out
+
+
+def blstm(sd: Dict[str, torch.Tensor], z: torch.Tensor) -> torch.Tensor:
+    """audiocraft `BLSTM(dim)`: nn.LSTM(dim, dim, num_layers=2, bidirectional=True) over time, then Linear(2 dim -> dim); z (1, C, T)."""
+    x = z[0].T  # (T, C)
+    for l in range(2):
+        outs = []
+        for suffix, rev in (("", False), ("_reverse", True)):
+            outs.append(_lstm_direction(x, sd[f"bilstm.lstm.weight_ih_l{l}{suffix}"], sd[f"bilstm.lstm.weight_hh_l{l}{suffix}"],
+                                        sd[f"bilstm.lstm.bias_ih_l{l}{suffix}"] + sd[f"bilstm.lstm.bias_hh_l{l}{suffix}"], rev))
+        x = torch.cat(outs, dim=1)
+    y = x @ sd["bilstm.linear.weight"].T + sd["bilstm.linear.bias"]
+    return y.T[None]
+
+
 def unet_forward(sd: Dict[str, torch.Tensor], cfg: UnetConfig, x: torch.Tensor, step: int, condition: Optional[torch.Tensor]) -> torch.Tensor:
     """DiffusionUnet.forward(x (B, chin, T), step, condition (B, codec_dim, frames)).sample."""
-    if cfg.bilstm or cfg.transformer or cfg.cross_attention:
-        raise NotImplementedError("bilstm / transformer bottlenecks are not part of the 24 kHz multi-band models")
+    if cfg.transformer or cfg.cross_attention:
+        raise NotImplementedError("transformer bottlenecks are not part of the 24 kHz multi-band models")
     sd = {k: v.float() for k, v in sd.items()}
     k, s = cfg.kernel, cfg.stride
     pad = (k - s) // 2
@@ -160,7 +188,11 @@ def unet_forward(sd: Dict[str, torch.Tensor], cfg: UnetConfig, x: torch.Tensor, 
         c = F.conv1d(condition.float(), sd["conv_codec.weight"], sd["conv_codec.bias"])
         assert c.shape[-1] <= 2 * z.shape[-1]
         z = z + F.interpolate(c, z.shape[-1])  # nearest
-    z = torch.zeros_like(z)  # `if self.bilstm is None: z = torch.zeros_like(z)` (unet.py, no-LSTM / no-transformer bottleneck)
+    if cfg.bilstm:
+        assert z.shape[0] == 1
+        z = blstm(sd, z)
+    else:
+        z = torch.zeros_like(z)  # `if self.bilstm is None: z = torch.zeros_like(z)` (unet.py, no-LSTM / no-transformer bottleneck)
     for i in range(cfg.depth):
         skip = skips.pop(-1)
         z = z[:, :, : skip.shape[2]] + skip

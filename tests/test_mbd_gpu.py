@@ -58,45 +58,30 @@ def test_unet_forward_matches_oracle(kw, T, frames):
 
 
 def test_unet_with_bilstm_bottleneck():
+    """BiLSTM bottleneck (codec conditioning reaches the output only through it): the HIP persistent LSTM kernel in both directions
+    against the oracle's explicit-gate restatement and against torch.nn.LSTM on the same weights."""
     kw = dict(hidden=16, depth=2, growth=2.0, codec_dim=24, bilstm=True)
     pkg = synthetic.mbd_package(seed=5, n_bands=1, proc_bands=1, **kw)
     g = torch.Generator().manual_seed(9)
     x, lat = torch.randn(3200, generator=g), torch.randn(1, 24, 10, generator=g)
     sd = {k: v.float() for k, v in pkg[0]["model_state"].items()}
-    # the oracle's UNet has no LSTM branch of its own: evaluate the graph here with torch.nn.LSTM on the same weights
-    import torch.nn.functional as F
-
     cfg = oracle_bands(pkg)[0].cfg
-    z = x.view(1, 1, -1)
-    skips = []
-    for i in range(2):
-        p = f"encoders.{i}."
-        z = F.conv1d(z, sd[p + "conv.weight"], None, stride=4, padding=2)
-        z = torch.relu(F.group_norm(z, 4, sd[p + "norm.weight"], sd[p + "norm.bias"]))
-        z = o_mbd._res_block(sd, p + "res_blocks.0.", z, cfg, 1)
-        z = z + (sd["embedding.weight"][500] if i == 0 else sd["embeddings.0.weight"][500]).view(1, -1, 1)
-        skips.append(z)
-    c = F.conv1d(lat, sd["conv_codec.weight"], sd["conv_codec.bias"])
-    z = z + F.interpolate(c, z.shape[-1])
-    H = z.shape[1]
-    lstm = torch.nn.LSTM(bidirectional=True, num_layers=2, hidden_size=H, input_size=H)
+    ref = o_mbd.unet_forward(sd, cfg, x.view(1, 1, -1), 500, lat).reshape(-1)
+    # the oracle's BLSTM against torch's own
+    z = torch.randn(1, 32, 50, generator=g)
+    lstm = torch.nn.LSTM(bidirectional=True, num_layers=2, hidden_size=32, input_size=32)
     lstm.load_state_dict({k[len("bilstm.lstm."):]: v for k, v in sd.items() if k.startswith("bilstm.lstm.")})
     with torch.no_grad():
-        y = lstm(z.permute(2, 0, 1))[0] @ sd["bilstm.linear.weight"].T + sd["bilstm.linear.bias"]
-    z = y.permute(1, 2, 0)
-    for i in range(2):
-        sk = skips.pop(-1)
-        z = z[:, :, : sk.shape[2]] + sk
-        p = f"decoders.{i}."
-        z = o_mbd._res_block(sd, p + "res_blocks.0.", z, cfg, 1)
-        z = torch.relu(F.group_norm(z, 4, sd[p + "norm.weight"], sd[p + "norm.bias"]))
-        z = F.conv_transpose1d(z, sd[p + "convtr.weight"], None, stride=4, padding=2)
-    ref = z.reshape(-1)[:3200]
+        want = (lstm(z.permute(2, 0, 1))[0] @ sd["bilstm.linear.weight"].T + sd["bilstm.linear.bias"]).permute(1, 2, 0)
+    assert float((o_mbd.blstm(sd, z) - want).abs().max()) < 1e-5
     eng = mbd.MultiBandDiffusionBands.from_package(pkg, precision=3, eq_bands=1)
     got = eng.unet_forward(0, x, 500, lat)
     s = snr_db(got, ref)
     print(f"[mbd unet + BiLSTM] SNR {s:.1f} dB")
     assert s >= 60.0
+    # the conditioning matters in this configuration
+    other = eng.unet_forward(0, x, 500, lat + 1.0)
+    assert float((other - got).abs().max()) > 1e-4
     eng.close()
 
 
