@@ -363,6 +363,21 @@ def main():
                               "algorithmic_bytes_per_step": total_bytes, "gpu_ms_per_step": round(gpu_ms / a.steps, 2)},
             "per_kernel": per_kernel,
         }
+        if diffusion is not None:
+            # the vocoder's dominant kernel is MFMA-bound: algorithmic flops of the band UNets' convolutions (2 x MACs, x the MFMA terms
+            # per product) over the whole multi-band-diffusion stage time (which also contains its element-wise kernels: a lower bound)
+            samples = 960 * 320
+            chans, k_, s_ = [48, 192, 768, 3072], 8, 4
+            t_len, macs, cin = samples, 0.0, 1
+            for c_ in chans:
+                t_len = (t_len + s_ - 1) // s_
+                macs += 2 * (t_len * c_ * cin * k_) + 4 * (t_len * c_ * c_ * 3)   # strided conv + its transposed twin, 2 ResBlocks x 2 convs
+                cin = c_
+            flops = 2 * macs * 4 * 20 * a.mbd_precision
+            mbd_s = stage_ms["multiband_diffusion"] / a.steps / n_utt * 1e-3
+            out["vocoder_roofline"] = {"bound": "mfma", "kernel": "mbd_gemm_kernel (overlapping-window conv GEMMs of the 4 band UNets, 20 evaluations)",
+                                       "achieved": round(flops / mbd_s / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flops / mbd_s / 2.5e15, 4),
+                                       "note": f"{flops / 1e12:.0f} TFLOP of bf16 MFMA work per utterance ({a.mbd_precision} terms per product) over the whole stage"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mv, cfgk)
         print(json.dumps(out))

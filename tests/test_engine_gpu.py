@@ -211,6 +211,28 @@ def test_two_utterances_with_ragged_prompts_match_single_runs():
     engine1.close()
 
 
+def test_batch_of_two_utterances_follows_the_oracle():
+    """SURVEY 8f row 2 against the ORACLE, not the engine itself: two utterances with ragged prompts, their own speaker embeddings
+    and seeds decoded together (persistent kernel, 2 utterances per launch) -- each stream must be the oracle's single-utterance
+    stream, or fork only at an oracle near-tie (`check_stream`)."""
+    engine, sd, cfg = build(SMALL, 6, max_utterances=2)
+    lens, n_new = [9, 17], 24
+    prompts = [synthetic.prompt_tokens(t, seed=20 + u) for u, t in enumerate(lens)]
+    spks = torch.cat([synthetic.speaker_embedding(20 + u) for u in range(2)])
+    sps = [mv.SamplingParams(top_k=1, seed=3 + u) for u in range(2)]
+    engine.begin(prompts, spks, sps, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
+    engine.run()
+    for u in range(2):
+        seq = engine.tokens(u)
+        ob = oracle_for(sd, cfg, "bf16")
+        oseq, ologits = o_s1.generate(ob, prompts[u], spks[u:u + 1], max_new_tokens=n_new, end_of_audio_token=9999, top_k=1, seed=3 + u,
+                                      return_logits=True)
+        agree = check_stream(seq, oseq, ologits, lens[u], gap_tol=0.05 * float(ologits.std()))
+        print(f"[batch of 2] utterance {u}: {agree}/{n_new} tokens identical to the oracle's single-utterance stream")
+        assert len(seq) == lens[u] + n_new and agree >= 1
+    engine.close()
+
+
 @pytest.mark.parametrize("name,cfgk,seed,T,n_new", [("small", SMALL, 0, 12, 20), ("wide2", WIDE2, 1, 130, 8)])
 def test_batched_prefill_matches_teacher_forcing_and_oracle(name, cfgk, seed, T, n_new):
     """`prefill()` (fast_inference_utils.py:123-132) as MFMA GEMMs + causal attention == the same prompt pushed token by
