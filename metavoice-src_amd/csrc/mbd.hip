@@ -169,6 +169,87 @@ __global__ void __launch_bounds__(256, 3) mbd_gemm_kernel(const MbdGemmArgs a) {
         }
 }
 
+// The same GEMM with DIRECT global -> LDS loads (`global_load_lds_dwordx4`, gfx950): no staging registers and no ds_write pass, so a
+// block needs ~110 VGPRs and 32 KB of LDS and FOUR blocks share a CU; one block's load round trip is covered by the MFMAs of the
+// other three (two barriers per K-step, no software pipeline inside a block).  A wave instruction writes 1 KB of LDS linearly
+// (wave-uniform base + lane x 16 B) = 8 rows x 8 chunks, so the XOR swizzle of the LDS image is applied on the SOURCE side: lane l
+// (row l >> 3, physical chunk l & 7) fetches logical chunk (l & 7) ^ (row & 7).  Used when every K-segment is a multiple of 64.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+__global__ void __launch_bounds__(256, 4) mbd_gemm_glds_kernel(const MbdGemmArgs a) {
+    constexpr int BM = 128, CH = 8;   // BK = 64
+    __shared__ __attribute__((aligned(1024))) u32x4 lds_a[BM * CH];
+    __shared__ __attribute__((aligned(1024))) u32x4 lds_w[BN * CH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile_m = blockIdx.y * BM, tile_n = blockIdx.x * BN, band = blockIdx.z;
+    const int M = a.M, N = a.N;
+    // this wave loads row groups (8 rows each) wave * 4 + i, i < 4, of both operands: lane -> (row lane >> 3, chunk (lane & 7) ^ (row & 7))
+    const int lr = lane >> 3, lc = (lane & 7) ^ (lr & 7);   // rows of a group are 8-aligned: (row & 7) == lr
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
+
+    for (int s = 0; s < a.n_seg; ++s) {
+        const GemmSeg sg = a.seg[s];
+        const bf16_t* abase = sg.a + (size_t)band * a.a_band + lc * 8;
+        const bf16_t* wbase = (sg.w_lo ? a.w_lo.p[band] : a.w_hi.p[band]) + sg.w_off + lc * 8;
+        uint32_t oa[4], ow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            oa[i] = (uint32_t)((size_t)min(tile_m + (wave * 4 + i) * 8 + lr, M - 1) * a.lda);
+            ow[i] = (uint32_t)((size_t)min(tile_n + (wave * 4 + i) * 8 + lr, N - 1) * a.ldw);
+        }
+        for (int k0 = 0; k0 < sg.K; k0 += 64) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(abase + oa[i] + k0), (lds_ptr_t)(lds_a + (wave * 4 + i) * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(wbase + ow[i] + k0), (lds_ptr_t)(lds_w + (wave * 4 + i) * 64), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();   // every wave's loads have landed
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t af[4], bf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = wm * 64 + i * 16 + (lane & 15);
+                    af[i] = __builtin_bit_cast(bf16x8_t, lds_a[r * CH + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = wn * 64 + j * 16 + (lane & 15);
+                    bf[j] = __builtin_bit_cast(bf16x8_t, lds_w[r * CH + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();   // everyone is done reading before the next tile overwrites the buffers
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = tile_n + wn * 64 + j * 16 + (lane & 15);
+            if (n >= N) continue;
+            const float add = (a.bias.p[band] ? a.bias.p[band][n] : 0.f) + (a.col_add.p[band] ? a.col_add.p[band][n] : 0.f);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int m = tile_m + wm * 64 + i * 16 + (lane >> 4) * 4 + reg;
+                if (m >= M) continue;
+                float y = acc[i][j][reg] + add;
+                if (a.residual) y += a.residual[(size_t)band * a.res_band + (size_t)m * a.ldr + n];
+                a.out[(size_t)band * a.out_band + (size_t)m * a.ldc + n] = y;
+            }
+        }
+}
+
 // ---- GroupNorm statistics: deterministic two stages ------------------------------------------------------------------------
 // stage 1: block (c, g) sums x and x^2 of group g over rows [c * rows_per, ...) -> part[c][g][2] (double).  A thread walks the
 // (rows x C / G) sub-matrix in float4 steps (C / G is a multiple of 4 whenever C is a multiple of 16; otherwise scalar steps).
@@ -836,7 +917,11 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
         }
     }
     const int nt = (g.N + BN - 1) / BN;
-    if ((size_t)nt * ((g.M + 127) / 128) * nb >= 400) hipLaunchKernelGGL(mbd_gemm_kernel<128>, dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
+    bool k64 = true;
+    for (int i = 0; i < g.n_seg; ++i) k64 = k64 && g.seg[i].K % 64 == 0;
+    if (k64 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400 && getenv("MV_MBD_NO_GLDS") == nullptr)
+        hipLaunchKernelGGL(mbd_gemm_glds_kernel, dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
+    else if ((size_t)nt * ((g.M + 127) / 128) * nb >= 400) hipLaunchKernelGGL(mbd_gemm_kernel<128>, dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
     else hipLaunchKernelGGL(mbd_gemm_kernel<64>, dim3(nt, (g.M + 63) / 64, nb), dim3(256), 0, s, g);
     return hipGetLastError();
 }

@@ -40,6 +40,7 @@ def oracle_bands(pkg, **ucfg):
     (dict(hidden=48, depth=2, growth=4.0, codec_dim=None), 4099, 0),          # 48 -> 192 channels: partial GEMM tiles, ragged length
     (dict(hidden=8, depth=4, growth=2.0, codec_dim=16, emb_all_layers=False, activation="gelu"), 5000, 16),
     (dict(hidden=16, depth=2, growth=2.0, codec_dim=16, res_blocks=2), 1600, 5),  # second ResBlock: dilation 2
+    (dict(hidden=64, depth=2, growth=4.0, codec_dim=None), 205003, 0),         # >= 400 GEMM tiles with K % 64 == 0: the direct-to-LDS GEMM
 ])
 def test_unet_forward_matches_oracle(kw, T, frames):
     pkg = synthetic.mbd_package(seed=3, n_bands=1, proc_bands=1, **kw)
