@@ -37,8 +37,12 @@ __device__ __forceinline__ float dot8_bf16(const u32x4& w, const u32x4& x, float
 }
 
 // Streaming (read-once) 16-byte load: global_load_dwordx4 ... nt  (MI355X_MICROARCH "nt-weights").
-__device__ __forceinline__ u32x4 load_stream16(const void* p) { return __builtin_nontemporal_load((const u32x4*)p); }
-__device__ __forceinline__ u32x4 load16(const void* p) { return *(const u32x4*)p; }
+// The pointer is cast to the GLOBAL address space: through a generic pointer (weights reach the kernels inside argument structs)
+// hipcc emits flat_load_dwordx4, and a FLAT load also counts in lgkmcnt -- so every LDS read issued while weight rows were in
+// flight (`s_waitcnt lgkmcnt(0)`) waited for the whole weight stream.  global_load counts in vmcnt only.
+typedef const __attribute__((address_space(1))) u32x4* mv_gptr16_t;
+__device__ __forceinline__ u32x4 load_stream16(const void* p) { return __builtin_nontemporal_load((mv_gptr16_t)p); }
+__device__ __forceinline__ u32x4 load16(const void* p) { return *(mv_gptr16_t)p; }
 
 // ---- cross-lane sums over a 64-lane wave; every lane ends up with the total -------------------------------
 template <int CTRL>
