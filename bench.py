@@ -73,6 +73,32 @@ def step_bytes(cfg, pos, fmt=None):
     return weight_bytes(cfg, fmt) + kv_bytes(cfg, pos)
 
 
+def make_work(mv, args, *, long_form, long_form_chars, utterances_per_gpu, rank, world):
+    """The work list of one bench step on this rank: groups of (prompt tokens, tokens to generate), one group per engine run."""
+    U = utterances_per_gpu
+    if long_form:
+        # configs[4]: C characters -> sentence chunks of <= 220 characters (longform.split_text), tokenised with the synthetic
+        # 512-rank BPE table (the real ranks live in the unreachable checkpoint); every chunk speaks 7.5 tokens per character,
+        # the rate of configs[1] (256 characters -> 1920 tokens), end-of-audio unreachable
+        longform = importlib.import_module("metavoice-src_amd.longform")
+        tok_mod = importlib.import_module("metavoice-src_amd.tokenise")
+        tokenizer = tok_mod.TrainedBPETokeniser(**tok_mod.byte_level_tokenizer_info(offset=2049))
+        sentence = "The quick brown fox jumps over the lazy dog near the quiet river bank, while the old mill turns slowly. "
+        text = (sentence * (long_form_chars // len(sentence) + 1))[:long_form_chars]
+        work = []
+        for c in longform.split_text(text):
+            ids = torch.tensor(tokenizer.encode(c), dtype=torch.int32)
+            work.append([(ids, min(args.block_size - len(ids), int(round(7.5 * len(c)))))])
+        return work
+    if U > 1:
+        # configs[2]: ragged prompts, lengths uniform in [96, 160] (seed 0 stream, offset by the rank), 12.8 s each unless the
+        # context window ends first (160 + 1920 > 2048)
+        g = torch.Generator().manual_seed(0)
+        lens = torch.randint(96, 161, (U * max(world, 1),), generator=g).tolist()[rank * U:(rank + 1) * U]
+        return [[(mv.synthetic.prompt_tokens(t, seed=rank * 100 + u), min(N_NEW, args.block_size - t)) for u, t in enumerate(lens)]]
+    return [[(mv.synthetic.prompt_tokens(T_PROMPT, seed=rank), N_NEW)]]
+
+
 def cpu_baseline(mv, cfgk, sample_steps=8):
     """Time the oracle (oracle/stage1.py, fp32, torch CPU) on the same workload shape: bounded sample."""
     from oracle import stage1 as o_s1
@@ -142,29 +168,7 @@ def main():
     engine.finalize()
     spk = mv.synthetic.speaker_embedding(rank)
     sp = mv.SamplingParams(guidance_scale=3.0, temperature=1.0, top_p=0.95, seed=1337 + rank)  # TTS.synthesise defaults
-    # ---- the work list of one step: (prompt tokens, tokens to generate) per utterance ----------------------------------
-    if a.long_form:
-        # configs[4]: C characters -> sentence chunks of <= 220 characters (longform.split_text), tokenised with the synthetic
-        # 512-rank BPE table (the real ranks live in the unreachable checkpoint); every chunk speaks 7.5 tokens per character,
-        # the rate of configs[1] (256 characters -> 1920 tokens), end-of-audio unreachable
-        longform = importlib.import_module("metavoice-src_amd.longform")
-        tok_mod = importlib.import_module("metavoice-src_amd.tokenise")
-        tokenizer = tok_mod.TrainedBPETokeniser(**tok_mod.byte_level_tokenizer_info(offset=2049))
-        sentence = "The quick brown fox jumps over the lazy dog near the quiet river bank, while the old mill turns slowly. "
-        text = (sentence * (a.long_form_chars // len(sentence) + 1))[:a.long_form_chars]
-        chunks = longform.split_text(text)
-        work = []
-        for c in chunks:
-            ids = torch.tensor(tokenizer.encode(c), dtype=torch.int32)
-            work.append([(ids, min(args.block_size - len(ids), int(round(7.5 * len(c)))))])
-    elif U > 1:
-        # configs[2]: ragged prompts, lengths uniform in [96, 160] (seed 0 stream, offset by the rank), 12.8 s each unless the
-        # context window ends first (160 + 1920 > 2048)
-        g = torch.Generator().manual_seed(0)
-        lens = torch.randint(96, 161, (U * max(world, 1),), generator=g).tolist()[rank * U:(rank + 1) * U]
-        work = [[(mv.synthetic.prompt_tokens(t, seed=rank * 100 + u), min(N_NEW, args.block_size - t)) for u, t in enumerate(lens)]]
-    else:
-        work = [[(mv.synthetic.prompt_tokens(T_PROMPT, seed=rank), N_NEW)]]
+    work = make_work(mv, args, long_form=a.long_form, long_form_chars=a.long_form_chars, utterances_per_gpu=U, rank=rank, world=world)
     prompt = work[0][0][0]
     dispatch = importlib.import_module("metavoice-src_amd.batch_dispatch")
 

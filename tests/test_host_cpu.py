@@ -5,7 +5,7 @@ import os
 
 import pytest
 
-from conftest import GOLDEN, load_pkg
+from conftest import GOLDEN, ROOT, load_pkg
 
 adapters = load_pkg("adapters")
 utils = load_pkg("utils")
@@ -129,3 +129,29 @@ def test_long_form_chunker():
     ten_k = ("The quick brown fox jumps over the lazy dog near the quiet river bank. " * 150)[:10000]
     n = len(longform.split_text(ten_k))
     assert 46 <= n <= 60  # ~46-50 chunks for 10k characters
+
+
+def test_bench_work_lists_for_every_baseline_config():
+    """bench.make_work (host logic, no GPU): configs[1] one 128-token prompt + 1920 tokens; configs[2] ragged prompts 96..160 that
+    differ per rank and never overrun the context window; configs[4] ~46-60 sentence chunks of <= 220 characters."""
+    import importlib
+    import sys
+
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    mv = load_pkg()
+    args = mv.ModelArgs.from_name("metavoice-1B")
+    one = bench.make_work(mv, args, long_form=False, long_form_chars=0, utterances_per_gpu=1, rank=0, world=1)
+    assert len(one) == 1 and len(one[0]) == 1 and len(one[0][0][0]) == 128 and one[0][0][1] == 1920
+    seen = set()
+    for rank in range(8):
+        (group,) = bench.make_work(mv, args, long_form=False, long_form_chars=0, utterances_per_gpu=4, rank=rank, world=8)
+        assert len(group) == 4
+        for prompt, n_new in group:
+            assert 96 <= len(prompt) <= 160 and len(prompt) + n_new <= args.block_size and n_new >= 1888
+            seen.add(tuple(prompt.tolist()))
+    assert len(seen) == 32  # batch 32: every utterance of every rank is different
+    long = bench.make_work(mv, args, long_form=True, long_form_chars=10000, utterances_per_gpu=1, rank=0, world=1)
+    assert 46 <= len(long) <= 60
+    for (ids, n_new), in long:
+        assert len(ids) + n_new <= args.block_size and n_new >= 100
