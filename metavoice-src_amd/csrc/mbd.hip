@@ -250,6 +250,93 @@ __global__ void __launch_bounds__(256, 4) mbd_gemm_glds_kernel(const MbdGemmArgs
         }
 }
 
+// Three-term products in ONE pass: per K-step the hi AND lo tiles of both operands are loaded (2 A + 2 W tiles instead of the
+// 3 A + 3 W of three separate segments) and every fragment pair feeds three MFMAs (a_hi w_hi + a_hi w_lo + a_lo w_hi): a third
+// fewer operand bytes and three times the MFMA work per barrier pair.  64 KB of LDS, two blocks per CU; segment 0 carries a_hi,
+// segment 2 a_lo (launch_gemm's order), one tap.
+__global__ void __launch_bounds__(256, 2) mbd_gemm_glds3_kernel(const MbdGemmArgs a) {
+    constexpr int BM = 128, CH = 8;   // BK = 64
+    __shared__ __attribute__((aligned(1024))) u32x4 lds_ah[BM * CH];
+    __shared__ __attribute__((aligned(1024))) u32x4 lds_al[BM * CH];
+    __shared__ __attribute__((aligned(1024))) u32x4 lds_wh[BN * CH];
+    __shared__ __attribute__((aligned(1024))) u32x4 lds_wl[BN * CH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile_m = blockIdx.y * BM, tile_n = blockIdx.x * BN, band = blockIdx.z;
+    const int M = a.M, N = a.N, K = a.seg[0].K;
+    const int lr = lane >> 3, lc = (lane & 7) ^ (lr & 7);
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
+
+    const bf16_t* ah = a.seg[0].a + (size_t)band * a.a_band + lc * 8;
+    const bf16_t* al = a.seg[2].a + (size_t)band * a.a_band + lc * 8;
+    const bf16_t* wh = a.w_hi.p[band] + a.seg[0].w_off + lc * 8;
+    const bf16_t* wl = a.w_lo.p[band] + a.seg[0].w_off + lc * 8;
+    uint32_t oa[4], ow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        oa[i] = (uint32_t)((size_t)min(tile_m + (wave * 4 + i) * 8 + lr, M - 1) * a.lda);
+        ow[i] = (uint32_t)((size_t)min(tile_n + (wave * 4 + i) * 8 + lr, N - 1) * a.ldw);
+    }
+    for (int k0 = 0; k0 < K; k0 += 64) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int slot = (wave * 4 + i) * 64;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(ah + oa[i] + k0), (lds_ptr_t)(lds_ah + slot), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(al + oa[i] + k0), (lds_ptr_t)(lds_al + slot), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wh + ow[i] + k0), (lds_ptr_t)(lds_wh + slot), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wl + ow[i] + k0), (lds_ptr_t)(lds_wl + slot), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll 1
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t afh[4], afl[4], bfh[4], bfl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wm * 64 + i * 16 + (lane & 15), idx = r * CH + ((kk * 4 + (lane >> 4)) ^ (r & 7));
+                afh[i] = __builtin_bit_cast(bf16x8_t, lds_ah[idx]);
+                afl[i] = __builtin_bit_cast(bf16x8_t, lds_al[idx]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = wn * 64 + j * 16 + (lane & 15), idx = r * CH + ((kk * 4 + (lane >> 4)) ^ (r & 7));
+                bfh[j] = __builtin_bit_cast(bf16x8_t, lds_wh[idx]);
+                bfl[j] = __builtin_bit_cast(bf16x8_t, lds_wl[idx]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[i], bfh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[i], bfl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[i], bfh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = tile_n + wn * 64 + j * 16 + (lane & 15);
+            if (n >= N) continue;
+            const float add = (a.bias.p[band] ? a.bias.p[band][n] : 0.f) + (a.col_add.p[band] ? a.col_add.p[band][n] : 0.f);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int m = tile_m + wm * 64 + i * 16 + (lane >> 4) * 4 + reg;
+                if (m >= M) continue;
+                float y = acc[i][j][reg] + add;
+                if (a.residual) y += a.residual[(size_t)band * a.res_band + (size_t)m * a.ldr + n];
+                a.out[(size_t)band * a.out_band + (size_t)m * a.ldc + n] = y;
+            }
+        }
+}
+
 // ---- GroupNorm statistics: deterministic two stages ------------------------------------------------------------------------
 // stage 1: block (c, g) sums x and x^2 of group g over rows [c * rows_per, ...) -> part[c][g][2] (double).  A thread walks the
 // (rows x C / G) sub-matrix in float4 steps (C / G is a multiple of 4 whenever C is a multiple of 16; otherwise scalar steps).
@@ -919,7 +1006,10 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
     const int nt = (g.N + BN - 1) / BN;
     bool k64 = true;
     for (int i = 0; i < g.n_seg; ++i) k64 = k64 && g.seg[i].K % 64 == 0;
-    if (k64 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400 && getenv("MV_MBD_NO_GLDS") == nullptr)
+    static const int glds_mode = getenv("MV_MBD_NO_GLDS") ? 0 : getenv("MV_MBD_NO_FUSED3") ? 1 : 2;
+    if (glds_mode == 2 && k64 && prec == 3 && taps == 1 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400)
+        hipLaunchKernelGGL(mbd_gemm_glds3_kernel, dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
+    else if (glds_mode >= 1 && k64 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400)
         hipLaunchKernelGGL(mbd_gemm_glds_kernel, dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
     else if ((size_t)nt * ((g.M + 127) / 128) * nb >= 400) hipLaunchKernelGGL(mbd_gemm_kernel<128>, dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
     else hipLaunchKernelGGL(mbd_gemm_kernel<64>, dim3(nt, (g.M + 63) / 64, nb), dim3(256), 0, s, g);
