@@ -449,38 +449,50 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__
     }
 }
 
-// first encoder convolution, 1 -> C channels: out[m][c] = sum_k w[c][k] x[m s + k - pad]   (zero padding, no bias)
+// first encoder convolution, 1 -> C channels: out[m][c] = sum_k w[c][k] x[m s + k - pad]   (zero padding, no bias).  A thread
+// produces four consecutive channels of one output step (one float4 store); the k input samples are shared by the C / 4 threads
+// of a step, the C x k weights sit in the scalar / L1 caches.  32-bit indexing (M C < 2^31).
 __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ x, int T, const PF ws, int C, int k, int s, int pad,
                                                       float* __restrict__ out, int64_t out_band, int M) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)M * C) return;
+    const int q4 = C >> 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * q4) return;
+    const int m = i / q4, c = (i - m * q4) * 4;
     x += (size_t)blockIdx.y * T;
-    out += (size_t)blockIdx.y * out_band;
-    const float* w = ws.p[blockIdx.y];
-    const int m = (int)(i / C), c = (int)(i % C);
-    float acc = 0.f;
+    const float* w = ws.p[blockIdx.y] + (size_t)c * k;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int j = 0; j < k; ++j) {
         const int t = m * s + j - pad;
-        if (t >= 0 && t < T) acc = fmaf(w[c * k + j], x[t], acc);
+        const float xv = (t >= 0 && t < T) ? x[t] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = fmaf(w[q * k + j], xv, acc[q]);
     }
-    out[i] = acc;
+    *(float4*)(out + (size_t)blockIdx.y * out_band + (size_t)m * C + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
-// last decoder transposed convolution, C -> 1 channel: out[t'] = sum_c sum_{(t, j): t s + j - pad = t'} x[t][c] w[c][j]
+// last decoder transposed convolution, C -> 1 channel: out[t'] = sum_c sum_{(t, j): t s + j - pad = t'} x[t][c] w[c][j].  One thread
+// per output sample: it walks the <= k / s input rows that reach it (a row is C contiguous floats, shared through L1 by the s
+// neighbouring samples); the weights are transposed into LDS as [j][c] once per block.
 __global__ void __launch_bounds__(256) convtr_out_kernel(const float* __restrict__ x, int64_t x_band, int Tin, int C, const PF ws, int k, int s,
                                                          int pad, float* __restrict__ out, int64_t out_band, int Tout) {
-    const int tp = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    extern __shared__ float wt[];  // [k][C]
+    const float* w = ws.p[blockIdx.y];
+    for (int i = threadIdx.x; i < k * C; i += 256) wt[(i % k) * C + i / k] = w[i];   // w is [C][k]
+    __syncthreads();
+    const int tp = blockIdx.x * 256 + threadIdx.x;
     if (tp >= Tout) return;
     x += (size_t)blockIdx.y * x_band;
-    out += (size_t)blockIdx.y * out_band;
-    const float* w = ws.p[blockIdx.y];
     float acc = 0.f;
     for (int j = (tp + pad) % s; j < k; j += s) {
         const int t = (tp + pad - j) / s;
         if (t < 0 || t >= Tin) continue;
-        for (int c = lane; c < C; c += 64) acc = fmaf(x[(size_t)t * C + c], w[c * k + j], acc);
+        const float4* row = (const float4*)(x + (size_t)t * C);
+        const float4* wj = (const float4*)(wt + j * C);
+        for (int c = 0; c < (C >> 2); ++c) {
+            const float4 xv = row[c], wv = wj[c];
+            acc = fmaf(xv.x, wv.x, fmaf(xv.y, wv.y, fmaf(xv.z, wv.z, fmaf(xv.w, wv.w, acc))));
+        }
     }
-    acc = wave_sum(acc);
-    if (lane == 0) out[tp] = acc;
+    out[(size_t)blockIdx.y * out_band + tp] = acc;
 }
 
 // z[t][c] = skip[t][c] (+ add[t][c])                      (decoder: z = z[:, :, :skip.T] + skip; the first z is zero or the LSTM's)
@@ -1179,7 +1191,7 @@ int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float*
             const int Cin = i == 0 ? 1 : m->ch[i - 1], Cout = m->ch[i], To = ub.T[i];
             auto E = [&](int b) -> const EncW& { return m->band[b].enc[i]; };
             if (i == 0) {
-                hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)(((size_t)To * Cout + 255) / 256), NB), dim3(256), 0, s, zin, Tin,
+                hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)(((size_t)To * (Cout / 4) + 255) / 256), NB), dim3(256), 0, s, zin, Tin,
                                    pf_of(NB, [&](int b) { return (const float*)E(b).conv_in_w; }), Cout, k, st, pad, ub.a32, WB, To);
             } else {
                 // operand: zin with `pad` zero rows in front and (Tpad - Tin) + k behind
@@ -1255,7 +1267,7 @@ int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float*
             const PF ng = pf_of(NB, [&](int b) { return (const float*)Dw(b).norm.g; }), nbias = pf_of(NB, [&](int b) { return (const float*)Dw(b).norm.b; });
             if (lvl == 0) {
                 launch_norm_act(s, ub, ub.c32, WB, Ts, C, G, ub.stats, ng, nbias, g.act, ub.a32, WB, nullptr, nullptr, 0, 0);
-                hipLaunchKernelGGL(convtr_out_kernel, dim3((T + 3) / 4, NB), dim3(256), 0, s, ub.a32, WB, Ts, C,
+                hipLaunchKernelGGL(convtr_out_kernel, dim3((T + 255) / 256, NB), dim3(256), (size_t)k * C * 4, s, ub.a32, WB, Ts, C,
                                    pf_of(NB, [&](int b) { return (const float*)Dw(b).convtr_out_w; }), k, st, pad, est, est_band, T);
             } else {
                 // operand rows: [zero row | z rows 0..Ts-1 | zero row]; GEMM row q = (x[q-1], x[q]), q = 0..Ts
