@@ -551,22 +551,36 @@ __global__ void init_noise_kernel(float* __restrict__ cur, const float* __restri
     if (i < T) cur[(size_t)b * T + i] = (noise ? noise[(size_t)b * T + i] : mb_gauss(seed, (uint32_t)b * 4096u, (uint32_t)i)) * c.noise_scale[b];
 }
 
-// julius.LowPassFilters: low[f][t] = sum_j bank[f][j] x[clamp(t + j - half)]  (replicate padding).  Block = 256 outputs of one
-// filter; the input tile with its halo and the taps sit in LDS (the taps are a broadcast read).
+// julius.LowPassFilters: low[f][t] = sum_j bank[f][j] x[clamp(t + j - half)]  (replicate padding).  Block = FIR_TILE outputs of
+// one filter; the input tile with its halo and the taps sit in LDS.  A thread produces 4 consecutive outputs from a sliding
+// register window: per tap one broadcast read of the coefficient and ONE new input sample for four MACs.
+constexpr int FIR_TILE = 1024;
 __global__ void __launch_bounds__(256) fir_bank_kernel(const float* __restrict__ x, int T, const float* __restrict__ bank, int taps,
                                                        float* __restrict__ low) {
-    extern __shared__ float sh[];  // [256 + taps - 1] input, then [taps] filter
-    const int f = blockIdx.y, t0 = blockIdx.x * 256, half = (taps - 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float sh[];  // [FIR_TILE + taps4 + 4] input, then [taps4] filter (zero padded)
+    const int f = blockIdx.y, t0 = blockIdx.x * FIR_TILE, half = (taps - 1) / 2;
+    const int taps4 = (taps + 3) & ~3, nx = FIR_TILE + taps4 + 4;
     float* xs = sh;
-    float* fs = sh + 256 + taps - 1;
-    for (int i = threadIdx.x; i < 256 + taps - 1; i += 256) xs[i] = x[min(max(t0 + i - half, 0), T - 1)];
-    for (int i = threadIdx.x; i < taps; i += 256) fs[i] = bank[(size_t)f * taps + i];
+    float* fs = sh + nx;
+    for (int i = threadIdx.x; i < nx; i += 256) xs[i] = x[min(max(t0 + i - half, 0), T - 1)];
+    for (int i = threadIdx.x; i < taps4; i += 256) fs[i] = i < taps ? bank[(size_t)f * taps + i] : 0.f;
     __syncthreads();
-    const int t = t0 + threadIdx.x;
-    if (t >= T) return;
-    float acc = 0.f;
-    for (int j = 0; j < taps; ++j) acc = fmaf(fs[j], xs[threadIdx.x + j], acc);
-    low[(size_t)f * T + t] = acc;
+    const int o = threadIdx.x * 4;   // outputs t0 + o .. + 3; 16-byte LDS reads at a 16-byte lane stride are conflict free
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    float4 cur = *reinterpret_cast<const float4*>(xs + o);
+    for (int j = 0; j < taps4; j += 4) {
+        const float4 nxt = *reinterpret_cast<const float4*>(xs + o + j + 4);
+        const float4 c = *reinterpret_cast<const float4*>(fs + j);
+        a0 = fmaf(c.x, cur.x, a0); a1 = fmaf(c.x, cur.y, a1); a2 = fmaf(c.x, cur.z, a2); a3 = fmaf(c.x, cur.w, a3);
+        a0 = fmaf(c.y, cur.y, a0); a1 = fmaf(c.y, cur.z, a1); a2 = fmaf(c.y, cur.w, a2); a3 = fmaf(c.y, nxt.x, a3);
+        a0 = fmaf(c.z, cur.z, a0); a1 = fmaf(c.z, cur.w, a1); a2 = fmaf(c.z, nxt.x, a2); a3 = fmaf(c.z, nxt.y, a3);
+        a0 = fmaf(c.w, cur.w, a0); a1 = fmaf(c.w, nxt.x, a1); a2 = fmaf(c.w, nxt.y, a2); a3 = fmaf(c.w, nxt.z, a3);
+        cur = nxt;
+    }
+    const int t = t0 + o;
+    float* dst = low + (size_t)f * T + t;
+    if (t + 3 < T) { dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3; }
+    else { if (t < T) dst[0] = a0; if (t + 1 < T) dst[1] = a1; if (t + 2 < T) dst[2] = a2; }
 }
 // bands from the low-passes in place: band[0] = low[0], band[i] = low[i] - low[i-1], band[n-1] = x - low[n-2]   (SplitBands.forward)
 __global__ void bands_kernel(const float* __restrict__ x, const float* __restrict__ low, int T, int n_bands, float* __restrict__ bands) {
@@ -917,7 +931,7 @@ int mv_mbd_set_processor(mv_mbd* m, int32_t band_idx, int32_t n_bands, const flo
 }
 
 int mv_mbd_set_filterbank(mv_mbd* m, int32_t which, int32_t n_filters, int32_t taps, const float* coeffs) {
-    if (!m || !coeffs || taps < 1 || taps % 2 == 0 || taps > 7679)  /* (256 + 2 taps) floats of LDS <= 64 KB */ return mv_fail(MV_ERR_INVALID, "mv_mbd_set_filterbank: bad argument");
+    if (!m || !coeffs || taps < 1 || taps % 2 == 0 || taps > 7000)  /* (1024 + 2 taps) floats of LDS <= 64 KB */ return mv_fail(MV_ERR_INVALID, "mv_mbd_set_filterbank: bad argument");
     const int want = (which == 0 ? m->cfg.proc_bands : m->cfg.eq_bands) - 1;
     if (n_filters != want) return mv_fail(MV_ERR_INVALID, "mv_mbd_set_filterbank: expected %d filters, got %d", want, n_filters);
     float** dst = which == 0 ? &m->proc_bank : &m->eq_bank;
@@ -1159,7 +1173,7 @@ int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float*
         MG_TRY(wk.get(&lstm_rev, (size_t)lstm_band * NB, false));
     }
     auto split = [&](const float* x, int n_bands, const float* bank, int taps, float* lowbuf, float* out_bands) -> hipError_t {
-        hipLaunchKernelGGL(fir_bank_kernel, dim3((T + 255) / 256, n_bands - 1), dim3(256), (size_t)(256 + 2 * taps) * 4, s, x, T, bank, taps, lowbuf);
+        hipLaunchKernelGGL(fir_bank_kernel, dim3((T + FIR_TILE - 1) / FIR_TILE, n_bands - 1), dim3(256), (size_t)(FIR_TILE + 2 * ((taps + 3) & ~3) + 4) * 4, s, x, T, bank, taps, lowbuf);
         hipLaunchKernelGGL(bands_kernel, dim3((T + 255) / 256), dim3(256), 0, s, x, lowbuf, T, n_bands, out_bands);
         return hipGetLastError();
     };
