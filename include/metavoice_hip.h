@@ -85,6 +85,11 @@ int mv_begin(mv_engine* e, int32_t n_utt, const int32_t* prompts, const int32_t*
  * "all done" word -- the reference synchronises every token (fast_inference_utils.py:161). */
 int mv_run(mv_engine* e, int32_t max_steps, int32_t poll_every, int32_t* steps_run);
 float mv_last_run_ms(const mv_engine* e);      /* HIP-event time of the last mv_run on the engine stream */
+/* Which decode path mv_run takes now: 2 = persistent kernel drawing the tokens itself (several steps per launch), 1 = persistent
+ * kernel + sampler launch per step, 0 = per-layer launches (configuration not supported, mv_tune("mega", 0), or sticky after a
+ * launch of the persistent kernel was abandoned).  *timeouts (optional) = persistent launches abandoned so far: a run that fell
+ * back produces the same bits, so a parity test that wants to cover the persistent kernel asserts this stays 0. */
+int32_t mv_decode_path(const mv_engine* e, int32_t* timeouts);
 /* Full sequence prompt ++ generated (generate() return value, :226-228), EOA included when drawn. */
 int mv_get_tokens(mv_engine* e, int32_t utt, int32_t* out, int32_t cap, int32_t* n_out);
 

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmetavoice_hip.so")
+LIB_PATH = os.environ.get("MV_HIP_LIB") or os.path.join(_HERE, "lib", "libmetavoice_hip.so")  # MV_HIP_LIB: another build (A/B experiments)
 
 MV_OK = 0
 MV_ERR_INVALID = -1
@@ -78,6 +78,7 @@ SYMBOLS = [
                            C.POINTER(mv_sampling), C.c_int32, C.c_int32, C.c_int32]),
     ("mv_run", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     ("mv_last_run_ms", C.c_float, [_P]),
+    ("mv_decode_path", C.c_int32, [_P, C.POINTER(C.c_int32)]),
     ("mv_get_tokens", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
     ("mv_set_logits_capture", C.c_int, [_P, C.c_int32, C.c_int32]),
     ("mv_get_captured_logits", C.c_int, [_P, C.POINTER(C.c_float), C.c_int32, C.c_int32]),

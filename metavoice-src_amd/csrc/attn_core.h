@@ -229,14 +229,27 @@ __device__ __forceinline__ bool attn_combine_tagged(AttnAcc& b, const u64* slots
     for (int tries = 0;; ++tries) {
         u32x4 v[2][5];
         bool ok = true;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const u64* p = slots + (size_t)min(g + 4 * q, nact - 1) * ATTN_TPART_STRIDE;  // clamped: weighted 0 below
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[q][0]) : "v"(p + 128) : "memory");
-#pragma unroll
-            for (int k = 0; k < 4; ++k) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[q][1 + k]) : "v"(p + dl * 8 + 2 * k) : "memory");
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the ten loads and their wait in ONE statement (see load6x16_agent): an output register must not be copied or spilled by
+        // the compiler between an inline-asm load and the s_waitcnt that covers it
+        const u64* p0 = slots + (size_t)min(g, nact - 1) * ATTN_TPART_STRIDE;       // clamped: weighted 0 below
+        const u64* p1 = slots + (size_t)min(g + 4, nact - 1) * ATTN_TPART_STRIDE;
+        const u64 *p0d = p0 + dl * 8, *p1d = p1 + dl * 8;
+        asm volatile(
+            "global_load_dwordx4 %0, %10, off offset:1024 sc1\n\t"
+            "global_load_dwordx4 %1, %11, off sc1\n\t"
+            "global_load_dwordx4 %2, %11, off offset:16 sc1\n\t"
+            "global_load_dwordx4 %3, %11, off offset:32 sc1\n\t"
+            "global_load_dwordx4 %4, %11, off offset:48 sc1\n\t"
+            "global_load_dwordx4 %5, %12, off offset:1024 sc1\n\t"
+            "global_load_dwordx4 %6, %13, off sc1\n\t"
+            "global_load_dwordx4 %7, %13, off offset:16 sc1\n\t"
+            "global_load_dwordx4 %8, %13, off offset:32 sc1\n\t"
+            "global_load_dwordx4 %9, %13, off offset:48 sc1\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]), "=&v"(v[0][3]), "=&v"(v[0][4]), "=&v"(v[1][0]), "=&v"(v[1][1]), "=&v"(v[1][2]),
+              "=&v"(v[1][3]), "=&v"(v[1][4])
+            : "v"(p0), "v"(p0d), "v"(p1), "v"(p1d)
+            : "memory");
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll

@@ -11,6 +11,7 @@
 // all-to-all dependency between phases costs one hand-off instead of a kernel boundary plus a cold start.
 // The hand-off protocol (tagged granules, bounded per-wave polls) lives in mega_core.h.
 #include "mega_core.h"
+#include "sample_core.h"
 #include "gemv_i4_core.h"
 #include "gemv_i8_core.h"
 
@@ -141,25 +142,37 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     __shared__ int geo[4][NU];                 // P, cs, nact, kw
     __shared__ uint32_t res_s[2][NU][MG_WAVES];  // x and h residuals of column 8 b + wave, rows packed
 
+    // n_steps >= 1: that many decode steps in this launch, the token drawn by the workgroup of its utterance (block u) at the end
+    // of every step; n_steps == 0: one step, logits only (sample_kernel follows; mv_probe_kernel, the captured decode graph)
+    __shared__ int pos_s[NU], done_s[NU], tok_s[NU];
+    __shared__ UttState st_s;      // block u < NU: the state of utterance u, carried across the steps of the launch
+    __shared__ SampleScratch smp_sc;
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    #ifdef MEGA_VARIANT_NOFOLD
+    constexpr bool CAN_FOLD = false;
+#else
+    constexpr bool CAN_FOLD = MEGA_FOLD_MAX_UTT >= NU;
+#endif  // instances above it keep sample_kernel behind every step (register budget)
+    const bool fold = CAN_FOLD && a.n_steps > 0;
+    const int n_steps = fold ? a.n_steps : 1;
     if (tid == 0) s_abort = 0;
+    if (tid < NU) { pos_s[tid] = a.pos[tid]; done_s[tid] = fold ? a.utt[tid].done : 0; }
+    if (fold && b < NU && tid == 0) st_s = a.utt[b];
     __syncthreads();
 #define MG_ABORTED() (*(volatile int*)&s_abort != 0)
-    const uint32_t epoch = a.step_counter[0] * 256u;
+    if (fold) {  // a launch queued behind the one in which the last utterance ended: nothing to do
+        bool all_done = true;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) all_done = all_done && done_s[u] != 0;
+        if (all_done) return;
+    }
+    const uint32_t counter0 = a.step_counter[0];
+    const int VP = (a.vocab + 1) & ~1;  // logits travel as row-paired granules, polled two at a time
 
     // attention geometry: block (r, h, s) = one of the (up to) 8 even key ranges of (row r, head h) of EVERY utterance; 8 waves x 32 keys
     const int at_r = b >> 7, at_h = (b >> 3) & 15, at_s = b & 7, at_w = wave;
     const int g = lane >> 4, dl = lane & 15;
-    bool any_att = false;
-    int first_att = -1;
-#pragma unroll
-    for (int u = NU - 1; u >= 0; --u) {
-        const int Pu = a.pos[u] + 1;  // keys [0, P): the cache holds [0, P-1), key P-1 is produced by this step's QKV phase
-        const int csu = attn_keys_per_split(Pu), nactu = (Pu + csu - 1) / csu;
-        if (tid == 0) { geo[0][u] = Pu; geo[1][u] = csu; geo[2][u] = nactu; geo[3][u] = attn_keys_per_wave(csu); }
-        if (at_s < nactu) { any_att = true; first_att = u; }
-    }
-    __syncthreads();
 #define GEO(k, u) __builtin_amdgcn_readfirstlane(geo[k][u])
 
     // optional phase stamps (blocks 0 and 255, wave 0): poll-wait vs compute per phase, for profiles/
@@ -172,8 +185,11 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     u32x4 cq[I8 ? 14 : 9];  // int8 slots (2 chunks per 2048-column row, 6 per w2 row): wqkv 0..5 | w1 0..5, w3 6..11, wo 12..13 | w2 0..5 | head 0..3
     uint32_t cz[9];
     float sc_a[3] = {1.f, 1.f, 1.f}, sc_b[3] = {1.f, 1.f, 1.f}, sc_c = 1.f;  // int8 row scales: wqkv|w1|head rows, w3 rows, wo|w2 row
-    // phase 0 of layer 0: rows 24 b + 3 wave + i of wqkv
-    {
+    // phase 0 of layer 0: rows 24 b + 3 wave + i of wqkv; the RMSNorm weights of the next norm ride along with the weight rows of
+    // its phase (thread t: columns 8 (t & 255) ..).  Called at the top of the launch and, with several steps per launch, at the end
+    // of every step -- before the wait for the next token.
+    u32x4 nw_attn, nw_ffn = u32x4{0u, 0u, 0u, 0u};
+    auto issue_layer0 = [&](int lane, int wave) {  // (lane, wave): the caller's ids, opaque to the optimiser inside the step loop
         const bf16_t* w = a.layers[0].wqkv;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -181,18 +197,42 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, a.layers[0].q8[0], 24 * b + 3 * wave + i, MG_DIM, lane); sc_a[i] = bf2f(a.layers[0].s8[0][24 * b + 3 * wave + i]); }
             else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave + i, MG_DIM, lane, a.ablate);
         }
-    }
-    // RMSNorm weights of the next norm, requested together with the weight rows of its phase (thread t: columns 8 (t & 255) ..)
-    u32x4 nw_attn = load16(a.layers[0].attn_norm + (tid & 255) * 8), nw_ffn = u32x4{0u, 0u, 0u, 0u};
-    // residual values of this wave's own column n = 8 b + wave, both rows packed (row 0 | row 1 << 16): x entering the layer
-    // (layer 0: the sampler's / prefill's output; later: what this wave published in P4) and h (published in P2)
-#pragma unroll 1
-    for (int u = 0; u < NU; ++u) {
-        const bf16_t* xi = a.x_in + (size_t)u * 2 * MG_DIM + 8 * b + wave;
-        if (lane == 0) res_s[0][u][wave] = (uint32_t)xi[0] | ((uint32_t)xi[MG_DIM] << 16);
-    }
+        nw_attn = load16(a.layers[0].attn_norm + ((wave * 64 + lane) & 255) * 8);
+    };
+    issue_layer0(lane, wave);
 
     u32x4 kv[ATTN_U], vv[ATTN_U];
+#pragma unroll 1
+    for (int step = 0; step < n_steps; ++step) {
+    const uint32_t epoch = (counter0 + (uint32_t)step) * 256u;
+    // this step's attention geometry (positions: a.pos at the first step, the control words of the sampling workgroups after)
+    bool any_att = false;
+    int first_att = -1;
+#pragma unroll
+    for (int u = NU - 1; u >= 0; --u) {
+#ifdef MEGA_VARIANT_APOS
+        const int Pu = (step == 0 ? a.pos[u] : pos_s[u]) + 1;
+#else
+        const int Pu = pos_s[u] + 1;  // keys [0, P)
+#endif
+        // keys [0, P): the cache holds [0, P-1), key P-1 is produced by this step's QKV phase
+        const int csu = attn_keys_per_split(Pu), nactu = (Pu + csu - 1) / csu;
+        if (tid == 0) { geo[0][u] = Pu; geo[1][u] = csu; geo[2][u] = nactu; geo[3][u] = attn_keys_per_wave(csu); }
+        if (at_s < nactu) { any_att = true; first_att = u; }
+    }
+    // residual values of this wave's own column n = 8 b + wave, both rows packed (row 0 | row 1 << 16): x entering the layer
+    // (layer 0: the sampler's / prefill's output -- in xs already after the first step; later: what this wave published in P4) and
+    // h (published in P2)
+#pragma unroll 1
+    for (int u = 0; u < NU; ++u) {
+        if (step == 0) {
+            const bf16_t* xi = a.x_in + (size_t)u * 2 * MG_DIM + 8 * b + wave;
+            if (lane == 0) res_s[0][u][wave] = (uint32_t)xi[0] | ((uint32_t)xi[MG_DIM] << 16);
+        } else if (lane == 0) {
+            res_s[0][u][wave] = (uint32_t)xs[u][8 * b + wave] | ((uint32_t)xs[u][MG_DIM + 8 * b + wave] << 16);
+        }
+    }
+    __syncthreads();
     for (int l = 0; l < a.n_layer; ++l) {
         // Address arithmetic below is a function of (lane, wave): left alone, the compiler hoists ~60 loop-invariant 64-bit
         // addresses out of the layer loop and spills them.  Making the two ids opaque once per layer keeps every address
@@ -231,9 +271,11 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         __syncthreads();
         MG_STAMP(l, 0);
         if (l == 0) {
+            if (step == 0) {
 #pragma unroll
-            for (int u = 0; u < NU; ++u)
-                *(u32x4*)(xs[u] + tid * 8) = load16(a.x_in + (size_t)u * 2 * MG_DIM + tid * 8);  // written by the sampler in the previous launch
+                for (int u = 0; u < NU; ++u)
+                    *(u32x4*)(xs[u] + tid * 8) = load16(a.x_in + (size_t)u * 2 * MG_DIM + tid * 8);  // written by the sampler in the previous launch
+            }  // later steps: built at the end of the previous step from the control word
         } else mega_poll_rowpairs<NU>(a.g_x, tag0 - 8u + 4u, xs, a.abort_flag, &s_abort, tid_o);
         __syncthreads();
         if (MG_ABORTED()) return;
@@ -273,8 +315,12 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                     const int which = (n - MG_DIM) / MG_DIM, hd = (n - MG_DIM) % MG_DIM;
                     bf16_t* cache = (which ? vc : kc) + (size_t)2 * u * MG_HEADS * a.cache_len * 128;
                     const size_t off = ((size_t)(hd / 128) * a.cache_len + (GEO(0, u) - 1)) * 128 + hd % 128;
-                    cache[off] = y0;
-                    cache[(size_t)MG_HEADS * a.cache_len * 128 + off] = y1;
+                    // agent-scope (write-through) stores: with several steps per launch the row is read by other CUs -- other XCDs,
+                    // other L2s -- in the next step, with no kernel boundary in between
+                    if (a.ablate & 32) { cache[off] = y0; cache[(size_t)MG_HEADS * a.cache_len * 128 + off] = y1; } else {
+                    __hip_atomic_store(cache + off, y0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cache + (size_t)MG_HEADS * a.cache_len * 128 + off, y1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
         }
@@ -375,6 +421,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                     if (nactu > 1) {
                         last = at_s == (NU == 1 ? 0 : u % nactu);
                         if (last && !attn_combine_tagged(bb, slots, tag0 + 5u, nactu, lane, MG_SPIN_LIMIT)) {
+                            mega_report_timeout(a.abort_flag, tag0 + 5u);
                             __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             *(volatile int*)&s_abort = 1;
                             last = false;
@@ -562,6 +609,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     }
 
     // ================= LM head on the last position: logits = head(norm(x))     fast_model.py:161-162 =================
+    const uint32_t tag_head = epoch + (uint32_t)a.n_layer * 8u + 1u;
     __syncthreads();
     mega_poll_rowpairs<NU>(a.g_x, epoch + (uint32_t)(a.n_layer - 1) * 8u + 1u + 4u, xs, a.abort_flag, &s_abort, tid);
     __syncthreads();
@@ -581,12 +629,137 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         }
         if (lane < 2) {
             const int slot = wave + 8 * lane, n = 11 * b + slot;
+            const bf16_t y0 = f2bf(v0), y1 = f2bf(v1);
             if (slot < 11 && n < a.vocab) {
-                a.logits[(size_t)(2 * u) * a.vocab + n] = f2bf(v0);
-                a.logits[(size_t)(2 * u + 1) * a.vocab + n] = f2bf(v1);
+                a.logits[(size_t)(2 * u) * a.vocab + n] = y0;
+                a.logits[(size_t)(2 * u + 1) * a.vocab + n] = y1;
             }
+            if (fold && slot < 11 && n < VP) gran_store(a.g_logits + (size_t)u * VP + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag_head);
         }
     }
+    if (!CAN_FOLD || !fold) return;
+
+    // ================= the token: sample() + the bookkeeping of decode_n_tokens + the next input rows ===================
+    // fast_inference_utils.py:61-120,148-174, fast_model.py:152-157 -- sample_core.h, the arithmetic of sample_kernel.  Block u
+    // draws for utterance u; everybody else has already queued layer 0's rows for the next step and waits for the control word.
+    // (address arithmetic on opaque ids, as in the layers: nothing of the tail is hoisted out of the step loop into live registers)
+    int lane_t = lane, wave_t = wave;
+    asm volatile("" : "+v"(lane_t), "+v"(wave_t));
+    const int tid_t = wave_t * 64 + lane_t;
+    const bool last_step = step + 1 == n_steps;
+    const uint32_t tag_next = (counter0 + (uint32_t)step + 1u) * 256u;  // phase code 0 of the next epoch: no layer phase uses it
+    __builtin_amdgcn_sched_barrier(0);
+    if (b < NU) {
+        const int u = b;
+        bf16_t* lg = xs[0];  // [2][VP]: conditioned | unconditioned logits of this utterance
+        __syncthreads();     // every wave is through with the head's operand in xs
+        const bool was_done = st_s.done != 0;
+        if (!was_done) {
+            wave_poll16<3>(a.g_logits + (size_t)u * VP, tag_head, a.abort_flag, &s_abort,
+                           [&](int k) { const int n = tid_t + k * MG_THREADS; return n < VP / 2 ? n : -1; },
+                           [&](int n, uint32_t p0, uint32_t p1) {
+                               *(uint32_t*)(lg + 2 * n) = (p0 & 0xFFFFu) | (p1 << 16);
+                               *(uint32_t*)(lg + VP + 2 * n) = (p0 >> 16) | (p1 & 0xFFFF0000u);
+                           });
+        }
+        // this workgroup's layer-0 rows: in flight while the token is drawn, landed before the publishes below
+        if (!last_step) issue_layer0(lane_t, wave_t);
+        __syncthreads();
+        if (MG_ABORTED()) return;
+        bool done_now = was_done;
+        int new_pos = st_s.pos, new_tok = 0;
+        (void)new_pos; (void)new_tok;
+        if (!was_done) {
+            const int pos = st_s.pos, next_index = pos + 1;     // sequence index of the token decided now
+            const bool forced = next_index < st_s.prompt_len;   // teacher-forced prompt token (prefill by decode steps)
+            const int V = a.vocab;
+            if (a.capture != nullptr && pos < a.capture_max) {
+                float* cap = a.capture + ((size_t)pos * (2 * NU) + 2 * u) * V;
+                for (int i = tid_t; i < V; i += MG_THREADS) { cap[i] = bf2f(lg[i]); cap[V + i] = bf2f(lg[VP + i]); }
+            }
+            int tok;
+            if (forced) tok = a.seq[(size_t)u * a.block_size + next_index];
+            else {
+                int par = 0;
+                const mv_sampling sp = st_s.s;
+                tok = sample_draw(sp, V, next_index, nullptr, smp_sc, par, tid_t, [&](int i, float& c, float& un) { c = bf2f(lg[i]); un = bf2f(lg[VP + i]); });
+            }
+            done_now = (!forced && tok == st_s.eoa_token) || (next_index + 1 >= st_s.max_len);
+            new_pos = next_index;
+            new_tok = tok;
+            // the control word first: it is what the other 255 workgroups are waiting for
+            if (tid_t == 0 && !last_step) gran_store(a.g_ctl + u, (uint32_t)tok | ((uint32_t)next_index << 12) | ((uint32_t)done_now << 31), tag_next);
+            __syncthreads();  // every thread has read st_s
+            if (tid_t == 0) {
+                if (!forced) a.seq[(size_t)u * a.block_size + next_index] = tok;
+                UttState* gs = a.utt + u;
+                gs->n_tokens = next_index + 1;
+                gs->pos = next_index;
+                a.pos_out[u] = next_index;
+                st_s.pos = next_index;
+                st_s.n_tokens = next_index + 1;
+                if (done_now) {
+                    gs->done = 1;
+                    st_s.done = 1;
+                    atomicSub(a.n_active, 1);
+                }
+            }
+            if (!done_now && last_step) {
+                // the next LAUNCH's (or the per-layer launches') input rows, as sample_kernel leaves them:
+                // bf16(bf16(tok_emb[tok] + pos_emb[pos]) + spk_proj * mask).  Between the steps of one launch every workgroup
+                // builds them itself from the control word (below).
+                const bf16_t* te = a.tok_emb + (size_t)tok * MG_DIM;
+                const bf16_t* pe = a.pos_emb + (size_t)next_index * MG_DIM;
+                const bf16_t* sp = a.spk_proj + (size_t)u * MG_DIM;
+                bf16_t* x0 = a.x_out + (size_t)(2 * u) * MG_DIM;
+                for (int i = tid_t; i < MG_DIM; i += MG_THREADS) {
+                    const float base = round_bf(bf2f(te[i]) + bf2f(pe[i]));
+                    x0[i] = f2bf(base + bf2f(sp[i]));
+                    x0[MG_DIM + i] = f2bf(base);  // + 0 * mask: the unconditioned row gets no speaker term
+                }
+            }
+        } else if (tid_t == 0 && !last_step) {
+            // a finished (or unused) utterance keeps its last input rows, as with sample_kernel: same token, same position
+            gran_store(a.g_ctl + u, (uint32_t)a.seq[(size_t)u * a.block_size + st_s.pos] | ((uint32_t)st_s.pos << 12) | (1u << 31), tag_next);
+        }
+        if (tid_t == 0 && u == 0) a.step_counter_out[0] = counter0 + (uint32_t)step + 1u;  // the next launch's first epoch
+    } else if (!last_step) {
+        issue_layer0(lane_t, wave_t);
+    }
+    if (last_step) return;
+    __builtin_amdgcn_sched_barrier(0);
+    // Every workgroup: wait for the control words {token | position << 12 | done << 31} (ONE wave polls, one granule per utterance:
+    // 2048 waves spinning on a 16 KB vector for the ~10 us of a draw saturate the few memory channels behind it -- 948 vs 733
+    // us/step when the input rows travelled as granules), then build the next input rows from the embedding tables.
+    if (wave_t == 0)
+        wave_poll<1>(tag_next, a.abort_flag, &s_abort,
+                     [&](int, u64& v) { if (lane_t >= NU) return false; v = gran_load(a.g_ctl + lane_t); return true; },
+                     [&](int, uint32_t p) { tok_s[lane_t] = (int)(p & 0xFFFu); pos_s[lane_t] = (int)((p >> 12) & 0x7FFFFu); done_s[lane_t] = (int)(p >> 31); });
+    __syncthreads();  // also: block u has read `lg`, xs may be overwritten
+    if (MG_ABORTED()) return;
+    {
+        bool all_done = true;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) all_done = all_done && done_s[u] != 0;
+        if (all_done) return;
+    }
+    if (tid_t < 256 * NU) {  // fast_model.py:152-157; thread t: columns 8 (t & 255) .. of both rows of utterance t >> 8
+        const int u = tid_t >> 8, c = (tid_t & 255) * 8;
+        const u32x4 te = load16(a.tok_emb + (size_t)tok_s[u] * MG_DIM + c), pe = load16(a.pos_emb + (size_t)pos_s[u] * MG_DIM + c);
+        const u32x4 sp = load16(a.spk_proj + (size_t)u * MG_DIM + c);
+        u32x4 r0, r1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t tw = te[j], pw = pe[j], sw = sp[j];
+            const float b0 = round_bf(bf2f((bf16_t)tw) + bf2f((bf16_t)pw)), b1 = round_bf(bf2f((bf16_t)(tw >> 16)) + bf2f((bf16_t)(pw >> 16)));
+            r0[j] = (uint32_t)f2bf(b0 + bf2f((bf16_t)sw)) | ((uint32_t)f2bf(b1 + bf2f((bf16_t)(sw >> 16))) << 16);
+            r1[j] = (uint32_t)f2bf(b0) | ((uint32_t)f2bf(b1) << 16);
+        }
+        *(u32x4*)(xs[u] + c) = r0;
+        *(u32x4*)(xs[u] + MG_DIM + c) = r1;
+    }
+    __syncthreads();
+    }  // steps
 }
 
 

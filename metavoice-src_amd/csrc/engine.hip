@@ -119,6 +119,7 @@ struct mv_engine {
     unsigned long long* granules = nullptr;   // g_x | g_qkv | g_attn | g_h | g_act
     uint32_t* step_counter = nullptr;
     uint32_t* abort_flag = nullptr;
+    int mega_timeouts = 0;      // launches of the persistent kernel that were abandoned (mv_decode_path reports it)
     unsigned long long* stamps = nullptr;  // MV_MEGA_STAMPS=1: s_memtime stamps of the persistent kernel's phases
     bf16_t* dbg = nullptr;   // MV_DEBUG_VECTORS=1: every layer's q|attn|h|act|x of the last step, both paths (mv_debug_vectors)
 
@@ -168,6 +169,12 @@ static MegaArgs mega_args(mv_engine* e) {
     m.partial = e->partial; m.counters = e->counters; m.abort_flag = e->abort_flag; m.eps = c.norm_eps; m.dbg = e->dbg; m.stamps = e->stamps;
     m.ablate = g_tune.gemv_ablate;
     m.fault = g_tune.mega_fault;
+    // the sampler inside the launch (mv_run sets n_steps; 0 here: one step, logits only)
+    const size_t VP = ((size_t)c.vocab + 1) & ~(size_t)1;
+    m.g_logits = m.g_act + U * c.intermediate; m.g_ctl = m.g_logits + U * VP;
+    m.block_size = c.block_size; m.utt = e->utt; m.pos_out = e->pos_arr; m.seq = e->seq; m.tok_emb = e->tok_emb; m.pos_emb = e->pos_emb;
+    m.spk_proj = e->spk_proj; m.x_out = e->x; m.n_active = e->n_active; m.step_counter_out = e->step_counter;
+    m.capture = e->capture_on ? e->capture : nullptr; m.capture_max = e->capture_max;
     return m;
 }
 
@@ -387,6 +394,8 @@ int mv_tune(mv_engine* e, const char* key, int32_t value) {
     else if (k == "use_graph") g_tune.use_graph = value;
     else if (k == "mega") { g_tune.mega = value; if (e) e->mega_failed = false; }
     else if (k == "gemv_ablate") g_tune.gemv_ablate = value;
+    else if (k == "mega_fold") g_tune.mega_fold = value;
+    else if (k == "mega_steps") g_tune.mega_steps = value < 1 ? 1 : value;
     else if (k == "mega_fault") g_tune.mega_fault = value;
     else return fail(MV_ERR_INVALID, "unknown tuning key '%s'", key);
     if (e && e->finalized) e->graph_dirty = true;  // launch geometry is frozen in the captured graph: re-capture at mv_begin
@@ -613,7 +622,7 @@ int mv_finalize(mv_engine* e) {
     HIP_TRY(hipMalloc((void**)&e->spk_emb, (size_t)U * c.spk_dim * 2));
     HIP_TRY(hipMalloc((void**)&e->spk_proj, (size_t)U * c.dim * 2));
     HIP_TRY(hipMalloc((void**)&e->n_active, 4));
-    HIP_TRY(hipHostMalloc((void**)&e->host_flag, 8, hipHostMallocDefault));  // [0] utterances still running, [1] abort flag
+    HIP_TRY(hipHostMalloc((void**)&e->host_flag, 32, hipHostMallocDefault));  // [0] utterances still running, [1..4] abort flag + what timed out
     HIP_TRY(hipMemset(e->x, 0, (size_t)R * c.dim * 2));
     if (getenv("MV_DEBUG_VECTORS") && c.dim == 2048 && c.intermediate == 5632) {
         HIP_TRY(hipMalloc((void**)&e->dbg, (size_t)c.n_layer * 5 * 2 * 5632 * 2));
@@ -624,11 +633,12 @@ int mv_finalize(mv_engine* e) {
         HIP_TRY(hipMemset(e->stamps, 0, (size_t)2 * c.n_layer * 24 * 8));
     }
     HIP_TRY(hipMalloc((void**)&e->step_counter, 4));
-    HIP_TRY(hipMalloc((void**)&e->abort_flag, 4));
+    HIP_TRY(hipMalloc((void**)&e->abort_flag, 16));  // [0] flag, [1..3] what the first timed-out wait was waiting for (mega_core.h)
     {
         const uint32_t one = 1, zero = 0;
         HIP_TRY(hipMemcpy(e->step_counter, &one, 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(e->abort_flag, &zero, 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(e->abort_flag, 0, 16));
+        (void)zero;
     }
     {
         int dev = 0, n_cus = 0;
@@ -645,7 +655,8 @@ int mv_finalize(mv_engine* e) {
             }
             HIP_TRY(hipMalloc((void**)&e->mega_layers, ml.size() * sizeof(MegaLayer)));
             HIP_TRY(hipMemcpy(e->mega_layers, ml.data(), ml.size() * sizeof(MegaLayer), hipMemcpyHostToDevice));
-            const size_t ngran = ((size_t)c.dim * 6 + c.intermediate) * c.max_utterances;  // per utterance: x, qkv (3), attn, h, act
+            // per utterance: x, qkv (3), attn, h, act; logits (padded to even), control word (padded)
+            const size_t ngran = ((size_t)c.dim * 6 + c.intermediate + (((size_t)c.vocab + 1) & ~(size_t)1) + 2) * c.max_utterances;
             HIP_TRY(hipMalloc((void**)&e->granules, ngran * 8));
             HIP_TRY(hipMemset(e->granules, 0, ngran * 8));
         }
@@ -790,26 +801,36 @@ int mv_run(mv_engine* e, int32_t max_steps, int32_t poll_every, int32_t* steps_r
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
     while (done_steps < limit) {
         const int chunk = (limit - done_steps) < poll_every ? (limit - done_steps) : poll_every;
-        for (int i = 0; i < chunk; ++i) {
-            if (e->graph_exec) {
-                HIP_TRY(hipGraphLaunch(e->graph_exec, e->stream));
-            } else {
-                const int rc = enqueue_step(e);
-                if (rc != MV_OK) return rc;
+        const bool mega_live = e->mega_ok && g_tune.mega && !e->mega_failed;
+        if (mega_live && g_tune.mega_fold && U <= MEGA_FOLD_MAX_UTT) {
+            // the persistent kernel draws the tokens itself: one launch per (up to) mv_tune("mega_steps") steps of the chunk; a launch
+            // queued behind the one in which the utterance ended returns at once
+            for (int left = chunk; left > 0; left -= g_tune.mega_steps) {
+                MegaArgs m = mega_args(e);
+                m.n_steps = left < g_tune.mega_steps ? left : g_tune.mega_steps;
+                HIP_TRY(launch_decode_mega(e->stream, m, e->cfg.weight_format));
+            }
+        } else {
+            for (int i = 0; i < chunk; ++i) {
+                if (e->graph_exec) {
+                    HIP_TRY(hipGraphLaunch(e->graph_exec, e->stream));
+                } else {
+                    const int rc = enqueue_step(e);
+                    if (rc != MV_OK) return rc;
+                }
             }
         }
-        const bool mega_live = e->mega_ok && g_tune.mega && !e->mega_failed;
         const bool last_chunk = done_steps + chunk >= limit;
         if (last_chunk && !mega_live) { done_steps += chunk; break; }
         HIP_TRY(hipMemcpyAsync(e->host_flag, e->n_active, 4, hipMemcpyDeviceToHost, e->stream));
-        if (mega_live) HIP_TRY(hipMemcpyAsync(e->host_flag + 1, e->abort_flag, 4, hipMemcpyDeviceToHost, e->stream));
+        if (mega_live) HIP_TRY(hipMemcpyAsync(e->host_flag + 1, e->abort_flag, 16, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
         if (mega_live && e->host_flag[1] != 0) {
             // A hand-off of the persistent kernel timed out (the 256 workgroups were not co-resident: another kernel held CUs).
             // A plain launch gives no residency guarantee, so this is a condition to survive, not an error: roll every utterance
             // back to the last poll, rebuild its input rows and redo the chunk -- and everything after it -- with per-layer launches
             // (bit-identical arithmetic; the Philox noise is keyed by (seed, token, sequence index), so the redo draws the same tokens).
-            HIP_TRY(hipMemsetAsync(e->abort_flag, 0, 4, e->stream));
+            HIP_TRY(hipMemsetAsync(e->abort_flag, 0, 16, e->stream));
             HIP_TRY(hipMemcpyAsync(e->utt, e->utt_shadow, (size_t)U * sizeof(UttState), hipMemcpyDeviceToDevice, e->stream));
             HIP_TRY(hipMemcpyAsync(e->pos_arr, e->pos_shadow, (size_t)U * 4, hipMemcpyDeviceToDevice, e->stream));
             std::vector<UttState> st(U);
@@ -823,8 +844,14 @@ int mv_run(mv_engine* e, int32_t max_steps, int32_t poll_every, int32_t* steps_r
             a.dim = e->cfg.dim; a.block_size = e->cfg.block_size; a.n_utt = U;
             HIP_TRY(launch_embed_current(e->stream, a));
             e->mega_failed = true;
-            fprintf(stderr, "metavoice_hip: persistent decode kernel timed out waiting for a peer workgroup (grid not co-resident: is "
-                            "another kernel occupying the GPU?); this engine continues with per-layer launches\n");
+            {
+                const uint32_t tag = (uint32_t)e->host_flag[2];
+                fprintf(stderr, "metavoice_hip: persistent decode kernel timed out waiting for a peer workgroup (grid not co-resident: is "
+                                "another kernel occupying the GPU?); this engine continues with per-layer launches [first wait to run out: "
+                                "workgroup %d wave %d, epoch %u layer %u phase code %u]\n",
+                        (int)e->host_flag[3], (int)e->host_flag[4], tag >> 8, (tag & 255u) >> 3, tag & 7u);
+            }
+            ++e->mega_timeouts;
             const int rc = build_graph(e);
             if (rc != MV_OK) return rc;
             continue;  // the chunk did not count
@@ -842,6 +869,13 @@ int mv_run(mv_engine* e, int32_t max_steps, int32_t poll_every, int32_t* steps_r
 }
 
 float mv_last_run_ms(const mv_engine* e) { return e ? e->last_ms : 0.f; }
+
+int32_t mv_decode_path(const mv_engine* e, int32_t* timeouts) {
+    if (!e) return -1;
+    if (timeouts) *timeouts = e->mega_timeouts;
+    if (!(e->mega_ok && g_tune.mega && !e->mega_failed)) return 0;
+    return g_tune.mega_fold && e->cfg.max_utterances <= MEGA_FOLD_MAX_UTT ? 2 : 1;
+}
 
 int mv_get_tokens(mv_engine* e, int32_t utt, int32_t* out, int32_t cap, int32_t* n_out) {
     if (!e || !e->begun) return fail(MV_ERR_STATE, "mv_begin has not been called");

@@ -16,6 +16,9 @@ struct MvTune {
     int gemv_ablate = 0;                 // profiling only (results are wrong): 1 no weight loads, 2 no dots, 4 no prologue, 8 no reductions
     int mega = 1;                        // 1: persistent decode-step kernel (decode_mega.hip) when the configuration supports it
                                          // (MetaVoice-1B shape, >= 256 CUs); 0: per-layer launches
+    int mega_steps = 512;                // decode steps per launch of the folding persistent kernel
+    int mega_fold = 1;                   // 1: the persistent kernel also draws the token and runs several steps per launch (engines
+                                         // of up to MEGA_FOLD_MAX_UTT utterances); 0: one step per launch + sample_kernel
 };
 extern MvTune g_tune;
 
@@ -212,6 +215,7 @@ struct MegaLayer {
     const signed char* q8[5];
     const bf16_t* s8[5];
 };
+#define MEGA_FOLD_MAX_UTT 1   // instances above it keep sample_kernel behind every step (register budget of the rolled utterance loops)
 struct MegaArgs {
     const bf16_t* x_in = nullptr;          // [2 n_utt][2048]: input rows of layer 0 (written by the sampler / prefill)
     const MegaLayer* layers = nullptr;     // device array [n_layer]
@@ -237,6 +241,20 @@ struct MegaArgs {
     unsigned long long* stamps = nullptr;  // optional [2 blocks][n_layer][24] s_memtime stamps of wave 0 (MV_MEGA_STAMPS)
     int32_t ablate = 0;                    // MvTune::gemv_ablate bit 0: no weight requests (profiling only)
     int32_t fault = 0;                     // MvTune::mega_fault (test hook)
+    // ---- sampler inside the launch (n_steps >= 1 decode steps per launch; 0 = one step, logits only, sample_kernel follows) ----
+    // The workgroup of utterance u (block u) polls the step's logits, draws the token (sample_core.h), does the bookkeeping of
+    // decode_n_tokens and publishes a control word (token | position | done) from which every workgroup builds the next input rows.
+    int32_t n_steps = 0;
+    int32_t block_size = 0, capture_max = 0;
+    unsigned long long *g_logits = nullptr, *g_ctl = nullptr;  // [n_utt][vocab padded to even], [n_utt]: {token | position << 12 | done << 31}
+    UttState* utt = nullptr;
+    int32_t* pos_out = nullptr;            // = pos (mirror of utt[].pos for the per-layer launches)
+    int32_t* seq = nullptr;
+    const bf16_t *tok_emb = nullptr, *pos_emb = nullptr, *spk_proj = nullptr;
+    bf16_t* x_out = nullptr;               // = x_in: the next launch's (or the per-layer launches') input rows
+    int32_t* n_active = nullptr;
+    float* capture = nullptr;
+    uint32_t* step_counter_out = nullptr;  // = step_counter: advanced once per step by block 0
 };
 bool mega_supported(const mv_config& c, int rows, int n_cus);
 hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a, int weight_format);  // every wave prefetches its weight rows into registers; bf16 or int4

@@ -30,6 +30,15 @@ __device__ __forceinline__ u64 gran_load(const gran_t* g) { return __hip_atomic_
 // optional phase stamps: needs `stamping`, `stamp_base` and `lane` in scope (MV_MEGA_STAMPS=1, tools/mega_stamps.py)
 #define MG_STAMP(l, k) do { if (stamping && lane == 0) stamp_base[(l) * MG_STAMP_SLOTS + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
+// The first wave whose wait runs out records what it was waiting for next to the abort flag: [1] the tag (epoch * 256 + layer * 8 +
+// phase + 1), [2] its workgroup, [3] its wave.  mv_run prints them with the fall-back notice.
+__device__ __forceinline__ void mega_report_timeout(uint32_t* abort_flag, uint32_t tag) {
+    if ((threadIdx.x & 63) == 0 && atomicCAS(abort_flag + 1, 0u, tag) == 0u) {
+        abort_flag[2] = blockIdx.x;
+        abort_flag[3] = threadIdx.x >> 6;
+    }
+}
+
 // One wave waits until all of ITS granules carry `tag` (no block barrier inside: the loaders only mirror the barrier after).
 template <int PER, typename Fetch, typename Sink>
 __device__ __forceinline__ void wave_poll(uint32_t tag, uint32_t* abort_flag, int* s_abort, Fetch fetch, Sink sink) {
@@ -50,6 +59,7 @@ __device__ __forceinline__ void wave_poll(uint32_t tag, uint32_t* abort_flag, in
         if ((tries & 1023) == 1023) {  // a peer is missing (grid not co-resident?) or already gave up
             const bool peer = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
             if (peer || tries >= MG_SPIN_LIMIT) {
+                if (!peer) mega_report_timeout(abort_flag, tag);
                 __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *(volatile int*)s_abort = 1;
                 return;
@@ -67,6 +77,86 @@ __device__ __forceinline__ void wave_poll_rowpair(const gran_t* g, uint32_t tag,
         [&](int k, uint32_t p) { const int n = tid + k * MG_THREADS; raw[n] = (bf16_t)p; raw[NCOL + n] = (bf16_t)(p >> 16); });
 }
 
+// PER 16-byte agent-scope loads AND their wait in ONE asm statement: hipcc does not know that an inline-asm load completes later
+// (cdna_hip_programming.md 5.7), so with the loads and the s_waitcnt in separate statements it is free to copy or spill an output
+// register in between -- before the data has landed.  It did, once the kernel grew (256 VGPRs, spills): every tag compared stale
+// and the wait ran out.  Early-clobber outputs: the address registers are read by later loads of the same statement.
+template <int PER>
+__device__ __forceinline__ void poll16_loads(u32x4 (&v)[PER], const gran_t* const (&p)[PER]) {
+    static_assert(PER == 1 || PER == 2 || PER == 3 || PER == 4 || PER == 6 || PER == 8 || PER == 12, "add the instance");
+    if constexpr (PER == 1)
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(v[0])
+                     : "v"(p[0])
+                     : "memory");
+    else if constexpr (PER == 2)
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                     "global_load_dwordx4 %1, %3, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1])
+                     : "v"(p[0]), "v"(p[1])
+                     : "memory");
+    else if constexpr (PER == 3)
+        asm volatile("global_load_dwordx4 %0, %3, off sc1\n\t"
+                     "global_load_dwordx4 %1, %4, off sc1\n\t"
+                     "global_load_dwordx4 %2, %5, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
+                     : "v"(p[0]), "v"(p[1]), "v"(p[2])
+                     : "memory");
+    else if constexpr (PER == 4)
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                     "global_load_dwordx4 %1, %5, off sc1\n\t"
+                     "global_load_dwordx4 %2, %6, off sc1\n\t"
+                     "global_load_dwordx4 %3, %7, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                     : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
+                     : "memory");
+    else if constexpr (PER == 6)
+        asm volatile("global_load_dwordx4 %0, %6, off sc1\n\t"
+                     "global_load_dwordx4 %1, %7, off sc1\n\t"
+                     "global_load_dwordx4 %2, %8, off sc1\n\t"
+                     "global_load_dwordx4 %3, %9, off sc1\n\t"
+                     "global_load_dwordx4 %4, %10, off sc1\n\t"
+                     "global_load_dwordx4 %5, %11, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
+                     : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5])
+                     : "memory");
+    else if constexpr (PER == 8)
+        asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
+                     "global_load_dwordx4 %1, %9, off sc1\n\t"
+                     "global_load_dwordx4 %2, %10, off sc1\n\t"
+                     "global_load_dwordx4 %3, %11, off sc1\n\t"
+                     "global_load_dwordx4 %4, %12, off sc1\n\t"
+                     "global_load_dwordx4 %5, %13, off sc1\n\t"
+                     "global_load_dwordx4 %6, %14, off sc1\n\t"
+                     "global_load_dwordx4 %7, %15, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                     : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+                     : "memory");
+    else if constexpr (PER == 12)
+        asm volatile("global_load_dwordx4 %0, %12, off sc1\n\t"
+                     "global_load_dwordx4 %1, %13, off sc1\n\t"
+                     "global_load_dwordx4 %2, %14, off sc1\n\t"
+                     "global_load_dwordx4 %3, %15, off sc1\n\t"
+                     "global_load_dwordx4 %4, %16, off sc1\n\t"
+                     "global_load_dwordx4 %5, %17, off sc1\n\t"
+                     "global_load_dwordx4 %6, %18, off sc1\n\t"
+                     "global_load_dwordx4 %7, %19, off sc1\n\t"
+                     "global_load_dwordx4 %8, %20, off sc1\n\t"
+                     "global_load_dwordx4 %9, %21, off sc1\n\t"
+                     "global_load_dwordx4 %10, %22, off sc1\n\t"
+                     "global_load_dwordx4 %11, %23, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11])
+                     : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]), "v"(p[8]), "v"(p[9]), "v"(p[10]), "v"(p[11])
+                     : "memory");
+}
+
 // The same with 16-byte agent-scope loads: two granules per lane per request, each 8-byte half validated by its own tag
 // (profiles/r01g_handoff: 2.0 vs 2.3 us per idle 2048-granule hand-off).  index(k) = pair index of the lane's k-th request or -1.
 template <int PER, typename Index, typename Sink>
@@ -74,12 +164,13 @@ __device__ __forceinline__ void wave_poll16(const gran_t* g, uint32_t tag, uint3
     for (int tries = 0;; ++tries) {
         u32x4 v[PER];
         int n[PER];
+        const gran_t* p[PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             n[k] = index(k);
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[k]) : "v"(g + 2 * max(n[k], 0)) : "memory");
+            p[k] = g + 2 * max(n[k], 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        poll16_loads<PER>(v, p);
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < PER; ++k) ok = ok && (n[k] < 0 || (v[k].y == tag && v[k].w == tag));
@@ -92,6 +183,7 @@ __device__ __forceinline__ void wave_poll16(const gran_t* g, uint32_t tag, uint3
         if ((tries & 1023) == 1023) {
             const bool peer = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
             if (peer || tries >= MG_SPIN_LIMIT) {
+                if (!peer) mega_report_timeout(abort_flag, tag);
                 __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *(volatile int*)s_abort = 1;
                 return;

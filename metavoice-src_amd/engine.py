@@ -131,6 +131,12 @@ class Stage1Engine:
         N.check(N.lib().mv_get_tokens(self._h, utt, out, cap, C.byref(n)))
         return list(out[: n.value])
 
+    def decode_path(self):
+        """(path, timeouts): path 2 = persistent kernel drawing the tokens itself, 1 = persistent kernel + sampler launch per step,
+        0 = per-layer launches; timeouts = persistent launches abandoned so far (each fell back to the launches, same bits)."""
+        t = C.c_int32(0)
+        return int(N.lib().mv_decode_path(self._h, C.byref(t))), int(t.value)
+
     def tune(self, **knobs: int):
         """mv_tune: launch knobs of the decode kernels / prefetcher (DESIGN.md "Tuning"); takes effect at the next begin()."""
         for k, v in knobs.items():

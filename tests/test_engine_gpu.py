@@ -279,13 +279,16 @@ def test_batched_prefill_ragged_two_utterances():
     engine2.close()
 
 
-@pytest.mark.parametrize("n_layer,T,n_new,combo", [(2, 16, 24, dict(top_k=1)), (4, 40, 48, dict(top_p=0.95)), (3, 300, 40, dict(top_p=0.9, temperature=0.8)),
-                                                   (2, 250, 16, dict(top_k=1)),       # crosses 256 keys: one key range -> 8 ranges + combine
-                                                   (2, 2030, 17, dict(top_p=0.95))])  # up to the last cache row (block_size - 1)
-def test_persistent_decode_kernel_is_bit_identical_to_per_layer_launches(n_layer, T, n_new, combo):
-    """decode_mega.hip (one launch per token: 24 layers + head, granule hand-offs) runs the same arithmetic in the same order
-    as gemv.hip / attention.hip: logits and token streams must be IDENTICAL, not merely close -- any difference is a
-    hand-off bug (stale or torn activation), which a tolerance would hide."""
+@pytest.mark.parametrize("n_layer,T,n_new,combo,poll", [(2, 16, 24, dict(top_k=1), 16), (4, 40, 48, dict(top_p=0.95), 1 << 20), (3, 300, 40, dict(top_p=0.9, temperature=0.8), 16),
+                                                        (2, 250, 16, dict(top_k=1), 5),       # crosses 256 keys: one key range -> 8 ranges + combine
+                                                        (2, 2030, 17, dict(top_p=0.95), 16),  # up to the last cache row (block_size - 1)
+                                                        (2, 16, 600, dict(top_p=0.95), 1 << 20)])  # more steps than one launch takes (512)
+def test_persistent_decode_kernel_is_bit_identical_to_per_layer_launches(n_layer, T, n_new, combo, poll):
+    """decode_mega.hip (24 layers + head + -- mega_fold=1, the default -- the sampler and the next input rows of up to 512 tokens per
+    launch, granule hand-offs) runs the same arithmetic in the same order as gemv.hip / attention.hip / sample_kernel: logits and
+    token streams must be IDENTICAL, not merely close -- any difference is a hand-off bug (stale or torn activation), which a
+    tolerance would hide.  Three paths: several steps per launch with the token drawn inside, one step per launch followed by
+    sample_kernel (the captured graph), per-layer launches."""
     cfgk = dict(WIDE2, n_layer=n_layer)
     engine, sd, cfg = build(cfgk, 7)
     prompt = synthetic.prompt_tokens(T, seed=7)
@@ -293,19 +296,22 @@ def test_persistent_decode_kernel_is_bit_identical_to_per_layer_launches(n_layer
     sp = mv.SamplingParams(guidance_scale=3.0, seed=21, **combo)
     engine.capture_logits(True)
     out = {}
-    for mega in (1, 0, 1):  # 1: persistent kernel (default), 0: per-layer launches
-        engine.tune(mega=mega)
+    for path in ((1, 1), (0, 0), (1, 0), (1, 1)):  # (mega, mega_fold)
+        engine.tune(mega=path[0], mega_fold=path[1])
         engine.begin([prompt], spk, sp, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
-        engine.run()
+        assert engine.run(poll_every=poll) == n_new - 1
         res = (engine.tokens(0), engine.captured_logits(T - 1, n_new))
-        if mega in out:
-            assert res[0] == out[mega][0] and torch.equal(res[1], out[mega][1])  # run-to-run reproducible
-        out[mega] = res
-    engine.tune(mega=1)  # the default
-    for m in (1,):
-        assert out[m][0] == out[0][0], f"token streams differ between the persistent kernel (mega={m}) and the per-layer launches"
-        assert torch.equal(out[m][1], out[0][1]), f"logits differ (mega={m}): max {float((out[m][1] - out[0][1]).abs().max())}"
-    assert len(out[1][0]) == T + n_new
+        if path in out:
+            assert res[0] == out[path][0] and torch.equal(res[1], out[path][1])  # run-to-run reproducible
+        out[path] = res
+    engine.tune(mega=1, mega_fold=1)  # the defaults
+    # a persistent launch that is abandoned falls back to the launches and produces the same bits: without this the test could pass
+    # on the fall-back alone
+    assert engine.decode_path() == (2, 0), "the persistent kernel was abandoned (hand-off timed out) during the test"
+    for path in ((1, 1), (1, 0)):
+        assert out[path][0] == out[(0, 0)][0], f"token streams differ between the persistent kernel {path} and the per-layer launches"
+        assert torch.equal(out[path][1], out[(0, 0)][1]), f"logits differ {path}: max {float((out[path][1] - out[(0, 0)][1]).abs().max())}"
+    assert len(out[(1, 1)][0]) == T + n_new
     engine.close()
 
 
@@ -334,6 +340,7 @@ def test_persistent_kernel_with_several_utterances_is_bit_identical_to_launches(
         first = min(lens) - 1
         out[mega] = (toks, engine.captured_logits(max(lens) - 1, n_new - 1))  # steps every utterance is decoding in
     engine.tune(mega=1)
+    assert engine.decode_path() == (1, 0), "the persistent kernel was abandoned (hand-off timed out) during the test"
     for u in range(n_utt):
         assert len(out[1][0][u]) == lens[u] + n_new
         assert out[1][0][u] == out[0][0][u], f"utterance {u}: token streams differ between the persistent kernel and the launches"
@@ -365,6 +372,7 @@ def test_persistent_kernel_times_out_cleanly_and_the_run_falls_back_to_launches(
         engine.begin([prompt], spk, sp, max_new_tokens=40, end_of_audio_token=9999, prefill_mode=1)
         steps = engine.run(poll_every=16)   # the first chunk aborts, is rolled back and redone by the launches
         assert steps == 39
+        assert engine.decode_path() == (0, 1)  # one launch abandoned, the engine stays on the per-layer launches
         assert engine.tokens(0) == good and torch.equal(engine.captured_logits(15, 40), good_logits)
         # the engine stays on the launches: the next utterance works without another timeout
         engine.begin([prompt], spk, sp, max_new_tokens=40, end_of_audio_token=9999, prefill_mode=1)
@@ -394,16 +402,18 @@ def test_hand_off_epoch_advances_across_an_utterance_that_ended_mid_chunk():
     prompt2, spk2 = synthetic.prompt_tokens(9, seed=6), synthetic.speaker_embedding(6)
     engine.capture_logits(True)
     out = {}
-    for mega in (0, 1):
-        engine.tune(mega=mega)
+    for path in ((0, 0), (1, 0), (1, 1)):  # (mega, mega_fold): launches | one step per launch + sample_kernel | tokens drawn inside the launch
+        engine.tune(mega=path[0], mega_fold=path[1])
         engine.begin([prompt], spk, sp, max_new_tokens=40, end_of_audio_token=eoa, prefill_mode=1)
-        engine.run(poll_every=16)
+        engine.run(poll_every=16)   # mega_fold: the launch leaves its step loop when the control word says "done"
         first = engine.tokens(0)
         assert first[-1] == eoa and len(first) <= 20 + 6
         engine.begin([prompt2], spk2, sp, max_new_tokens=6, end_of_audio_token=9999, prefill_mode=0)  # teacher-forced prompt
         engine.run()
-        out[mega] = (first, engine.tokens(0), engine.captured_logits(0, 9 + 6 - 1))
-    engine.tune(mega=1)
-    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
-    assert torch.equal(out[0][2], out[1][2]), f"max {float((out[0][2] - out[1][2]).abs().max())}"
+        out[path] = (first, engine.tokens(0), engine.captured_logits(0, 9 + 6 - 1))
+    engine.tune(mega=1, mega_fold=1)
+    assert engine.decode_path() == (2, 0)
+    for path in ((1, 0), (1, 1)):
+        assert out[(0, 0)][0] == out[path][0] and out[(0, 0)][1] == out[path][1], path
+        assert torch.equal(out[(0, 0)][2], out[path][2]), f"{path}: max {float((out[(0, 0)][2] - out[path][2]).abs().max())}"
     engine.close()
