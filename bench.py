@@ -327,6 +327,37 @@ def main():
             for p, n in group:
                 total_bytes += sum(kv_bytes(args, q) for q in range(len(p), len(p) + n - 1))
         step_frac = total_bytes / ((gpu_ms / a.steps) * 1e-3) / 1e9 / HBM_PEAK_GBS
+        path, timeouts = engine.decode_path()
+        if timeouts:
+            raise SystemExit(f"bench: {timeouts} launch(es) of the persistent decode kernel were abandoned and redone by per-layer launches: "
+                             "the timed region is not the path this line describes")
+        if path == 2:
+            # The persistent kernel draws the tokens itself and runs up to MEGA_STEPS decode steps per launch: the dominant kernel's
+            # launches ARE the timed decode region.  achieved = algorithmic bytes of those steps / HIP-event time of mv_run;
+            # per launch = both divided by the launches of one bench step (what `rocprofv3 --stats` averages over).  The single-step
+            # probe above (no token draw, one launch per step) stays on file as `step_probe`.
+            MEGA_STEPS = 512
+            launches = sum(-(-(max(n for _, n in group) - 1) // MEGA_STEPS) for group in work)
+            run_ms = gpu_ms / a.steps
+            ach = total_bytes / (run_ms * 1e-3) / 1e9
+            step_probe = {k: roofline[k] for k in ("kernel", "achieved", "frac", "bytes_per_launch", "avg_launch_us")}
+            roofline = {"bound": "hbm",
+                        "kernel": (f"decode_mega_kernel (persistent: up to {MEGA_STEPS} decode steps per launch -- per step 24 layers + LM head + "
+                                   f"the token draw and the next input rows -- for {U} utterance(s); the {launches} launches of one bench step = "
+                                   f"its {n_steps} decode steps)"),
+                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": None, "bytes_per_launch": total_bytes / launches, "avg_launch_us": round(run_ms * 1e3 / launches, 1),
+                        "launches_per_bench_step": launches, "avg_step_us": round(run_ms * 1e3 / n_steps, 2), "step_probe": step_probe}
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "roofline_traffic.json")) as f:
+                    tr = json.load(f)
+                if tr.get("launch_form") == "multi-step" and tr.get("mode", "bf16") == (a.quantisation_mode or "bf16") and tr.get("utterances", 1) == U:
+                    # FETCH_SIZE is per dispatch; the ratio traffic / algorithmic bytes of the profiled launches carries over
+                    roofline["traffic"] = round(tr["ratio"] * total_bytes / launches)
+                    roofline["traffic_note"] = (f"{tr['source']}; {tr['launch_contexts']}; HBM bytes / algorithmic bytes of those launches = "
+                                                f"{tr['ratio']}, applied to this run's bytes per launch")
+            except (OSError, KeyError, ValueError):
+                pass
         n_utt = sum(len(gp) for gp in work)
         tok_per_step = sum(n for gp in work for _, n in gp)
         mode = a.quantisation_mode or "bf16"
