@@ -287,13 +287,15 @@ def main():
         # The kernel's duration grows linearly with the context; it is probed at the MEAN context of the first timed group, so
         # that `avg_launch_us` is the average launch of the timed region (what the rocprofv3 --stats average in profiles/ shows)
         # and `bytes_per_launch` the average algorithmic bytes of those launches.
+        path, timeouts = engine.decode_path()   # of the timed region
+        engine.tune(mega_fold=0)                # the probe times the one-step instance; its set-up step must not add a launch of the timed kernel
         g0 = work[0]
         ctxs = [len(p) + (n - 1) // 2 for p, n in g0]
         engine.begin([mv.synthetic.prompt_tokens(c, seed=rank + u) for u, c in enumerate(ctxs)], spk.expand(len(g0), -1), sp,
                      max_new_tokens=2, end_of_audio_token=9999, prefill_mode=1)
         engine.run(max_steps=1)
         if N.lib().mv_probe_kernel(engine._h, 6, 200, C.byref(ms), C.byref(nbytes)) == 0:
-            kname = ("decode_mega_kernel (persistent: 24 layers + LM head of one token for %d utterance(s); probed at context %s = the "
+            kname = ("decode_mega_kernel<.., false> (persistent: 24 layers + LM head of one token for %d utterance(s); probed at context %s = the "
                      "mean of the timed utterances)" % (len(g0), [c + 1 for c in ctxs]))
         else:
             N.check(N.lib().mv_probe_kernel(engine._h, 3, 24 * 20, C.byref(ms), C.byref(nbytes)))
@@ -307,7 +309,7 @@ def main():
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "roofline_traffic.json")) as f:
                 tr = json.load(f)
-            if tr["kernel"] in kname and tr.get("mode", "bf16") == (a.quantisation_mode or "bf16") and tr.get("utterances", 1) == U:
+            if tr.get("launch_form") != "multi-step" and tr["kernel"] in kname and tr.get("mode", "bf16") == (a.quantisation_mode or "bf16") and tr.get("utterances", 1) == U:
                 roofline["traffic"] = tr["traffic_bytes_per_launch"]
                 roofline["traffic_note"] = (f"{tr['source']}; {tr['launch_contexts']}; algorithmic bytes of those launches "
                                             f"{tr['algorithmic_bytes_same_launches']} (ratio {tr['ratio']})")
@@ -327,7 +329,6 @@ def main():
             for p, n in group:
                 total_bytes += sum(kv_bytes(args, q) for q in range(len(p), len(p) + n - 1))
         step_frac = total_bytes / ((gpu_ms / a.steps) * 1e-3) / 1e9 / HBM_PEAK_GBS
-        path, timeouts = engine.decode_path()
         if timeouts:
             raise SystemExit(f"bench: {timeouts} launch(es) of the persistent decode kernel were abandoned and redone by per-layer launches: "
                              "the timed region is not the path this line describes")
@@ -342,7 +343,7 @@ def main():
             ach = total_bytes / (run_ms * 1e-3) / 1e9
             step_probe = {k: roofline[k] for k in ("kernel", "achieved", "frac", "bytes_per_launch", "avg_launch_us")}
             roofline = {"bound": "hbm",
-                        "kernel": (f"decode_mega_kernel (persistent: up to {MEGA_STEPS} decode steps per launch -- per step 24 layers + LM head + "
+                        "kernel": (f"decode_mega_kernel<.., true> (persistent: up to {MEGA_STEPS} decode steps per launch -- per step 24 layers + LM head + "
                                    f"the token draw and the next input rows -- for {U} utterance(s); the {launches} launches of one bench step = "
                                    f"its {n_steps} decode steps)"),
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),

@@ -126,7 +126,8 @@ __device__ __forceinline__ void mega_poll_rowpairs(const gran_t* g, uint32_t tag
                         });
 }
 
-template <int WF, int NU>  // WF: MV_W_BF16, MV_W_INT4_G128 (LM head bf16) or MV_W_INT8 (LM head int8 too); NU utterances
+template <int WF, int NU, bool FOLD>  // WF: MV_W_BF16, MV_W_INT4_G128 (LM head bf16) or MV_W_INT8 (LM head int8 too); NU utterances;
+                                      // FOLD: a.n_steps decode steps per launch, the token drawn inside (else one step, logits only)
 __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_kernel(const MegaArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mg_lds[];
     // the GEMV operand of the current phase, per utterance; the residual stream is NOT kept here: a wave produces exactly the
@@ -149,12 +150,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     __shared__ SampleScratch smp_sc;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
-    #ifdef MEGA_VARIANT_NOFOLD
-    constexpr bool CAN_FOLD = false;
-#else
-    constexpr bool CAN_FOLD = MEGA_FOLD_MAX_UTT >= NU;
-#endif  // instances above it keep sample_kernel behind every step (register budget)
-    const bool fold = CAN_FOLD && a.n_steps > 0;
+    constexpr bool fold = FOLD;  // compile time: the one-step instance carries no sampler code (and shows up under its own name in rocprofv3)
     const int n_steps = fold ? a.n_steps : 1;
     if (tid == 0) s_abort = 0;
     if (tid < NU) { pos_s[tid] = a.pos[tid]; done_s[tid] = fold ? a.utt[tid].done : 0; }
@@ -210,12 +206,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     int first_att = -1;
 #pragma unroll
     for (int u = NU - 1; u >= 0; --u) {
-#ifdef MEGA_VARIANT_APOS
-        const int Pu = (step == 0 ? a.pos[u] : pos_s[u]) + 1;
-#else
-        const int Pu = pos_s[u] + 1;  // keys [0, P)
-#endif
-        // keys [0, P): the cache holds [0, P-1), key P-1 is produced by this step's QKV phase
+        const int Pu = pos_s[u] + 1;  // keys [0, P): the cache holds [0, P-1), key P-1 is produced by this step's QKV phase
         const int csu = attn_keys_per_split(Pu), nactu = (Pu + csu - 1) / csu;
         if (tid == 0) { geo[0][u] = Pu; geo[1][u] = csu; geo[2][u] = nactu; geo[3][u] = attn_keys_per_wave(csu); }
         if (at_s < nactu) { any_att = true; first_att = u; }
@@ -637,7 +628,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             if (fold && slot < 11 && n < VP) gran_store(a.g_logits + (size_t)u * VP + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag_head);
         }
     }
-    if (!CAN_FOLD || !fold) return;
+    if constexpr (fold) {
 
     // ================= the token: sample() + the bookkeeping of decode_n_tokens + the next input rows ===================
     // fast_inference_utils.py:61-120,148-174, fast_model.py:152-157 -- sample_core.h, the arithmetic of sample_kernel.  Block u
@@ -759,6 +750,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         *(u32x4*)(xs[u] + MG_DIM + c) = r1;
     }
     __syncthreads();
+    }  // if constexpr (fold)
     }  // steps
 }
 
@@ -779,24 +771,24 @@ size_t mega_lds_bytes(int n_utt) {
     return (size_t)n_utt * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2) + ATTN_WAVES * 16 * 12 * 4 + (size_t)n_utt * MG_WAVES * 2 * 4;
 }
 
-template <int WF, int NU>
+template <int WF, int NU, bool FOLD>
 static hipError_t launch_mega_instance(hipStream_t s, const MegaArgs& a) {
     static bool raised = false;  // > 64 KB of LDS for more than one utterance: dynamic, raised once per instance
     const size_t lds = mega_lds_bytes(NU);
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)decode_mega_kernel<WF, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)decode_mega_kernel<WF, NU, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL((decode_mega_kernel<WF, NU>), dim3(256), dim3(MG_THREADS), lds, s, a);
+    hipLaunchKernelGGL((decode_mega_kernel<WF, NU, FOLD>), dim3(256), dim3(MG_THREADS), lds, s, a);
     return hipGetLastError();
 }
 template <int WF>
 static hipError_t launch_mega_format(hipStream_t s, const MegaArgs& a) {
     switch (a.n_utt) {
-        case 1: return launch_mega_instance<WF, 1>(s, a);
-        case 2: return launch_mega_instance<WF, 2>(s, a);
-        case 4: return launch_mega_instance<WF, 4>(s, a);
+        case 1: return a.n_steps > 0 ? launch_mega_instance<WF, 1, MEGA_FOLD_MAX_UTT >= 1>(s, a) : launch_mega_instance<WF, 1, false>(s, a);
+        case 2: return a.n_steps > 0 ? hipErrorInvalidValue : launch_mega_instance<WF, 2, false>(s, a);
+        case 4: return a.n_steps > 0 ? hipErrorInvalidValue : launch_mega_instance<WF, 4, false>(s, a);
         default: return hipErrorInvalidValue;
     }
 }
