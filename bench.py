@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--long-form-chars", type=int, default=10000)
     ap.add_argument("--mbd-precision", type=int, default=3, choices=[0, 1, 3],
                     help="multi-band diffusion vocoder: MFMA terms per product (3 = bf16 hi/lo split, ~fp32; 1 = bf16 operands; 0 = EnCodec decode only)")
+    ap.add_argument("--decode-path", choices=["auto", "step", "launches"], default="auto",
+                    help="A/B switch: auto = the engine's choice (persistent kernel drawing its own tokens where supported), step = persistent "
+                         "kernel, one step per launch + sampler launch, launches = per-layer launches")
     a = ap.parse_args()
     U = a.utterances_per_gpu
     if a.long_form and U != 1:
@@ -166,6 +169,8 @@ def main():
     del sd
     torch.cuda.empty_cache()
     engine.finalize()
+    if a.decode_path != "auto":
+        engine.tune(mega=int(a.decode_path == "step"), mega_fold=0)
     spk = mv.synthetic.speaker_embedding(rank)
     sp = mv.SamplingParams(guidance_scale=3.0, temperature=1.0, top_p=0.95, seed=1337 + rank)  # TTS.synthesise defaults
     work = make_work(mv, args, long_form=a.long_form, long_form_chars=a.long_form_chars, utterances_per_gpu=U, rank=rank, world=world)

@@ -308,10 +308,8 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                     const size_t off = ((size_t)(hd / 128) * a.cache_len + (GEO(0, u) - 1)) * 128 + hd % 128;
                     // agent-scope (write-through) stores: with several steps per launch the row is read by other CUs -- other XCDs,
                     // other L2s -- in the next step, with no kernel boundary in between
-                    if (a.ablate & 32) { cache[off] = y0; cache[(size_t)MG_HEADS * a.cache_len * 128 + off] = y1; } else {
                     __hip_atomic_store(cache + off, y0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(cache + (size_t)MG_HEADS * a.cache_len * 128 + off, y1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
                 }
             }
         }
@@ -658,8 +656,6 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         __syncthreads();
         if (MG_ABORTED()) return;
         bool done_now = was_done;
-        int new_pos = st_s.pos, new_tok = 0;
-        (void)new_pos; (void)new_tok;
         if (!was_done) {
             const int pos = st_s.pos, next_index = pos + 1;     // sequence index of the token decided now
             const bool forced = next_index < st_s.prompt_len;   // teacher-forced prompt token (prefill by decode steps)
@@ -676,8 +672,6 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 tok = sample_draw(sp, V, next_index, nullptr, smp_sc, par, tid_t, [&](int i, float& c, float& un) { c = bf2f(lg[i]); un = bf2f(lg[VP + i]); });
             }
             done_now = (!forced && tok == st_s.eoa_token) || (next_index + 1 >= st_s.max_len);
-            new_pos = next_index;
-            new_tok = tok;
             // the control word first: it is what the other 255 workgroups are waiting for
             if (tid_t == 0 && !last_step) gran_store(a.g_ctl + u, (uint32_t)tok | ((uint32_t)next_index << 12) | ((uint32_t)done_now << 31), tag_next);
             __syncthreads();  // every thread has read st_s
@@ -761,6 +755,11 @@ bool mega_supported(const mv_config& c, int rows, int n_cus) {
            c.n_layer <= 31;  // hand-off tag = step * 256 + layer * 8 + phase + 1: layer * 8 + 6 must stay below 256
 }
 
+// One utterance per engine (the rolled utterance loops of the 2 / 4-utterance instances spill inside the layer loop once the sampler
+// tail is compiled in), bf16 or int4: the int8 instance measured SLOWER with the tail (1426 vs 1452 tok/s on the same box; bf16
+// +1.4 %, int4 +2.2 %), so int8 engines keep one step per launch + sample_kernel.
+bool mega_folds(const mv_config& c) { return c.max_utterances <= MEGA_FOLD_MAX_UTT && c.weight_format != MV_W_INT8; }
+
 __global__ void bump_counter_kernel(uint32_t* c) { c[0] += 1u; }
 hipError_t launch_bump_counter(hipStream_t s, uint32_t* c) {
     hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, s, c);
@@ -786,7 +785,7 @@ static hipError_t launch_mega_instance(hipStream_t s, const MegaArgs& a) {
 template <int WF>
 static hipError_t launch_mega_format(hipStream_t s, const MegaArgs& a) {
     switch (a.n_utt) {
-        case 1: return a.n_steps > 0 ? launch_mega_instance<WF, 1, MEGA_FOLD_MAX_UTT >= 1>(s, a) : launch_mega_instance<WF, 1, false>(s, a);
+        case 1: return a.n_steps > 0 ? (WF == MV_W_INT8 ? hipErrorInvalidValue : launch_mega_instance<WF, 1, WF != MV_W_INT8>(s, a)) : launch_mega_instance<WF, 1, false>(s, a);
         case 2: return a.n_steps > 0 ? hipErrorInvalidValue : launch_mega_instance<WF, 2, false>(s, a);
         case 4: return a.n_steps > 0 ? hipErrorInvalidValue : launch_mega_instance<WF, 4, false>(s, a);
         default: return hipErrorInvalidValue;

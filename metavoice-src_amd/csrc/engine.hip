@@ -802,7 +802,7 @@ int mv_run(mv_engine* e, int32_t max_steps, int32_t poll_every, int32_t* steps_r
     while (done_steps < limit) {
         const int chunk = (limit - done_steps) < poll_every ? (limit - done_steps) : poll_every;
         const bool mega_live = e->mega_ok && g_tune.mega && !e->mega_failed;
-        if (mega_live && g_tune.mega_fold && U <= MEGA_FOLD_MAX_UTT) {
+        if (mega_live && g_tune.mega_fold && mega_folds(e->cfg)) {
             // the persistent kernel draws the tokens itself: one launch per (up to) mv_tune("mega_steps") steps of the chunk; a launch
             // queued behind the one in which the utterance ended returns at once
             for (int left = chunk; left > 0; left -= g_tune.mega_steps) {
@@ -874,7 +874,7 @@ int32_t mv_decode_path(const mv_engine* e, int32_t* timeouts) {
     if (!e) return -1;
     if (timeouts) *timeouts = e->mega_timeouts;
     if (!(e->mega_ok && g_tune.mega && !e->mega_failed)) return 0;
-    return g_tune.mega_fold && e->cfg.max_utterances <= MEGA_FOLD_MAX_UTT ? 2 : 1;
+    return g_tune.mega_fold && mega_folds(e->cfg) ? 2 : 1;
 }
 
 int mv_get_tokens(mv_engine* e, int32_t utt, int32_t* out, int32_t cap, int32_t* n_out) {

@@ -89,6 +89,7 @@ def test_full_size_engine_follows_the_reference(golden, weights, mode):
     # (ii) free-running greedy: MFMA prefill + decode steps, the engine's own sampler
     engine.begin([prompt], spk, sp, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
     engine.run()
+    assert engine.decode_path() == (1 if mode == "int8" else 2, 0), "the persistent kernel was abandoned: these numbers would be the launches'"
     seq = engine.tokens(0)
     assert len(seq) == T + n_new and seq[:T] == prompt.tolist()
     fork = next((i for i, (a, b) in enumerate(zip(seq, gseq)) if a != b), None)

@@ -50,7 +50,12 @@ def test_full_size_path_equivalences(full):
     engine.tune(mega=1)  # persistent one-launch-per-token kernel: identical bits
     c = run(engine, prompt, spk, sp, n_new, prefill_mode=1)
     lc = engine.captured_logits(T - 1, n_new)
+    assert engine.decode_path() == (2, 0), "a persistent launch was abandoned: the comparison would be launches against launches"
     assert a == c and torch.equal(la, lc)
+    engine.tune(mega_fold=0)  # one step per launch + sample_kernel (what engines of several utterances and int8 engines run)
+    assert run(engine, prompt, spk, sp, n_new, prefill_mode=1) == a and torch.equal(la, engine.captured_logits(T - 1, n_new))
+    assert engine.decode_path() == (1, 0)
+    engine.tune(mega_fold=1)
     # MFMA prefill vs the prompt teacher-forced through the decode kernels: same first-token logits to summation order
     d = run(engine, prompt, spk, sp, n_new, prefill_mode=0)
     ld = engine.captured_logits(T - 1, 1)
@@ -82,6 +87,7 @@ def test_full_size_two_utterances_in_the_persistent_kernel():
         engine.run()
         out[mega] = ([engine.tokens(u) for u in range(2)], engine.captured_logits(max(lens) - 1, n_new - 1))
     engine.tune(mega=1)
+    assert engine.decode_path() == (1, 0), "a persistent launch was abandoned: the comparison would be launches against launches"
     assert out[1][0] == out[0][0] and torch.equal(out[1][1], out[0][1])
     assert [len(t) for t in out[1][0]] == [lens[0] + n_new, lens[1] + n_new]
     engine.close()

@@ -23,7 +23,7 @@ def run(n_layer, cases, steps=40):
         n = e.run(max_steps=steps, poll_every=8)
         print(f"layers {n_layer:2d} {name:28s}: {n} steps {e.last_run_ms / max(n, 1) * 1e3:8.1f} us/step, path {e.decode_path()[0]}, new timeouts {e.decode_path()[1] - t0}", flush=True)
     e.close()
-cases = [("mega+sampler", dict(mega_fold=0, gemv_ablate=0)), ("mega+sampler plain kv", dict(mega_fold=0, gemv_ablate=32)),
+cases = [("mega+sampler", dict(mega_fold=0, gemv_ablate=0)), 
          ("fold 8/launch", dict(mega_fold=1, mega_steps=8, gemv_ablate=0)), ("fold 1/launch", dict(mega_fold=1, mega_steps=1, gemv_ablate=0))]
 cases = cases[: int(os.environ.get("DIAG_CASES", "4"))]
 for nl in [int(x) for x in os.environ.get("DIAG_LAYERS", "2,6,24").split(",")]:
