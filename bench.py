@@ -335,9 +335,11 @@ def main():
                 total_bytes += sum(kv_bytes(args, q) for q in range(len(p), len(p) + n - 1))
         step_frac = total_bytes / ((gpu_ms / a.steps) * 1e-3) / 1e9 / HBM_PEAK_GBS
         if timeouts:
-            raise SystemExit(f"bench: {timeouts} launch(es) of the persistent decode kernel were abandoned and redone by per-layer launches: "
-                             "the timed region is not the path this line describes")
-        if path == 2:
+            # an abandoned persistent launch is redone by the per-layer launches (same tokens): the wall-clock value stands, but the
+            # timed region is then not the kernel `roofline` would describe -- say so instead of attributing the time to it
+            print(f"bench: {timeouts} launch(es) of the persistent decode kernel were abandoned and redone by per-layer launches",
+                  file=sys.stderr)
+        if path == 2 and not timeouts:
             # The persistent kernel draws the tokens itself and runs up to MEGA_STEPS decode steps per launch: the dominant kernel's
             # launches ARE the timed decode region.  achieved = algorithmic bytes of those steps / HIP-event time of mv_run;
             # per launch = both divided by the launches of one bench step (what `rocprofv3 --stats` averages over).  The single-step
@@ -399,6 +401,7 @@ def main():
             "tokens_per_s_per_gpu": round((tok_per_step - n_utt) / (gpu_ms / a.steps * 1e-3), 1),
             "stage_ms_per_step": {k: round(v / a.steps, 2) for k, v in stage_ms.items()},
             "roofline": roofline,
+            "decode_fallbacks": timeouts,   # persistent launches abandoned (time-out) and redone by per-layer launches inside the timed region
             "step_roofline": {"bound": "hbm", "achieved": round(step_frac * HBM_PEAK_GBS, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(step_frac, 4), "scope": f"the {n_steps} decode steps of one bench step (HIP-event time of mv_run)",
                               "algorithmic_bytes_per_step": total_bytes, "gpu_ms_per_step": round(gpu_ms / a.steps, 2)},

@@ -1,7 +1,10 @@
 // Persistent decode-step kernel: all 24 layers + the LM head of one token in ONE launch (MetaVoice-1B shape; NU = 1, 2 or 4
 // utterances = 2 NU CFG rows decoded together: the weight rows a wave holds in registers are applied to every utterance, so
-// the weight stream and the six hand-offs of a layer are shared by all of them).  Same arithmetic, in the same order, as the per-layer launches (gemv.hip / attention.hip share
-// gemv_core.h / attn_core.h with this file): the two paths produce identical bits (tests/test_engine_gpu.py).
+// the weight stream and the six hand-offs of a layer are shared by all of them).  The FOLD instance (one utterance, bf16 / int4) also
+// draws the token (sample_core.h), does the bookkeeping of decode_n_tokens, builds the next input rows and goes on with the next
+// step: up to 512 steps per launch.  Same arithmetic, in the same order, as the per-layer launches (gemv.hip / attention.hip /
+// sampling.hip share gemv_core.h / attn_core.h / sample_core.h with this file): the paths produce identical bits
+// (tests/test_engine_gpu.py).
 //
 // Why (profiles/r01b_attn_sampler/NOTES.md): with one launch per op a decode step is 122 dependent launches of 1.5-9 us
 // of streaming each; every launch pays ~2.8 us of boundary + ramp + tail during which HBM idles, ~34 % of the step.  The

@@ -4,8 +4,10 @@
 // Hand-off (cdna_hip_programming.md Guideline 16, recipe R2): every activation vector is exchanged as 8-byte granules
 // {payload: 2 x bf16, tag: 32-bit epoch}, written with ONE agent-scope (sc1, write-through) store by the producing lane
 // and re-read with agent-scope loads by every consumer until all tags match -- the data is the flag: no fence, no
-// barrier object, no dependence on workgroup placement.  epoch = step counter (bumped by the sampler kernel, i.e. across
-// a kernel boundary) x 256 + layer x 8 + phase + 1: strictly increasing, so a stale granule can never match.
+// barrier object, no dependence on workgroup placement.  tag = epoch x 256 + layer x 8 + phase + 1 with epoch = the step counter
+// (one per decode step: advanced by block 0 at the end of every step of a multi-step launch, by sample_kernel when the token is
+// drawn by a launch of its own): strictly increasing, so a stale granule can never match.  Layer index n_layer tags the logits,
+// phase code 0 of the NEXT epoch the control word {token, position, done} that ends a step.
 // Every wait is bounded; a timeout raises a device flag that the host turns into an error (a plain launch gives no
 // residency guarantee: if another kernel occupies CUs the grid may not be co-resident).
 #pragma once
