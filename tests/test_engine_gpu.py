@@ -417,3 +417,36 @@ def test_hand_off_epoch_advances_across_an_utterance_that_ended_mid_chunk():
         assert out[(0, 0)][0] == out[path][0] and out[(0, 0)][1] == out[path][1], path
         assert torch.equal(out[(0, 0)][2], out[path][2]), f"{path}: max {float((out[(0, 0)][2] - out[path][2]).abs().max())}"
     engine.close()
+
+
+def test_persistent_kernel_next_to_a_competing_kernel_finishes_with_the_same_tokens():
+    """The persistent kernel needs all 256 workgroups resident; a plain launch gives no such guarantee.  With another stream keeping
+    CUs busy (large matmuls queued right before the decode steps) the run must neither hang nor change its output: either the grid
+    became resident in time (no launch abandoned) or a wait ran out, the chunk was rolled back and the per-layer launches finished
+    it -- same tokens, same logits either way.  (The fault-injection test above forces the second outcome; this one takes what the
+    device gives and prints it.)"""
+    engine, sd, cfg = build(dict(WIDE2, n_layer=3), 17)
+    prompt, spk = synthetic.prompt_tokens(280, seed=17), synthetic.speaker_embedding(17)
+    sp = mv.SamplingParams(top_p=0.95, guidance_scale=3.0, seed=4)
+    engine.capture_logits(True)
+    engine.tune(mega=0)
+    engine.begin([prompt], spk, sp, max_new_tokens=48, end_of_audio_token=9999, prefill_mode=1)
+    engine.run()
+    want, want_logits = engine.tokens(0), engine.captured_logits(279, 48)
+    engine.tune(mega=1)
+    a = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+    side = torch.cuda.Stream()
+    outcomes = []
+    for attempt in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(12):          # ~1.1 TFLOP each: tens of milliseconds of every CU, queued BEFORE the decode steps
+                a = (a @ a).clamp_(-1, 1)
+        engine.begin([prompt], spk, sp, max_new_tokens=48, end_of_audio_token=9999, prefill_mode=1)
+        steps = engine.run(poll_every=8)
+        assert steps == 47
+        assert engine.tokens(0) == want and torch.equal(engine.captured_logits(279, 48), want_logits)
+        outcomes.append(engine.decode_path())
+        side.synchronize()
+        engine.tune(mega=1)  # re-arm after a fall-back
+    print(f"[competing kernel] (path, abandoned launches so far) per attempt: {outcomes}")
+    engine.close()
