@@ -716,9 +716,9 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     }
     if (last_step) return;
     __builtin_amdgcn_sched_barrier(0);
-    // Every workgroup: wait for the control words {token | position << 12 | done << 31} (ONE wave polls, one granule per utterance:
-    // 2048 waves spinning on a 16 KB vector for the ~10 us of a draw saturate the few memory channels behind it -- 948 vs 733
-    // us/step when the input rows travelled as granules), then build the next input rows from the embedding tables.
+    // Every workgroup: wait for the control words {token | position << 12 | done << 31} -- ONE wave polls, one granule per utterance,
+    // instead of 2048 waves spinning on a 16 KB vector of input rows for the ~10 us of a draw -- then build the next input rows from
+    // the embedding tables (three 16-byte loads per thread; the token's row is shared by all 256 workgroups, i.e. L2 / MALL hits).
     if (wave_t == 0)
         wave_poll<1>(tag_next, a.abort_flag, &s_abort,
                      [&](int, u64& v) { if (lane_t >= NU) return false; v = gran_load(a.g_ctl + lane_t); return true; },
