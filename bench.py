@@ -187,8 +187,7 @@ def main():
     first_adapter = adapters.FlattenedInterleavedEncodec2Codebook(end_of_audio_token=1024)
     second_adapter = adapters.TiltedEncodec(end_of_audio_token=1024)
     stage1_only = a.quantisation_mode is not None  # configs[3] is "first-stage decode" only
-    # codec stage: EnCodec's own decoder (8 codebooks -> 24 kHz waveform) in HIP; the reference's multi-band diffusion
-    # refinement on top of it is not built yet and is NOT in this number
+    # codec stage: EnCodec's own decoder (8 codebooks -> 24 kHz waveform + the latent the diffusion bands are conditioned on) in HIP
     codec_mod = importlib.import_module("metavoice-src_amd.codec")
     vocoder = codec_mod.EncodecDecoder.from_state_dict(mv.synthetic.encodec_state_dict(seed=rank))
     # multi-band diffusion on top of it (fam/llm/decoders.py:13,84-85): 4 band models x 20 evaluations + processor + 32-band re_eq.
