@@ -18,7 +18,7 @@ from __future__ import annotations
 import os
 import re
 import warnings
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 
