@@ -63,6 +63,15 @@ def weight_bytes(cfg, fmt=None):
     return 2 * (cfg.n_layer * (lin + 2 * cfg.dim) + head + cfg.dim)
 
 
+MEGA_STEPS_PER_LAUNCH = 512  # mv_tune("mega_steps") default: decode steps per launch of the persistent kernel that draws its own tokens
+
+
+def decode_launches(work, steps_per_launch=MEGA_STEPS_PER_LAUNCH):
+    """Launches of the multi-step persistent kernel in one bench step: a group of n new tokens takes n - 1 decode steps after the
+    prefill (which draws the first token), `mv_run` cuts them into launches of at most `steps_per_launch`."""
+    return sum(-(-(max(n for _, n in group) - 1) // steps_per_launch) for group in work)
+
+
 def kv_bytes(cfg, pos):
     """K and V rows [0, pos] of both CFG rows of ONE utterance, all layers (bf16)."""
     return 2 * 2 * cfg.n_head * 128 * 2 * cfg.n_layer * (pos + 1)
@@ -343,13 +352,12 @@ def main():
             # launches ARE the timed decode region.  achieved = algorithmic bytes of those steps / HIP-event time of mv_run;
             # per launch = both divided by the launches of one bench step (what `rocprofv3 --stats` averages over).  The single-step
             # probe above (no token draw, one launch per step) stays on file as `step_probe`.
-            MEGA_STEPS = 512
-            launches = sum(-(-(max(n for _, n in group) - 1) // MEGA_STEPS) for group in work)
+            launches = decode_launches(work)
             run_ms = gpu_ms / a.steps
             ach = total_bytes / (run_ms * 1e-3) / 1e9
             step_probe = {k: roofline[k] for k in ("kernel", "achieved", "frac", "bytes_per_launch", "avg_launch_us")}
             roofline = {"bound": "hbm",
-                        "kernel": (f"decode_mega_kernel<.., true> (persistent: up to {MEGA_STEPS} decode steps per launch -- per step 24 layers + LM head + "
+                        "kernel": (f"decode_mega_kernel<.., true> (persistent: up to {MEGA_STEPS_PER_LAUNCH} decode steps per launch -- per step 24 layers + LM head + "
                                    f"the token draw and the next input rows -- for {U} utterance(s); the {launches} launches of one bench step = "
                                    f"its {n_steps} decode steps)"),
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),

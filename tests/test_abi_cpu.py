@@ -38,6 +38,10 @@ def test_argument_validation_needs_no_gpu():
         N.check(N.MV_ERR_INVALID)
     with pytest.raises(RuntimeError):
         N.check(N.MV_ERR_HIP)
+    # operational hooks tolerate a null engine instead of dereferencing it
+    t = C.c_int32(7)
+    assert lib.mv_decode_path(None, C.byref(t)) == -1 and t.value == 7
+    assert lib.mv_last_run_ms(None) == 0.0
 
 
 def test_no_cpu_fallback(monkeypatch):

@@ -155,3 +155,15 @@ def test_bench_work_lists_for_every_baseline_config():
     assert 46 <= len(long) <= 60
     for (ids, n_new), in long:
         assert len(ids) + n_new <= args.block_size and n_new >= 100
+
+
+def test_bench_counts_the_launches_of_the_multi_step_decode_kernel():
+    """`roofline.avg_launch_us` = HIP-event time of the decode region / this count: it has to equal what rocprofv3 sees as calls of
+    decode_mega_kernel<.., true> (profiles/r02b_fold: 4 for the default utterance)."""
+    import bench
+    p = [0] * 128
+    assert bench.decode_launches([[(p, 1920)]]) == 4                      # 1919 steps = 512 + 512 + 512 + 383
+    assert bench.decode_launches([[(p, 513)]]) == 1 and bench.decode_launches([[(p, 514)]]) == 2
+    assert bench.decode_launches([[(p, 40), (p, 700)], [(p, 2)]]) == 2 + 1  # a group runs as long as its longest utterance
+    assert bench.decode_launches([[(p, 1920)]], steps_per_launch=16) == 120
+
