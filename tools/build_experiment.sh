@@ -8,6 +8,6 @@ set -eu
 MACRO=$1
 cd "$(dirname "$0")/../metavoice-src_amd/csrc"
 make -j8 > /dev/null
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -I../../include -D$MACRO -c decode_mega.hip -o ../lib/obj/decode_mega_$MACRO.oo
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls ../lib/obj/*.o | grep -v '/decode_mega.o') ../lib/obj/decode_mega_$MACRO.oo -o ../lib/libmv_$MACRO.so
-ls -la ../lib/libmv_$MACRO.so
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -I../../include -D$MACRO -c decode_mega.hip -o "../lib/obj/decode_mega_${MACRO// /_}.oo"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls ../lib/obj/*.o | grep -v '/decode_mega.o') "../lib/obj/decode_mega_${MACRO// /_}.oo" -o "../lib/libmv_${MACRO// /_}.so"
+ls -la "../lib/libmv_${MACRO// /_}.so"
