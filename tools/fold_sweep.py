@@ -17,7 +17,7 @@ e = mv.Stage1Engine(args, max_utterances=1)
 e.load_state_dict(sd); del sd
 e.finalize()
 prompt, spk, sp = mv.synthetic.prompt_tokens(T, seed=0), mv.synthetic.speaker_embedding(0), mv.SamplingParams(top_p=0.95, guidance_scale=3.0, seed=1)
-paths = [("launches", dict(mega=0)), ("mega + sample_kernel", dict(mega=1, mega_fold=0))]
+paths = ([] if os.environ.get("FOLD_SKIP_LAUNCHES") else [("launches", dict(mega=0))]) + [("mega + sample_kernel", dict(mega=1, mega_fold=0))]
 paths += [(f"mega_fold, {s} steps/launch", dict(mega=1, mega_fold=1, mega_steps=int(s))) for s in os.environ.get("FOLD_STEPS", "8,64,512").split(",")]
 ref = None
 for name, knobs in paths:
