@@ -4,6 +4,12 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+`--gpus N` with N > 1 outside a launcher re-executes itself under `torch.distributed.run` (one rank per GPU, 127.0.0.1); under a
+launcher it checks that the launcher started exactly N ranks.  The line carries `rccl_ranks` = the size of the process group.
+The default N = 1 line also carries `extra_configs`: short measured legs of the other BASELINE.json configurations (int4 and int8
+first-stage decode, 4 utterances per GPU with the full vocoder, long-form 10 000 characters), each with its own value,
+ms_per_step, roofline and decode_fallbacks (`--no-extra-configs` skips them).
+
 A "step" is one pass of the hot path over one utterance per GPU: BASELINE.json configs[1] -- MetaVoice-1B bf16, one
 utterance, synthetic 256-char-equivalent prompt (T = 128 text tokens), batched MFMA prefill, N = 1920 generated
 first-stage tokens forced (end-of-audio unreachable) = 12.8 s of audio at 150 tokens/s, token adapter,
@@ -31,7 +37,10 @@ Extra objects on the JSON line:
                    host's cores on a bounded sample, rank 0, N=1 only.
 """
 import argparse
+import contextlib
+import copy
 import importlib
+import io
 import json
 import os
 import sys
@@ -136,36 +145,11 @@ def cpu_baseline(mv, cfgk, sample_steps=8):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--quantisation_mode", choices=["int4", "int8"], default=None)
-    ap.add_argument("--utterances-per-gpu", type=int, default=1)
-    ap.add_argument("--long-form", action="store_true")
-    ap.add_argument("--long-form-chars", type=int, default=10000)
-    ap.add_argument("--mbd-precision", type=int, default=3, choices=[0, 1, 3],
-                    help="multi-band diffusion vocoder: MFMA terms per product (3 = bf16 hi/lo split, ~fp32; 1 = bf16 operands; 0 = EnCodec decode only)")
-    ap.add_argument("--decode-path", choices=["auto", "step", "launches"], default="auto",
-                    help="A/B switch: auto = the engine's choice (persistent kernel drawing its own tokens where supported), step = persistent "
-                         "kernel, one step per launch + sampler launch, launches = per-layer launches")
-    a = ap.parse_args()
+def measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline):
+    """One bench configuration (the flags in `a`): builds its first-stage engine, runs `a.warmup` + `a.steps` bench steps between
+    fences and returns the JSON object of the line (rank 0; None elsewhere).  Second stage, codec and diffusion bands are built
+    once per process (`shared`) and reused by every configuration."""
     U = a.utterances_per_gpu
-    if a.long_form and U != 1:
-        ap.error("--long-form runs one chunk at a time")
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
     mv = importlib.import_module("metavoice-src_amd")
     args = mv.ModelArgs.from_name("metavoice-1B")
     cfgk = dict(n_layer=args.n_layer, n_head=args.n_head, dim=args.dim, vocab_size=args.vocab_size, block_size=args.block_size)
@@ -190,22 +174,28 @@ def main():
     # 960 frames + 128 text ids of this workload fit untruncated
     adapters = importlib.import_module("metavoice-src_amd.adapters")
     inference = importlib.import_module("metavoice-src_amd.inference")
-    s2_args = mv.synthetic.stage2_model_args(block_size=2048)
-    stage2 = mv.GPT(mv.GPTConfig(**s2_args), speaker_emb_dim=256, max_batch=1)
-    stage2.load_state_dict(mv.synthetic.stage2_state_dict(s2_args, speaker_emb_dim=256, seed=100 + rank))
+    if "stage2" not in shared:
+        s2_args = mv.synthetic.stage2_model_args(block_size=2048)
+        stage2 = mv.GPT(mv.GPTConfig(**s2_args), speaker_emb_dim=256, max_batch=1)
+        stage2.load_state_dict(mv.synthetic.stage2_state_dict(s2_args, speaker_emb_dim=256, seed=100 + rank))
+        # codec stage: EnCodec's own decoder (8 codebooks -> 24 kHz waveform + the latent the diffusion bands are conditioned on) in HIP
+        codec_mod = importlib.import_module("metavoice-src_amd.codec")
+        shared.update(s2_args=s2_args, stage2=stage2,
+                      vocoder=codec_mod.EncodecDecoder.from_state_dict(mv.synthetic.encodec_state_dict(seed=rank)))
+    s2_args, stage2, vocoder = shared["s2_args"], shared["stage2"], shared["vocoder"]
     first_adapter = adapters.FlattenedInterleavedEncodec2Codebook(end_of_audio_token=1024)
     second_adapter = adapters.TiltedEncodec(end_of_audio_token=1024)
     stage1_only = a.quantisation_mode is not None  # configs[3] is "first-stage decode" only
-    # codec stage: EnCodec's own decoder (8 codebooks -> 24 kHz waveform + the latent the diffusion bands are conditioned on) in HIP
-    codec_mod = importlib.import_module("metavoice-src_amd.codec")
-    vocoder = codec_mod.EncodecDecoder.from_state_dict(mv.synthetic.encodec_state_dict(seed=rank))
-    # multi-band diffusion on top of it (fam/llm/decoders.py:13,84-85): 4 band models x 20 evaluations + processor + 32-band re_eq.
+    # multi-band diffusion on top of the codec (fam/llm/decoders.py:13,84-85): 4 band models x 20 evaluations + processor + 32-band re_eq.
     # The released mbd_comp_8.pt is not reachable offline: the sizes are audiocraft's config/model/score/basic.yaml as recalled
     # (hidden 48, depth 4, growth 4, kernel 8, stride 4: 166 M parameters per band), synthetic weights.
     diffusion = None
     if a.mbd_precision and a.quantisation_mode is None:
-        mbd_mod = importlib.import_module("metavoice-src_amd.mbd")
-        diffusion = mbd_mod.MultiBandDiffusionBands.from_package(mv.synthetic.mbd_package(seed=rank), seed=1234 + rank, precision=a.mbd_precision)
+        key = ("diffusion", a.mbd_precision)
+        if key not in shared:
+            mbd_mod = importlib.import_module("metavoice-src_amd.mbd")
+            shared[key] = mbd_mod.MultiBandDiffusionBands.from_package(mv.synthetic.mbd_package(seed=rank), seed=1234 + rank, precision=a.mbd_precision)
+        diffusion = shared[key]
     stage_ms = {"stage1_prefill+decode": 0.0, "stage1_decode_gpu": 0.0, "adapters+stage2": 0.0, "encodec_decode": 0.0, "multiband_diffusion": 0.0}
 
     def fold_onto_codebooks(toks, n_prompt):
@@ -242,7 +232,8 @@ def main():
                 grid = inference.pack_second_stage_input(text_ids, cbs, s2_args["block_size"])
                 in_x = torch.tensor([grid], dtype=torch.long)
                 y = stage2.generate(in_x, None, temperature=1.0, top_k=200, speaker_embs=spk, batch_size=1, seed=sp.seed)
-                _, audio_ids = second_adapter.decode(torch.cat([in_x, y], dim=1)[0].tolist())
+                with contextlib.redirect_stdout(io.StringIO()):  # the adapter's "Truncating to min length" warning: random weights emit pad ids
+                    _, audio_ids = second_adapter.decode(torch.cat([in_x, y], dim=1)[0].tolist())
                 t2 = time.perf_counter()
                 grid8 = torch.tensor(audio_ids, dtype=torch.long).unsqueeze(0)
                 if diffusion is not None:
@@ -429,8 +420,118 @@ def main():
             out["vocoder_roofline"] = {"bound": "mfma", "kernel": "mbd_gemm_kernel (overlapping-window conv GEMMs of the 4 band UNets, 20 evaluations)",
                                        "achieved": round(flops / mbd_s / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flops / mbd_s / 2.5e15, 4),
                                        "note": f"{flops / 1e12:.0f} TFLOP of bf16 MFMA work per utterance ({a.mbd_precision} terms per product) over the whole stage"}
-        if world == 1 and not a.no_cpu_baseline:
+        if with_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mv, cfgk)
+        engine.close()
+        return out
+    engine.close()
+    return None
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the short legs of the other BASELINE configurations the default N=1 line carries under `extra_configs`")
+    ap.add_argument("--quantisation_mode", choices=["int4", "int8"], default=None)
+    ap.add_argument("--utterances-per-gpu", type=int, default=1)
+    ap.add_argument("--long-form", action="store_true")
+    ap.add_argument("--long-form-chars", type=int, default=10000)
+    ap.add_argument("--mbd-precision", type=int, default=3, choices=[0, 1, 3],
+                    help="multi-band diffusion vocoder: MFMA terms per product (3 = bf16 hi/lo split, ~fp32; 1 = bf16 operands; 0 = EnCodec decode only)")
+    ap.add_argument("--decode-path", choices=["auto", "step", "launches"], default="auto",
+                    help="A/B switch: auto = the engine's choice (persistent kernel drawing its own tokens where supported), step = persistent "
+                         "kernel, one step per launch + sampler launch, launches = per-layer launches")
+    a = ap.parse_args(argv)
+    if a.long_form and a.utterances_per_gpu != 1:
+        ap.error("--long-form runs one chunk at a time")
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    return a
+
+
+def self_launch_argv(a, argv, port=None):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: the command line this process replaces itself with -- one rank per GPU
+    under `torch.distributed.run` on 127.0.0.1, the form the driver uses.  None when no re-launch is needed (N = 1, or the
+    launcher's environment is already present)."""
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+# The other BASELINE.json configurations, as short measured legs of the default N = 1 run (VERDICT r2 item 2): flag overrides + steps.
+EXTRA_CONFIGS = [
+    ("configs[3] int4 first-stage decode", dict(quantisation_mode="int4", steps=3, warmup=1)),
+    ("configs[3'] int8 first-stage decode", dict(quantisation_mode="int8", steps=3, warmup=1)),
+    ("configs[2] 4 utterances per GPU, full vocoder", dict(utterances_per_gpu=4, steps=2, warmup=1)),
+    ("configs[4] long-form 10000 characters, full vocoder", dict(long_form=True, long_form_chars=10000, steps=1, warmup=0)),
+]
+
+
+def summarise_extra(o):
+    r = o["roofline"]
+    return {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"],
+            "dtype": o["dtype"], "tokens_per_s_per_gpu": o["tokens_per_s_per_gpu"], "decode_fallbacks": o["decode_fallbacks"],
+            "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch", "avg_launch_us") if k in r},
+            "step_roofline_frac": o["step_roofline"]["frac"], "stage_ms_per_step": o["stage_ms_per_step"],
+            "audio_s_per_step": round(o["config"]["tokens_per_step"] / TOKENS_PER_AUDIO_SECOND, 1), "workload": o["config"]["workload"]}
+
+
+def main():
+    a = parse_args()
+    relaunch = self_launch_argv(a, sys.argv[1:])
+    if relaunch is not None:
+        os.execv(relaunch[0], relaunch)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)")
+    if os.environ.get("MV_BENCH_LAUNCH_CHECK"):
+        # test hook (tests/test_bench_cpu.py, no GPU): prove that `--gpus N` ends up as N ranks of one process group, then stop
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        seen = torch.tensor([1.0])
+        dist.all_reduce(seen)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "rccl_ranks": dist.get_world_size(), "ranks_seen": int(seen.item()), "n_gpus": a.gpus}))
+        dist.destroy_process_group()
+        return
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == a.gpus
+
+    shared = {}
+    default_line = a.quantisation_mode is None and a.utterances_per_gpu == 1 and not a.long_form and a.decode_path == "auto"
+    out = measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline=(world == 1 and not a.no_cpu_baseline))
+    if rank == 0:
+        out["rccl_ranks"] = dist.get_world_size() if world > 1 else 1
+        if world == 1 and default_line and not a.no_extra_configs:
+            extras = {}
+            for name, over in EXTRA_CONFIGS:
+                b = copy.copy(a)
+                for k, v in over.items():
+                    setattr(b, k, v)
+                t0 = time.perf_counter()
+                extras[name] = summarise_extra(measure(b, rank, local_rank, world, dist, shared, with_cpu_baseline=False))
+                extras[name]["leg_wall_s"] = round(time.perf_counter() - t0, 1)   # incl. weight generation, quantisation and warm-up
+            out["extra_configs"] = extras
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

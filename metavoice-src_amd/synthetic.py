@@ -134,6 +134,16 @@ def prompt_tokens(n: int = 128, seed: int = 0, text_offset: int = 2049, n_text: 
     return torch.cat([body, torch.tensor([text_offset + n_text])]).to(torch.int32)
 
 
+def long_prompt_tokens(n: int, seed: int = 0, n_text: int = 128) -> torch.Tensor:
+    """A context as the decode loop sees it deep into an utterance: the `prompt_tokens(n_text, seed)` text prompt followed by
+    n - n_text audio tokens, codebook 0 (ids < 1024) and codebook 1 (ids 1024..2047) alternating as
+    `fam/llm/preprocessing/audio_token_mode.py:38-49` flattens them (int32)."""
+    g = torch.Generator().manual_seed(3000 + seed)
+    k = n - n_text
+    audio = torch.randint(0, 1024, (k,), generator=g) + 1024 * (torch.arange(k) % 2)
+    return torch.cat([prompt_tokens(n_text, seed), audio.to(torch.int32)])
+
+
 def write_model_dir(path: str, *, stage1: Optional[dict] = None, stage2_args: Optional[dict] = None, seed: int = 0,
                     mbd: Optional[dict] = None) -> str:
     """Write `first_stage.pt` / `second_stage.pt` / `speaker_encoder.pt` (+ `encodec_24khz.pt`, which the reference fetches from

@@ -191,6 +191,105 @@ def stage1_full_noise_floor(seq, logits_fp32, T, n_new, seed):
     return dict(noise_raw_refbf16=raw.numpy(), noise_mix_refbf16=mixed.numpy())
 
 
+def _ref_bf16_along(model16, prompt, spk16, seq, T, n_new):
+    """The reference `Transformer` in bf16 end to end (eager, CPU), teacher-forced along `seq`: logits (n_new, 2, V) as fp32."""
+    got = [model16(prompt.view(1, -1).repeat(2, 1), spk16, torch.arange(T))[:, -1].float()]
+    for i in range(n_new - 1):
+        got.append(model16(torch.full((2, 1), seq[T + i], dtype=torch.int32), spk16, torch.tensor([T + i]))[:, -1].float())
+    return torch.stack(got)
+
+
+def _ref_bf16_choice(lb):
+    """What the reference picks when it runs in bf16: the CFG mix exactly as `sample()` evaluates it on bf16 tensors with bf16
+    scalars (fast_inference_utils.py:113-117; every product and the sum rounded to bf16), its argmax (lowest index among equal
+    maxima: `top_k=1` keeps every tied maximum and the Exp(1) race picks one of them, SURVEY 8c gotcha 8), the number of tied
+    maxima and the top-2 margin of that bf16 mix."""
+    lb16 = lb.to(torch.bfloat16)
+    g = torch.tensor(3.0, dtype=torch.bfloat16)
+    mixed = (g * lb16[:, 0] + (1 - g) * lb16[:, 1]).float()  # (n, V) bf16 values
+    top2 = mixed.topk(2, dim=-1).values
+    mx = mixed.amax(dim=-1, keepdim=True)
+    first = (mixed == mx).float().argmax(dim=-1)
+    return first.to(torch.int32).numpy(), (mixed == mx).sum(dim=-1).to(torch.int32).numpy(), (top2[:, 0] - top2[:, 1]).numpy()
+
+
+def stage1_long_case(T, n_new=32, seed=0, modes=("bf16", "int4", "int8")):
+    """Long-context goldens at BASELINE's own size: a context of T tokens (the bench's 128-token text prompt +
+    T - 128 flattened audio tokens, `synthetic.long_prompt_tokens`), n_new greedy tokens through the reference's `generate()`
+    (fp32 compute on the bf16-rounded / quantised weights), the logits of every forward call it makes -- and, along the same
+    stream, the reference evaluated in bf16 end to end: what IT picks (argmax of its bf16 CFG mix, ties, margin) and how far its
+    logits are from its own fp32 ones (the noise floor the GPU test's tolerance derives from).  T = 1100 is the bench's mean
+    context (8-range split attention); T = 2016 ends at the last position the reference can generate (sequence index 2047)."""
+    import time
+    out = dict(cfg=json.dumps(FULL), seed=seed, T=T, n_new=n_new, n_text=128)
+    prompt = synthetic.long_prompt_tokens(T, seed=seed)
+    spk = synthetic.speaker_embedding(seed)
+    for mode in modes:
+        t0 = time.time()
+        model, _ = build_ref_stage1(FULL, seed, torch.bfloat16)
+        if mode != "bf16":
+            model = _quantise_like_the_reference(model, mode)
+        model16 = model  # bf16 end to end: the state the reference's `_load_model` reaches (fast_inference_utils.py:283-321)
+        import copy
+        model = copy.deepcopy(model16).to(torch.float32).eval()
+        model.config.dtype = torch.float32
+        model.setup_spk_cond_mask()
+        model.setup_caches(max_batch_size=2, max_seq_length=FULL["block_size"])
+        cap = []
+        hook = model.register_forward_hook(lambda m, i, o: cap.append(o[:, -1].float().clone()))
+        torch.manual_seed(0)
+        seq = ref_fiu.generate(model, prompt, spk, max_new_tokens=n_new, temperature=torch.tensor(1.0), top_k=1, top_p=None,
+                               guidance_scale=torch.tensor(3.0), end_of_audio_token=9999).tolist()
+        hook.remove()
+        del model
+        logits = torch.stack(cap)
+        assert logits.shape[0] == n_new and len(seq) == T + n_new
+        mix = 3.0 * logits[:, 0] + (1 - 3.0) * logits[:, 1]
+        assert mix.argmax(-1).tolist() == seq[T:]
+        top2 = mix.topk(2, dim=-1).values
+        t1 = time.time()
+        # the reference in bf16 along that stream
+        model16.config.dtype = torch.bfloat16
+        model16.setup_spk_cond_mask()
+        model16.setup_caches(max_batch_size=2, max_seq_length=FULL["block_size"])
+        lb = _ref_bf16_along(model16, prompt, spk.to(torch.bfloat16), seq, T, n_new)
+        del model16
+        raw = (lb - logits).abs().amax(dim=(1, 2))
+        pick, ties, margin16 = _ref_bf16_choice(lb)
+        mix16 = 3.0 * lb[:, 0] - 2.0 * lb[:, 1]
+        mixed = (mix16 - mix).abs().amax(dim=1)
+        agree = int((torch.from_numpy(pick).long() == torch.tensor(seq[T:])).sum())
+        print(f"[long24 T={T} {mode}] fp32 {t1 - t0:.0f} s + bf16 {time.time() - t1:.0f} s; raw logit std {float(logits.std()):.3f}, "
+              f"mix std {float(mix.std()):.3f}, fp32 top-2 margin min {float((top2[:, 0] - top2[:, 1]).min()):.4f} median "
+              f"{float((top2[:, 0] - top2[:, 1]).median()):.3f}; reference-bf16 vs its fp32: raw max {float(raw.max()):.4f}, mix max "
+              f"{float(mixed.max()):.4f}, picks the fp32 token at {agree}/{n_new} steps ({int((ties > 1).sum())} steps with tied maxima)",
+              flush=True)
+        out[f"seq_{mode}"] = np.array(seq, dtype=np.int32)
+        out[f"logits_{mode}"] = logits.numpy() if mode == "bf16" else logits.numpy().astype(np.float16)
+        out[f"noise_raw_refbf16_{mode}"] = raw.numpy()
+        out[f"noise_mix_refbf16_{mode}"] = mixed.numpy()
+        out[f"pick_refbf16_{mode}"] = pick
+        out[f"ties_refbf16_{mode}"] = ties
+        out[f"margin_refbf16_{mode}"] = margin16
+    np.savez_compressed(os.path.join(HERE, f"stage1_long24_T{T}.npz"), **out)
+
+
+def stage1_full_refbf16_choice(seed=0):
+    """For the T = 128 case of `stage1_full24.npz`: what the reference evaluated in bf16 picks along the stored fp32 stream
+    (bf16 weights only; the int4 / int8 streams of that file keep their fp32 logits as the only comparator)."""
+    g = np.load(os.path.join(HERE, "stage1_full24.npz"))
+    T, n_new, seq = int(g["T"]), int(g["n_new"]), g["seq_bf16"].tolist()
+    model, _ = build_ref_stage1(FULL, seed, torch.bfloat16)
+    lb = _ref_bf16_along(model, synthetic.prompt_tokens(T, seed=seed), synthetic.speaker_embedding(seed).to(torch.bfloat16), seq, T, n_new)
+    pick, ties, margin16 = _ref_bf16_choice(lb)
+    raw = (lb - torch.from_numpy(g["logits_bf16"])).abs().amax(dim=(1, 2))
+    agree = int((torch.from_numpy(pick).long() == torch.tensor(seq[T:])).sum())
+    print(f"[full24 refbf16] raw max {float(raw.max()):.4f} (stored floor {float(g['noise_raw_refbf16'].max()):.4f}); "
+          f"reference-bf16 picks the fp32 token at {agree}/{n_new} steps, {int((ties > 1).sum())} steps with tied maxima")
+    np.savez_compressed(os.path.join(HERE, "stage1_full24_refbf16.npz"), T=T, n_new=n_new, pick_refbf16_bf16=pick,
+                        ties_refbf16_bf16=ties, margin_refbf16_bf16=margin16)
+
+
 def slow_vs_fast_selftest(cfg_kwargs, seed):
     """the nanoGPT-style `GPT` and the gpt-fast `Transformer` are two independent reference
     implementations of stage 1; they must agree on the same checkpoint."""
@@ -398,6 +497,11 @@ if __name__ == "__main__":
     if "--extra" in sys.argv:  # cases added in round 2 (the round-1 files are reproduced bit for bit by the default run)
         speaker_encoder_case()
         packing_case()
+        sys.exit(0)
+    if "--long24" in sys.argv:  # round 3: ~1 h of CPU; T = 1100 and T = 2016 contexts + the reference's own bf16 picks
+        which = [int(a) for a in sys.argv[sys.argv.index("--long24") + 1:] if a.isdigit()] or [128, 1100, 2016]
+        for T in which:
+            stage1_full_refbf16_choice() if T == 128 else stage1_long_case(T)
         sys.exit(0)
     if "--full24" in sys.argv:  # ~5 min and ~12 GB of RAM: minted separately from the small cases
         stage1_full_case()
