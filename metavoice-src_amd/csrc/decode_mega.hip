@@ -75,6 +75,38 @@ __device__ __forceinline__ void mega_issue_row(u32x4* wv, const bf16_t* w, int n
     for (int j = 0; j < KCH; ++j) wv[j] = load_stream16(row + min(j * 512 + lane * 8, K - 8));
 }
 
+// Early rows (bf16, one utterance).  A phase's weight rows are requested after the previous phase's publish, so the norm / dots /
+// publish of a phase (1.1-1.8 us) run with nothing new in flight (profiles/r02b_fold/stamps_final.txt).  About half of the NEXT
+// phase's rows is therefore requested into LDS (global_load_lds_dwordx4: the registers are full; ~130 KB of LDS are free at one
+// utterance) right after a phase's input has arrived, i.e. BEFORE its compute: ~45 KB per CU drain in the 1.5 us the compute takes,
+// so the publish still finds the CU's queue nearly empty (publish-before-prefetch in time instead of in program order).  The other
+// half is requested where all of it used to be.  Round 2 measured W1 + W2 together: 704.9 vs 717-721 us/step, identical bits.
+//   MEGA_EARLY_W2 : chunks 0..4 of the wave's w2 row, after "h ready", consumed from LDS in P4
+//   MEGA_EARLY_W1 : chunks 0, 1 of each of the wave's 3 w1 rows, after "q/k/v ready", consumed from LDS in P3
+//   MEGA_EARLY_QKV: chunks 0, 1 of each of the wave's 3 wqkv rows of the NEXT layer, after "act ready", consumed from LDS in P0
+//                   (shares the W1 slots: those are dead between P3's dots and the next layer's "q/k/v ready")
+// Visibility: a wave reads only LDS slots it requested itself, and between every request and its first read sits one of the
+// wave's hand-off polls, whose asm statement ends in `s_waitcnt vmcnt(0)` (mega_core.h: poll16_loads) -- loads retire in order,
+// so the rows have landed.  Every early `return` of the kernel drains the wave's requests first (MG_ABORT_RETURN): a row landing
+// after the workgroup's LDS has been handed to the next workgroup would be written into somebody else's memory.
+#ifndef MEGA_EARLY_W1
+#define MEGA_EARLY_W1 1
+#endif
+#ifndef MEGA_EARLY_W2
+#define MEGA_EARLY_W2 1
+#endif
+#ifndef MEGA_EARLY_QKV
+#define MEGA_EARLY_QKV 0
+#endif
+#define MEGA_EARLY_W2_BYTES (MG_WAVES * 5 * 1024)
+#define MEGA_EARLY_W1_BYTES (MG_WAVES * 6 * 1024)
+__device__ __forceinline__ void mega_row_to_lds(uint32_t lds, const bf16_t* g) {  // 64 lanes x 16 B -> 1 KB of LDS at `lds`
+    uint32_t m0_save;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_save) : "s"(lds), "v"(g) : "memory");
+}
+__host__ __device__ constexpr bool mega_early_rows(int wf, int nu) { return wf == MV_W_BF16 && nu == 1 && (MEGA_EARLY_W1 || MEGA_EARLY_W2 || MEGA_EARLY_QKV); }
+
 // int4 (group-128) weight rows: per 2048-column chunk a lane requests 16 B of codes (32 columns) and the (scale, zero) word of
 // their 128-column group -- the same loads, and through i4_dots the same arithmetic, as gemv_i4.hip.
 template <int KCH>
@@ -129,6 +161,75 @@ __device__ __forceinline__ void mega_poll_rowpairs(const gran_t* g, uint32_t tag
                         });
 }
 
+__host__ __device__ constexpr size_t mega_lds_bytes(int n_utt) {  // dynamic LDS of the kernel below: xs, qkv_s, sm, red
+    return (size_t)n_utt * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2) + ATTN_WAVES * 16 * 12 * 4 + (size_t)n_utt * MG_WAVES * 2 * 4;
+}
+
+// The token draw OUT OF LINE: sample_draw keeps ~60 values per thread; inlined they are part of the layer loop's register
+// allocation and the 2- and 4-utterance instances spill inside the layer loop.  The workgroup of utterance u calls it with nothing in
+// flight (its layer-0 rows are requested after the control word has left: publish before prefetch).
+// sample() + the bookkeeping of decode_n_tokens + (last step of a launch) the next launch's input rows:
+// fast_inference_utils.py:61-120,148-174, fast_model.py:152-157 -- sample_core.h, the arithmetic of sample_kernel.
+template <int NU>
+__device__ __attribute__((noinline)) void mega_draw_and_publish(const MegaArgs& a, const int u, const bf16_t* lg, UttState* st_p, SampleScratch* sc_p,
+                                                                const int VP, const uint32_t tag_next, const bool last_step, const int tid_t) {
+    UttState& st_s = *st_p;
+    SampleScratch& smp_sc = *sc_p;
+    const bool was_done = st_s.done != 0;
+        bool done_now = was_done;
+        if (!was_done) {
+            const int pos = st_s.pos, next_index = pos + 1;     // sequence index of the token decided now
+            const bool forced = next_index < st_s.prompt_len;   // teacher-forced prompt token (prefill by decode steps)
+            const int V = a.vocab;
+            if (a.capture != nullptr && pos < a.capture_max) {
+                float* cap = a.capture + ((size_t)pos * (2 * NU) + 2 * u) * V;
+                for (int i = tid_t; i < V; i += MG_THREADS) { cap[i] = bf2f(lg[i]); cap[V + i] = bf2f(lg[VP + i]); }
+            }
+            int tok;
+            if (forced) tok = a.seq[(size_t)u * a.block_size + next_index];
+            else {
+                int par = 0;
+                const mv_sampling sp = st_s.s;
+                tok = sample_draw(sp, V, next_index, nullptr, smp_sc, par, tid_t, [&](int i, float& c, float& un) { c = bf2f(lg[i]); un = bf2f(lg[VP + i]); });
+            }
+            done_now = (!forced && tok == st_s.eoa_token) || (next_index + 1 >= st_s.max_len);
+            // the control word first: it is what the other 255 workgroups are waiting for
+            if (tid_t == 0 && !last_step) gran_store(a.g_ctl + u, (uint32_t)tok | ((uint32_t)next_index << 12) | ((uint32_t)done_now << 31), tag_next);
+            __syncthreads();  // every thread has read st_s
+            if (tid_t == 0) {
+                if (!forced) a.seq[(size_t)u * a.block_size + next_index] = tok;
+                UttState* gs = a.utt + u;
+                gs->n_tokens = next_index + 1;
+                gs->pos = next_index;
+                a.pos_out[u] = next_index;
+                st_s.pos = next_index;
+                st_s.n_tokens = next_index + 1;
+                if (done_now) {
+                    gs->done = 1;
+                    st_s.done = 1;
+                    atomicSub(a.n_active, 1);
+                }
+            }
+            if (!done_now && last_step) {
+                // the next LAUNCH's (or the per-layer launches') input rows, as sample_kernel leaves them:
+                // bf16(bf16(tok_emb[tok] + pos_emb[pos]) + spk_proj * mask).  Between the steps of one launch every workgroup
+                // builds them itself from the control word (below).
+                const bf16_t* te = a.tok_emb + (size_t)tok * MG_DIM;
+                const bf16_t* pe = a.pos_emb + (size_t)next_index * MG_DIM;
+                const bf16_t* sp = a.spk_proj + (size_t)u * MG_DIM;
+                bf16_t* x0 = a.x_out + (size_t)(2 * u) * MG_DIM;
+                for (int i = tid_t; i < MG_DIM; i += MG_THREADS) {
+                    const float base = round_bf(bf2f(te[i]) + bf2f(pe[i]));
+                    x0[i] = f2bf(base + bf2f(sp[i]));
+                    x0[MG_DIM + i] = f2bf(base);  // + 0 * mask: the unconditioned row gets no speaker term
+                }
+            }
+        } else if (tid_t == 0 && !last_step) {
+            // a finished (or unused) utterance keeps its last input rows, as with sample_kernel: same token, same position
+            gran_store(a.g_ctl + u, (uint32_t)a.seq[(size_t)u * a.block_size + st_s.pos] | ((uint32_t)st_s.pos << 12) | (1u << 31), tag_next);
+        }
+}
+
 template <int WF, int NU, bool FOLD>  // WF: MV_W_BF16, MV_W_INT4_G128 (LM head bf16) or MV_W_INT8 (LM head int8 too); NU utterances;
                                       // FOLD: a.n_steps decode steps per launch, the token drawn inside (else one step, logits only)
 __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_kernel(const MegaArgs a) {
@@ -139,6 +240,12 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     bf16_t (*qkv_s)[3 * 2 * 128] = (bf16_t(*)[3 * 2 * 128])(mg_lds + (size_t)NU * 2 * MG_INTER * 2);  // q, k_new, v_new of this block's head
     float (*sm)[16][12] = (float(*)[16][12])(mg_lds + (size_t)NU * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2));
     float* red = (float*)(sm + ATTN_WAVES);  // [NU][MG_WAVES * 2]
+    constexpr bool EARLY_ANY = mega_early_rows(WF, NU);
+    constexpr bool EARLY_W2 = EARLY_ANY && MEGA_EARLY_W2, EARLY_W1 = EARLY_ANY && MEGA_EARLY_W1, EARLY_QKV = EARLY_ANY && MEGA_EARLY_QKV;
+    u32x4* w2_lds = (u32x4*)(mg_lds + mega_lds_bytes(1));                        // [MG_WAVES][5 chunks][64 lanes]
+    u32x4* w1_lds = (u32x4*)(mg_lds + mega_lds_bytes(1) + MEGA_EARLY_W2_BYTES);  // [MG_WAVES][3 rows x 2 chunks][64 lanes]; wqkv rows of the next layer between P4 and P0
+    bool w1_half_issued = false;
+    auto lds_addr = [&](const u32x4* p) { return __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p); };
     __shared__ int s_abort;
     // per-utterance attention geometry and the residual values of each wave's own column: in LDS so that the loops over the
     // utterances stay ROLLED (unrolled they interleave the utterances' temporaries: 60-190 spilled VGPRs, and a scratch
@@ -160,6 +267,8 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     if (fold && b < NU && tid == 0) st_s = a.utt[b];
     __syncthreads();
 #define MG_ABORTED() (*(volatile int*)&s_abort != 0)
+    // leaving early: first drain this wave's LDS-direct requests (they write into LDS this workgroup is about to give back)
+#define MG_ABORT_RETURN() do { if (MG_ABORTED()) { if (EARLY_ANY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; } } while (0)
     if (fold) {  // a launch queued behind the one in which the last utterance ended: nothing to do
         bool all_done = true;
 #pragma unroll
@@ -272,7 +381,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }  // later steps: built at the end of the previous step from the control word
         } else mega_poll_rowpairs<NU>(a.g_x, tag0 - 8u + 4u, xs, a.abort_flag, &s_abort, tid_o);
         __syncthreads();
-        if (MG_ABORTED()) return;
+        MG_ABORT_RETURN();
         MG_STAMP(l, 1);
         // The K/V stream of the first attention slice is requested here, before the norm and the wqkv dots: it lands while they
         // run.  (Requested after the q/k/v publish instead it sits in front of the q/k/v poll: 831 vs 794 us/step.)
@@ -290,6 +399,21 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             float acc[3][2];
             if (I4) mega_dots_i4<1, 3, MG_DIM>(cq, cz, xs[u], MG_DIM, lane, acc);
             else if (I8) mega_dots_i8<2, 3, MG_DIM>(cq, xs[u], MG_DIM, lane, acc);
+            else if (EARLY_QKV && l > 0) {  // layer 0's rows come whole, in registers (issue_layer0); same order as mega_dots
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[i][0] = acc[i][1] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const u32x4 xv = *(const u32x4*)(xs[u] + r * MG_DIM + j * 512 + lane * 8);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            const u32x4 w = j < 2 ? w1_lds[(wave * 6 + i * 2 + j) * 64 + lane] : wv[4 * i + j];
+                            acc[i][r] = dot8_bf16(w, xv, acc[i][r]);
+                        }
+                    }
+            }
             else mega_dots<4, 3, MG_DIM>(wv, xs[u], lane, acc);
             __builtin_amdgcn_sched_barrier(0);
             if (u == 0) MG_STAMP(l, 13);  // wqkv dots done
@@ -335,8 +459,18 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             for (int i = 0; i < 3; ++i) {
                 if (I4) mega_issue_row_i4<1>(cq + i, cz + i, L.q[2], L.sz[2], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
                 else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, L.q8[2], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o); sc_a[i] = bf2f(L.s8[2][min(rb13 + i, MG_INTER - 1)]); }
+                else if (EARLY_W1) {
+                    const bf16_t* row = L.w1 + (size_t)min(rb13 + i, MG_INTER - 1) * MG_DIM;
+                    if (!w1_half_issued) {  // a workgroup that does not attend in this step (its key range is empty)
+                        mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + 0) * 64)), row + lane_o * 8);
+                        mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + 1) * 64)), row + 512 + lane_o * 8);
+                    }
+                    wv[4 * i + 2] = load_stream16(row + 2 * 512 + lane_o * 8);
+                    wv[4 * i + 3] = load_stream16(row + 3 * 512 + lane_o * 8);
+                }
                 else mega_issue_row<4>(wv + 4 * i, L.w1, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o, a.ablate);
             }
+            w1_half_issued = false;  // next layer
             nw_ffn = load16(L.ffn_norm + (tid_o & 255) * 8);
         };
         auto request_wo_w1 = [&]() { request_wo(); request_w1(); };
@@ -363,8 +497,17 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                               [&](int k, uint32_t p) { qkv_s[k][(sec * 2 + 0) * 128 + c] = (bf16_t)p; qkv_s[k][(sec * 2 + 1) * 128 + c] = (bf16_t)(p >> 16); });
             }
             __syncthreads();
-            if (MG_ABORTED()) return;
+            MG_ABORT_RETURN();
             MG_STAMP(l, 3);
+            if constexpr (EARLY_W1) {  // half of w1 on its way while the partial is computed, merged and published
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + j) * 64)),
+                                        L.w1 + (size_t)min(rb13 + i, MG_INTER - 1) * MG_DIM + j * 512 + lane_o * 8);
+                w1_half_issued = true;
+            }
             // One K/V register set.  After an utterance's partial has been merged and published (workgroup-wide
             // publish-before-prefetch) EVERY wave requests its slice of the next attending utterance -- wave 0 too, before the
             // combine polls it may owe.  The split partials of utterance u are combined by the workgroup of split u % nact (not
@@ -445,7 +588,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             wave_poll16<2 * NU>(a.g_attn, tag0 + 1u, a.abort_flag, &s_abort, [&](int k) { return (k >> 1) * (MG_DIM / 2) * 2 / 2 + tid_o + (k & 1) * MG_THREADS; },
                                 [&](int n, uint32_t p0, uint32_t p1) { ((uint2*)xs[n / (MG_DIM / 2)])[n % (MG_DIM / 2)] = make_uint2(p0, p1); });
             __syncthreads();
-            if (MG_ABORTED()) return;
+            MG_ABORT_RETURN();
             MG_STAMP(l, 5);
 #pragma unroll 1
             for (int u = 0; u < NU; ++u) {
@@ -488,8 +631,13 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         {
             mega_poll_rowpairs<NU>(a.g_h, tag0 + 2u, xs, a.abort_flag, &s_abort, tid_o);
             __syncthreads();
-            if (MG_ABORTED()) return;
+            MG_ABORT_RETURN();
             MG_STAMP(l, 7);
+            if constexpr (EARLY_W2) {  // chunks 0..4 of the w2 row on their way while the norm, the w1|w3 dots and the act publish run
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    mega_row_to_lds(lds_addr(w2_lds + ((wave_o * 5 + j) * 64)), L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8);
+            }
             mega_norm<NU>(xs, nw_ffn, red, a.eps);
             MG_STAMP(l, 18);  // norm done
             const int nrows = wave < 6 ? 3 : 2;
@@ -504,6 +652,21 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                     mega_dots_i8<2, 3, MG_DIM>(cq, xs[u], MG_DIM, lane, acc1);
                     mega_dots_i8<2, 3, MG_DIM>(cq + 6, xs[u], MG_DIM, lane, acc3);
                 } else {
+                    if constexpr (EARLY_W1) {  // same order as mega_dots: chunk j ascending, row r, weight row i
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) acc1[i][0] = acc1[i][1] = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int r = 0; r < 2; ++r) {
+                                const u32x4 xv = *(const u32x4*)(xs[u] + r * MG_DIM + j * 512 + lane * 8);
+#pragma unroll
+                                for (int i = 0; i < 3; ++i) {
+                                    const u32x4 w = j < 2 ? w1_lds[(wave * 6 + i * 2 + j) * 64 + lane] : wv[4 * i + j];
+                                    acc1[i][r] = dot8_bf16(w, xv, acc1[i][r]);
+                                }
+                            }
+                    } else
                     mega_dots<4, 3, MG_DIM>(wv, xs[u], lane, acc1);
                     mega_dots<4, 3, MG_DIM>(wv + 12, xs[u], lane, acc3);
                 }
@@ -527,6 +690,10 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             // next: w2 row 8 b + wave (K = 5632: 11 chunks)
             if (I4) mega_issue_row_i4<3>(cq + 6, cz + 6, L.q[4], L.sz[4], 8 * b + wave_o, MG_INTER, lane_o);
             else if (I8) { mega_issue_row_i8<6>(cq, L.q8[4], 8 * b + wave_o, MG_INTER, lane_o); sc_c = bf2f(L.s8[4][8 * b + wave_o]); }
+            else if (EARLY_W2) {
+#pragma unroll
+                for (int j = 5; j < 11; ++j) wv[j] = load_stream16(L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8);
+            }
             else mega_issue_row<11>(wv, L.w2, 8 * b + wave_o, MG_INTER, lane_o, a.ablate);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -554,13 +721,32 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                                        });
             }
             __syncthreads();
-            if (MG_ABORTED()) return;
+            MG_ABORT_RETURN();
             MG_STAMP(l, 9);
+            if constexpr (EARLY_QKV) {  // chunks 0, 1 of the next layer's three wqkv rows on their way while the w2 dots and the x publish run
+                if (l + 1 < a.n_layer) {
+                    const bf16_t* w = a.layers[l + 1].wqkv;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + j) * 64)), w + (size_t)(24 * b + 3 * wave_o + i) * MG_DIM + j * 512 + lane_o * 8);
+                }
+            }
 #pragma unroll 1
             for (int u = 0; u < NU; ++u) {
                 float acc[1][2];
                 if (I4) mega_dots_i4<3, 1, MG_INTER>(cq + 6, cz + 6, xs[u], MG_INTER, lane, acc);
                 else if (I8) mega_dots_i8<6, 1, MG_INTER>(cq, xs[u], MG_INTER, lane, acc);
+                else if (EARLY_W2) {  // same order as mega_dots: chunk j ascending, row r
+                    acc[0][0] = acc[0][1] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 11; ++j) {
+                        const u32x4 w = j < 5 ? w2_lds[(wave * 5 + j) * 64 + lane] : wv[j];
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) acc[0][r] = dot8_bf16(w, *(const u32x4*)(xs[u] + r * MG_INTER + j * 512 + lane * 8), acc[0][r]);
+                    }
+                }
                 else mega_dots<11, 1, MG_INTER>(wv, xs[u], lane, acc);
                 __builtin_amdgcn_sched_barrier(0);
                 if (u == 0) MG_STAMP(l, 21);  // w2 dots done
@@ -585,6 +771,11 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 for (int i = 0; i < 3; ++i) {
                     if (I4) mega_issue_row_i4<1>(cq + i, cz + i, a.layers[l + 1].q[0], a.layers[l + 1].sz[0], 24 * b + 3 * wave_o + i, MG_DIM, lane_o);
                     else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, a.layers[l + 1].q8[0], 24 * b + 3 * wave_o + i, MG_DIM, lane_o); sc_a[i] = bf2f(a.layers[l + 1].s8[0][24 * b + 3 * wave_o + i]); }
+                    else if (EARLY_QKV) {
+                        const bf16_t* row = w + (size_t)(24 * b + 3 * wave_o + i) * MG_DIM;
+                        wv[4 * i + 2] = load_stream16(row + 2 * 512 + lane_o * 8);
+                        wv[4 * i + 3] = load_stream16(row + 3 * 512 + lane_o * 8);
+                    }
                     else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave_o + i, MG_DIM, lane_o, a.ablate);
                 }
             } else {
@@ -605,7 +796,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     __syncthreads();
     mega_poll_rowpairs<NU>(a.g_x, epoch + (uint32_t)(a.n_layer - 1) * 8u + 1u + 4u, xs, a.abort_flag, &s_abort, tid);
     __syncthreads();
-    if (MG_ABORTED()) return;
+    MG_ABORT_RETURN();
     mega_norm<NU>(xs, nw_attn, red, a.eps);
 #pragma unroll 1
     for (int u = 0; u < NU; ++u) {
@@ -654,63 +845,11 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                                *(uint32_t*)(lg + VP + 2 * n) = (p0 >> 16) | (p1 & 0xFFFF0000u);
                            });
         }
-        // this workgroup's layer-0 rows: in flight while the token is drawn, landed before the publishes below
-        if (!last_step) issue_layer0(lane_t, wave_t);
         __syncthreads();
-        if (MG_ABORTED()) return;
-        bool done_now = was_done;
-        if (!was_done) {
-            const int pos = st_s.pos, next_index = pos + 1;     // sequence index of the token decided now
-            const bool forced = next_index < st_s.prompt_len;   // teacher-forced prompt token (prefill by decode steps)
-            const int V = a.vocab;
-            if (a.capture != nullptr && pos < a.capture_max) {
-                float* cap = a.capture + ((size_t)pos * (2 * NU) + 2 * u) * V;
-                for (int i = tid_t; i < V; i += MG_THREADS) { cap[i] = bf2f(lg[i]); cap[V + i] = bf2f(lg[VP + i]); }
-            }
-            int tok;
-            if (forced) tok = a.seq[(size_t)u * a.block_size + next_index];
-            else {
-                int par = 0;
-                const mv_sampling sp = st_s.s;
-                tok = sample_draw(sp, V, next_index, nullptr, smp_sc, par, tid_t, [&](int i, float& c, float& un) { c = bf2f(lg[i]); un = bf2f(lg[VP + i]); });
-            }
-            done_now = (!forced && tok == st_s.eoa_token) || (next_index + 1 >= st_s.max_len);
-            // the control word first: it is what the other 255 workgroups are waiting for
-            if (tid_t == 0 && !last_step) gran_store(a.g_ctl + u, (uint32_t)tok | ((uint32_t)next_index << 12) | ((uint32_t)done_now << 31), tag_next);
-            __syncthreads();  // every thread has read st_s
-            if (tid_t == 0) {
-                if (!forced) a.seq[(size_t)u * a.block_size + next_index] = tok;
-                UttState* gs = a.utt + u;
-                gs->n_tokens = next_index + 1;
-                gs->pos = next_index;
-                a.pos_out[u] = next_index;
-                st_s.pos = next_index;
-                st_s.n_tokens = next_index + 1;
-                if (done_now) {
-                    gs->done = 1;
-                    st_s.done = 1;
-                    atomicSub(a.n_active, 1);
-                }
-            }
-            if (!done_now && last_step) {
-                // the next LAUNCH's (or the per-layer launches') input rows, as sample_kernel leaves them:
-                // bf16(bf16(tok_emb[tok] + pos_emb[pos]) + spk_proj * mask).  Between the steps of one launch every workgroup
-                // builds them itself from the control word (below).
-                const bf16_t* te = a.tok_emb + (size_t)tok * MG_DIM;
-                const bf16_t* pe = a.pos_emb + (size_t)next_index * MG_DIM;
-                const bf16_t* sp = a.spk_proj + (size_t)u * MG_DIM;
-                bf16_t* x0 = a.x_out + (size_t)(2 * u) * MG_DIM;
-                for (int i = tid_t; i < MG_DIM; i += MG_THREADS) {
-                    const float base = round_bf(bf2f(te[i]) + bf2f(pe[i]));
-                    x0[i] = f2bf(base + bf2f(sp[i]));
-                    x0[MG_DIM + i] = f2bf(base);  // + 0 * mask: the unconditioned row gets no speaker term
-                }
-            }
-        } else if (tid_t == 0 && !last_step) {
-            // a finished (or unused) utterance keeps its last input rows, as with sample_kernel: same token, same position
-            gran_store(a.g_ctl + u, (uint32_t)a.seq[(size_t)u * a.block_size + st_s.pos] | ((uint32_t)st_s.pos << 12) | (1u << 31), tag_next);
-        }
+        MG_ABORT_RETURN();
+        mega_draw_and_publish<NU>(a, u, lg, &st_s, &smp_sc, VP, tag_next, last_step, tid_t);
         if (tid_t == 0 && u == 0) a.step_counter_out[0] = counter0 + (uint32_t)step + 1u;  // the next launch's first epoch
+        if (!last_step) issue_layer0(lane_t, wave_t);  // after the control word has left (publish before prefetch)
     } else if (!last_step) {
         issue_layer0(lane_t, wave_t);
     }
@@ -724,15 +863,15 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                      [&](int, u64& v) { if (lane_t >= NU) return false; v = gran_load(a.g_ctl + lane_t); return true; },
                      [&](int, uint32_t p) { tok_s[lane_t] = (int)(p & 0xFFFu); pos_s[lane_t] = (int)((p >> 12) & 0x7FFFFu); done_s[lane_t] = (int)(p >> 31); });
     __syncthreads();  // also: block u has read `lg`, xs may be overwritten
-    if (MG_ABORTED()) return;
+    MG_ABORT_RETURN();
     {
         bool all_done = true;
 #pragma unroll
         for (int u = 0; u < NU; ++u) all_done = all_done && done_s[u] != 0;
         if (all_done) return;
     }
-    if (tid_t < 256 * NU) {  // fast_model.py:152-157; thread t: columns 8 (t & 255) .. of both rows of utterance t >> 8
-        const int u = tid_t >> 8, c = (tid_t & 255) * 8;
+    for (int t = tid_t; t < 256 * NU; t += MG_THREADS) {  // fast_model.py:152-157; item t: columns 8 (t & 255) .. of both rows of utterance t >> 8
+        const int u = t >> 8, c = (t & 255) * 8;
         const u32x4 te = load16(a.tok_emb + (size_t)tok_s[u] * MG_DIM + c), pe = load16(a.pos_emb + (size_t)pos_s[u] * MG_DIM + c);
         const u32x4 sp = load16(a.spk_proj + (size_t)u * MG_DIM + c);
         u32x4 r0, r1;
@@ -761,7 +900,9 @@ bool mega_supported(const mv_config& c, int rows, int n_cus) {
 // One utterance per engine (the rolled utterance loops of the 2 / 4-utterance instances spill inside the layer loop once the sampler
 // tail is compiled in), bf16 or int4: the int8 instance measured SLOWER with the tail (1426 vs 1452 tok/s on the same box; bf16
 // +1.4 %, int4 +2.2 %), so int8 engines keep one step per launch + sample_kernel.
-bool mega_folds(const mv_config& c) { return c.max_utterances <= MEGA_FOLD_MAX_UTT && c.weight_format != MV_W_INT8; }
+bool mega_folds(const mv_config& c) {
+    return c.max_utterances <= g_tune.mega_fold_max_utt && (c.weight_format != MV_W_INT8 || g_tune.mega_fold_int8);
+}
 
 __global__ void bump_counter_kernel(uint32_t* c) { c[0] += 1u; }
 hipError_t launch_bump_counter(hipStream_t s, uint32_t* c) {
@@ -769,14 +910,11 @@ hipError_t launch_bump_counter(hipStream_t s, uint32_t* c) {
     return hipGetLastError();
 }
 
-size_t mega_lds_bytes(int n_utt) {
-    return (size_t)n_utt * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2) + ATTN_WAVES * 16 * 12 * 4 + (size_t)n_utt * MG_WAVES * 2 * 4;
-}
 
 template <int WF, int NU, bool FOLD>
 static hipError_t launch_mega_instance(hipStream_t s, const MegaArgs& a) {
     static bool raised = false;  // > 64 KB of LDS for more than one utterance: dynamic, raised once per instance
-    const size_t lds = mega_lds_bytes(NU);
+    const size_t lds = mega_lds_bytes(NU) + (mega_early_rows(WF, NU) ? MEGA_EARLY_W2_BYTES + MEGA_EARLY_W1_BYTES : 0);
     if (!raised) {
         hipError_t e = hipFuncSetAttribute((const void*)decode_mega_kernel<WF, NU, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -788,9 +926,9 @@ static hipError_t launch_mega_instance(hipStream_t s, const MegaArgs& a) {
 template <int WF>
 static hipError_t launch_mega_format(hipStream_t s, const MegaArgs& a) {
     switch (a.n_utt) {
-        case 1: return a.n_steps > 0 ? (WF == MV_W_INT8 ? hipErrorInvalidValue : launch_mega_instance<WF, 1, WF != MV_W_INT8>(s, a)) : launch_mega_instance<WF, 1, false>(s, a);
-        case 2: return a.n_steps > 0 ? hipErrorInvalidValue : launch_mega_instance<WF, 2, false>(s, a);
-        case 4: return a.n_steps > 0 ? hipErrorInvalidValue : launch_mega_instance<WF, 4, false>(s, a);
+        case 1: return a.n_steps > 0 ? launch_mega_instance<WF, 1, true>(s, a) : launch_mega_instance<WF, 1, false>(s, a);
+        case 2: return a.n_steps > 0 ? launch_mega_instance<WF, 2, true>(s, a) : launch_mega_instance<WF, 2, false>(s, a);
+        case 4: return a.n_steps > 0 ? launch_mega_instance<WF, 4, true>(s, a) : launch_mega_instance<WF, 4, false>(s, a);
         default: return hipErrorInvalidValue;
     }
 }

@@ -6,6 +6,10 @@
 
 typedef uint16_t bf16_t;
 
+// defaults of the token-draw-in-launch policy (mv_tune "mega_fold_max_utt" / "mega_fold_int8")
+#define MEGA_FOLD_MAX_UTT 4
+#define MEGA_FOLD_INT8 1
+
 // ---- tuning knobs (mv_tune): defaults are the measured best for MetaVoice-1B on MI355X (DESIGN.md "Tuning") ------
 struct MvTune {
     int gemv_threads[4] = {0, 0, 0, 0};  // per epilogue kind (GEMV_*): 0 = built-in choice
@@ -18,7 +22,9 @@ struct MvTune {
                                          // (MetaVoice-1B shape, >= 256 CUs); 0: per-layer launches
     int mega_steps = 512;                // decode steps per launch of the folding persistent kernel
     int mega_fold = 1;                   // 1: the persistent kernel also draws the token and runs several steps per launch (engines
-                                         // of up to MEGA_FOLD_MAX_UTT utterances); 0: one step per launch + sample_kernel
+                                         // of up to mega_fold_max_utt utterances); 0: one step per launch + sample_kernel
+    int mega_fold_max_utt = MEGA_FOLD_MAX_UTT;  // engines of more utterances keep sample_kernel behind every step
+    int mega_fold_int8 = MEGA_FOLD_INT8;        // int8 engines draw in the launch too (round 2, inlined draw: 1426 vs 1452 tok/s, i.e. slower)
 };
 extern MvTune g_tune;
 
@@ -215,7 +221,6 @@ struct MegaLayer {
     const signed char* q8[5];
     const bf16_t* s8[5];
 };
-#define MEGA_FOLD_MAX_UTT 1   // instances above it keep sample_kernel behind every step (register budget of the rolled utterance loops)
 struct MegaArgs {
     const bf16_t* x_in = nullptr;          // [2 n_utt][2048]: input rows of layer 0 (written by the sampler / prefill)
     const MegaLayer* layers = nullptr;     // device array [n_layer]

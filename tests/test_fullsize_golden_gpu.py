@@ -13,6 +13,12 @@ Checks per weight format (SURVEY.md 8c "parity criteria"):
         reference's token at every step whose reference top-2 margin exceeds twice the measured mix error of that step;
   (ii)  free-running greedy stream (MFMA prefill + decode): identical to the reference's, or forked at a step whose reference
         margin is inside that noise; the length of agreement is printed (the headline "bit-exact" number).
+
+Round 3 (`make_golden.py --long24`): the same at the contexts the bench actually decodes in -- `stage1_long24_T1100.npz` (the
+bench's mean context: the 8-range split attention of the persistent kernel) and `stage1_long24_T2016.npz` (ends at the last
+position the reference can generate, sequence index 2047) -- and, for every case, what the REFERENCE ITSELF picks when it is
+evaluated in bf16 end to end along the same stream (`pick_refbf16_*`): "the engine agrees with the fp32 stream at x/n steps, the
+reference in bf16 at y/n" is printed and x may not fall behind y by more than LAG steps.
 """
 import json
 import os
@@ -31,6 +37,7 @@ fiu = load_pkg("fast_inference_utils")
 
 FULL = dict(n_layer=24, n_head=16, dim=2048, vocab_size=2562, block_size=2048)
 NOISE_FACTOR = 1.5  # engine-vs-fp32 error allowed, in units of the reference's own bf16-vs-fp32 error (different summation orders)
+LAG = 3             # steps by which the engine's agreement with the fp32 stream may trail the reference-in-bf16's own agreement
 
 
 @pytest.fixture(scope="module")
@@ -85,11 +92,17 @@ def test_full_size_engine_follows_the_reference(golden, weights, mode):
     assert float(d_raw.mean()) <= NOISE_FACTOR * float(golden["noise_raw_refbf16"].mean())  # not just the tail: the typical step too
     assert bool(same[decided].all()), "argmax differs from the reference at a step the reference decides clearly"
     assert int(decided.sum()) >= n_new // 3, "the measured error is too large to decide even a third of the steps"
+    if mode == "bf16":
+        rb = np.load(os.path.join(GOLDEN, "stage1_full24_refbf16.npz"))
+        ref_same = int((torch.from_numpy(rb["pick_refbf16_bf16"]).long() == torch.tensor(gseq[T:])).sum())
+        print(f"[full24 bf16] agreement with the reference's fp32 stream: engine {int(same.sum())}/{n_new}, the reference evaluated in bf16 "
+              f"{ref_same}/{n_new} ({int((rb['ties_refbf16_bf16'] > 1).sum())} of its steps end in tied maxima)")
+        assert int(same.sum()) >= ref_same - LAG
 
     # (ii) free-running greedy: MFMA prefill + decode steps, the engine's own sampler
     engine.begin([prompt], spk, sp, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
     engine.run()
-    assert engine.decode_path() == (1 if mode == "int8" else 2, 0), "the persistent kernel was abandoned: these numbers would be the launches'"
+    assert engine.decode_path() == (2, 0), "the persistent kernel was abandoned: these numbers would be the launches'"
     seq = engine.tokens(0)
     assert len(seq) == T + n_new and seq[:T] == prompt.tolist()
     fork = next((i for i, (a, b) in enumerate(zip(seq, gseq)) if a != b), None)
@@ -107,4 +120,66 @@ def test_full_size_engine_follows_the_reference(golden, weights, mode):
             # teacher-forced, this step agreed with the reference: then the free-running fork comes from the prefill path
             # (different summation order), which must still be inside the same bound
             assert float(margin[fork - T]) <= 4 * float(d_mix.max())
+    engine.close()
+
+
+@pytest.mark.parametrize("mode", ["bf16", "int4", "int8"])
+@pytest.mark.parametrize("T", [1100, 2016])
+def test_full_size_engine_follows_the_reference_at_long_context(weights, T, mode):
+    """The contexts the bench decodes in: T = 1100 (8 key ranges per head, the split-partial combine) and T = 2016 (ends at the
+    last position the reference's `generate()` reaches).  Teacher-forced through the persistent kernel -- every one of the T + 31
+    positions is a decode step of `decode_mega_kernel`, `decode_path() == (2, 0)` -- against the logits of the reference's own
+    forward calls; tolerances from the reference's own bf16-vs-fp32 error on this very stream; then MFMA prefill of the T-token
+    context + free-running greedy decode."""
+    g = np.load(os.path.join(GOLDEN, f"stage1_long24_T{T}.npz"))
+    assert json.loads(str(g["cfg"])) == FULL and int(g["T"]) == T
+    n_new = int(g["n_new"])
+    gseq = g[f"seq_{mode}"].tolist()
+    glog = torch.from_numpy(g[f"logits_{mode}"].astype(np.float32))
+    prompt, spk = synthetic.long_prompt_tokens(T, seed=0), synthetic.speaker_embedding(0)
+    assert gseq[:T] == prompt.tolist() and len(gseq) == T + n_new
+    engine = mv.Stage1Engine(mv.ModelArgs(**FULL), max_utterances=1, quantisation_mode=None if mode == "bf16" else mode)
+    engine.load_state_dict(weights)
+    engine.finalize()
+    engine.capture_logits(True)
+    sp = mv.SamplingParams(top_k=1, guidance_scale=3.0, seed=1)
+
+    engine.begin([gseq[:T + n_new - 1]], spk, sp, max_new_tokens=1, end_of_audio_token=9999, prefill_mode=0)
+    engine.run()
+    assert engine.decode_path() == (2, 0), "the persistent kernel was abandoned: these numbers would be the launches'"
+    got = engine.captured_logits(T - 1, n_new)
+    raw_floor, mix_floor = g[f"noise_raw_refbf16_{mode}"], g[f"noise_mix_refbf16_{mode}"]
+    d_raw = (got - glog).abs().amax(dim=(1, 2))
+    gm, em = mix(glog), mix(got)
+    d_mix = (em - gm).abs().amax(dim=1)
+    top2 = gm.topk(2, dim=-1).values
+    margin = top2[:, 0] - top2[:, 1]
+    decided = margin > 2 * d_mix
+    same = em.argmax(-1) == torch.tensor(gseq[T:])
+    ref_same = int((torch.from_numpy(g[f"pick_refbf16_{mode}"]).long() == torch.tensor(gseq[T:])).sum())
+    print(f"[long24 T={T} {mode}] teacher-forced through the persistent kernel, positions {T - 1}..{T + n_new - 2}: max|draw| "
+          f"{float(d_raw.max()):.4f} (reference-bf16 floor {float(raw_floor.max()):.4f}), max|dmix| {float(d_mix.max()):.4f} (floor "
+          f"{float(mix_floor.max()):.4f}); agreement with the reference's fp32 stream: engine {int(same.sum())}/{n_new}, the reference "
+          f"evaluated in bf16 {ref_same}/{n_new}; {int(decided.sum())} steps decided")
+    assert float(d_raw.max()) <= NOISE_FACTOR * float(raw_floor.max())
+    assert float(d_mix.max()) <= NOISE_FACTOR * float(mix_floor.max())
+    assert float(d_raw.mean()) <= NOISE_FACTOR * float(raw_floor.mean())
+    assert bool(same[decided].all()), "argmax differs from the reference at a step the reference decides clearly"
+    assert int(decided.sum()) >= n_new // 3
+    assert int(same.sum()) >= ref_same - LAG, "the engine leaves the fp32 stream more often than the reference's own bf16 evaluation does"
+
+    # MFMA prefill of the whole T-token context, then the engine's own greedy decode
+    engine.begin([prompt], spk, sp, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
+    engine.run()
+    assert engine.decode_path() == (2, 0)
+    seq = engine.tokens(0)
+    assert len(seq) == T + n_new and seq[:T] == prompt.tolist()
+    fork = next((i for i, (a, b) in enumerate(zip(seq, gseq)) if a != b), None)
+    d_pre = float((engine.captured_logits(T - 1, 1) - glog[:1]).abs().max())
+    print(f"[long24 T={T} {mode}] free-running greedy stream identical to the reference's for {n_new if fork is None else fork - T}/{n_new} "
+          f"tokens; MFMA-prefill (2 x {T} rows) first-token max|draw| {d_pre:.4f}")
+    assert d_pre <= NOISE_FACTOR * float(raw_floor.max())
+    if fork is not None:
+        assert float(margin[fork - T]) <= 2 * NOISE_FACTOR * float(mix_floor.max()), \
+            f"stream forks at generated token {fork - T} where the reference's top-2 margin is {float(margin[fork - T]):.4f}"
     engine.close()

@@ -134,3 +134,27 @@ def test_philox_known_answer():
     assert [int(x) for x in out] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
     q = o_rng.exp1_noise(1234, 5, 2562)
     assert q.dtype == np.float32 and np.all(q > 0) and np.isfinite(q).all() and abs(float(q.mean()) - 1.0) < 0.1
+
+
+@pytest.mark.parametrize("T", [1100, 2016])
+def test_long_context_goldens_are_self_consistent(T):
+    """`stage1_long24_T*.npz` (make_golden.py --long24; 24 layers, minted by the reference's `generate()`): the stored stream is the
+    argmax of the stored CFG-mixed fp32 logits, the context is `synthetic.long_prompt_tokens`, and the reference-in-bf16 picks /
+    noise floors cover every step.  (The 24-layer oracle needs ~1 min per forward pass on a CPU: the engine-vs-golden comparison
+    itself is tests/test_fullsize_golden_gpu.py.)"""
+    g = np.load(os.path.join(GOLDEN, f"stage1_long24_T{T}.npz"))
+    n_new = int(g["n_new"])
+    assert int(g["T"]) == T and T + n_new <= 2048
+    prompt = synthetic.long_prompt_tokens(T, seed=int(g["seed"]))
+    lg = torch.from_numpy(g["logits_bf16"])
+    assert lg.shape == (n_new, 2, 2562) and lg.dtype == torch.float32
+    seq = g["seq_bf16"].tolist()
+    assert seq[:T] == prompt.tolist()
+    assert (3.0 * lg[:, 0] - 2.0 * lg[:, 1]).argmax(-1).tolist() == seq[T:]
+    for mode in ("bf16", "int4", "int8"):
+        assert g[f"seq_{mode}"].shape == (T + n_new,) and g[f"seq_{mode}"][:T].tolist() == prompt.tolist()
+        for k in ("noise_raw_refbf16", "noise_mix_refbf16", "pick_refbf16", "ties_refbf16", "margin_refbf16"):
+            assert g[f"{k}_{mode}"].shape == (n_new,)
+        # the reference's own bf16 evaluation stays within ~0.2 sigma of its fp32 logits and mostly picks the fp32 token
+        assert 0.05 < float(g[f"noise_raw_refbf16_{mode}"].max()) < 0.25
+        assert int((g[f"pick_refbf16_{mode}"] == g[f"seq_{mode}"][T:]).sum()) >= n_new - 6
