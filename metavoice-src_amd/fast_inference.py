@@ -11,8 +11,9 @@ all deliberate:
   * the DeepFilterNet enhancer (`:158-163`, third-party Rust) is an optional pluggable post-step, off by default;
   * the vocoder (`fam/llm/decoders.py:13`: `MultiBandDiffusion.get_mbd_24khz(bw=6)`, fetched from the hub there) is built from
     `encodec_24khz.pt` (+ `mbd_comp_8.pt`) in the model directory -- `vocoder.py`; a callable can be injected instead;
-  * additions with no counterpart in the reference: `synthesise_long` (BASELINE configs[4]: the reference stops at 220
-    characters, `fam/llm/inference.py:535-541`) and `synthesise_batch` (several utterances decoded together).
+  * additions with no counterpart in the reference: `synthesise_long` / `synthesise_long_stream` (BASELINE configs[4]: the
+    reference stops at 220 characters, `fam/llm/inference.py:535-541`; the stream yields every chunk's waveform as soon as its
+    vocoder pass ends) and `synthesise_batch` (several utterances decoded together).
 """
 from __future__ import annotations
 
@@ -93,6 +94,21 @@ class TTS:
         check_audio_file(p)
         return self.smodel.embed_utterance_from_file(p, numpy=False).unsqueeze(0)
 
+    def check_speaker_reference(self, spk_ref) -> None:
+        """Raises what `synthesise` would raise for this speaker reference before any GPU work (serving.py validates requests with
+        it on rank 0 before a batch is announced to the other ranks): missing file, unreadable format, shorter than 30 s
+        (`fam/llm/utils.py:55-70`).  Precomputed embeddings (.pt / .npy / tensors) only have to exist."""
+        if isinstance(spk_ref, torch.Tensor):
+            return
+        p = str(spk_ref)
+        if p.endswith((".pt", ".npy")):
+            if not os.path.exists(p):
+                raise FileNotFoundError(p)
+            return
+        if self.smodel is None:
+            raise FileNotFoundError(f"no speaker encoder available to embed {p}; pass a precomputed (1, 256) embedding instead")
+        check_audio_file(p)
+
     def synthesise(self, text: str, spk_ref_path, top_p=0.95, guidance_scale=3.0, temperature=1.0) -> str:
         """`fast_inference.py:111-195`: text -> path of the synthesised `.wav`."""
         text = normalize_text(text)
@@ -142,34 +158,86 @@ class TTS:
             out.extend(engine.tokens(u) for u in range(len(group)))
         return out
 
-    def synthesise_wavs(self, texts: Sequence[str], spk_refs, top_p=0.95, guidance_scale=3.0, temperature=1.0) -> List[torch.Tensor]:
-        """`synthesise` for a list of texts, waveforms kept in memory: (1, 1, samples) fp32 at 24 kHz each, in input order.
-        `spk_refs`: one reference for all texts or one per text."""
-        texts = [normalize_text(t) for t in texts]
-        if isinstance(spk_refs, (str, os.PathLike, torch.Tensor)):
-            spk_refs = [spk_refs] * len(texts)
-        cache = {}
-        embs = []
-        for r in spk_refs:
-            key = r if isinstance(r, (str, os.PathLike)) else id(r)
-            if key not in cache:
-                cache[key] = self._speaker_embedding(r).to(dtype=self.precision)
-            embs.append(cache[key])
-        spk = torch.cat(embs, dim=0)
-        streams = self._first_stage(texts, spk, top_p, guidance_scale, temperature)
-        wavs: List[torch.Tensor] = []
-        for text, tokens, emb in zip(texts, streams, embs):
-            _, ids = self.first_stage_adapter.decode([tokens])
-            wavs.extend(self.llm_second_stage.non_causal_wavs(
-                texts=[text], encodec_tokens=[torch.tensor(ids, dtype=torch.int32).unsqueeze(0)], speaker_embs=emb.unsqueeze(0),
-                batch_size=1, top_k=200, temperature=1.0))
-        return wavs
+    def _expand_tokens(self, text: str, tokens: List[int], emb: torch.Tensor) -> torch.Tensor:
+        """First-stage stream of one text -> (1, 1, samples) fp32 waveform: adapter, second stage, vocoder."""
+        _, ids = self.first_stage_adapter.decode([tokens])
+        return self.llm_second_stage.non_causal_wavs(
+            texts=[text], encodec_tokens=[torch.tensor(ids, dtype=torch.int32).unsqueeze(0)], speaker_embs=emb.unsqueeze(0),
+            batch_size=1, top_k=200, temperature=1.0)[0]
 
-    def synthesise_batch(self, texts: Sequence[str], spk_refs, top_p=0.95, guidance_scale=3.0, temperature=1.0) -> List[bytes]:
+    def synthesise_wavs(self, texts: Sequence[str], spk_refs, top_p=0.95, guidance_scale=3.0, temperature=1.0,
+                        return_exceptions: bool = False) -> list:
+        """`synthesise` for a list of texts, waveforms kept in memory: (1, 1, samples) fp32 at 24 kHz each, in input order.
+        `spk_refs`: one reference for all texts or one per text.  With `return_exceptions` a text that fails (characters
+        `normalize_text` refuses, an unreadable or too short speaker reference, 'wav predicted is shorter than 400ms!') leaves
+        its exception in its slot and the other texts of the call are still synthesised -- what a batching server needs: one bad
+        request must not take down the requests it happened to be grouped with."""
+        n = len(texts)
+        if isinstance(spk_refs, (str, os.PathLike, torch.Tensor)):
+            spk_refs = [spk_refs] * n
+        out: list = [None] * n
+        norm: List[Optional[str]] = [None] * n
+        embs: List[Optional[torch.Tensor]] = [None] * n
+        cache = {}
+        for i, (t, r) in enumerate(zip(texts, spk_refs)):
+            try:
+                norm[i] = normalize_text(t)
+                key = r if isinstance(r, (str, os.PathLike)) else id(r)
+                if key not in cache:
+                    cache[key] = self._speaker_embedding(r).to(dtype=self.precision)
+                embs[i] = cache[key]
+            except Exception as e:
+                if not return_exceptions:
+                    raise
+                out[i] = e
+        good = [i for i in range(n) if out[i] is None]
+        if good:
+            try:
+                streams = self._first_stage([norm[i] for i in good], torch.cat([embs[i] for i in good], dim=0), top_p, guidance_scale, temperature)
+            except Exception as e:  # the group decodes together: an engine failure is everybody's
+                if not return_exceptions:
+                    raise
+                for i in good:
+                    out[i] = e
+                return out
+            for i, tokens in zip(good, streams):
+                try:
+                    out[i] = self._expand_tokens(norm[i], tokens, embs[i])
+                except Exception as e:
+                    if not return_exceptions:
+                        raise
+                    out[i] = e
+        return out
+
+    def synthesise_batch(self, texts: Sequence[str], spk_refs, top_p=0.95, guidance_scale=3.0, temperature=1.0,
+                         return_exceptions: bool = False) -> list:
         """-> loudness-normalised 16-bit PCM RIFF bytes per text (what `synthesise` writes to disk), in input order; the
-        batched-serving entry point (serving.py)."""
+        batched-serving entry point (serving.py).  `return_exceptions`: see `synthesise_wavs`."""
         dec = self.llm_second_stage.decoder
-        return [dec.wav_bytes(w) for w in self.synthesise_wavs(texts, spk_refs, top_p, guidance_scale, temperature)]
+        return [w if isinstance(w, Exception) else dec.wav_bytes(w)
+                for w in self.synthesise_wavs(texts, spk_refs, top_p, guidance_scale, temperature, return_exceptions=return_exceptions)]
+
+    def synthesise_long_stream(self, text: str, spk_ref_path, top_p=0.95, guidance_scale=3.0, temperature=1.0, max_chars: int = MAX_CHARS,
+                               gap_s: float = 0.15):
+        """Streaming long-form synthesis (BASELINE configs[4] "streaming decode"): a generator that yields
+        `(chunk_index, n_chunks, wav)` -- wav (1, 1, samples) fp32 at 24 kHz, loudness-normalised per chunk, followed by `gap_s` of
+        silence except after the last chunk -- as soon as that chunk's vocoder pass ends, so playback (or the chunked HTTP response
+        of `serving.py`) starts after ONE chunk instead of after the whole text.  Chunks are independent generations with the same
+        speaker embedding on the same resident engine; the stages of a chunk cannot overlap the next chunk's first stage on one
+        GPU (the persistent decode kernel needs every CU), so the stream is chunk-sequential."""
+        from .loudness import normalize_loudness
+
+        chunks = split_text(normalize_text(text), max_chars)
+        if not chunks:
+            raise ValueError("empty text")
+        emb = self._speaker_embedding(spk_ref_path).to(dtype=self.precision)
+        gap = torch.zeros(1, 1, int(gap_s * 24000))
+        for i, chunk in enumerate(chunks):
+            tokens = self._first_stage([chunk], emb, top_p, guidance_scale, temperature)[0]
+            wav = self._expand_tokens(chunk, tokens, emb)
+            wav = normalize_loudness(wav.detach().float().cpu().reshape(1, -1), 24000, loudness_headroom_db=14.0,
+                                     loudness_compressor=True).reshape(1, 1, -1)
+            yield i, len(chunks), (torch.cat([wav, gap], dim=-1) if i + 1 < len(chunks) else wav)
 
     def synthesise_long(self, text: str, spk_ref_path, top_p=0.95, guidance_scale=3.0, temperature=1.0, max_chars: int = MAX_CHARS,
                         gap_s: float = 0.15) -> str:

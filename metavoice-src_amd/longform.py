@@ -10,7 +10,8 @@ from typing import List
 
 MAX_CHARS = 220  # fam/llm/inference.py:537
 
-_SENTENCE_END = re.compile(r"(?<=[.!?])[\"')\]]*\s+")
+# a sentence ends at . ! ? plus any closing quotes / brackets, which STAY with the sentence: only the whitespace after them is the cut
+_SENTENCE_END = re.compile(r"[.!?][\"')\]]*(\s+)")
 _CLAUSE_END = re.compile(r"(?<=[,;:])\s+")
 
 
@@ -59,6 +60,9 @@ def split_text(text: str, max_chars: int = MAX_CHARS) -> List[str]:
     if not text:
         return []
     sentences: List[str] = []
-    for s in _SENTENCE_END.split(text):
-        sentences.extend(_split_oversized(s.strip(), max_chars))
+    start = 0
+    for m in _SENTENCE_END.finditer(text):
+        sentences.extend(_split_oversized(text[start:m.start(1)], max_chars))
+        start = m.end(1)
+    sentences.extend(_split_oversized(text[start:], max_chars))
     return _pack(sentences, max_chars)

@@ -5,6 +5,8 @@ Same contract (`serving.py:54-109`): `GET /health -> {"status": "ok"}`; `POST /t
 (default 0.95) -> `audio/wav` body; 400 when neither speaker input is given; 500 with the reference's fixed text on any
 failure; the synthesised file is deleted after the response.  Same flags (`ServingConfig`, `:29-42`):
 --huggingface_repo_id --temperature --seed --port (58003) --quantisation_mode.
+Addition: `POST /tts_stream`, the same form for texts of any length, answered with chunked transfer encoding -- a RIFF header
+with open-ended sizes, then each sentence chunk's PCM as soon as its vocoder pass ends (BASELINE configs[4] "streaming decode").
 
 Dispatch (the part SURVEY.md 8a row a20 / 8e asks to be new): the reference serialises requests on one global TTS (its
 `async def` handler calls the blocking `synthesise`, `:89`).  Here requests wait in a queue; a dispatcher thread groups the
@@ -78,6 +80,8 @@ class BatchingDispatcher:
         self.q: "queue.Queue" = queue.Queue()
         self.batches: List[int] = []  # sizes of the batches dispatched so far (observability / tests)
         self._thread: Optional[threading.Thread] = None
+        # an mv_engine is not re-entrant: the dispatcher thread holds this around its shard, `/tts_stream` around every chunk
+        self.engine_lock = threading.Lock()
 
     # ---- rank 0 --------------------------------------------------------------------------------------------------
     def start(self):
@@ -121,23 +125,48 @@ class BatchingDispatcher:
             self.q.put(h)
         return batch
 
+    def _validate(self, item: dict) -> Optional[Exception]:
+        """Rank 0, before the work list is announced: a speaker reference that cannot be used fails its own request here and
+        never reaches the other ranks (`TTS.check_speaker_reference`: the reference's checks, `fam/llm/utils.py:55-70`)."""
+        check = getattr(self.tts, "check_speaker_reference", None)
+        if check is None:
+            return None
+        try:
+            check(item["spk"])
+        except Exception as e:
+            return e
+        return None
+
     def _loop(self):
         while True:
             batch = self._take_batch()
             if batch is None:
                 self._broadcast([self.STOP])
                 return
-            items = [b[0] for b in batch]
+            live = []
+            for entry in batch:
+                err = self._validate(entry[0])
+                if err is None:
+                    live.append(entry)
+                else:
+                    entry[2]["error"] = err
+                    entry[1].set()
+            if not live:
+                continue
+            items = [b[0] for b in live]
             self.batches.append(len(items))
             try:
+                # Every rank enters BOTH collectives of a batch whatever happens to its requests: a failing request travels
+                # as an error payload through the same gather (a rank that skipped the gather would leave the others blocked in
+                # it, and its next broadcast would meet their gather: the process group hangs).
                 self._broadcast(items)
-                wavs = self._run(items)
-                for (_, done, slot), w in zip(batch, wavs):
-                    slot["wav"] = w
+                results = self._run(items)
+                for (_, done, slot), r in zip(live, results):
+                    slot["error" if isinstance(r, Exception) else "wav"] = r
                     done.set()
-            except Exception as e:  # every waiter of the batch gets the failure (-> 500 with the fixed text)
+            except Exception as e:  # the collectives themselves failed: every waiter of the batch gets the failure
                 logger.exception("batch failed")
-                for _, done, slot in batch:
+                for _, done, slot in live:
                     slot["error"] = e
                     done.set()
 
@@ -149,23 +178,42 @@ class BatchingDispatcher:
         self.dist.broadcast_object_list(box, src=0, group=self.group)
         return box[0]
 
-    def _run(self, items: list) -> List[bytes]:
+    OK, FAILED = b"\x00", b"\x01"  # first byte of every gathered payload: RIFF bytes follow / an error message follows
+
+    def _run(self, items: list) -> list:
+        """This rank's shard of `items` -> one payload per item, then THE gather.  Returns, for every item in input order, the RIFF
+        bytes or the exception of that item.  Never raises before the gather."""
         import torch
 
         from .batch_dispatch import gather_variable, shard_indices
 
         mine = shard_indices(len(items), self.rank, self.world)
-        local: List["torch.Tensor"] = []
+        payloads: List[bytes] = []
         if mine:
-            blobs = self.tts.synthesise_batch([items[i]["text"] for i in mine], [items[i]["spk"] for i in mine],
-                                              top_p=items[0]["top_p"], guidance_scale=items[0]["guidance"])
-            local = [torch.frombuffer(bytearray(b), dtype=torch.uint8) for b in blobs]
+            try:
+                with self.engine_lock:
+                    blobs = self.tts.synthesise_batch([items[i]["text"] for i in mine], [items[i]["spk"] for i in mine],
+                                                      top_p=items[0]["top_p"], guidance_scale=items[0]["guidance"], return_exceptions=True)
+            except Exception as e:  # anything per-item handling did not catch: this rank's items fail, the batch goes on
+                logger.exception("rank %d failed on its shard", self.rank)
+                blobs = [e] * len(mine)
+            for b in blobs:
+                if isinstance(b, Exception):
+                    logger.error("request failed on rank %d: %r", self.rank, b)
+                    payloads.append(self.FAILED + f"{type(b).__name__}: {b}".encode("utf-8", "replace"))
+                else:
+                    payloads.append(self.OK + b)
+        local = [torch.frombuffer(bytearray(b), dtype=torch.uint8) for b in payloads]
         device = None
         if self.dist is not None and self.world > 1 and self.dist.get_backend(self.group) == "nccl":
             device = torch.device("cuda", torch.cuda.current_device())
             local = [t.to(device) for t in local]
         out = gather_variable(local, len(items), group=self.group, device=device, dtype=torch.uint8)
-        return [bytes(t.cpu().numpy().tobytes()) for t in out]
+        results: list = []
+        for t in out:
+            raw = bytes(t.cpu().numpy().tobytes())
+            results.append(raw[1:] if raw[:1] == self.OK else RuntimeError(raw[1:].decode("utf-8", "replace")))
+        return results
 
     def serve_worker(self):
         """Ranks > 0: take part in every batch rank 0 announces until it announces the end."""
@@ -174,11 +222,7 @@ class BatchingDispatcher:
             items = self._broadcast([])
             if items and items[0] == self.STOP:
                 return
-            try:
-                self._run(items)
-            except Exception:
-                logger.exception("worker rank %d failed on a batch", self.rank)
-                raise
+            self._run(items)  # per-request failures travel through the gather; only a broken process group raises here
 
 
 GlobalState = _GlobalState()
@@ -206,10 +250,10 @@ def _parse_form(content_type: str, body: bytes) -> Tuple[Dict[str, str], Dict[st
     return fields, files
 
 
-def text_to_speech(fields: Dict[str, str], files: Dict[str, bytes]) -> Tuple[int, str, bytes]:
-    """The `/tts` handler body (`serving.py:59-109`) -> (status, content type, body)."""
-    text = fields.get("text")
-    if text is None:
+def _validate_form(fields: Dict[str, str], files: Dict[str, bytes]):
+    """The form checks of `/tts` (FastAPI's `Form(..., ge=, le=)` validation and `serving.py:69-73` in the reference) ->
+    either (status, content type, body) of the refusal, or None."""
+    if fields.get("text") is None:
         return 422, "application/json", json.dumps({"detail": "field 'text' is required"}).encode()
     try:
         guidance = float(fields.get("guidance", 3.0))
@@ -218,11 +262,72 @@ def text_to_speech(fields: Dict[str, str], files: Dict[str, bytes]) -> Tuple[int
         return 422, "application/json", json.dumps({"detail": "guidance / top_p must be numbers"}).encode()
     if not (0.0 <= guidance <= 5.0) or not (0.0 <= top_p <= 1.0):
         return 422, "application/json", json.dumps({"detail": "guidance must be in [0, 5] and top_p in [0, 1]"}).encode()
-    speaker_ref_path = fields.get("speaker_ref_path")
-    audiodata = files.get("audiodata")
-    if not audiodata and not speaker_ref_path:
+    if not files.get("audiodata") and not fields.get("speaker_ref_path"):
         return 400, "application/json", json.dumps(
             {"detail": "Either an audio file or a speaker reference path must be provided."}).encode()
+    return None
+
+
+STREAM_WAV_HEADER = (b"RIFF" + b"\xff\xff\xff\xff" + b"WAVE" + b"fmt " + (16).to_bytes(4, "little") + (1).to_bytes(2, "little") +
+                     (1).to_bytes(2, "little") + (24000).to_bytes(4, "little") + (48000).to_bytes(4, "little") + (2).to_bytes(2, "little") +
+                     (16).to_bytes(2, "little") + b"data" + b"\xff\xff\xff\xff")  # 24 kHz mono PCM16, sizes unknown (streamed)
+
+
+def text_to_speech_stream(fields: Dict[str, str], files: Dict[str, bytes]):
+    """`POST /tts_stream` (no counterpart in the reference, which stops at 220 characters: BASELINE configs[4] "streaming decode"):
+    the same form as `/tts`, any text length.  Returns (refusal, None) or (None, generator of body pieces): the RIFF header with
+    open-ended sizes, then the 16-bit PCM of every sentence chunk as soon as its vocoder pass ends (`TTS.synthesise_long_stream`).
+    The first piece is produced before the response is committed, so a request that fails early still gets the 500 of `/tts`."""
+    refusal = _validate_form(fields, files)
+    if refusal is not None:
+        return refusal, None
+    text, guidance, top_p = fields["text"], float(fields.get("guidance", 3.0)), float(fields.get("top_p", 0.95))
+    lock = GlobalState.dispatcher.engine_lock if GlobalState.dispatcher is not None else threading.Lock()
+
+    def pieces():
+        with tempfile.NamedTemporaryFile(suffix=".wav") as wav_tmp:
+            if fields.get("speaker_ref_path") is None:
+                wav_tmp.write(files["audiodata"])
+                wav_tmp.flush()
+                spk = wav_tmp.name
+            else:
+                spk = fields["speaker_ref_path"]
+            gen = GlobalState.tts.synthesise_long_stream(text, spk, top_p=top_p, guidance_scale=guidance, temperature=GlobalState.config.temperature)
+            yield STREAM_WAV_HEADER
+            while True:
+                with lock:  # one chunk at a time on the engine; batches of the dispatcher interleave between chunks
+                    try:
+                        _, _, wav = next(gen)
+                    except StopIteration:
+                        return
+                x = wav.detach().reshape(-1).float().cpu().clamp(-1.0, 1.0)
+                yield (x * 32767.0).round().short().numpy().tobytes()
+
+    it = pieces()
+    try:
+        head = next(it)
+        first = next(it, b"")
+    except Exception:
+        logger.exception(f"Error processing streaming request. text: {text[:80]!r}")
+        return (500, "text/plain", ERROR_TEXT.encode()), None
+
+    def body():
+        yield head
+        if first:
+            yield first
+        yield from it
+
+    return None, body()
+
+
+def text_to_speech(fields: Dict[str, str], files: Dict[str, bytes]) -> Tuple[int, str, bytes]:
+    """The `/tts` handler body (`serving.py:59-109`) -> (status, content type, body)."""
+    refusal = _validate_form(fields, files)
+    if refusal is not None:
+        return refusal
+    text, guidance, top_p = fields["text"], float(fields.get("guidance", 3.0)), float(fields.get("top_p", 0.95))
+    speaker_ref_path = fields.get("speaker_ref_path")
+    audiodata = files.get("audiodata")
     wav_out_path = None
     try:
         with tempfile.NamedTemporaryFile(suffix=".wav") as wav_tmp:
@@ -246,6 +351,24 @@ def text_to_speech(fields: Dict[str, str], files: Dict[str, bytes]) -> Tuple[int
 
 
 class _Handler(BaseHTTPRequestHandler):
+    protocol_version = "HTTP/1.1"  # chunked transfer for /tts_stream; every other response carries its Content-Length
+
+    def _send_chunked(self, ctype: str, pieces):
+        self.send_response(200)
+        self.send_header("Content-Type", ctype)
+        self.send_header("Transfer-Encoding", "chunked")
+        self.send_header("Access-Control-Allow-Origin", "*")
+        self.end_headers()
+        try:
+            for p in pieces:
+                if p:
+                    self.wfile.write(f"{len(p):x}\r\n".encode() + p + b"\r\n")
+                    self.wfile.flush()
+            self.wfile.write(b"0\r\n\r\n")
+        except Exception:  # a chunk failed after the response was committed: cut the stream, the client sees a truncated body
+            logger.exception("streaming response aborted")
+            self.close_connection = True
+
     def _send(self, status: int, ctype: str, body: bytes):
         self.send_response(status)
         self.send_header("Content-Type", ctype)
@@ -261,11 +384,19 @@ class _Handler(BaseHTTPRequestHandler):
             self._send(404, "application/json", b'{"detail": "Not Found"}')
 
     def do_POST(self):
-        if self.path.split("?")[0] != "/tts":
+        route = self.path.split("?")[0]
+        body = self.rfile.read(int(self.headers.get("Content-Length", 0)))
+        if route not in ("/tts", "/tts_stream"):
             self._send(404, "application/json", b'{"detail": "Not Found"}')
             return
-        body = self.rfile.read(int(self.headers.get("Content-Length", 0)))
         fields, files = _parse_form(self.headers.get("Content-Type", "application/x-www-form-urlencoded"), body)
+        if route == "/tts_stream":
+            refusal, pieces = text_to_speech_stream(fields, files)
+            if refusal is not None:
+                self._send(*refusal)
+            else:
+                self._send_chunked("audio/wav", pieces)
+            return
         self._send(*text_to_speech(fields, files))
 
     def log_message(self, fmt, *args):

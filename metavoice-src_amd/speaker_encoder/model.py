@@ -65,48 +65,47 @@ class SpeakerEncoder:
     __call__ = forward
 
     @staticmethod
-    def compute_partial_slices(n_samples: int, rate, min_coverage):
-        """`model.py:59-84`: partial utterances of 160 frames every round(16000 / rate / 160) frames; the last one is dropped
-        when it covers less than `min_coverage` of real signal."""
-        samples_per_frame = int(sampling_rate * mel_window_step / 1000)
-        n_frames = int(np.ceil((n_samples + 1) / samples_per_frame))
-        frame_step = int(np.round((sampling_rate / rate) / samples_per_frame))
-        wav_slices, mel_slices = [], []
-        steps = max(1, n_frames - partials_n_frames + frame_step + 1)
-        for i in range(0, steps, frame_step):
-            mel_range = np.array([i, i + partials_n_frames])
-            wav_range = mel_range * samples_per_frame
-            mel_slices.append(slice(*mel_range))
-            wav_slices.append(slice(*wav_range))
-        last = wav_slices[-1]
-        coverage = (n_samples - last.start) / (last.stop - last.start)
-        if coverage < min_coverage and len(mel_slices) > 1:
-            mel_slices, wav_slices = mel_slices[:-1], wav_slices[:-1]
-        return wav_slices, mel_slices
+    def partial_table(n_samples: int, rate: float, min_coverage: float) -> np.ndarray:
+        """First mel frame of every partial utterance, as one int array (the windows are `partials_n_frames` long, so the whole
+        slicing of `model.py:59-84` is this table): a window every round(16000 / rate / 160) frames while the start stays below
+        n_frames - 160 + step + 1, at least one window; the last one goes when less than `min_coverage` of its 25 600 samples is
+        real signal (and it is not the only one)."""
+        hop = sampling_rate * mel_window_step // 1000                      # samples per mel frame
+        n_frames = -(-(n_samples + 1) // hop)                              # ceil
+        step = int(np.round(sampling_rate / rate / hop))
+        starts = np.arange(0, max(1, n_frames - partials_n_frames + step + 1), step, dtype=np.int64)
+        covered = (n_samples - starts[-1] * hop) / float(partials_n_frames * hop)
+        return starts[:-1] if (covered < min_coverage and starts.size > 1) else starts
+
+    @classmethod
+    def compute_partial_slices(cls, n_samples: int, rate, min_coverage):
+        """The reference's call form (`model.py:59-84`): (wav slices, mel slices) of the partial utterances."""
+        hop = sampling_rate * mel_window_step // 1000
+        starts = cls.partial_table(n_samples, rate, min_coverage).tolist()
+        return ([slice(a * hop, (a + partials_n_frames) * hop) for a in starts], [slice(a, a + partials_n_frames) for a in starts])
 
     def embed_utterance(self, wav: np.ndarray, return_partials=False, rate=1.3, min_coverage=0.75, numpy: bool = True):
-        """`model.py:86-107`."""
-        wav_slices, mel_slices = self.compute_partial_slices(len(wav), rate, min_coverage)
-        max_wave_length = wav_slices[-1].stop
-        if max_wave_length >= len(wav):
-            wav = np.pad(wav, (0, max_wave_length - len(wav)), "constant")
+        """`model.py:86-107`: zero-pad the signal to the end of the last partial, one mel spectrogram, all partials gathered with
+        one index table and embedded in ONE call of the HIP LSTM, mean of the partial embeddings, L2-normalised."""
+        hop = sampling_rate * mel_window_step // 1000
+        n_samples = len(wav)
+        starts = self.partial_table(n_samples, rate, min_coverage)
+        need = int(starts[-1] + partials_n_frames) * hop
+        if need >= len(wav):
+            wav = np.concatenate([wav, np.zeros(need - len(wav), dtype=wav.dtype)])
         mel = audio.wav_to_mel_spectrogram(wav)
-        mels = torch.from_numpy(np.array([mel[s] for s in mel_slices]))
-        partial_embeds = self(mels)
-        if numpy:
-            raw_embed = np.mean(partial_embeds.numpy(), axis=0)
-            embed = raw_embed / np.linalg.norm(raw_embed, 2)
-        else:
-            raw_embed = partial_embeds.mean(dim=0)
-            embed = raw_embed / torch.linalg.norm(raw_embed, 2)
+        frames = starts[:, None] + np.arange(partials_n_frames)[None, :]   # (n_partials, 160) frame indices
+        partial_embeds = self(torch.from_numpy(np.ascontiguousarray(mel[frames])))
+        mean = partial_embeds.numpy().mean(axis=0) if numpy else partial_embeds.mean(dim=0)
+        embed = mean / (np.linalg.norm(mean, 2) if numpy else torch.linalg.norm(mean, 2))
         if return_partials:
-            return embed, partial_embeds, wav_slices
+            return embed, partial_embeds, self.compute_partial_slices(n_samples, rate, min_coverage)[0]
         return embed
 
     def embed_speaker(self, wavs: List[np.ndarray], **kwargs):
-        """`model.py:109-111`."""
-        raw_embed = np.mean([self.embed_utterance(wav, return_partials=False, **kwargs) for wav in wavs], axis=0)
-        return raw_embed / np.linalg.norm(raw_embed, 2)
+        """`model.py:109-111`: mean of the utterance embeddings, L2-normalised again."""
+        centre = np.stack([self.embed_utterance(w, return_partials=False, **kwargs) for w in wavs]).mean(axis=0)
+        return centre / np.linalg.norm(centre, 2)
 
     def embed_utterance_from_file(self, fpath: str, numpy: bool):
         """`model.py:112-117`: load at 16 kHz, trim leading / trailing silence (top_db 20), embed."""

@@ -167,3 +167,27 @@ def test_bench_counts_the_launches_of_the_multi_step_decode_kernel():
     assert bench.decode_launches([[(p, 40), (p, 700)], [(p, 2)]]) == 2 + 1  # a group runs as long as its longest utterance
     assert bench.decode_launches([[(p, 1920)]], steps_per_launch=16) == 120
 
+
+
+def test_split_text_keeps_closing_quotes_and_brackets_with_their_sentence():
+    """the sentence-end pattern used to swallow the quotes / brackets that follow the punctuation, so the text fed to
+    the first stage differed from the input ('He said "Stop." Then left.' lost its closing quote)."""
+    import random
+
+    longform = load_pkg("longform")
+    text = 'He said "Stop." Then left. (Really?) She asked: \'Why?\' No answer... [sic.] The end!'
+    chunks = longform.split_text(text, max_chars=24)
+    assert " ".join(chunks) == text and all(len(c) <= 24 for c in chunks)
+    assert chunks[0] == 'He said "Stop."'
+    rng = random.Random(7)
+    alphabet = 'ab c.!?,;:"\')]( \n'
+    for _ in range(3000):
+        t = "".join(rng.choice(alphabet) for _ in range(rng.randint(0, 90)))
+        mc = rng.randint(8, 40)
+        ch = longform.split_text(t, mc)
+        norm = " ".join(t.split())
+        assert all(0 < len(c) <= mc for c in ch)
+        if all(len(w) <= mc for w in norm.split()):
+            assert " ".join(ch) == norm, (t, mc, ch)   # nothing dropped, nothing reordered; only hard cuts of over-long words add spaces
+        else:
+            assert "".join(ch).replace(" ", "") == norm.replace(" ", "")

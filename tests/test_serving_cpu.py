@@ -28,6 +28,16 @@ class FakeTTS:
         self.last = path
         return path
 
+    def synthesise_long_stream(self, text, spk_ref_path, top_p=0.95, guidance_scale=3.0, temperature=1.0):
+        import torch
+        if "boom" in text:
+            raise RuntimeError("synthetic failure")
+        sentences = [t for t in text.split(". ") if t]
+        for i, t in enumerate(sentences):
+            if "late" in t:
+                raise RuntimeError("fails after the response was committed")
+            yield i, len(sentences), torch.full((1, 1, 10 * (i + 1)), 0.25 * (i + 1))
+
 
 @pytest.fixture()
 def server(tmp_path):
@@ -90,11 +100,24 @@ class FakeBatchTTS:
     def __init__(self, rank=0, max_utterances=2):
         self.rank, self.max_utterances, self.batches = rank, max_utterances, []
 
-    def synthesise_batch(self, texts, spk_refs, top_p=0.95, guidance_scale=3.0, temperature=1.0):
-        if any("boom" in t for t in texts):
-            raise RuntimeError("synthetic failure")
+    def check_speaker_reference(self, spk):
+        if "missing" in spk:
+            raise FileNotFoundError(spk)
+
+    def synthesise_batch(self, texts, spk_refs, top_p=0.95, guidance_scale=3.0, temperature=1.0, return_exceptions=False):
+        if any("crash" in t for t in texts):
+            raise RuntimeError("the whole call fails")  # something the per-item handling of TTS.synthesise_wavs does not catch
         self.batches.append(list(texts))
-        return [b"RIFF" + f"|{t}|{s}|{top_p}|{guidance_scale}|rank{self.rank}".encode() * (1 + len(t) % 3) for t, s in zip(texts, spk_refs)]
+        out = []
+        for t, s in zip(texts, spk_refs):
+            if "boom" in t:
+                e = RuntimeError("synthetic failure")
+                if not return_exceptions:
+                    raise e
+                out.append(e)
+            else:
+                out.append(b"RIFF" + f"|{t}|{s}|{top_p}|{guidance_scale}|rank{self.rank}".encode() * (1 + len(t) % 3))
+        return out
 
 
 def test_batching_dispatcher_groups_concurrent_requests(tmp_path):
@@ -125,11 +148,24 @@ def test_batching_dispatcher_groups_concurrent_requests(tmp_path):
     assert all(len({"guid" for _ in b}) == 1 for b in tts.batches)
     code, _, body = post(base + "/tts", urllib.parse.urlencode({"text": "boom", "speaker_ref_path": "x"}).encode())
     assert code == 500 and body.decode() == serving.ERROR_TEXT
+    # ONE bad request in a batch fails alone: the requests grouped with it still get their audio (it used to 500 them all)
+    results.clear()
+    threads = [threading.Thread(target=call, args=(i,)) for i in (20, 21)]
+    threads.append(threading.Thread(target=call, args=(22, {"text": "boom 22"})))
+    threads.append(threading.Thread(target=call, args=(23, {"speaker_ref_path": "/refs/missing.wav"})))  # refused before dispatch
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert results[20][0] == 200 and results[21][0] == 200 and b"|request 21|" in results[21][2]
+    assert results[22][0] == 500 and results[22][2].decode() == serving.ERROR_TEXT
+    assert results[23][0] == 500
+    assert not any("request 23" in t for b in tts.batches for t in b)
     srv.shutdown()
     disp.stop()
 
 
-def _dispatch_worker(rank, world, port, q):
+def _dispatch_worker(rank, world, port, q, texts_by_round=None):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -143,13 +179,21 @@ def _dispatch_worker(rank, world, port, q):
     else:
         disp.start()
         out = {}
-        ths = [threading.Thread(target=lambda i=i: out.__setitem__(i, disp.submit(f"utt {i}", f"/r/{i}.wav", 0.95, 3.0))) for i in range(4)]
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
+
+        def ask(i, text):
+            try:
+                out[i] = disp.submit(text, f"/r/{i}.wav", 0.95, 3.0).decode()
+            except Exception as e:
+                out[i] = f"ERROR {e}"
+
+        for texts in (texts_by_round or [[f"utt {i}" for i in range(4)]]):
+            ths = [threading.Thread(target=ask, args=(len(out) + j, t)) for j, t in enumerate(texts)]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
         disp.stop()
-        q.put((rank, tts.batches, {i: v.decode() for i, v in out.items()}, disp.batches))
+        q.put((rank, tts.batches, dict(out), disp.batches))
     dist.destroy_process_group()
 
 
@@ -183,3 +227,84 @@ def test_dispatcher_shards_a_batch_over_two_ranks():
     assert sum(a for a, _ in by_rank.values()) + sum(b for _, b in by_rank.values()) == 4
     assert any(b for _, b in by_rank.values()), "rank 1 never produced a result"
     assert sum(len(b) for b in r0[1]) + sum(len(b) for b in r1[1]) == 4
+
+
+def test_a_failing_request_does_not_hang_the_other_rank():
+    """a request that raises on one rank used to make that rank skip the gather the other rank was already
+    blocked in.  Now the failure travels through the gather as an error payload: only that request fails, the ranks stay in step
+    and the NEXT batch is served normally -- also when a rank's whole `synthesise_batch` call raises."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    rounds = [["ok a", "boom b", "ok c", "boom d"], ["crash e", "ok f", "ok g", "ok h"], ["after 1", "after 2"]]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dispatch_worker, args=(r, 2, port, q, rounds)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0, "a rank died or hung"
+    out = next(g for g in got if g[0] == 0)[2]
+    texts = [t for r in rounds for t in r]
+    assert len(out) == len(texts)
+    by_text = {}
+    for v in out.values():
+        for t in texts:
+            if f"|{t}|" in v:
+                by_text[t] = v
+    failed = [v for v in out.values() if v.startswith("ERROR")]
+    for t in ("ok a", "ok c", "after 1", "after 2"):
+        assert t in by_text and by_text[t].startswith("RIFF")
+    assert sum("synthetic failure" in v for v in failed) == 2
+    # the crashed call takes down only the items that shared its rank in that batch
+    assert 1 <= sum("the whole call fails" in v for v in failed) <= 2
+    assert len(failed) + len(by_text) == len(texts)
+
+
+def test_tts_stream_is_chunked_and_starts_with_an_open_ended_riff_header(server):
+    import http.client
+    import struct
+
+    base, _ = server
+    host, port = base.replace("http://", "").split(":")
+    conn = http.client.HTTPConnection(host, int(port), timeout=10)
+    conn.request("POST", "/tts_stream", body=urllib.parse.urlencode({"text": "one. two. three", "speaker_ref_path": "/refs/a.wav"}),
+                 headers={"Content-Type": "application/x-www-form-urlencoded"})
+    r = conn.getresponse()
+    assert r.status == 200 and r.getheader("Transfer-Encoding") == "chunked" and r.getheader("Content-Type") == "audio/wav"
+    body = r.read()
+    assert body[:4] == b"RIFF" and body[8:16] == b"WAVEfmt " and body[4:8] == b"\xff\xff\xff\xff"
+    fmt = struct.unpack("<HHIIHH", body[20:36])
+    assert fmt == (1, 1, 24000, 48000, 2, 16) and body[36:40] == b"data"
+    pcm = struct.unpack(f"<{(len(body) - 44) // 2}h", body[44:])
+    assert len(pcm) == 10 + 20 + 30  # three chunks, in order
+    assert pcm[0] == round(0.25 * 32767) and pcm[10] == round(0.5 * 32767) and pcm[-1] == round(0.75 * 32767)
+    # the same connection serves the next request (HTTP/1.1 keep-alive with explicit lengths everywhere else)
+    conn.request("GET", "/health")
+    r = conn.getresponse()
+    assert r.status == 200 and json.loads(r.read()) == {"status": "ok"}
+    conn.close()
+    # failures before the first chunk: the contract of /tts
+    code, _, body = post(base + "/tts_stream", urllib.parse.urlencode({"text": "boom", "speaker_ref_path": "x"}).encode())
+    assert code == 500 and body.decode() == serving.ERROR_TEXT
+    code, _, body = post(base + "/tts_stream", urllib.parse.urlencode({"text": "no speaker"}).encode())
+    assert code == 400
+    # a failure after the response was committed truncates the stream instead of hanging the client
+    conn = http.client.HTTPConnection(host, int(port), timeout=10)
+    conn.request("POST", "/tts_stream", body=urllib.parse.urlencode({"text": "fine. also fine. late failure", "speaker_ref_path": "x"}),
+                 headers={"Content-Type": "application/x-www-form-urlencoded"})
+    r = conn.getresponse()
+    assert r.status == 200
+    try:
+        got = r.read()
+    except http.client.IncompleteRead as e:
+        got = e.partial
+    assert got[:4] == b"RIFF" and len(got) == 44 + 2 * (10 + 20)
+    conn.close()
