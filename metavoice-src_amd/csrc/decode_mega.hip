@@ -165,13 +165,14 @@ __host__ __device__ constexpr size_t mega_lds_bytes(int n_utt) {  // dynamic LDS
     return (size_t)n_utt * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2) + ATTN_WAVES * 16 * 12 * 4 + (size_t)n_utt * MG_WAVES * 2 * 4;
 }
 
-// The token draw OUT OF LINE: sample_draw keeps ~60 values per thread; inlined they are part of the layer loop's register
-// allocation and the 2- and 4-utterance instances spill inside the layer loop.  The workgroup of utterance u calls it with nothing in
-// flight (its layer-0 rows are requested after the control word has left: publish before prefetch).
-// sample() + the bookkeeping of decode_n_tokens + (last step of a launch) the next launch's input rows:
-// fast_inference_utils.py:61-120,148-174, fast_model.py:152-157 -- sample_core.h, the arithmetic of sample_kernel.
+// sample() + the bookkeeping of decode_n_tokens + (last step of a launch) the next launch's input rows, by the workgroup of
+// utterance u: fast_inference_utils.py:61-120,148-174, fast_model.py:152-157 -- sample_core.h, the arithmetic of sample_kernel.
+// Inlined on purpose.  Round 3 measured it OUT of line (`noinline`, so that sample_draw's ~60 live values stay out of the layer
+// loop's register allocation and engines of 2 / 4 utterances and int8 engines could draw in the launch too): every instance got
+// SLOWER by 100-220 us/step (bf16 866 vs 722, int8 792 vs 680, 2 / 4 utterances 1211 / 1863 vs 1092 / 1643; profiles/r03a) -- the
+// call site saves and restores the kernel's live registers through scratch (368 B/lane) and the allocation around it degraded.
 template <int NU>
-__device__ __attribute__((noinline)) void mega_draw_and_publish(const MegaArgs& a, const int u, const bf16_t* lg, UttState* st_p, SampleScratch* sc_p,
+__device__ __forceinline__ void mega_draw_and_publish(const MegaArgs& a, const int u, const bf16_t* lg, UttState* st_p, SampleScratch* sc_p,
                                                                 const int VP, const uint32_t tag_next, const bool last_step, const int tid_t) {
     UttState& st_s = *st_p;
     SampleScratch& smp_sc = *sc_p;
@@ -845,11 +846,12 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                                *(uint32_t*)(lg + VP + 2 * n) = (p0 >> 16) | (p1 & 0xFFFF0000u);
                            });
         }
+        // this workgroup's layer-0 rows: in flight while the token is drawn, landed before the publishes
+        if (!last_step) issue_layer0(lane_t, wave_t);
         __syncthreads();
         MG_ABORT_RETURN();
         mega_draw_and_publish<NU>(a, u, lg, &st_s, &smp_sc, VP, tag_next, last_step, tid_t);
         if (tid_t == 0 && u == 0) a.step_counter_out[0] = counter0 + (uint32_t)step + 1u;  // the next launch's first epoch
-        if (!last_step) issue_layer0(lane_t, wave_t);  // after the control word has left (publish before prefetch)
     } else if (!last_step) {
         issue_layer0(lane_t, wave_t);
     }
@@ -900,9 +902,7 @@ bool mega_supported(const mv_config& c, int rows, int n_cus) {
 // One utterance per engine (the rolled utterance loops of the 2 / 4-utterance instances spill inside the layer loop once the sampler
 // tail is compiled in), bf16 or int4: the int8 instance measured SLOWER with the tail (1426 vs 1452 tok/s on the same box; bf16
 // +1.4 %, int4 +2.2 %), so int8 engines keep one step per launch + sample_kernel.
-bool mega_folds(const mv_config& c) {
-    return c.max_utterances <= g_tune.mega_fold_max_utt && (c.weight_format != MV_W_INT8 || g_tune.mega_fold_int8);
-}
+bool mega_folds(const mv_config& c) { return c.max_utterances <= MEGA_FOLD_MAX_UTT && c.weight_format != MV_W_INT8; }
 
 __global__ void bump_counter_kernel(uint32_t* c) { c[0] += 1u; }
 hipError_t launch_bump_counter(hipStream_t s, uint32_t* c) {
@@ -926,9 +926,9 @@ static hipError_t launch_mega_instance(hipStream_t s, const MegaArgs& a) {
 template <int WF>
 static hipError_t launch_mega_format(hipStream_t s, const MegaArgs& a) {
     switch (a.n_utt) {
-        case 1: return a.n_steps > 0 ? launch_mega_instance<WF, 1, true>(s, a) : launch_mega_instance<WF, 1, false>(s, a);
-        case 2: return a.n_steps > 0 ? launch_mega_instance<WF, 2, true>(s, a) : launch_mega_instance<WF, 2, false>(s, a);
-        case 4: return a.n_steps > 0 ? launch_mega_instance<WF, 4, true>(s, a) : launch_mega_instance<WF, 4, false>(s, a);
+        case 1: return a.n_steps > 0 ? (WF == MV_W_INT8 ? hipErrorInvalidValue : launch_mega_instance<WF, 1, WF != MV_W_INT8>(s, a)) : launch_mega_instance<WF, 1, false>(s, a);
+        case 2: return a.n_steps > 0 ? hipErrorInvalidValue : launch_mega_instance<WF, 2, false>(s, a);
+        case 4: return a.n_steps > 0 ? hipErrorInvalidValue : launch_mega_instance<WF, 4, false>(s, a);
         default: return hipErrorInvalidValue;
     }
 }

@@ -396,8 +396,6 @@ int mv_tune(mv_engine* e, const char* key, int32_t value) {
     else if (k == "gemv_ablate") g_tune.gemv_ablate = value;
     else if (k == "mega_fold") g_tune.mega_fold = value;
     else if (k == "mega_steps") g_tune.mega_steps = value < 1 ? 1 : value;
-    else if (k == "mega_fold_max_utt") g_tune.mega_fold_max_utt = value;
-    else if (k == "mega_fold_int8") g_tune.mega_fold_int8 = value;
     else if (k == "mega_fault") g_tune.mega_fault = value;
     else return fail(MV_ERR_INVALID, "unknown tuning key '%s'", key);
     if (e && e->finalized) e->graph_dirty = true;  // launch geometry is frozen in the captured graph: re-capture at mv_begin

@@ -6,9 +6,9 @@
 
 typedef uint16_t bf16_t;
 
-// defaults of the token-draw-in-launch policy (mv_tune "mega_fold_max_utt" / "mega_fold_int8")
-#define MEGA_FOLD_MAX_UTT 4
-#define MEGA_FOLD_INT8 1
+// Engines of more utterances keep sample_kernel behind every step, and so do int8 engines: with the token draw compiled in (inlined
+// or out of line) those instances measured slower (r02: int8 1426 vs 1452 tok/s; r03a out of line: see decode_mega.hip)
+#define MEGA_FOLD_MAX_UTT 1
 
 // ---- tuning knobs (mv_tune): defaults are the measured best for MetaVoice-1B on MI355X (DESIGN.md "Tuning") ------
 struct MvTune {
@@ -22,9 +22,7 @@ struct MvTune {
                                          // (MetaVoice-1B shape, >= 256 CUs); 0: per-layer launches
     int mega_steps = 512;                // decode steps per launch of the folding persistent kernel
     int mega_fold = 1;                   // 1: the persistent kernel also draws the token and runs several steps per launch (engines
-                                         // of up to mega_fold_max_utt utterances); 0: one step per launch + sample_kernel
-    int mega_fold_max_utt = MEGA_FOLD_MAX_UTT;  // engines of more utterances keep sample_kernel behind every step
-    int mega_fold_int8 = MEGA_FOLD_INT8;        // int8 engines draw in the launch too (round 2, inlined draw: 1426 vs 1452 tok/s, i.e. slower)
+                                         // of up to MEGA_FOLD_MAX_UTT utterances, bf16 / int4); 0: one step per launch + sample_kernel
 };
 extern MvTune g_tune;
 

@@ -81,19 +81,13 @@ def test_full_size_two_utterances_in_the_persistent_kernel():
     sps = [mv.SamplingParams(top_p=0.95, guidance_scale=3.0, seed=80 + u) for u in range(2)]
     engine.capture_logits(True)
     out = {}
-    for mega, fold in ((1, 1), (1, 0), (0, 0)):
-        engine.tune(mega=mega, mega_fold=fold)
+    for mega in (1, 0):
+        engine.tune(mega=mega)
         engine.begin(prompts, spks, sps, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
         engine.run()
-        res = ([engine.tokens(u) for u in range(2)], engine.captured_logits(max(lens) - 1, n_new - 1))
-        if mega:
-            assert engine.decode_path() == (1 + fold, 0), "a persistent launch was abandoned: the comparison would be launches against launches"
-        if mega and fold:
-            folded = res
-        else:
-            out[mega] = res
-    engine.tune(mega=1, mega_fold=1)
-    assert folded[0] == out[0][0] and torch.equal(folded[1], out[0][1]), "token draw inside the launch differs from the launches"
+        out[mega] = ([engine.tokens(u) for u in range(2)], engine.captured_logits(max(lens) - 1, n_new - 1))
+    engine.tune(mega=1)
+    assert engine.decode_path() == (1, 0), "a persistent launch was abandoned: the comparison would be launches against launches"
     assert out[1][0] == out[0][0] and torch.equal(out[1][1], out[0][1])
     assert [len(t) for t in out[1][0]] == [lens[0] + n_new, lens[1] + n_new]
     engine.close()
