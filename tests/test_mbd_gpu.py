@@ -58,6 +58,33 @@ def test_unet_forward_matches_oracle(kw, T, frames):
         eng.close()
 
 
+@pytest.mark.parametrize("kw,T", [
+    (dict(hidden=64, depth=2, growth=4.0, codec_dim=None), 20011),    # 256 channels: one column tile, ragged last row tile
+    (dict(hidden=96, depth=2, growth=4.0, codec_dim=None), 9000),     # 384 channels: a ragged second column tile (rows clamped)
+    (dict(hidden=32, depth=3, growth=4.0, codec_dim=24), 16000),      # 512 channels at the bottom: two full column tiles, K = 1536 / 1024
+])
+def test_unet_forward_on_the_256x256_tile_gemm(kw, T, monkeypatch):
+    """`mbd_gemm_t256_kernel` (256 x 256 tiles, double-buffered direct-to-LDS stages, three-term products): the kernel the 768- and
+    3072-channel layers of the bench run on.  Its block-count threshold is lowered so that small shapes with ragged row / column
+    tiles take it; the result must match the oracle like every other GEMM path -- and the 128 x 128 path on the same input."""
+    pkg = synthetic.mbd_package(seed=11, n_bands=2, proc_bands=1, **kw)
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(T, generator=g)
+    lat = torch.randn(1, kw["codec_dim"], 11, generator=g) if kw.get("codec_dim") else None
+    band = oracle_bands(pkg)[1]
+    ref = o_mbd.unet_forward(band.sd, band.cfg, x.view(1, 1, -1), 412, lat).reshape(-1)
+    eng = mbd.MultiBandDiffusionBands.from_package(pkg, precision=3, eq_bands=1)
+    small = eng.unet_forward(1, x, 412, lat)               # default thresholds: 128 x 128 / 64 x 128 tiles at these sizes
+    monkeypatch.setenv("MV_MBD_T256_MIN_BLOCKS", "1")
+    big = eng.unet_forward(1, x, 412, lat)
+    monkeypatch.delenv("MV_MBD_T256_MIN_BLOCKS")
+    s_big, s_small, s_pair = snr_db(big, ref), snr_db(small, ref), snr_db(big, small)
+    print(f"[mbd t256 {kw} T={T}] SNR vs oracle: 256x256 tiles {s_big:.1f} dB, 128x128 tiles {s_small:.1f} dB; between the two {s_pair:.1f} dB")
+    assert s_big >= 60.0 and s_small >= 60.0 and s_pair >= 80.0
+    assert not torch.equal(big, small) or s_pair == float("inf")
+    eng.close()
+
+
 def test_unet_with_bilstm_bottleneck():
     """BiLSTM bottleneck (codec conditioning reaches the output only through it): the HIP persistent LSTM kernel in both directions
     against the oracle's explicit-gate restatement and against torch.nn.LSTM on the same weights."""
