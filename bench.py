@@ -237,9 +237,10 @@ def measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline):
                 t2 = time.perf_counter()
                 grid8 = torch.tensor(audio_ids, dtype=torch.long).unsqueeze(0)
                 if diffusion is not None:
-                    wav, latent = vocoder.decode(grid8, return_latent=True)
+                    # the codec's waveform and latent stay in device memory for the diffusion bands (vocoder.MultiBandDiffusion.tokens_to_wav)
+                    d_wav, d_lat, samples, frames = vocoder.decode_device(grid8)
                     t3 = time.perf_counter()
-                    wav = diffusion.tokens_to_wav(latent, wav)
+                    wav = diffusion.tokens_to_wav_device(d_lat, frames, d_wav, samples)
                     stage_ms["multiband_diffusion"] += (time.perf_counter() - t3) * 1e3
                 else:
                     wav = vocoder.decode(grid8)

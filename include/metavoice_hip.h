@@ -193,6 +193,11 @@ int64_t mv_codec_samples(const mv_codec* c, int32_t frames);   /* frames x prod(
 /* tokens: host int32 [n_q][frames]; wav_out: host fp32 [audio_channels][samples]; latent_out (optional): host fp32
  * [hidden][frames], the summed codebook vectors (`decode_latent`, the diffusion decoder's conditioning). */
 int mv_codec_decode(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t frames, float* wav_out, float* latent_out);
+/* The same decode with the results LEFT ON THE DEVICE for the next stage (mv_mbd_generate_device): *d_wav fp32 [samples] and
+ * *d_latent fp32 [hidden][frames] point into the codec's own workspace and stay valid until the next call on this codec; the
+ * codec's stream has been synchronised when the call returns.  (fam/llm/decoders.py:84-85: `mbd.tokens_to_wav` hands the codec's
+ * outputs to the diffusion bands on the GPU; so does this pair of entry points -- no PCIe leg between the two stages.) */
+int mv_codec_decode_device(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t frames, const float** d_wav, const float** d_latent);
 
 /* ---- multi-band diffusion vocoder: replaces `mbd.tokens_to_wav` after the codec decode (fam/llm/decoders.py:13,84-85 ->
  * audiocraft==1.2.0 MultiBandDiffusion.generate / re_eq, third party): n_models DiffusionUnets (one per frequency band), n_eval
@@ -234,6 +239,10 @@ int mv_mbd_finalize(mv_mbd* m);
  * re_eq); noise: host fp32 [n_models][n_eval + 1][samples] injected Gaussian draws (parity tests) or NULL = Philox stream of `seed` */
 int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float* wav_ref, int32_t samples, const float* noise, uint64_t seed,
                     float* wav_out);
+/* the same with the codec's outputs read in place from DEVICE memory (mv_codec_decode_device): d_latent fp32 [codec_dim][frames]
+ * (NULL when codec_dim == 0), d_wav_ref fp32 [samples] (NULL: no re_eq); the engine's own Philox noise stream */
+int mv_mbd_generate_device(mv_mbd* m, const float* d_latent, int32_t frames, const float* d_wav_ref, int32_t samples, uint64_t seed,
+                           float* wav_out);
 /* parity hook: one DiffusionUnet evaluation of band `band` at diffusion step `step` on x host fp32 [samples] */
 int mv_mbd_unet_forward(mv_mbd* m, int32_t band, const float* x, int32_t samples, int32_t step, const float* latent, int32_t frames, float* out);
 

@@ -104,6 +104,7 @@ SYMBOLS = [
     ("mv_codec_finalize", C.c_int, [_P]),
     ("mv_codec_samples", C.c_int64, [_P, C.c_int32]),
     ("mv_codec_decode", C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("mv_codec_decode_device", C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("mv_mbd_create", C.c_int, [C.POINTER(mv_mbd_config), C.POINTER(_P)]),
     ("mv_mbd_destroy", C.c_int, [_P]),
     ("mv_mbd_load_weight", C.c_int, [_P, C.c_int32, C.c_char_p, C.POINTER(C.c_float), C.c_int64]),
@@ -114,6 +115,7 @@ SYMBOLS = [
     ("mv_mbd_finalize", C.c_int, [_P]),
     ("mv_mbd_generate", C.c_int, [_P, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.c_uint64,
                                   C.POINTER(C.c_float)]),
+    ("mv_mbd_generate_device", C.c_int, [_P, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(C.c_float)]),
     ("mv_mbd_unet_forward", C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32,
                                       C.POINTER(C.c_float)]),
     ("mv_spkenc_create", C.c_int, [C.POINTER(mv_spkenc_config), C.POINTER(_P)]),

@@ -87,4 +87,15 @@ class EncodecDecoder:
         w = torch.from_numpy(wav).unsqueeze(0)
         return (w, torch.from_numpy(lat).unsqueeze(0)) if return_latent else w
 
+    def decode_device(self, tokens: torch.Tensor):
+        """The same decode with the results left in the codec's device workspace: -> (wav pointer, latent pointer, samples, frames),
+        raw device addresses valid until the next call on this codec -- what `mbd.MultiBandDiffusionBands.tokens_to_wav_device`
+        consumes (the reference hands the codec's outputs to the diffusion bands on the GPU as well, `fam/llm/decoders.py:84-85`)."""
+        assert tokens.dim() == 3 and tokens.shape[0] == 1
+        nq, frames = int(tokens.shape[1]), int(tokens.shape[2])
+        tok = np.ascontiguousarray(tokens[0].detach().cpu().numpy().astype(np.int32))
+        d_wav, d_lat = C.c_void_p(), C.c_void_p()
+        N.check(N.lib().mv_codec_decode_device(self._h, tok.ctypes.data_as(C.POINTER(C.c_int32)), nq, frames, C.byref(d_wav), C.byref(d_lat)))
+        return d_wav.value, d_lat.value, int(N.lib().mv_codec_samples(self._h, frames)), frames
+
     __call__ = decode

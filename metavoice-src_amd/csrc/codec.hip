@@ -154,6 +154,9 @@ struct mv_codec {
     std::vector<int> lstm_loaded;                    // bitmask: 1 w_ih, 2 w_hh, 4 b_ih, 8 b_hh
     bool finalized = false;
     int dim0 = 0;  // channels after conv_in (num_filters * 2^n_ratios)
+    // per-call workspace, kept between calls (grown on demand): token ids, four activation buffers, the latent of the last call
+    void* ws[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t ws_cap[6] = {0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -261,6 +264,7 @@ int mv_codec_destroy(mv_codec* c) {
     if (!c) return MV_OK;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void* p : c->allocs) (void)hipFree(p);
+    for (void* p : c->ws) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return MV_OK;
@@ -355,10 +359,15 @@ int64_t mv_codec_samples(const mv_codec* c, int32_t frames) {
     return n;
 }
 
-int mv_codec_decode(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t frames, float* wav_out, float* latent_out) {
+}  // extern "C"
+
+// Shared body of mv_codec_decode (results copied to host buffers) and mv_codec_decode_device (results left in the codec's own
+// device workspace for the next stage).
+static int codec_run(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t frames, float* wav_out, float* latent_out,
+                     const float** d_wav, const float** d_latent) {
     if (!c || !c->finalized) return mv_fail(MV_ERR_STATE, "codec not finalized");
     const mv_codec_config& g = c->cfg;
-    if (!tokens || !wav_out || n_q < 1 || n_q > g.n_q || frames < 8) return mv_fail(MV_ERR_INVALID, "bad tokens / n_q / frames (>= 8)");
+    if (!tokens || (!wav_out && !d_wav) || n_q < 1 || n_q > g.n_q || frames < 8) return mv_fail(MV_ERR_INVALID, "bad tokens / n_q / frames (>= 8)");
     for (size_t i = 0; i < (size_t)n_q * frames; ++i)
         if (tokens[i] < 0 || tokens[i] >= g.bins) return mv_fail(MV_ERR_INVALID, "token %d outside the codebook", tokens[i]);
     hipStream_t s = c->stream;
@@ -372,18 +381,27 @@ int mv_codec_decode(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t fra
     }
     int32_t* d_tok = nullptr;
     float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
-    auto cleanup = [&]() {
-        if (d_tok) (void)hipFree(d_tok);
-        for (float* b : buf) if (b) (void)hipFree(b);
-    };
+    float* d_lat_keep = nullptr;
+    auto cleanup = [&]() {};   // the workspace stays with the codec (hipMalloc / hipFree per call cost more than the small kernels)
 #define CD_TRY2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return mv_fail(MV_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
-    CD_TRY2(hipMalloc((void**)&d_tok, (size_t)n_q * frames * 4));
-    for (auto& b : buf) CD_TRY2(hipMalloc((void**)&b, widest * 4));
+    {
+        const size_t need[6] = {(size_t)n_q * frames * 4, widest * 4, widest * 4, widest * 4, widest * 4, (size_t)g.hidden * frames * 4};
+        for (int i = 0; i < 6; ++i)
+            if (c->ws_cap[i] < need[i]) {
+                if (c->ws[i]) { CD_TRY2(hipStreamSynchronize(s)); (void)hipFree(c->ws[i]); c->ws[i] = nullptr; c->ws_cap[i] = 0; }
+                CD_TRY2(hipMalloc(&c->ws[i], need[i]));
+                c->ws_cap[i] = need[i];
+            }
+        d_tok = (int32_t*)c->ws[0];
+        for (int i = 0; i < 4; ++i) buf[i] = (float*)c->ws[1 + i];
+        d_lat_keep = (float*)c->ws[5];
+    }
     CD_TRY2(hipMemcpyAsync(d_tok, tokens, (size_t)n_q * frames * 4, hipMemcpyHostToDevice, s));
     int T = frames;
     float *x = buf[0], *e = buf[1], *u = buf[2], *h = buf[3];
     hipLaunchKernelGGL(rvq_decode_kernel, dim3((T + 255) / 256, g.hidden), dim3(256), 0, s, d_tok, c->embed, e, n_q, g.bins, g.hidden, T);
     if (latent_out) CD_TRY2(hipMemcpyAsync(latent_out, e, (size_t)g.hidden * T * 4, hipMemcpyDeviceToHost, s));
+    if (d_latent) CD_TRY2(hipMemcpyAsync(d_lat_keep, e, (size_t)g.hidden * T * 4, hipMemcpyDeviceToDevice, s));  // `e` is reused below
     CD_TRY2(run_conv(s, c->conv_in, e, x, T, false));
     // LSTM stack with a skip connection around it (EncodecLSTM.forward): y = lstm(x) + x
     {
@@ -422,7 +440,9 @@ int mv_codec_decode(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t fra
     }
     hipLaunchKernelGGL(elu_kernel, dim3((unsigned)(((size_t)ch * T + 255) / 256)), dim3(256), 0, s, x, e, (size_t)ch * T);
     CD_TRY2(run_conv(s, c->conv_out, e, u, T, false));
-    CD_TRY2(hipMemcpyAsync(wav_out, u, (size_t)g.audio_channels * n_out * 4, hipMemcpyDeviceToHost, s));
+    if (wav_out) CD_TRY2(hipMemcpyAsync(wav_out, u, (size_t)g.audio_channels * n_out * 4, hipMemcpyDeviceToHost, s));
+    if (d_wav) *d_wav = u;
+    if (d_latent) *d_latent = d_lat_keep;
     uint32_t aborted = 0;
     if (c->lstm_abort) CD_TRY2(hipMemcpyAsync(&aborted, c->lstm_abort, 4, hipMemcpyDeviceToHost, s));
     CD_TRY2(hipStreamSynchronize(s));
@@ -433,6 +453,18 @@ int mv_codec_decode(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t fra
         return mv_fail(MV_ERR_HIP, "mv_codec_decode: the LSTM workgroups timed out waiting for each other (device shared with another kernel?)");
     }
     return MV_OK;
+}
+
+extern "C" {
+
+int mv_codec_decode(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t frames, float* wav_out, float* latent_out) {
+    if (!wav_out) return mv_fail(MV_ERR_INVALID, "mv_codec_decode: wav_out is null");
+    return codec_run(c, tokens, n_q, frames, wav_out, latent_out, nullptr, nullptr);
+}
+
+int mv_codec_decode_device(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t frames, const float** d_wav, const float** d_latent) {
+    if (!d_wav) return mv_fail(MV_ERR_INVALID, "mv_codec_decode_device: d_wav is null");
+    return codec_run(c, tokens, n_q, frames, nullptr, nullptr, d_wav, d_latent);
 }
 
 }  // extern "C"

@@ -354,6 +354,20 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_glds3_kernel(const MbdGemmArg
 // Workgroup -> tile: XCD-aware (workgroup L runs on XCD L mod 8): the m-tiles that share a W tile get consecutive ids on ONE XCD,
 // so a weight tile crosses the fabric once per XCD instead of once per m-tile.
 constexpr int T256_STAGE_BYTES = 4 * 16 * 1024;   // a_hi | a_lo | w_hi | w_lo, 16 sub-tiles of 1 KB each
+#ifndef T256_SPREAD
+#define T256_SPREAD 0
+#endif
+// L2 prefetch distance in K-steps (0: none).  Two stages are all the LDS holds, so a stage's loads have ONE step (~1.4 us of MFMA
+// work) to land; a line that misses the L2 takes longer than that and the step time becomes the miss latency (r03b: 2.8 us per
+// step = 48 % of the MFMA peak).  Each wave therefore touches the lines its loads of step k + T256_PREFETCH will fetch with two
+// 4-byte-per-lane LDS-DMA requests into a scratch slot (64 row segments per request; nothing is read from the slot): the lines
+// are on their way into the XCD's L2 three steps ahead and the real loads hit.  The step barrier waits with a COUNTED vmcnt that
+// leaves exactly those two requests outstanding (loads retire in issue order), and is a raw s_barrier: __syncthreads() would
+// drain them (cdna_hip_programming.md 5, "Pipelining across barriers").
+#ifndef T256_PREFETCH
+#define T256_PREFETCH 3
+#endif
+constexpr int T256_LDS_BYTES = 2 * T256_STAGE_BYTES + 8 * 256;   // + a 256-byte scratch slot per wave for the prefetch requests
 __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs a, int nt_m, int nt_n, int n_blocks) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char t256_lds[];   // [2 stages][4 halves][16 sub-tiles][1 KB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -380,15 +394,37 @@ __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs
         oa[i] = (uint32_t)((size_t)min(tile_m + (2 * wave + i) * 16 + lrow, M - 1) * a.lda);
         ow[i] = (uint32_t)((size_t)min(tile_n + (2 * wave + i) * 16 + lrow, N - 1) * a.ldw);
     }
+    // piece p of a stage (8 per wave): sub-tile 2 wave + (p >> 2) of operand half p & 3
+    auto stage_piece = [&](int stage, int k0, int p) {
+        unsigned char* dst = t256_lds + stage * T256_STAGE_BYTES + (p & 3) * 16384 + (2 * wave + (p >> 2)) * 1024;
+        const bf16_t* src = (p & 3) == 0 ? ah + oa[p >> 2] : (p & 3) == 1 ? al + oa[p >> 2] : (p & 3) == 2 ? wh + ow[p >> 2] : wl + ow[p >> 2];
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + k0), (lds_ptr_t)dst, 16, 0, 0);
+    };
     auto stage_load = [&](int stage, int k0) {
-        unsigned char* base = t256_lds + stage * T256_STAGE_BYTES + (2 * wave) * 1024;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(ah + oa[i] + k0), (lds_ptr_t)(base + 0 * 16384 + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(al + oa[i] + k0), (lds_ptr_t)(base + 1 * 16384 + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wh + ow[i] + k0), (lds_ptr_t)(base + 2 * 16384 + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wl + ow[i] + k0), (lds_ptr_t)(base + 3 * 16384 + i * 1024), 16, 0, 0);
+        for (int p = 0; p < 8; ++p) stage_piece(stage, k0, p);
+    };
+    // prefetch: lane -> row segment (operand half lane >> 4, row lane & 15) of sub-tile 2 wave + q, q = 0, 1
+    uint32_t pa[2];
+    const bf16_t* pbase[2];
+    {
+        const int ph = lane >> 4, pr = lane & 15;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t ra = (uint32_t)((size_t)min(tile_m + (2 * wave + q) * 16 + pr, M - 1) * a.lda);
+            const uint32_t rw = (uint32_t)((size_t)min(tile_n + (2 * wave + q) * 16 + pr, N - 1) * a.ldw);
+            pa[q] = ph < 2 ? ra : rw;
         }
+        const bf16_t* b0 = a.seg[0].a + (size_t)band * a.a_band;
+        const bf16_t* b1 = a.seg[2].a + (size_t)band * a.a_band;
+        const bf16_t* b2 = a.w_hi.p[band] + a.seg[0].w_off;
+        const bf16_t* b3 = a.w_lo.p[band] + a.seg[0].w_off;
+        pbase[0] = pbase[1] = ph == 0 ? b0 : ph == 1 ? b1 : ph == 2 ? b2 : b3;
+    }
+    auto prefetch_step = [&](int k0) {
+        unsigned char* slot = t256_lds + 2 * T256_STAGE_BYTES + wave * 256;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) __builtin_amdgcn_global_load_lds((glb_ptr_t)(pbase[q] + pa[q] + k0), (lds_ptr_t)slot, 4, 0, 0);
     };
     // fragment reads: lane -> row lane & 15, chunk lane >> 4 of a sub-tile
     const int frow = lane & 15;
@@ -403,9 +439,22 @@ __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs
     const int nk = K / 32;
     stage_load(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // stage kt has landed for every wave; everybody is through with the other buffer (step kt - 1)
-        if (kt + 1 < nk) stage_load((kt + 1) & 1, (kt + 1) * 32);
+        // stage kt has landed for every wave; everybody is through with the other buffer (step kt - 1)
+        if (T256_PREFETCH > 0) {
+            // the two newest requests of this wave are the prefetches of step kt - 1 (if it issued any): they may stay in flight
+            if (kt >= 1 && kt - 1 + T256_PREFETCH < nk) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        // The next stage's 8 load instructions per wave: all at once here (SPREAD 0), or two in front of each of the first four MFMA
+        // groups (SPREAD 1): a wave issuing 8 LDS-DMA pieces back to back sits ~100 cycles on each (MI355X_MICROARCH.md, LDS-DMA
+        // piece issue cost) while its SIMD partner does the same, i.e. the MFMA pipe idles
+        const bool more = kt + 1 < nk;
+        if (T256_SPREAD == 0 && more) stage_load((kt + 1) & 1, (kt + 1) * 32);
+        if (T256_PREFETCH > 0 && T256_SPREAD == 0 && kt + T256_PREFETCH < nk) prefetch_step((kt + T256_PREFETCH) * 32);
         const unsigned char* st = t256_lds + (kt & 1) * T256_STAGE_BYTES;
         bf16x8_t bfh[4], bfl[4];
 #pragma unroll
@@ -424,7 +473,12 @@ __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs
                 afl[i] = __builtin_bit_cast(bf16x8_t, *(const u32x4*)(st + 1 * 16384 + off));
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+                if (T256_SPREAD == 1 && half == 0 && more) {
+                    stage_piece((kt + 1) & 1, (kt + 1) * 32, 2 * i);
+                    stage_piece((kt + 1) & 1, (kt + 1) * 32, 2 * i + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4_t c = acc[half * 4 + i][j];
@@ -433,6 +487,7 @@ __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[i], bfh[j], c, 0, 0, 0);
                     acc[half * 4 + i][j] = c;
                 }
+            }
         }
     }
 #pragma unroll
@@ -772,6 +827,29 @@ struct BandW {
     std::vector<float> proc_scale, proc_mean;
 };
 
+// device workspace of mv_mbd_generate: the same sequence of requests every call, so slot i is reused as long as it is large
+// enough (about 25 hipMalloc + hipFree pairs per utterance otherwise: milliseconds, and hipFree synchronises the device)
+struct Work {
+    std::vector<void*> slots;
+    std::vector<size_t> cap;
+    size_t next = 0;
+    hipStream_t stream = nullptr;
+    void rewind(hipStream_t s) { next = 0; stream = s; }
+    void release() { for (void* p : slots) if (p) (void)hipFree(p); slots.clear(); cap.clear(); next = 0; }
+    template <typename T> hipError_t get(T** p, size_t count, bool zero) {
+        const size_t bytes = count * sizeof(T) + 64;
+        if (next == slots.size()) { slots.push_back(nullptr); cap.push_back(0); }
+        if (cap[next] < bytes) {
+            if (slots[next]) { (void)hipStreamSynchronize(stream); (void)hipFree(slots[next]); slots[next] = nullptr; cap[next] = 0; }
+            hipError_t e = hipMalloc(&slots[next], bytes);
+            if (e != hipSuccess) return e;
+            cap[next] = bytes;
+        }
+        *p = (T*)slots[next++];
+        return zero ? hipMemsetAsync(*p, 0, bytes, stream) : hipSuccess;
+    }
+};
+
 }  // namespace
 
 struct mv_mbd {
@@ -787,6 +865,7 @@ struct mv_mbd {
     unsigned long long* lstm_hx = nullptr;
     uint32_t* lstm_abort = nullptr;
     uint32_t lstm_serial = 0;
+    Work work;   // device workspace of mv_mbd_generate, kept between calls
 };
 
 namespace {
@@ -828,18 +907,6 @@ int upload_gemm_weight(mv_mbd* m, ConvW& cw, const std::vector<float>& rows, int
     return MV_OK;
 }
 
-// per-run device workspace
-struct Work {
-    std::vector<void*> allocs;
-    ~Work() { for (void* p : allocs) (void)hipFree(p); }
-    template <typename T> hipError_t get(T** p, size_t count, bool zero) {
-        hipError_t e = hipMalloc((void**)p, count * sizeof(T) + 64);
-        if (e != hipSuccess) return e;
-        allocs.push_back(*p);
-        return zero ? hipMemset(*p, 0, count * sizeof(T) + 64) : hipSuccess;
-    }
-};
-
 }  // namespace
 
 extern "C" {
@@ -877,6 +944,8 @@ int mv_mbd_create(const mv_mbd_config* cfg, mv_mbd** out) {
 
 int mv_mbd_destroy(mv_mbd* m) {
     if (!m) return MV_OK;
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    m->work.release();
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -1157,12 +1226,12 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
     const size_t t256_min = t256_min_env ? (size_t)atoi(t256_min_env) : 192;
     if (t256 && glds_mode == 2 && k64 && prec == 3 && taps == 1 && g.N >= 256 && (size_t)nt_m256 * nt_n256 * nb >= t256_min) {
         if (!t256_raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)mbd_gemm_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE_BYTES);
+            hipError_t e = hipFuncSetAttribute((const void*)mbd_gemm_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS_BYTES);
             if (e != hipSuccess) return e;
             t256_raised = true;
         }
         const int n_blocks = nt_m256 * nt_n256 * nb;
-        hipLaunchKernelGGL(mbd_gemm_t256_kernel, dim3(n_blocks), dim3(512), 2 * T256_STAGE_BYTES, s, g, nt_m256, nt_n256, n_blocks);
+        hipLaunchKernelGGL(mbd_gemm_t256_kernel, dim3(n_blocks), dim3(512), T256_LDS_BYTES, s, g, nt_m256, nt_n256, n_blocks);
     } else if (glds_mode == 2 && k64 && prec == 3 && taps == 1 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400)
         hipLaunchKernelGGL(mbd_gemm_glds3_kernel, dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
     else if (glds_mode >= 1 && k64 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400)
@@ -1225,18 +1294,23 @@ hipError_t res_block(hipStream_t s, const mv_mbd* m, RW rw, const float* x, int6
 
 extern "C" {
 
-// latent: host fp32 [codec_dim][frames] (mv_codec_decode's latent_out) or NULL when codec_dim == 0; wav_ref: host fp32 [T], the
-// EnCodec decode the result is re-equalised against (NULL: no re_eq); noise: host fp32 [n_models][n_eval + 1][T] (initial noise,
-// then one draw per evaluation; parity tests) or NULL = the engine's Philox stream keyed by `seed`; wav_out: host fp32 [T].
-int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float* wav_ref, int32_t T, const float* noise, uint64_t seed,
-                    float* wav_out) {
+}  // extern "C"
+
+// latent: fp32 [codec_dim][frames] (the codec's latent) or NULL when codec_dim == 0; wav_ref: fp32 [T], the EnCodec decode the
+// result is re-equalised against (NULL: no re_eq) -- both on the host, or (inputs_on_device) in device memory, where they are read
+// in place (mv_codec_decode_device's buffers: no PCIe leg between the codec and this stage); noise: host fp32
+// [n_models][n_eval + 1][T] (initial noise, then one draw per evaluation; parity tests) or NULL = the engine's Philox stream keyed
+// by `seed`; wav_out: host fp32 [T].
+static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, const float* wav_ref, int32_t T, const float* noise, uint64_t seed,
+                             float* wav_out, bool inputs_on_device) {
     if (!m || !wav_out) return mv_fail(MV_ERR_INVALID, "mv_mbd_generate: null argument");
     if (!m->finalized) return mv_fail(MV_ERR_STATE, "mv_mbd_generate before mv_mbd_finalize");
     const mv_mbd_config& g = m->cfg;
     if (T < g.kernel * 4 || (g.codec_dim > 0 && (!latent || frames < 1))) return mv_fail(MV_ERR_INVALID, "mv_mbd_generate: bad sizes (T = %d, frames = %d)", T, frames);
     hipStream_t s = m->stream;
     const int k = g.kernel, st = g.stride, pad = (k - st) / 2, D = g.depth, G = g.norm_groups, NB = g.n_models;
-    Work wk;
+    Work& wk = m->work;
+    wk.rewind(s);
     UnetBuffers ub;
     ub.NB = NB;
     // geometry
@@ -1279,7 +1353,8 @@ int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float*
     MG_TRY(wk.get(&total, (size_t)T, true));
     if (g.codec_dim > 0) {
         MG_TRY(wk.get(&d_lat, (size_t)g.codec_dim * frames, false));
-        MG_TRY(hipMemcpyAsync(d_lat, latent, (size_t)g.codec_dim * frames * 4, hipMemcpyHostToDevice, s));
+        if (inputs_on_device) d_lat = const_cast<float*>(latent);   // read-only below
+        else MG_TRY(hipMemcpyAsync(d_lat, latent, (size_t)g.codec_dim * frames * 4, hipMemcpyHostToDevice, s));
     }
     if (noise) MG_TRY(wk.get(&d_noise, (size_t)T * NB, false));
     const int max_bands = std::max(g.proc_bands, g.eq_bands);
@@ -1450,7 +1525,8 @@ int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float*
     float* result = total;
     if (wav_ref && g.eq_bands > 1) {
         MG_TRY(wk.get(&d_ref, (size_t)T, false));
-        MG_TRY(hipMemcpyAsync(d_ref, wav_ref, (size_t)T * 4, hipMemcpyHostToDevice, s));
+        if (inputs_on_device) d_ref = const_cast<float*>(wav_ref);
+        else MG_TRY(hipMemcpyAsync(d_ref, wav_ref, (size_t)T * 4, hipMemcpyHostToDevice, s));
         float* low = nullptr;
         MG_TRY(wk.get(&low, (size_t)g.eq_bands * T, false));
         MG_TRY(split(d_ref, g.eq_bands, m->eq_bank, m->eq_taps, low, bands2));
@@ -1474,7 +1550,19 @@ int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float*
     return MV_OK;
 }
 
-// One UNet evaluation (parity hook): x host fp32 [T] -> estimate host fp32 [T] for band `band_idx` at diffusion step `step`.
+extern "C" {
+
+int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float* wav_ref, int32_t T, const float* noise, uint64_t seed,
+                    float* wav_out) {
+    return mbd_generate_impl(m, latent, frames, wav_ref, T, noise, seed, wav_out, false);
+}
+
+// The same with the codec's outputs read in place from DEVICE memory (mv_codec_decode_device): d_latent fp32 [codec_dim][frames],
+// d_wav_ref fp32 [T]; the engine's own noise stream.
+int mv_mbd_generate_device(mv_mbd* m, const float* d_latent, int32_t frames, const float* d_wav_ref, int32_t T, uint64_t seed, float* wav_out) {
+    return mbd_generate_impl(m, d_latent, frames, d_wav_ref, T, nullptr, seed, wav_out, true);
+}
+
 int mv_mbd_unet_forward(mv_mbd* m, int32_t band_idx, const float* x, int32_t T, int32_t step, const float* latent, int32_t frames, float* out) {
     if (!m || !x || !out || band_idx < 0 || band_idx >= m->cfg.n_models) return mv_fail(MV_ERR_INVALID, "mv_mbd_unet_forward: bad argument");
     // run the generator for ONE evaluation with a schedule that makes the update the identity on the estimate: cur' = -est * 1

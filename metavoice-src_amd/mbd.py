@@ -174,6 +174,16 @@ class MultiBandDiffusionBands:
                                         (self._seed + 7919 * self._calls) & 0xFFFFFFFFFFFFFFFF, out.ctypes.data_as(fp)))
         return torch.from_numpy(out).view(1, 1, -1)
 
+    def tokens_to_wav_device(self, d_latent: Optional[int], frames: int, d_wav_encodec: Optional[int], samples: int) -> torch.Tensor:
+        """`tokens_to_wav` on the codec's DEVICE buffers (`codec.EncodecDecoder.decode_device`): no host round trip between the
+        codec and the diffusion bands; the engine's own Philox noise stream.  -> (1, 1, samples) fp32 on the host."""
+        out = np.empty(samples, dtype=np.float32)
+        self._calls += 1
+        N.check(N.lib().mv_mbd_generate_device(self._h, C.c_void_p(d_latent if self.codec_dim else None), frames if self.codec_dim else 0,
+                                               C.c_void_p(d_wav_encodec), samples, (self._seed + 7919 * self._calls) & 0xFFFFFFFFFFFFFFFF,
+                                               out.ctypes.data_as(C.POINTER(C.c_float))))
+        return torch.from_numpy(out).view(1, 1, -1)
+
     def unet_forward(self, band: int, x: torch.Tensor, step: int, latent: Optional[torch.Tensor]) -> torch.Tensor:
         """Parity hook: one DiffusionUnet evaluation, x (samples,) -> (samples,)."""
         fp = C.POINTER(C.c_float)

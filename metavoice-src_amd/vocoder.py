@@ -82,6 +82,10 @@ class MultiBandDiffusion:
         bands (parity tests); default = the engine's own Philox stream."""
         if self.diffusion is None:
             return self.codec_model.decode(tokens)
+        if noise is None and hasattr(self.codec_model, "decode_device") and hasattr(self.diffusion, "tokens_to_wav_device"):
+            # the codec's waveform and latent stay in device memory for the diffusion bands (no PCIe leg between the stages)
+            d_wav, d_lat, samples, frames = self.codec_model.decode_device(tokens)
+            return self.diffusion.tokens_to_wav_device(d_lat, frames, d_wav, samples)
         wav_encodec, latent = self.codec_model.decode(tokens, return_latent=True)
         return self.diffusion.tokens_to_wav(latent, wav_encodec, noise=noise)  # band processes, sum, re_eq against wav_encodec
 

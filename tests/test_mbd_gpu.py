@@ -141,3 +141,28 @@ def test_tokens_to_wav_with_injected_noise_matches_oracle():
     a, b = eng.tokens_to_wav(lat, wav_ref), eng.tokens_to_wav(lat, wav_ref)
     assert torch.isfinite(a).all() and not torch.equal(a, b)
     eng.close()
+
+
+def test_device_hand_off_from_the_codec_equals_the_host_path():
+    """`mv_codec_decode_device` -> `mv_mbd_generate_device` (the codec's waveform and latent read in place from device memory, what
+    `vocoder.MultiBandDiffusion.tokens_to_wav` does by default) against the host-buffer path: same kernels, same Philox stream
+    (same seed, same call count) => identical samples."""
+    codec_mod, vocoder = load_pkg("codec"), load_pkg("vocoder")
+    codec = codec_mod.EncodecDecoder.from_state_dict(synthetic.encodec_state_dict(seed=3))
+    kw = dict(hidden=16, depth=3, growth=2.0, codec_dim=128)
+    pkg = synthetic.mbd_package(seed=9, n_bands=2, proc_bands=4, **kw)
+    tokens = torch.randint(0, 1024, (1, 8, 40), generator=torch.Generator().manual_seed(5))
+    dev = vocoder.MultiBandDiffusion(codec, mbd.MultiBandDiffusionBands.from_package(pkg, precision=3, seed=77, step_list=[999, 500, 0], eq_bands=8))
+    a = dev.tokens_to_wav(tokens)
+    host = mbd.MultiBandDiffusionBands.from_package(pkg, precision=3, seed=77, step_list=[999, 500, 0], eq_bands=8)
+    wav_encodec, latent = codec.decode(tokens, return_latent=True)
+    b = host.tokens_to_wav(latent, wav_encodec)
+    assert a.shape == b.shape == (1, 1, 40 * 320) and torch.isfinite(a).all()
+    assert torch.equal(a, b), f"max |d| {float((a - b).abs().max()):.3e}"
+    # the workspace is kept between calls: a second utterance of another length on the same engines
+    tokens2 = torch.randint(0, 1024, (1, 8, 64), generator=torch.Generator().manual_seed(6))
+    a2 = dev.tokens_to_wav(tokens2)
+    w2, l2 = codec.decode(tokens2, return_latent=True)
+    assert torch.equal(a2, host.tokens_to_wav(l2, w2))
+    host.close()
+    dev.close()

@@ -3,11 +3,13 @@
 #   tools/build_variant.sh noearly "-DMEGA_EARLY_W1=0 -DMEGA_EARLY_W2=0"   ->  metavoice-src_amd/lib/libmv_noearly.so
 #   MV_HIP_LIB=$PWD/metavoice-src_amd/lib/libmv_noearly.so python tools/fold_sweep.py
 # (compile-time switches of decode_mega.hip: MEGA_EARLY_W1 / MEGA_EARLY_W2 / MEGA_EARLY_QKV; the product build uses its defaults)
+#   tools/build_variant.sh spread "-DT256_SPREAD=1" mbd                      (third argument: the source to recompile, default decode_mega)
 set -eu
 NAME=$1
 FLAGS=$2
+SRC=${3:-decode_mega}
 cd "$(dirname "$0")/../metavoice-src_amd/csrc"
 make -j8 > /dev/null
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -I../../include $FLAGS -c decode_mega.hip -o "../lib/obj/decode_mega_${NAME}.oo"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls ../lib/obj/*.o | grep -v '/decode_mega.o') "../lib/obj/decode_mega_${NAME}.oo" -o "../lib/libmv_${NAME}.so"
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -I../../include $FLAGS -c $SRC.hip -o "../lib/obj/${SRC}_${NAME}.oo"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls ../lib/obj/*.o | grep -v "/${SRC}.o") "../lib/obj/${SRC}_${NAME}.oo" -o "../lib/libmv_${NAME}.so"
 ls -la "../lib/libmv_${NAME}.so"
