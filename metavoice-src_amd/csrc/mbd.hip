@@ -355,17 +355,16 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_glds3_kernel(const MbdGemmArg
 // so a weight tile crosses the fabric once per XCD instead of once per m-tile.
 constexpr int T256_STAGE_BYTES = 4 * 16 * 1024;   // a_hi | a_lo | w_hi | w_lo, 16 sub-tiles of 1 KB each
 #ifndef T256_SPREAD
-#define T256_SPREAD 0
+#define T256_SPREAD 1   // r03c, same box: 140.0 ms (spread) vs 142.2 ms (all eight requests right after the barrier) for the whole stage
 #endif
-// L2 prefetch distance in K-steps (0: none).  Two stages are all the LDS holds, so a stage's loads have ONE step (~1.4 us of MFMA
-// work) to land; a line that misses the L2 takes longer than that and the step time becomes the miss latency (r03b: 2.8 us per
-// step = 48 % of the MFMA peak).  Each wave therefore touches the lines its loads of step k + T256_PREFETCH will fetch with two
-// 4-byte-per-lane LDS-DMA requests into a scratch slot (64 row segments per request; nothing is read from the slot): the lines
-// are on their way into the XCD's L2 three steps ahead and the real loads hit.  The step barrier waits with a COUNTED vmcnt that
-// leaves exactly those two requests outstanding (loads retire in issue order), and is a raw s_barrier: __syncthreads() would
-// drain them (cdna_hip_programming.md 5, "Pipelining across barriers").
+// T256_PREFETCH (default 0 = off; the code is kept as a measured negative result): an L2 prefetch T256_PREFETCH K-steps ahead --
+// every wave touches the lines its loads of step k + T256_PREFETCH will fetch with two 4-byte-per-lane LDS-DMA requests into a
+// scratch slot, and the step barrier becomes a raw s_barrier behind a COUNTED vmcnt that leaves those two requests in flight.
+// The idea: two stages are all the LDS holds, so a stage's loads have one step to land, and an L2 miss would stretch the step.
+// Measured on one box (profiles/r03c): the whole vocoder stage 142 ms without, 156 / 157 / 161 ms with distance 2 / 3 / 5 -- the
+// step is not waiting for misses (the tile order already makes ~80 % of a stage's bytes L2 hits), the extra requests only add load.
 #ifndef T256_PREFETCH
-#define T256_PREFETCH 3
+#define T256_PREFETCH 0
 #endif
 constexpr int T256_LDS_BYTES = 2 * T256_STAGE_BYTES + 8 * 256;   // + a 256-byte scratch slot per wave for the prefetch requests
 __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs a, int nt_m, int nt_n, int n_blocks) {
