@@ -124,7 +124,7 @@ struct mv_engine {
     bf16_t* dbg = nullptr;   // MV_DEBUG_VECTORS=1: every layer's q|attn|h|act|x of the last step, both paths (mv_debug_vectors)
 
     // prefill workspace (M = 2 T rows of one utterance), allocated on the first batched prefill
-    bf16_t *px = nullptr, *ph = nullptr, *pn = nullptr, *pq = nullptr, *pattn = nullptr, *pact = nullptr;
+    bf16_t *px = nullptr, *ph = nullptr, *pn = nullptr, *pq = nullptr, *pattn = nullptr, *pact = nullptr, *pvt = nullptr;
 
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -298,6 +298,7 @@ int enqueue_prefill(mv_engine* e, int u, int T) {
         HIP_TRY(hipMalloc((void**)&e->pq, rows * c.dim * 2));
         HIP_TRY(hipMalloc((void**)&e->pattn, rows * c.dim * 2));
         HIP_TRY(hipMalloc((void**)&e->pact, rows * c.intermediate * 2));
+        HIP_TRY(hipMalloc((void**)&e->pvt, attn_rows_scratch_elems(2, c.n_head, 128, c.block_size) * 2));  // V transposed, for the MFMA attention
     }
     HIP_TRY(launch_embed_rows(s, e->seq + (size_t)u * c.block_size, T, c.dim, e->tok_emb, e->pos_emb,
                               e->spk_proj + (size_t)u * c.dim, e->px));
@@ -317,7 +318,7 @@ int enqueue_prefill(mv_engine* e, int u, int T) {
         AttnRowsArgs at;
         at.q = e->pq; at.k = kc; at.v = vc; at.out = e->pattn; at.k_batch_stride = (int64_t)c.n_head * c.block_size * 128;
         at.k_head_stride = (int64_t)c.block_size * 128; at.k_key_stride = 128; at.q_row_stride = c.dim; at.out_row_stride = c.dim;
-        at.T = T; at.n_head = c.n_head; at.batch = 2; at.head_dim = 128; at.causal = 1;
+        at.T = T; at.n_head = c.n_head; at.batch = 2; at.head_dim = 128; at.causal = 1; at.vt_scratch = e->pvt;
         HIP_TRY(launch_attn_rows(s, at));
         g = GemmArgs();
         g.a = e->pattn; g.w = w.wo; g.res_bf16 = e->px; g.out_bf16 = e->ph; g.M = M; g.N = c.dim; g.K = c.dim; g.lda = c.dim; g.ldc = c.dim;
@@ -478,7 +479,7 @@ int mv_engine_destroy(mv_engine* e) {
     if (e->graph) hipGraphDestroy(e->graph);
     void* bufs[] = {e->q_arena, e->arena, e->x, e->h, e->q, e->attn, e->act, e->logits, e->kcache, e->vcache, e->partial, e->counters,
                     e->utt, e->pos_arr, e->seq, e->spk_emb, e->spk_proj, e->n_active, e->capture, e->px, e->ph, e->pn, e->pq,
-                    e->pattn, e->pact, e->mega_layers, e->granules, e->step_counter, e->abort_flag, e->dbg, e->stamps, e->utt_shadow,
+                    e->pattn, e->pact, e->pvt, e->mega_layers, e->granules, e->step_counter, e->abort_flag, e->dbg, e->stamps, e->utt_shadow,
                     e->pos_shadow};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -1071,7 +1072,13 @@ int mv_op_attention_rows(void* stream, int32_t batch, int32_t T, int32_t n_head,
     a.q = (const bf16_t*)qkv; a.k = a.q + C; a.v = a.q + 2 * C; a.out = (bf16_t*)out;
     a.k_batch_stride = (int64_t)T * 3 * C; a.k_head_stride = head_dim; a.k_key_stride = 3 * C; a.q_row_stride = 3 * C; a.out_row_stride = C;
     a.T = T; a.n_head = n_head; a.batch = batch; a.head_dim = head_dim; a.causal = causal;
-    if (launch_attn_rows((hipStream_t)stream, a) != hipSuccess) return fail(MV_ERR_INVALID, "attention_rows: head_dim %d not supported", head_dim);
+    // the engines hand in their own scratch; this test entry allocates one per call (and runs the one-query-per-block VALU kernel too
+    // when MV_ATTN_VALU is set, so that both kernels stay covered by the same parity test)
+    const bool valu = getenv("MV_ATTN_VALU") != nullptr;
+    if (!valu) HIP_TRY(hipMalloc((void**)&a.vt_scratch, attn_rows_scratch_elems(batch, n_head, head_dim, T) * 2));
+    const hipError_t le = launch_attn_rows((hipStream_t)stream, a);
+    if (a.vt_scratch) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(a.vt_scratch); }
+    if (le != hipSuccess) return fail(MV_ERR_INVALID, "attention_rows: head_dim %d not supported", head_dim);
     return MV_OK;
 }
 

@@ -279,7 +279,158 @@ __global__ void __launch_bounds__(256) attn_rows_kernel(const AttnRowsArgs a) {
         *(u32x4*)(a.out + ((size_t)b * a.T + t) * a.out_row_stride + h * HD + dl * 8) = y;
     }
 }
+// ---- MFMA attention over whole rows (prefill of the first stage: causal; second stage: all positions) ------------------------
+// One wave = 16 queries of one (batch row, head); no LDS, no barriers: every MFMA operand is a K-contiguous fragment loaded
+// straight from global memory (the K / V of a (row, head) is at most 512 KB: L2-resident, re-read by the query blocks).
+//   S^T = K Q^T  (the "swapped" product): v_mfma_f32_16x16x32_bf16 with A = 16 keys x head_dim (rows of the KV cache), B = the wave's
+//   16 queries; the accumulator then holds, for query lane & 15, the scores of keys 4 (lane >> 4) + reg -- a lane owns ONE query's
+//   scores, so the softmax statistics are per-lane running values merged once across the 4 lanes that share a query.
+//   O = P V: A = P (the lane's own query row: its 8 probabilities of a 32-key block are exactly the 8 k-slots the MFMA asks this
+//   lane for -- keys 4 g .. 4 g + 3 and 16 + 4 g .. + 3, g = lane >> 4; the order of keys inside a 32-key block is free as long as
+//   V uses the same one), B = V^T rows (head dim x keys, key-contiguous): V is transposed once per call by vt_transpose_kernel into
+//   the caller's scratch, zero-padded to a multiple of 64 keys.
+// Two passes over the keys (pass 1: running max / sum, pass 2: P = exp(s - m) / l and P V), scores and softmax in fp32; P enters the
+// MFMA as bf16 hi + lo (two MFMAs per tile: ~16 bits of P; attention is < 1 % of the prefill's FLOPs), output bf16.
+// fast_model.py:218-222 (causal mask over the cache just written), fam/llm/layers/attn.py:132-159 (is_causal=False).
+template <int HD>
+__global__ void __launch_bounds__(256) vt_transpose_kernel(const AttnRowsArgs a, int Tpad) {
+    __shared__ bf16_t tile[64][HD + 2];
+    const int kb = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const bf16_t* vb = a.v + (size_t)b * a.k_batch_stride + (size_t)h * a.k_head_stride;
+    for (int i = threadIdx.x; i < 64 * (HD / 8); i += 256) {
+        const int key = i / (HD / 8), c = i % (HD / 8);
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (kb + key < a.T) v = load16(vb + (size_t)(kb + key) * a.k_key_stride + c * 8);
+        bf16_t* row = &tile[key][c * 8];
+        *(uint32_t*)(row + 0) = v.x; *(uint32_t*)(row + 2) = v.y; *(uint32_t*)(row + 4) = v.z; *(uint32_t*)(row + 6) = v.w;
+    }
+    __syncthreads();
+    bf16_t* vt = a.vt_scratch + ((size_t)b * a.n_head + h) * HD * Tpad + kb;
+    for (int i = threadIdx.x; i < HD * 8; i += 256) {
+        const int d = i >> 3, k8 = (i & 7) * 8;
+        u32x4 o;
+        o.x = (uint32_t)tile[k8 + 0][d] | ((uint32_t)tile[k8 + 1][d] << 16);
+        o.y = (uint32_t)tile[k8 + 2][d] | ((uint32_t)tile[k8 + 3][d] << 16);
+        o.z = (uint32_t)tile[k8 + 4][d] | ((uint32_t)tile[k8 + 5][d] << 16);
+        o.w = (uint32_t)tile[k8 + 6][d] | ((uint32_t)tile[k8 + 7][d] << 16);
+        *(u32x4*)(vt + (size_t)d * Tpad + k8) = o;
+    }
+}
+
+template <int HD>
+__global__ void __launch_bounds__(64) attn_mfma_kernel(const AttnRowsArgs a, int Tpad) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int KJ = HD / 32;   // MFMAs per 16 x 16 score tile
+    constexpr int DT = HD / 16;   // output tiles along the head dimension
+    const int qb = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    const int T = a.T;
+    const int query = min(qb + c, T - 1);                   // this lane's query (clamped: rows past T are computed, not stored)
+    const int last_key = a.causal ? min(qb + 15, T - 1) : T - 1;   // keys any query of the block can see
+    const int my_last = a.causal ? query : T - 1;
+    const float scale = rsqrtf((float)HD);
+    const bf16_t* kbase = a.k + (size_t)b * a.k_batch_stride + (size_t)h * a.k_head_stride + g * 8;
+    const bf16_t* vt = a.vt_scratch + ((size_t)b * a.n_head + h) * HD * Tpad;
+
+    bf16x8_t qf[KJ];
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) qf[j] = __builtin_bit_cast(bf16x8_t, load16(a.q + ((size_t)b * T + query) * a.q_row_stride + h * HD + 32 * j + g * 8));
+
+    // scores of keys kb + 4 g + reg for this lane's query; masked ones come back as -inf
+    auto score_tile = [&](int kb) {
+        const int key = min(kb + c, T - 1);
+        f32x4_t sacc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+            const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, load16(kbase + (size_t)key * a.k_key_stride + 32 * j));
+            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[j], sacc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc[r] = (kb + 4 * g + r <= my_last) ? sacc[r] * scale : -INFINITY;
+        return sacc;
+    };
+
+    // ---- pass 1: running max and sum over this lane's keys, merged across the 4 lanes of the query
+    float m = -INFINITY, l = 0.f;
+    for (int kb = 0; kb <= last_key; kb += 16) {
+        const f32x4_t sv = score_tile(kb);
+        const float mc = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+        if (mc == -INFINITY) continue;
+        const float mn = fmaxf(m, mc);
+        l *= (m == -INFINITY) ? 0.f : fast_exp(m - mn);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) l += (sv[r] == -INFINITY) ? 0.f : fast_exp(sv[r] - mn);
+        m = mn;
+    }
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) {
+        const float mo = __shfl_xor(m, off, 64), lo = __shfl_xor(l, off, 64);
+        const float mn = fmaxf(m, mo);   // finite: key 0 is visible to every query
+        l = l * ((m == -INFINITY) ? 0.f : fast_exp(m - mn)) + lo * ((mo == -INFINITY) ? 0.f : fast_exp(mo - mn));
+        m = mn;
+    }
+    const float inv_l = 1.0f / l;
+
+    // ---- pass 2: P = exp(s - m) / l in 32-key blocks, O += P V
+    f32x4_t oacc[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) oacc[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb <= last_key; kb += 32) {
+        float p[8];
+        {
+            const f32x4_t s0 = score_tile(kb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = (s0[r] == -INFINITY) ? 0.f : fast_exp(s0[r] - m) * inv_l;
+            if (kb + 16 <= last_key) {
+                const f32x4_t s1 = score_tile(kb + 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[4 + r] = (s1[r] == -INFINITY) ? 0.f : fast_exp(s1[r] - m) * inv_l;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[4 + r] = 0.f;
+            }
+        }
+        u32x4 ph, pl;
+        ph.x = pack_bf2(p[0], p[1]); ph.y = pack_bf2(p[2], p[3]); ph.z = pack_bf2(p[4], p[5]); ph.w = pack_bf2(p[6], p[7]);
+        pl.x = pack_bf2(p[0] - bf_lo(ph.x), p[1] - bf_hi(ph.x)); pl.y = pack_bf2(p[2] - bf_lo(ph.y), p[3] - bf_hi(ph.y));
+        pl.z = pack_bf2(p[4] - bf_lo(ph.z), p[5] - bf_hi(ph.z)); pl.w = pack_bf2(p[6] - bf_lo(ph.w), p[7] - bf_hi(ph.w));
+        const bf16x8_t pfh = __builtin_bit_cast(bf16x8_t, ph), pfl = __builtin_bit_cast(bf16x8_t, pl);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            // V^T row d 16 + c, keys kb + 4 g .. + 3 and kb + 16 + 4 g .. + 3 (the k-slots of lane group g)
+            const bf16_t* row = vt + (size_t)(d * 16 + c) * Tpad + kb + 4 * g;
+            const uint2 v0 = *(const uint2*)row, v1 = *(const uint2*)(row + 16);
+            const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, u32x4{v0.x, v0.y, v1.x, v1.y});
+            oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfh, vf, oacc[d], 0, 0, 0);
+            oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfl, vf, oacc[d], 0, 0, 0);
+        }
+    }
+    // oacc[d][reg] = O[query qb + 4 g + reg][d 16 + c]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qr = qb + 4 * g + r;
+        if (qr >= T) continue;
+        bf16_t* orow = a.out + ((size_t)b * T + qr) * a.out_row_stride + h * HD + c;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) orow[d * 16] = f2bf(oacc[d][r]);
+    }
+}
+
+template <int HD>
+static hipError_t launch_attn_mfma(hipStream_t s, const AttnRowsArgs& a) {
+    const int Tpad = (a.T + 63) / 64 * 64;
+    hipLaunchKernelGGL(vt_transpose_kernel<HD>, dim3(Tpad / 64, a.n_head, a.batch), dim3(256), 0, s, a, Tpad);
+    hipLaunchKernelGGL(attn_mfma_kernel<HD>, dim3((a.T + 15) / 16, a.n_head, a.batch), dim3(64), 0, s, a, Tpad);
+    return hipGetLastError();
+}
+
 hipError_t launch_attn_rows(hipStream_t s, const AttnRowsArgs& a) {
+    if (a.vt_scratch != nullptr) {
+        if (a.head_dim == 128) return launch_attn_mfma<128>(s, a);
+        if (a.head_dim == 64) return launch_attn_mfma<64>(s, a);
+        return hipErrorInvalidValue;
+    }
     const dim3 grid(a.T, a.n_head, a.batch);
     if (a.head_dim == 128) hipLaunchKernelGGL(attn_rows_kernel<128>, grid, dim3(256), 0, s, a);
     else if (a.head_dim == 64) hipLaunchKernelGGL(attn_rows_kernel<64>, grid, dim3(256), 0, s, a);

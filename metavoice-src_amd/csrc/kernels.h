@@ -188,8 +188,11 @@ struct AttnRowsArgs {
     int64_t k_batch_stride = 0, k_head_stride = 0, k_key_stride = 0;
     int32_t q_row_stride = 0, out_row_stride = 0;
     int32_t T = 0, n_head = 0, batch = 0, head_dim = 128, causal = 0;
+    bf16_t* vt_scratch = nullptr;   // device scratch of attn_rows_scratch_elems(batch, n_head, head_dim, T) bf16 for V transposed; with it the
+                                    // MFMA kernel runs (attn_mfma_kernel), without it the one-query-per-block VALU kernel
 };
 hipError_t launch_attn_rows(hipStream_t s, const AttnRowsArgs& a);
+inline size_t attn_rows_scratch_elems(int batch, int n_head, int head_dim, int T) { return (size_t)batch * n_head * head_dim * ((T + 63) / 64 * 64); }
 
 // ---- lstm.hip: persistent LSTM recurrence (EnCodec decoder LSTMs, speaker encoder) -----------------------------------------
 struct LstmSeqArgs {

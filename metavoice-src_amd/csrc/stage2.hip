@@ -201,7 +201,7 @@ struct mv_stage2 {
     int32_t* idx = nullptr;
     bf16_t *spk_in = nullptr, *spk = nullptr;
     float* x = nullptr;
-    bf16_t *xn = nullptr, *qkv = nullptr, *y = nullptr, *h = nullptr;
+    bf16_t *xn = nullptr, *qkv = nullptr, *y = nullptr, *h = nullptr, *vt = nullptr;
     bf16_t* logits[8] = {};
     int32_t* tokens = nullptr;
     int cur_batch = 0, cur_T = 0;
@@ -326,6 +326,7 @@ int mv_stage2_finalize(mv_stage2* s) {
     S2_TRY(alloc((void**)&s->qkv, M * 3 * c.n_embd * 2));
     S2_TRY(alloc((void**)&s->y, M * c.n_embd * 2));
     S2_TRY(alloc((void**)&s->h, M * c.hidden * 2));
+    S2_TRY(alloc((void**)&s->vt, attn_rows_scratch_elems(c.max_batch, c.n_head, c.n_embd / c.n_head, c.block_size) * 2));  // V transposed (MFMA attention)
     for (int i = 0; i < c.n_out; ++i) S2_TRY(alloc((void**)&s->logits[i], M * c.vocab_out[i] * 2));
     S2_TRY(alloc((void**)&s->tokens, M * c.n_out * 4));
     s->finalized = true;
@@ -368,6 +369,7 @@ int mv_stage2_forward(mv_stage2* s, int32_t batch, int32_t T, const int32_t* idx
         at.q = s->qkv; at.k = s->qkv + C; at.v = s->qkv + 2 * C; at.out = s->y;
         at.k_batch_stride = (int64_t)T * 3 * C; at.k_head_stride = hd; at.k_key_stride = 3 * C; at.q_row_stride = 3 * C;
         at.out_row_stride = C; at.T = T; at.n_head = c.n_head; at.batch = batch; at.head_dim = hd; at.causal = c.causal;
+        at.vt_scratch = (hd == 64 || hd == 128) ? s->vt : nullptr;
         S2_TRY(launch_attn_rows(st, at));
         g = GemmArgs();
         g.a = s->y; g.w = L.proj_w; g.bias = L.proj_b; g.res_f32 = s->x; g.out_f32 = s->x; g.M = M; g.N = C; g.K = C; g.lda = C; g.ldc = C;

@@ -75,12 +75,18 @@ def test_gemm(M, N_, K, mode):
     assert nbad == 0, f"{nbad} outputs off, worst {worst:.2f} tolerance units"
 
 
-@pytest.mark.parametrize("batch,T,H,hd,causal", [(1, 64, 6, 64, 0), (2, 100, 2, 64, 0), (1, 257, 16, 128, 1), (2, 33, 2, 128, 0), (1, 96, 4, 64, 1)])
-def test_attention_rows(batch, T, H, hd, causal):
+@pytest.mark.parametrize("kernel", ["mfma", "valu"])
+@pytest.mark.parametrize("batch,T,H,hd,causal", [(1, 64, 6, 64, 0), (2, 100, 2, 64, 0), (1, 257, 16, 128, 1), (2, 33, 2, 128, 0), (1, 96, 4, 64, 1),
+                                                 (2, 128, 16, 128, 1), (1, 1, 2, 128, 1), (1, 17, 2, 64, 1), (2, 2047, 2, 128, 1), (1, 1100, 3, 64, 0)])
+def test_attention_rows(batch, T, H, hd, causal, kernel, monkeypatch):
+    """Both whole-row attention kernels behind `launch_attn_rows`: the MFMA one (16 queries per wave, S^T = K Q^T and O = P V on
+    v_mfma_f32_16x16x32_bf16, V transposed into scratch; what the engines run) and the one-query-per-block VALU one."""
+    if kernel == "valu":
+        monkeypatch.setenv("MV_ATTN_VALU", "1")
     g = torch.Generator().manual_seed(T * H + hd)
     Cdim = H * hd
     qkv = rb(torch.randn(batch, T, 3, H, hd, generator=g))
-    qkv[0, 3, 1, 0] *= 8.0  # a dominant key (power of two: stays bf16-representable)
+    qkv[0, min(3, T - 1), 1, 0] *= 8.0  # a dominant key (power of two: stays bf16-representable)
     q, k, v = (qkv[:, :, j].transpose(1, 2).double() for j in range(3))  # (b, H, T, hd)
     s = q @ k.transpose(-1, -2) / np.sqrt(hd)
     if causal:
