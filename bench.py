@@ -416,11 +416,15 @@ def measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline):
                 t_len = (t_len + s_ - 1) // s_
                 macs += 2 * (t_len * c_ * cin * k_) + 4 * (t_len * c_ * c_ * 3)   # strided conv + its transposed twin, 2 ResBlocks x 2 convs
                 cin = c_
-            flops = 2 * macs * 4 * 20 * a.mbd_precision
+            useful = 2 * macs * 4 * 20                       # one product per multiply-accumulate: the arithmetic the reference's fp32 convolutions ask for
+            flops = useful * a.mbd_precision                 # what the MFMA units execute: three bf16 terms per product (a_hi w_hi + a_hi w_lo + a_lo w_hi)
             mbd_s = stage_ms["multiband_diffusion"] / a.steps / n_utt * 1e-3
-            out["vocoder_roofline"] = {"bound": "mfma", "kernel": "mbd_gemm_kernel (overlapping-window conv GEMMs of the 4 band UNets, 20 evaluations)",
+            out["vocoder_roofline"] = {"bound": "mfma", "kernel": "mbd_gemm_t256_kernel / mbd_gemm_glds3_kernel (overlapping-window conv GEMMs of the 4 band UNets, 20 evaluations)",
                                        "achieved": round(flops / mbd_s / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flops / mbd_s / 2.5e15, 4),
-                                       "note": f"{flops / 1e12:.0f} TFLOP of bf16 MFMA work per utterance ({a.mbd_precision} terms per product) over the whole stage"}
+                                       "useful_achieved": round(useful / mbd_s / 1e12, 1), "useful_frac_of_bf16_peak": round(useful / mbd_s / 2.5e15, 4),
+                                       "note": f"hardware: {flops / 1e12:.0f} TFLOP of bf16 MFMA work per utterance ({a.mbd_precision} terms per product); useful: {useful / 1e12:.0f} TFLOP "
+                                               "of fp32-class multiply-accumulates (for scale: gfx950's exact-fp32 MFMA peaks at 157 TFLOP/s); both over the WHOLE stage time, "
+                                               "which also holds its element-wise / GroupNorm / FIR kernels (a lower bound for the GEMM kernels themselves: profiles/)"}
         if with_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mv, cfgk)
         engine.close()

