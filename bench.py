@@ -117,7 +117,7 @@ def make_work(mv, args, *, long_form, long_form_chars, utterances_per_gpu, rank,
     return [[(mv.synthetic.prompt_tokens(T_PROMPT, seed=rank), N_NEW)]]
 
 
-def cpu_baseline(mv, cfgk, sample_steps=8):
+def cpu_baseline(mv, cfgk, sample_steps=24):
     """Time the oracle (oracle/stage1.py, fp32, torch CPU) on the same workload shape: bounded sample."""
     from oracle import stage1 as o_s1
 
@@ -227,7 +227,8 @@ def measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline):
                 if stage1_only:
                     continue
                 t1 = time.perf_counter()
-                _, cbs = first_adapter.decode([fold_onto_codebooks(toks, len(prompts[u]))])
+                with contextlib.redirect_stdout(io.StringIO()):  # "Truncating to min length": an utterance capped by the context window at an odd count
+                    _, cbs = first_adapter.decode([fold_onto_codebooks(toks, len(prompts[u]))])
                 text_ids = [int(t) - 1024 for t in prompts[u].tolist()]  # the same text in the second stage's id space (offset 1025)
                 grid = inference.pack_second_stage_input(text_ids, cbs, s2_args["block_size"])
                 in_x = torch.tensor([grid], dtype=torch.long)
