@@ -155,8 +155,9 @@ struct mv_codec {
     bool finalized = false;
     int dim0 = 0;  // channels after conv_in (num_filters * 2^n_ratios)
     // per-call workspace, kept between calls (grown on demand): token ids, four activation buffers, the latent of the last call
-    void* ws[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t ws_cap[6] = {0, 0, 0, 0, 0, 0};
+    // [6]: the [T][H] granule sequence layer 1 of the fused two-layer LSTM launch leaves for layer 2
+    void* ws[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t ws_cap[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -228,7 +229,7 @@ int mv_codec_create(const mv_codec_config* cfg, mv_codec** out) {
     if (rc == MV_OK && g.lstm_layers > 0) {
         const int H0 = g.num_filters << g.n_ratios;
         if (H0 % 8 != 0 || lstm_seq_lds_bytes(1, H0) > 160 * 1024 - 256) rc = mv_fail(MV_ERR_INVALID, "LSTM width %d unsupported", H0);
-        if (rc == MV_OK && (hipMalloc((void**)&c->lstm_hx, (size_t)2 * H0 * 8) != hipSuccess || hipMemset(c->lstm_hx, 0, (size_t)2 * H0 * 8) != hipSuccess ||
+        if (rc == MV_OK && (hipMalloc((void**)&c->lstm_hx, (size_t)4 * H0 * 8) != hipSuccess || hipMemset(c->lstm_hx, 0, (size_t)4 * H0 * 8) != hipSuccess ||
                             hipMalloc((void**)&c->lstm_abort, 4) != hipSuccess || hipMemset(c->lstm_abort, 0, 4) != hipSuccess))
             rc = mv_fail(MV_ERR_HIP, "hipMalloc failed");
         if (c->lstm_hx) c->allocs.push_back(c->lstm_hx);
@@ -385,12 +386,14 @@ static int codec_run(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t fr
     auto cleanup = [&]() {};   // the workspace stays with the codec (hipMalloc / hipFree per call cost more than the small kernels)
 #define CD_TRY2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return mv_fail(MV_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
     {
-        const size_t need[6] = {(size_t)n_q * frames * 4, widest * 4, widest * 4, widest * 4, widest * 4, (size_t)g.hidden * frames * 4};
-        for (int i = 0; i < 6; ++i)
+        const size_t need[7] = {(size_t)n_q * frames * 4, widest * 4, widest * 4, widest * 4, widest * 4, (size_t)g.hidden * frames * 4,
+                                g.lstm_layers == 2 ? (size_t)frames * c->dim0 * 8 : 0};
+        for (int i = 0; i < 7; ++i)
             if (c->ws_cap[i] < need[i]) {
                 if (c->ws[i]) { CD_TRY2(hipStreamSynchronize(s)); (void)hipFree(c->ws[i]); c->ws[i] = nullptr; c->ws_cap[i] = 0; }
                 CD_TRY2(hipMalloc(&c->ws[i], need[i]));
                 c->ws_cap[i] = need[i];
+                if (i == 6) CD_TRY2(hipMemsetAsync(c->ws[i], 0, need[i], s));   // granule tags start from a known state
             }
         d_tok = (int32_t*)c->ws[0];
         for (int i = 0; i < 4; ++i) buf[i] = (float*)c->ws[1 + i];
@@ -408,6 +411,23 @@ static int codec_run(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t fr
         const int H = c->dim0;
         float* cur = x;   // input of the layer, [H][T]
         float* gin = u;   // [4H][T]
+        if (g.lstm_layers == 2) {
+            // both layers in ONE persistent launch (lstm.hip: lstm_seq2_kernel): layer 2's step t right behind layer 1's step t
+            CD_TRY2(run_conv(s, c->lstm_ih[0], cur, gin, T, false));
+            if (++c->lstm_serial >= 65535u) {
+                CD_TRY2(hipMemsetAsync(c->lstm_hx, 0, (size_t)4 * H * 8, s));
+                CD_TRY2(hipMemsetAsync(c->ws[6], 0, c->ws_cap[6], s));
+                c->lstm_serial = 1;
+            }
+            LstmSeq2Args a{};
+            a.gin1 = gin; a.gs_t = 1; a.gs_r = T;
+            a.whh1 = c->lstm_hh[0];
+            a.wih2 = c->lstm_ih[1].w; a.wih2_ks = c->lstm_ih[1].coutp; a.bias2 = c->lstm_ih[1].b; a.whh2 = c->lstm_hh[1];
+            a.y = e; a.ys_t = 1; a.ys_u = T; a.skip = x;   // y = lstm(x) + x lands in `e`
+            a.hx1 = c->lstm_hx; a.hx2 = c->lstm_hx + (size_t)2 * H; a.seq1 = (unsigned long long*)c->ws[6];
+            a.tag_base = c->lstm_serial << 16; a.abort_flag = c->lstm_abort; a.H = H; a.T = T;
+            CD_TRY2(launch_lstm_seq2(s, a));
+        } else
         for (int l = 0; l < g.lstm_layers; ++l) {
             CD_TRY2(run_conv(s, c->lstm_ih[l], cur, gin, T, false));
             float* y = (l == g.lstm_layers - 1) ? e : h;  // the last layer adds the skip and lands in `e`

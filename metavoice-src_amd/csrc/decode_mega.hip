@@ -98,6 +98,9 @@ __device__ __forceinline__ void mega_issue_row(u32x4* wv, const bf16_t* w, int n
 #ifndef MEGA_EARLY_QKV
 #define MEGA_EARLY_QKV 0
 #endif
+#ifndef MEGA_NU_EARLY_KV
+#define MEGA_NU_EARLY_KV 0
+#endif
 #define MEGA_EARLY_W2_BYTES (MG_WAVES * 5 * 1024)
 #define MEGA_EARLY_W1_BYTES (MG_WAVES * 6 * 1024)
 __device__ __forceinline__ void mega_row_to_lds(uint32_t lds, const bf16_t* g) {  // 64 lanes x 16 B -> 1 KB of LDS at `lds`
@@ -532,6 +535,9 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 }
                 const AttnAcc w = attn_wave_partial(kv, vv, qv, at_s0, at_s1, g);
                 if (u == 0) MG_STAMP(l, 14);  // wave partial done
+                // MEGA_NU_EARLY_KV: the K/V registers are free from here on -- the next attending utterance's slice is requested NOW, so
+                // it streams while this utterance's partial is merged and published (instead of after the publish)
+                if (MEGA_NU_EARLY_KV && NU > 1 && next_att >= 0) issue_kv(next_att);
                 if (g == 0) {
                     sm[at_w][dl][0] = w.m;
                     sm[at_w][dl][1] = w.l;
@@ -550,7 +556,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 }
                 if (next_att >= 0) {
                     __syncthreads();  // the partial has left, `sm` has been consumed
-                    issue_kv(next_att);
+                    if (!(MEGA_NU_EARLY_KV && NU > 1)) issue_kv(next_att);
                 }
                 if (at_w == 0) {
                     bool last = true;

@@ -211,6 +211,27 @@ struct LstmSeqArgs {
 hipError_t launch_lstm_seq(hipStream_t s, const LstmSeqArgs& a);   // H % 8 == 0, T <= 65535, LDS (32 H + B (H + 8)) * 4 <= 160 KB
 size_t lstm_seq_lds_bytes(int B, int H);
 hipError_t launch_lstm_inproj(hipStream_t s, const float* x, const float* w, const float* bias, float* gin, int BT, int I, int R);
+// Two stacked LSTM layers (batch 1, same H) in ONE persistent launch: layer 2's step t runs right behind layer 1's step t, so the
+// chain is T + 1 dependent steps instead of 2 T (the EnCodec decoder's LSTM pair: 960 frames, 2 x 4.7 ms -> ~5 ms).
+struct LstmSeq2Args {
+    const float* gin1 = nullptr;     // layer 1: W_ih x_t + b of (t, gate row r) at gin1[t * gs_t + r * gs_r]
+    int64_t gs_t = 0, gs_r = 0;
+    const float* whh1 = nullptr;     // [4H][H]
+    const float* wih2 = nullptr;     // layer 2 input weights, element (row r, column k) at wih2[k * wih2_ks + r]
+    int64_t wih2_ks = 0;
+    const float* bias2 = nullptr;    // [4H]: b_ih + b_hh of layer 2
+    const float* whh2 = nullptr;     // [4H][H]
+    float* y = nullptr;              // layer 2's h_t[u] (+ skip) at y[t * ys_t + u * ys_u]
+    int64_t ys_t = 0, ys_u = 0;
+    const float* skip = nullptr;     // same indexing as y, or null
+    unsigned long long* hx1 = nullptr;   // [2][H] tagged granules, the recurrence of layer 1
+    unsigned long long* hx2 = nullptr;   // [2][H] tagged granules, the recurrence of layer 2
+    unsigned long long* seq1 = nullptr;  // [T][H] tagged granules: layer 1's outputs, read by layer 2 at its own pace
+    uint32_t tag_base = 0;
+    uint32_t* abort_flag = nullptr;
+    int32_t H = 0, T = 0;
+};
+hipError_t launch_lstm_seq2(hipStream_t s, const LstmSeq2Args& a);   // H % 8 == 0, (64 H + 2 H + 8) * 4 bytes of LDS <= 160 KB
 
 // ---- decode_mega.hip: persistent decode-step kernel (MetaVoice-1B shape, one utterance) -----------------------------
 struct MegaLayer {

@@ -139,6 +139,117 @@ __global__ void __launch_bounds__(LS_THREADS) lstm_seq_kernel(const LstmSeqArgs 
     }
 }
 
+// Poll `n` tagged granules at `src` into `dst` (LDS): all of a thread's granules are requested before the first is examined; only the
+// ones still carrying an old tag are re-read.  Returns false when the wait ran out (abort word raised).
+__device__ __forceinline__ bool lstm_poll(const gran_t* src, uint32_t tag, float* dst, int n, uint32_t* abort_flag, int tid) {
+    for (int n0 = tid; n0 < n; n0 += 4 * LS_THREADS) {
+        unsigned long long v[4];
+        bool need[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { need[k] = n0 + k * LS_THREADS < n; v[k] = 0; }
+        for (int tries = 0;; ++tries) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (need[k]) v[k] = __hip_atomic_load(src + n0 + k * LS_THREADS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool pending = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (need[k]) {
+                    if ((uint32_t)(v[k] >> 32) == tag) { dst[n0 + k * LS_THREADS] = __uint_as_float((uint32_t)v[k]); need[k] = false; }
+                    else pending = true;
+                }
+            if (!pending) break;
+            if ((tries & 1023) == 1023) {
+                const bool peer = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                if (peer || tries >= LS_SPIN_LIMIT) {
+                    __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return false;
+                }
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return true;
+}
+
+// Two stacked layers, batch 1 (kernels.h: LstmSeq2Args).  Workgroups [0, H/8) are layer 1 -- exactly lstm_seq_kernel, plus a copy of
+// every h1_t into the [T][H] granule sequence --, workgroups [H/8, 2 H/8) are layer 2: they keep their 32 rows of W_ih2 AND of W_hh2
+// in LDS, and at step t wait for h1_t (sequence buffer: never overwritten, so layer 2 may lag by any number of steps) and h2_{t-1}
+// (their own two-slot ring).  Gate pre-activation of layer 2 = (W_hh2 h2_{t-1}) + ((W_ih2 h1_t) + b): both dot products per wave,
+// the same reduction as the single-layer kernel.
+__global__ void __launch_bounds__(LS_THREADS) lstm_seq2_kernel(const LstmSeq2Args a) {
+    extern __shared__ float lds[];
+    const int H = a.H, nwg = H / LS_UPW;
+    const bool second = (int)blockIdx.x >= nwg;
+    float* w_s = lds;                               // [4 * LS_UPW][H]: W_hh rows of this workgroup's units
+    float* wi_s = w_s + 4 * LS_UPW * H;             // layer 2 only: [4 * LS_UPW][H] rows of W_ih2
+    float* h_s = wi_s + (second ? 4 * LS_UPW * H : 0);   // [H]: h_{t-1} of this layer
+    float* x_s = h_s + H;                           // layer 2 only: [H]: h1_t
+    float* c_s = x_s + H;                           // [LS_UPW]
+    __shared__ int s_abort;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u0 = ((int)blockIdx.x - (second ? nwg : 0)) * LS_UPW;
+    const float* whh = second ? a.whh2 : a.whh1;
+    if (tid == 0) s_abort = 0;
+    for (int i = tid; i < 4 * LS_UPW * H; i += LS_THREADS) {
+        const int r = i / H, k = i - r * H, q = r / LS_UPW, u = r - q * LS_UPW;
+        w_s[i] = whh[(size_t)(q * H + u0 + u) * H + k];
+        if (second) wi_s[i] = a.wih2[(size_t)k * a.wih2_ks + (q * H + u0 + u)];
+    }
+    for (int i = tid; i < H; i += LS_THREADS) { h_s[i] = 0.f; x_s[i] = 0.f; }
+    if (tid < LS_UPW) c_s[tid] = 0.f;
+    __syncthreads();
+    gran_t* ring = second ? a.hx2 : a.hx1;
+    for (int t = 0; t < a.T; ++t) {
+        bool ok = true;
+        if (second) ok = lstm_poll(a.seq1 + (size_t)t * H, a.tag_base + (uint32_t)t + 1u, x_s, H, a.abort_flag, tid);
+        if (ok && t > 0) ok = lstm_poll(ring + (size_t)(t & 1) * H, a.tag_base + (uint32_t)t, h_s, H, a.abort_flag, tid);
+        if (!ok) *(volatile int*)&s_abort = 1;
+        __syncthreads();
+        if (s_abort) return;
+        float mine = 0.f;
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = q * LS_UPW + wave * 2 + uu;
+                const float* w = w_s + (size_t)row * H;
+                float sh = 0.f;
+                for (int k = lane; k < H; k += 64) sh = fmaf(w[k], h_s[k], sh);
+                sh = wave_sum(sh);
+                if (second) {
+                    const float* wi = wi_s + (size_t)row * H;
+                    float sx = 0.f;
+                    for (int k = lane; k < H; k += 64) sx = fmaf(wi[k], x_s[k], sx);
+                    sh += wave_sum(sx) + a.bias2[q * H + u0 + wave * 2 + uu];
+                }
+                if (lane == uu * 4 + q) mine = sh;
+            }
+        float act = 0.f;
+        if (lane < 8) {
+            const int u = wave * 2 + (lane >> 2), q = lane & 3;
+            const float g = second ? mine : mine + a.gin1[(size_t)t * a.gs_t + (size_t)(q * H + u0 + u) * a.gs_r];
+            act = q == 2 ? tanhf(g) : sigmoidf_(g);
+        }
+        const int base = lane & 4;
+        const float ig = __shfl(act, base + 0, 64), fg = __shfl(act, base + 1, 64), gg = __shfl(act, base + 2, 64), og = __shfl(act, base + 3, 64);
+        if (lane == 0 || lane == 4) {
+            const int u = wave * 2 + (lane >> 2);
+            const float c = fmaf(fg, c_s[u], ig * gg);
+            const float h = og * tanhf(c);
+            c_s[u] = c;
+            const unsigned long long gr = ((unsigned long long)(a.tag_base + (uint32_t)t + 1u) << 32) | __float_as_uint(h);
+            if (t + 1 < a.T) __hip_atomic_store(ring + (size_t)((t + 1) & 1) * H + u0 + u, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!second) __hip_atomic_store(a.seq1 + (size_t)t * H + u0 + u, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else {
+                const size_t o = (size_t)t * a.ys_t + (size_t)(u0 + u) * a.ys_u;
+                a.y[o] = h + (a.skip ? a.skip[o] : 0.f);
+            }
+        }
+        __syncthreads();  // h_s / x_s are overwritten by the next polls
+    }
+}
+
 // gin[b][t][row] = bias[row] + sum_k w[row][k] * x[b][t][k]      (the non-recurrent half of every gate, all time steps at once)
 constexpr int IP_TT = 8;
 __global__ void __launch_bounds__(256) lstm_inproj_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
@@ -209,6 +320,20 @@ hipError_t launch_lstm_seq(hipStream_t s, const LstmSeqArgs& a) {
         raised = lds;
     }
     hipLaunchKernelGGL(lstm_seq_kernel, dim3(a.H / LS_UPW), dim3(LS_THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_lstm_seq2(hipStream_t s, const LstmSeq2Args& a) {
+    if (a.H % LS_UPW != 0 || a.T < 1 || a.T > 65535) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)8 * LS_UPW * a.H + (size_t)2 * a.H + LS_UPW) * sizeof(float);
+    if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
+    static size_t raised = 0;
+    if (lds > raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_seq2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised = lds;
+    }
+    hipLaunchKernelGGL(lstm_seq2_kernel, dim3(2 * a.H / LS_UPW), dim3(LS_THREADS), lds, s, a);
     return hipGetLastError();
 }
 

@@ -366,6 +366,10 @@ constexpr int T256_STAGE_BYTES = 4 * 16 * 1024;   // a_hi | a_lo | w_hi | w_lo, 
 #ifndef T256_PREFETCH
 #define T256_PREFETCH 0
 #endif
+// profiling only (results are garbage): 1 = no global loads after the first stage, 2 = additionally no LDS fragment reads
+#ifndef T256_ABLATE
+#define T256_ABLATE 0
+#endif
 constexpr int T256_LDS_BYTES = 2 * T256_STAGE_BYTES + 8 * 256;   // + a 256-byte scratch slot per wave for the prefetch requests
 __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs a, int nt_m, int nt_n, int n_blocks) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char t256_lds[];   // [2 stages][4 halves][16 sub-tiles][1 KB]
@@ -451,16 +455,20 @@ __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs
         // The next stage's 8 load instructions per wave: all at once here (SPREAD 0), or two in front of each of the first four MFMA
         // groups (SPREAD 1): a wave issuing 8 LDS-DMA pieces back to back sits ~100 cycles on each (MI355X_MICROARCH.md, LDS-DMA
         // piece issue cost) while its SIMD partner does the same, i.e. the MFMA pipe idles
-        const bool more = kt + 1 < nk;
+        const bool more = kt + 1 < nk && T256_ABLATE == 0;
         if (T256_SPREAD == 0 && more) stage_load((kt + 1) & 1, (kt + 1) * 32);
         if (T256_PREFETCH > 0 && T256_SPREAD == 0 && kt + T256_PREFETCH < nk) prefetch_step((kt + T256_PREFETCH) * 32);
         const unsigned char* st = t256_lds + (kt & 1) * T256_STAGE_BYTES;
+        auto frag = [&](const unsigned char* p) {
+            if (T256_ABLATE == 2) return __builtin_bit_cast(bf16x8_t, u32x4{(uint32_t)(uintptr_t)p, (uint32_t)kt, 0x3c003c00u, 0x3c003c00u});
+            return __builtin_bit_cast(bf16x8_t, *(const u32x4*)p);
+        };
         bf16x8_t bfh[4], bfl[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int off = (wn * 4 + j) * 1024 + fslot;
-            bfh[j] = __builtin_bit_cast(bf16x8_t, *(const u32x4*)(st + 2 * 16384 + off));
-            bfl[j] = __builtin_bit_cast(bf16x8_t, *(const u32x4*)(st + 3 * 16384 + off));
+            bfh[j] = frag(st + 2 * 16384 + off);
+            bfl[j] = frag(st + 3 * 16384 + off);
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {   // the A fragments four sub-tiles at a time: 32 registers instead of 64
@@ -468,8 +476,8 @@ __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int off = (wm * 8 + half * 4 + i) * 1024 + fslot;
-                afh[i] = __builtin_bit_cast(bf16x8_t, *(const u32x4*)(st + 0 * 16384 + off));
-                afl[i] = __builtin_bit_cast(bf16x8_t, *(const u32x4*)(st + 1 * 16384 + off));
+                afh[i] = frag(st + 0 * 16384 + off);
+                afl[i] = frag(st + 1 * 16384 + off);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
