@@ -632,18 +632,22 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__
 // of a step, the C x k weights sit in the scalar / L1 caches.  32-bit indexing (M C < 2^31).
 __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ x, int T, const PF ws, int C, int k, int s, int pad,
                                                       float* __restrict__ out, int64_t out_band, int M) {
+    // the C x k weights once per block into LDS, transposed to [j][c] (a thread reads its four channels of tap j as one float4):
+    // read per output from global they were 32 loads per 16-byte store and the kernel ran at 0.4 TB/s of output (r03_final)
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [k][C]
+    for (int i = threadIdx.x; i < C * k; i += 256) wl[(i % k) * C + i / k] = ws.p[blockIdx.y][i];
+    __syncthreads();
     const int q4 = C >> 2;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M * q4) return;
     const int m = i / q4, c = (i - m * q4) * 4;
     x += (size_t)blockIdx.y * T;
-    const float* w = ws.p[blockIdx.y] + (size_t)c * k;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int j = 0; j < k; ++j) {
         const int t = m * s + j - pad;
         const float xv = (t >= 0 && t < T) ? x[t] : 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = fmaf(w[q * k + j], xv, acc[q]);
+        const float4 wv = *(const float4*)(wl + j * C + c);
+        acc[0] = fmaf(wv.x, xv, acc[0]); acc[1] = fmaf(wv.y, xv, acc[1]); acc[2] = fmaf(wv.z, xv, acc[2]); acc[3] = fmaf(wv.w, xv, acc[3]);
     }
     *(float4*)(out + (size_t)blockIdx.y * out_band + (size_t)m * C + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
@@ -1417,7 +1421,7 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
             const int Cin = i == 0 ? 1 : m->ch[i - 1], Cout = m->ch[i], To = ub.T[i];
             auto E = [&](int b) -> const EncW& { return m->band[b].enc[i]; };
             if (i == 0) {
-                hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)(((size_t)To * (Cout / 4) + 255) / 256), NB), dim3(256), 0, s, zin, Tin,
+                hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)(((size_t)To * (Cout / 4) + 255) / 256), NB), dim3(256), (size_t)Cout * k * 4, s, zin, Tin,
                                    pf_of(NB, [&](int b) { return (const float*)E(b).conv_in_w; }), Cout, k, st, pad, ub.a32, WB, To);
             } else {
                 // operand: zin with `pad` zero rows in front and (Tpad - Tin) + k behind

@@ -342,7 +342,9 @@ def text_to_speech(fields: Dict[str, str], files: Dict[str, bytes]) -> Tuple[int
             wav_out_path = GlobalState.tts.synthesise(text=text, spk_ref_path=wav_path, top_p=top_p, guidance_scale=guidance)
         with open(wav_out_path, "rb") as f:
             return 200, "audio/wav", f.read()
-    except Exception:
+    except Exception as e:
+        if type(e).__name__ == "UnsupportedAudioFormat":  # the speaker reference is in a format nothing here can decode: the client's to fix
+            return 415, "application/json", json.dumps({"detail": str(e)}).encode()
         logger.exception(f"Error processing request. text: {text}, speaker_ref_path: {speaker_ref_path}, guidance: {guidance}, top_p: {top_p}")
         return 500, "text/plain", ERROR_TEXT.encode()
     finally:

@@ -91,16 +91,66 @@ def trim_silence(y: np.ndarray, top_db: float = 20.0, frame_length: int = 2048, 
     return y[start:end]
 
 
+class UnsupportedAudioFormat(ValueError):
+    """The file is not RIFF/WAVE and no decoder for it is available in this process (serving.py answers 415 for it)."""
+
+
+def _decode_with_whatever_is_installed(path: str):
+    """-> (rate, float32 samples [n] or [n, channels]) through the first decoder present: `soundfile` (libsndfile: FLAC / OGG / AIFF and,
+    in recent builds, MP3), `audioread` (what librosa falls back to), an `ffmpeg` executable on PATH (what the reference's serving
+    path uses, `serving.py:112-124`).  None of them is in the build image; on a host that has one the reference's own assets
+    (`assets/*.mp3`) load unchanged."""
+    import shutil
+    import subprocess
+
+    errors = []
+    try:
+        import soundfile  # type: ignore
+
+        data, rate = soundfile.read(path, dtype="float32", always_2d=False)
+        return int(rate), np.asarray(data, dtype=np.float32)
+    except ImportError:
+        errors.append("soundfile not installed")
+    except Exception as e:  # libsndfile could not parse it
+        errors.append(f"soundfile: {e}")
+    try:
+        import audioread  # type: ignore
+
+        with audioread.audio_open(path) as f:
+            rate, ch = int(f.samplerate), int(f.channels)
+            pcm = np.frombuffer(b"".join(f), dtype="<i2").astype(np.float32) / 32768.0
+        return rate, (pcm.reshape(-1, ch) if ch > 1 else pcm)
+    except ImportError:
+        errors.append("audioread not installed")
+    except Exception as e:
+        errors.append(f"audioread: {e}")
+    ffmpeg = shutil.which("ffmpeg")
+    if ffmpeg:
+        p = subprocess.run([ffmpeg, "-v", "error", "-i", path, "-f", "f32le", "-ac", "1", "-ar", str(sampling_rate), "-"],
+                           capture_output=True, timeout=120)
+        if p.returncode == 0 and p.stdout:
+            return sampling_rate, np.frombuffer(p.stdout, dtype="<f4").copy()
+        errors.append(f"ffmpeg: {p.stderr.decode('utf-8', 'replace')[:200]}")
+    else:
+        errors.append("no ffmpeg on PATH")
+    raise UnsupportedAudioFormat(f"{path}: not a RIFF/WAVE file and no other decoder is available ({'; '.join(errors)}); "
+                                 "convert it to .wav first (`ffmpeg -i in.mp3 out.wav`)")
+
+
 def load_audio(path: str, sr: int = sampling_rate) -> np.ndarray:
-    """Mono float32 waveform at `sr`.  Reads RIFF/WAVE (PCM 8/16/24/32-bit, float) through scipy; compressed formats (the
-    reference's assets/*.mp3) need a decoder this image does not have -- convert them to .wav first (`ffmpeg -i in.mp3 out.wav`)."""
+    """Mono float32 waveform at `sr` (`librosa.load(fpath, sr=16000)` in the reference, `speaker_encoder/model.py:112-114`).  RIFF/WAVE
+    (PCM 8/16/24/32-bit, float) is read through scipy whatever the file is called (serving.py stores every upload as `.wav`, like the
+    reference); anything else goes to the first decoder this process has (`_decode_with_whatever_is_installed`), and raises
+    `UnsupportedAudioFormat` when there is none."""
     from scipy.io import wavfile
     from scipy.signal import resample_poly
 
-    try:
+    with open(path, "rb") as f:
+        magic = f.read(12)
+    if magic[:4] in (b"RIFF", b"RIFX", b"RF64") and magic[8:12] == b"WAVE":
         rate, data = wavfile.read(path)
-    except ValueError as e:
-        raise ValueError(f"{path}: only RIFF/WAVE files can be read here ({e}); convert other formats to .wav first") from e
+    else:
+        rate, data = _decode_with_whatever_is_installed(path)
     if data.dtype == np.uint8:
         x = (data.astype(np.float32) - 128.0) / 128.0
     elif np.issubdtype(data.dtype, np.integer):

@@ -20,6 +20,8 @@ class FakeTTS:
     def synthesise(self, text, spk_ref_path, top_p=0.95, guidance_scale=3.0, temperature=1.0):
         if "boom" in text:
             raise RuntimeError("synthetic failure")
+        if str(spk_ref_path).endswith(".mp3"):
+            raise type("UnsupportedAudioFormat", (ValueError,), {})("no decoder for this speaker reference")
         self.calls.append(dict(text=text, spk=spk_ref_path, top_p=top_p, guidance=guidance_scale,
                                ref_bytes=open(spk_ref_path, "rb").read() if os.path.exists(spk_ref_path) else None))
         path = os.path.join(self.out_dir, f"out{len(self.calls)}.wav")
@@ -73,6 +75,9 @@ def test_health_and_tts_contract(server):
     # any failure -> 500 with the fixed text
     code, _, body = post(base + "/tts", urllib.parse.urlencode({"text": "boom", "speaker_ref_path": "x"}).encode())
     assert code == 500 and body.decode() == serving.ERROR_TEXT
+    # a speaker reference in a format nothing here can decode is the client's problem: 415 with the reason, not the fixed 500 text
+    code, ctype, body = post(base + "/tts", urllib.parse.urlencode({"text": "hi", "speaker_ref_path": "/refs/bria.mp3"}).encode())
+    assert code == 415 and b"no decoder" in body
     # out-of-range guidance is rejected before synthesis (FastAPI's ge/le validation in the reference)
     code, _, _ = post(base + "/tts", urllib.parse.urlencode({"text": "hi", "speaker_ref_path": "x", "guidance": "9"}).encode())
     assert code == 422

@@ -5,6 +5,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import GOLDEN, load_pkg
@@ -75,3 +76,32 @@ def test_trim_and_wav_reader(tmp_path):
     assert abs(len(x) - int(len(y) * 16000 / sr)) <= 2 and x.dtype == np.float32
     assert abs(float(np.abs(x).max()) - 0.5) < 0.02
     assert audio.trim_silence(np.zeros(5000, np.float32)).size == 0
+
+
+def test_load_audio_falls_back_to_an_installed_decoder_or_says_so(tmp_path, monkeypatch):
+    """RIFF/WAVE is sniffed by content (serving stores every upload as `.wav`, like the reference); anything else goes to the first
+    decoder the process has -- none in this image: `UnsupportedAudioFormat`, which serving turns into 415 -- e.g. `soundfile`."""
+    import sys
+    import types
+
+    import numpy as np
+    from scipy.io import wavfile
+
+    audio = load_pkg("speaker_encoder.audio")
+    wav = tmp_path / "upload.mp3"   # a WAVE file under another name still loads
+    wavfile.write(wav, 8000, (np.sin(np.arange(4000) / 7.0) * 12000).astype(np.int16))
+    x = audio.load_audio(str(wav))
+    assert x.dtype == np.float32 and x.shape == (8000,) and 0.3 < float(np.abs(x).max()) < 0.4
+    mp3 = tmp_path / "voice.wav"    # ...and something that is not WAVE does not, whatever it is called
+    mp3.write_bytes(b"ID3\x03\x00" + bytes(range(256)) * 8)
+    for m in ("soundfile", "audioread"):
+        monkeypatch.setitem(sys.modules, m, None)   # make sure the import fails even on a host that has them
+    monkeypatch.setenv("PATH", str(tmp_path))       # ...and that no ffmpeg is found
+    with pytest.raises(audio.UnsupportedAudioFormat) as ei:
+        audio.load_audio(str(mp3))
+    assert "convert it to .wav" in str(ei.value) and isinstance(ei.value, ValueError)
+    fake = types.ModuleType("soundfile")
+    fake.read = lambda path, dtype="float32", always_2d=False: (np.stack([np.full(32000, 0.25, np.float32), np.full(32000, 0.75, np.float32)], axis=1), 32000)
+    monkeypatch.setitem(sys.modules, "soundfile", fake)
+    y = audio.load_audio(str(mp3))
+    assert y.shape == (16000,) and abs(float(y[8000]) - 0.5) < 1e-3   # stereo -> mono, 32 kHz -> 16 kHz
