@@ -411,7 +411,7 @@ static int codec_run(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t fr
         const int H = c->dim0;
         float* cur = x;   // input of the layer, [H][T]
         float* gin = u;   // [4H][T]
-        if (g.lstm_layers == 2) {
+        if (g.lstm_layers == 2 && !lstm_stepwise_mode()) {
             // both layers in ONE persistent launch (lstm.hip: lstm_seq2_kernel): layer 2's step t right behind layer 1's step t
             CD_TRY2(run_conv(s, c->lstm_ih[0], cur, gin, T, false));
             if (++c->lstm_serial >= 65535u) {
@@ -470,7 +470,11 @@ static int codec_run(mv_codec* c, const int32_t* tokens, int32_t n_q, int32_t fr
     cleanup();
     if (aborted) {
         (void)hipMemset(c->lstm_abort, 0, 4);
-        return mv_fail(MV_ERR_HIP, "mv_codec_decode: the LSTM workgroups timed out waiting for each other (device shared with another kernel?)");
+        if (!lstm_stepwise_mode()) {   // survive it: redo the decode with one LSTM launch per time step (and stay there)
+            lstm_force_stepwise();
+            return codec_run(c, tokens, n_q, frames, wav_out, latent_out, d_wav, d_latent);
+        }
+        return mv_fail(MV_ERR_HIP, "mv_codec_decode: the LSTM recurrence failed");
     }
     return MV_OK;
 }

@@ -13,6 +13,8 @@
 // memory, 512 KB per CU) BEFORE waiting for the current phase's input: the weight stream never stops, and the
 // all-to-all dependency between phases costs one hand-off instead of a kernel boundary plus a cold start.
 // The hand-off protocol (tagged granules, bounded per-wave polls) lives in mega_core.h.
+#include <atomic>
+
 #include "mega_core.h"
 #include "sample_core.h"
 #include "gemv_i4_core.h"
@@ -919,7 +921,11 @@ hipError_t launch_bump_counter(hipStream_t s, uint32_t* c) {
 
 template <int WF, int NU, bool FOLD>
 static hipError_t launch_mega_instance(hipStream_t s, const MegaArgs& a) {
-    static bool raised = false;  // > 64 KB of LDS for more than one utterance: dynamic, raised once per instance
+    // > 64 KB of LDS: dynamic, raised once per instance and DEVICE (the attribute belongs to the device's copy of the function)
+    static std::atomic<bool> raised_on[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<bool>& raised = raised_on[dev & 63];
     const size_t lds = mega_lds_bytes(NU) + (mega_early_rows(WF, NU) ? MEGA_EARLY_W2_BYTES + MEGA_EARLY_W1_BYTES : 0);
     if (!raised) {
         hipError_t e = hipFuncSetAttribute((const void*)decode_mega_kernel<WF, NU, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

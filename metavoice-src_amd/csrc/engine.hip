@@ -112,7 +112,9 @@ struct mv_engine {
 
     // persistent decode-step kernel (decode_mega.hip)
     bool mega_ok = false;
-    bool mega_failed = false;            // a hand-off timed out once: this engine keeps to the per-layer launches from then on
+    bool mega_failed = false;            // a hand-off timed out: this engine keeps to the per-layer launches ...
+    int mega_retry_in = 0;               // ... for this many more utterances (mv_begin calls), then tries the persistent kernel again;
+    int mega_backoff = 0;                // the wait doubles with every failed attempt (4, 8, ... 256) and resets after a clean utterance
     UttState* utt_shadow = nullptr;      // state at the last successful poll (mv_run rolls back to it when the persistent kernel aborts)
     int32_t* pos_shadow = nullptr;
     MegaLayer* mega_layers = nullptr;
@@ -393,7 +395,7 @@ int mv_tune(mv_engine* e, const char* key, int32_t value) {
     if (found) {}
     else if (k == "gemv_nt") g_tune.gemv_nt = value;
     else if (k == "use_graph") g_tune.use_graph = value;
-    else if (k == "mega") { g_tune.mega = value; if (e) e->mega_failed = false; }
+    else if (k == "mega") { g_tune.mega = value; if (e) { e->mega_failed = false; e->mega_backoff = 0; } }
     else if (k == "gemv_ablate") g_tune.gemv_ablate = value;
     else if (k == "mega_fold") g_tune.mega_fold = value;
     else if (k == "mega_steps") g_tune.mega_steps = value < 1 ? 1 : value;
@@ -715,6 +717,11 @@ int mv_begin(mv_engine* e, int32_t n_utt, const int32_t* prompts, const int32_t*
     const mv_config& c = e->cfg;
     const int U = c.max_utterances;
     if (n_utt < 1 || n_utt > U) return fail(MV_ERR_INVALID, "n_utt %d not in [1,%d]", n_utt, U);
+    if (e->mega_failed && --e->mega_retry_in <= 0) {
+        // whatever kept the grid from being co-resident may be gone: give the persistent kernel another chance with this utterance
+        e->mega_failed = false;
+        e->graph_dirty = true;
+    }
     std::vector<UttState> st(U);
     std::vector<int32_t> seq((size_t)U * c.block_size, 0), pos(U, 0);
     int budget = 0;
@@ -845,12 +852,14 @@ int mv_run(mv_engine* e, int32_t max_steps, int32_t poll_every, int32_t* steps_r
             a.dim = e->cfg.dim; a.block_size = e->cfg.block_size; a.n_utt = U;
             HIP_TRY(launch_embed_current(e->stream, a));
             e->mega_failed = true;
+            e->mega_backoff = e->mega_backoff ? (e->mega_backoff < 128 ? 2 * e->mega_backoff : 256) : 4;
+            e->mega_retry_in = e->mega_backoff;
             {
                 const uint32_t tag = (uint32_t)e->host_flag[2];
                 fprintf(stderr, "metavoice_hip: persistent decode kernel timed out waiting for a peer workgroup (grid not co-resident: is "
-                                "another kernel occupying the GPU?); this engine continues with per-layer launches [first wait to run out: "
+                                "another kernel occupying the GPU?); this engine continues with per-layer launches and tries again in %d utterances [first wait to run out: "
                                 "workgroup %d wave %d, epoch %u layer %u phase code %u]\n",
-                        (int)e->host_flag[3], (int)e->host_flag[4], tag >> 8, (tag & 255u) >> 3, tag & 7u);
+                        e->mega_retry_in, (int)e->host_flag[3], (int)e->host_flag[4], tag >> 8, (tag & 255u) >> 3, tag & 7u);
             }
             ++e->mega_timeouts;
             const int rc = build_graph(e);
@@ -863,6 +872,7 @@ int mv_run(mv_engine* e, int32_t max_steps, int32_t poll_every, int32_t* steps_r
     }
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->mega_ok && g_tune.mega && !e->mega_failed) e->mega_backoff = 0;   // a run on the persistent kernel without a time-out
     HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1));
     e->steps_budget -= done_steps;
     if (steps_run) *steps_run = done_steps;

@@ -231,6 +231,8 @@ struct LstmSeq2Args {
     uint32_t* abort_flag = nullptr;
     int32_t H = 0, T = 0;
 };
+bool lstm_stepwise_mode();    // true once a persistent LSTM launch has timed out in this process: launch_lstm_seq then runs one launch per step
+void lstm_force_stepwise();
 hipError_t launch_lstm_seq2(hipStream_t s, const LstmSeq2Args& a);   // H % 8 == 0, (64 H + 2 H + 8) * 4 bytes of LDS <= 160 KB
 
 // ---- decode_mega.hip: persistent decode-step kernel (MetaVoice-1B shape, one utterance) -----------------------------

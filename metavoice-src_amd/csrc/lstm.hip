@@ -19,6 +19,7 @@
 // before the launch (`lstm_inproj_kernel` here, a k = 1 convolution in codec.hip).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -305,21 +306,100 @@ __global__ void __launch_bounds__(256) spk_head_kernel(const float* __restrict__
     for (int e = threadIdx.x; e < E; e += 256, ++n) out[(size_t)b * E + e] = v[n] / norm;
 }
 
+// Fallback when the persistent kernels cannot run (their H / 8 workgroups were not co-resident: another process on the GPU): ONE
+// launch per time step, h_{t-1} / h_t / c in plain global buffers, W_hh rows read through the caches.  Same unit -> wave -> lane
+// layout and the same reductions as lstm_seq_kernel, so the results agree to fp32 rounding; ~5 us per step instead of ~4, and no
+// residency requirement.
+__global__ void __launch_bounds__(LS_THREADS) lstm_step_kernel(const LstmSeqArgs a, int t, const float* __restrict__ h_prev, float* __restrict__ h_next,
+                                                               float* __restrict__ c_state) {
+    const int H = a.H, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u0 = blockIdx.x * LS_UPW;
+    for (int b = 0; b < a.B; ++b) {
+        const float* hb = h_prev + (size_t)b * H;
+        float mine = 0.f;
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float* w = a.whh + (size_t)(q * H + u0 + wave * 2 + uu) * H;
+                float s = 0.f;
+                for (int k = lane; k < H; k += 64) s = fmaf(w[k], hb[k], s);
+                s = wave_sum(s);
+                if (lane == uu * 4 + q) mine = s;
+            }
+        float act = 0.f;
+        if (lane < 8) {
+            const int u = wave * 2 + (lane >> 2), q = lane & 3;
+            const float g = mine + a.gin[(size_t)b * a.gs_b + (size_t)t * a.gs_t + (size_t)(q * H + u0 + u) * a.gs_r];
+            act = q == 2 ? tanhf(g) : sigmoidf_(g);
+        }
+        const int base = lane & 4;
+        const float ig = __shfl(act, base + 0, 64), fg = __shfl(act, base + 1, 64), gg = __shfl(act, base + 2, 64), og = __shfl(act, base + 3, 64);
+        if (lane == 0 || lane == 4) {
+            const int u = u0 + wave * 2 + (lane >> 2);
+            const float c = fmaf(fg, c_state[(size_t)b * H + u], ig * gg);
+            const float h = og * tanhf(c);
+            c_state[(size_t)b * H + u] = c;
+            h_next[(size_t)b * H + u] = h;
+            if (a.y) {
+                const size_t o = (size_t)b * a.ys_b + (size_t)t * a.ys_t + (size_t)u * a.ys_u;
+                a.y[o] = h + (a.skip ? a.skip[o] : 0.f);
+            }
+            if (a.h_last && t == a.T - 1) a.h_last[(size_t)b * H + u] = h;
+        }
+    }
+}
+
+bool g_lstm_stepwise = false;   // process-wide and sticky, like the first-stage engine's fall-back to per-layer launches
+
 }  // namespace
+
+// test hooks: MV_LSTM_FORCE_STEPWISE=1 starts in the per-step mode; MV_LSTM_FAULT=1 raises the abort word behind the first persistent
+// launch of the process, as a timed-out wait would (tests/test_codec_gpu.py runs both in a child process: the mode is sticky)
+static bool lstm_fault_pending() {
+    static int armed = getenv("MV_LSTM_FAULT") ? 1 : 0;
+    if (armed == 1) { armed = 2; return true; }
+    return false;
+}
+bool lstm_stepwise_mode() {
+    static const bool forced = getenv("MV_LSTM_FORCE_STEPWISE") != nullptr;
+    return g_lstm_stepwise || forced;
+}
+void lstm_force_stepwise() {
+    if (!g_lstm_stepwise)
+        fprintf(stderr, "metavoice_hip: a persistent LSTM launch timed out waiting for a peer workgroup (grid not co-resident: is another kernel "
+                        "occupying the GPU?); the LSTM recurrences of this process continue with one launch per time step\n");
+    g_lstm_stepwise = true;
+}
 
 size_t lstm_seq_lds_bytes(int B, int H) { return ((size_t)4 * LS_UPW * H + (size_t)B * H + (size_t)B * LS_UPW) * sizeof(float); }
 
 hipError_t launch_lstm_seq(hipStream_t s, const LstmSeqArgs& a) {
     if (a.H % LS_UPW != 0 || a.T < 1 || a.T > 65535 || a.B < 1) return hipErrorInvalidValue;
+    if (lstm_stepwise_mode()) {
+        // the granule scratch doubles as plain fp32 state: h ping | h pong | c, 12 of its 16 bytes per (row, unit)
+        float* h0 = (float*)a.hx;
+        float* h1 = h0 + (size_t)a.B * a.H;
+        float* cs = h1 + (size_t)a.B * a.H;
+        hipError_t e = hipMemsetAsync(a.hx, 0, (size_t)2 * a.B * a.H * 8, s);
+        if (e != hipSuccess) return e;
+        for (int t = 0; t < a.T; ++t)
+            hipLaunchKernelGGL(lstm_step_kernel, dim3(a.H / LS_UPW), dim3(LS_THREADS), 0, s, a, t, (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, cs);
+        e = hipMemsetAsync(a.hx, 0, (size_t)2 * a.B * a.H * 8, s);   // leave no float that could pass for a tagged granule
+        return e != hipSuccess ? e : hipGetLastError();
+    }
     const size_t lds = lstm_seq_lds_bytes(a.B, a.H);
     if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;  // the kernel also has a few static words
-    static size_t raised = 0;
+    static std::atomic<size_t> raised_on[64];   // per device: the attribute belongs to the device's copy of the function
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<size_t>& raised = raised_on[dev & 63];
     if (lds > raised) {
         hipError_t e = hipFuncSetAttribute((const void*)lstm_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         raised = lds;
     }
     hipLaunchKernelGGL(lstm_seq_kernel, dim3(a.H / LS_UPW), dim3(LS_THREADS), lds, s, a);
+    if (lstm_fault_pending()) (void)hipMemsetAsync(a.abort_flag, 1, 1, s);
     return hipGetLastError();
 }
 
@@ -327,13 +407,17 @@ hipError_t launch_lstm_seq2(hipStream_t s, const LstmSeq2Args& a) {
     if (a.H % LS_UPW != 0 || a.T < 1 || a.T > 65535) return hipErrorInvalidValue;
     const size_t lds = ((size_t)8 * LS_UPW * a.H + (size_t)2 * a.H + LS_UPW) * sizeof(float);
     if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
-    static size_t raised = 0;
+    static std::atomic<size_t> raised_on[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<size_t>& raised = raised_on[dev & 63];
     if (lds > raised) {
         hipError_t e = hipFuncSetAttribute((const void*)lstm_seq2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         raised = lds;
     }
     hipLaunchKernelGGL(lstm_seq2_kernel, dim3(2 * a.H / LS_UPW), dim3(LS_THREADS), lds, s, a);
+    if (lstm_fault_pending()) (void)hipMemsetAsync(a.abort_flag, 1, 1, s);
     return hipGetLastError();
 }
 
@@ -518,7 +602,11 @@ int mv_spkenc_embed(mv_spkenc* e, const float* mels, int32_t B, int32_t T, float
 #undef SE_TRY2
     if (aborted) {
         (void)hipMemset(e->abort_flag, 0, 4);
-        return mv_fail(MV_ERR_HIP, "mv_spkenc_embed: the LSTM workgroups timed out waiting for each other (device shared with another kernel?)");
+        if (!lstm_stepwise_mode()) {   // survive it: redo the call with one launch per time step (and stay there)
+            lstm_force_stepwise();
+            return mv_spkenc_embed(e, mels, B, T, out);
+        }
+        return mv_fail(MV_ERR_HIP, "mv_spkenc_embed: the LSTM recurrence failed");
     }
     return MV_OK;
 }

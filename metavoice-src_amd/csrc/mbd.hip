@@ -21,6 +21,7 @@
 // windowed-sinc low-pass bank, replicate padding) and the band statistics are HBM-bound elementwise / stencil kernels.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -1230,7 +1231,10 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
     for (int i = 0; i < g.n_seg; ++i) k64 = k64 && g.seg[i].K % 64 == 0;
     static const int glds_mode = getenv("MV_MBD_NO_GLDS") ? 0 : getenv("MV_MBD_NO_FUSED3") ? 1 : 2;
     static const bool t256 = !getenv("MV_MBD_NO_T256");
-    static bool t256_raised = false;
+    static std::atomic<bool> t256_raised_on[64];   // per device
+    int t256_dev = 0;
+    (void)hipGetDevice(&t256_dev);
+    std::atomic<bool>& t256_raised = t256_raised_on[t256_dev & 63];
     // 256 x 256 tiles once such tiles fill at least ~3/4 of the CUs (the 768- and 3072-channel layers with all bands in one launch)
     const int nt_m256 = (g.M + 255) / 256, nt_n256 = (g.N + 255) / 256;
     const char* t256_min_env = getenv("MV_MBD_T256_MIN_BLOCKS");   // tests lower it so that small shapes (ragged tiles) take this kernel
@@ -1556,7 +1560,11 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
 #undef MG_TRY
     if (aborted) {
         (void)hipMemset(m->lstm_abort, 0, 4);
-        return mv_fail(MV_ERR_HIP, "mv_mbd_generate: the BiLSTM workgroups timed out waiting for each other");
+        if (!lstm_stepwise_mode()) {   // survive it: redo the call with one LSTM launch per time step (and stay there)
+            lstm_force_stepwise();
+            return mbd_generate_impl(m, latent, frames, wav_ref, T, noise, seed, wav_out, inputs_on_device);
+        }
+        return mv_fail(MV_ERR_HIP, "mv_mbd_generate: the BiLSTM recurrence failed");
     }
     return MV_OK;
 }

@@ -45,3 +45,49 @@ def test_rejects_bad_tokens():
     with pytest.raises(ValueError):
         dec.decode(torch.zeros(1, 8, 3, dtype=torch.long))  # too short for the reflect padding
     dec.close()
+
+
+@pytest.mark.parametrize("hook", ["MV_LSTM_FAULT", "MV_LSTM_FORCE_STEPWISE"])
+def test_lstm_falls_back_to_one_launch_per_step(hook):
+    """when the persistent LSTM kernels cannot run (their workgroups not co-resident: a wait times out and raises the abort
+    word) the codec and the speaker encoder used to fail the request.  Now the call is redone with one launch per time step, and the
+    process stays in that mode.  `MV_LSTM_FAULT` raises the abort word behind the first persistent launch as a timed-out wait would;
+    `MV_LSTM_FORCE_STEPWISE` starts in the per-step mode.  Run in a child process: the mode is sticky."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = r'''
+import sys, torch
+sys.path.insert(0, "tests")
+from conftest import load_pkg
+from oracle import codec as o_codec
+from oracle import speaker_encoder as o_spk
+from test_codec_cpu import seeded_encodec
+codec, synthetic = load_pkg("codec"), load_pkg("synthetic")
+model = seeded_encodec(2)
+dec = codec.EncodecDecoder.from_state_dict(model.state_dict(), n_q=8)
+sd = {k: v.float() for k, v in codec.fold_weight_norm(model.state_dict()).items()}
+tokens = torch.randint(0, 1024, (8, 40), generator=torch.Generator().manual_seed(1))
+for rep in range(2):   # the first call takes the fault (or starts stepwise), the second one runs in the sticky mode
+    wav = dec.decode(tokens.unsqueeze(0))
+    with torch.no_grad():
+        owav, _ = o_codec.decode(sd, tokens)
+    d = float((wav - owav).abs().max())
+    assert d < 1e-4 * max(float(owav.abs().max()), 1.0), d
+spk = load_pkg("speaker_encoder.model")
+ssd = synthetic.speaker_encoder_state_dict(seed=4)
+enc = spk.SpeakerEncoder(state_dict=ssd, verbose=False)
+mels = torch.rand(3, 160, 40, generator=torch.Generator().manual_seed(12)) * 3.0
+d2 = float((enc(mels) - o_spk.forward(ssd, mels)).abs().max())
+assert d2 < 1e-5, d2
+print("FALLBACK_OK", d, d2)
+'''
+    env = dict(os.environ)
+    env[hook] = "1"
+    p = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "FALLBACK_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
+    if hook == "MV_LSTM_FAULT":
+        assert "continue with one launch per time step" in p.stderr

@@ -374,10 +374,25 @@ def test_persistent_kernel_times_out_cleanly_and_the_run_falls_back_to_launches(
         assert steps == 39
         assert engine.decode_path() == (0, 1)  # one launch abandoned, the engine stays on the per-layer launches
         assert engine.tokens(0) == good and torch.equal(engine.captured_logits(15, 40), good_logits)
-        # the engine stays on the launches: the next utterance works without another timeout
+        # the engine stays on the launches for the next three utterances (no further time-out) ...
+        for _ in range(3):
+            engine.begin([prompt], spk, sp, max_new_tokens=40, end_of_audio_token=9999, prefill_mode=1)
+            engine.run()
+            assert engine.tokens(0) == good and engine.decode_path() == (0, 1)
+        # ... and gives the persistent kernel another chance with the fourth: the fault is still there, so that attempt is abandoned
+        # too (same tokens) and the next retry is 8 utterances away
+        engine.begin([prompt], spk, sp, max_new_tokens=40, end_of_audio_token=9999, prefill_mode=1)
+        engine.run(poll_every=16)
+        assert engine.tokens(0) == good and engine.decode_path() == (0, 2)
+        engine.tune(mega_fault=0)
+        for _ in range(7):
+            engine.begin([prompt], spk, sp, max_new_tokens=40, end_of_audio_token=9999, prefill_mode=1)
+            engine.run()
+            assert engine.decode_path() == (0, 2)
+        # the obstacle is gone: the eighth utterance after the second failure runs on the persistent kernel again
         engine.begin([prompt], spk, sp, max_new_tokens=40, end_of_audio_token=9999, prefill_mode=1)
         engine.run()
-        assert engine.tokens(0) == good
+        assert engine.tokens(0) == good and engine.decode_path() == (2, 2)
     finally:
         engine.tune(mega_fault=0)
     engine.tune(mega=1)  # explicit re-enable clears the sticky fallback
