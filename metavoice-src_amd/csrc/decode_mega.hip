@@ -103,6 +103,13 @@ __device__ __forceinline__ void mega_issue_row(u32x4* wv, const bf16_t* w, int n
 #ifndef MEGA_NU_EARLY_KV
 #define MEGA_NU_EARLY_KV 0
 #endif
+// MEGA_KV_AFTER_NORM: the first attention slice's K/V rows are requested AFTER the RMSNorm of P0 instead of before it.  Before the
+// norm the requests sit behind the 96 KB of wqkv rows still draining from the end of the previous layer, so the wave is stalled in
+// the issue (2.3 us, profiles/r02b_fold/stamps_final.txt) with the norm still to do; the norm needs only LDS and the norm weights
+// (requested AHEAD of the wqkv rows in this mode), so it can run while the backlog drains.
+#ifndef MEGA_KV_AFTER_NORM
+#define MEGA_KV_AFTER_NORM 0
+#endif
 #define MEGA_EARLY_W2_BYTES (MG_WAVES * 5 * 1024)
 #define MEGA_EARLY_W1_BYTES (MG_WAVES * 6 * 1024)
 __device__ __forceinline__ void mega_row_to_lds(uint32_t lds, const bf16_t* g) {  // 64 lanes x 16 B -> 1 KB of LDS at `lds`
@@ -305,13 +312,14 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     u32x4 nw_attn, nw_ffn = u32x4{0u, 0u, 0u, 0u};
     auto issue_layer0 = [&](int lane, int wave) {  // (lane, wave): the caller's ids, opaque to the optimiser inside the step loop
         const bf16_t* w = a.layers[0].wqkv;
+        if (MEGA_KV_AFTER_NORM) nw_attn = load16(a.layers[0].attn_norm + ((wave * 64 + lane) & 255) * 8);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             if (I4) mega_issue_row_i4<1>(cq + i, cz + i, a.layers[0].q[0], a.layers[0].sz[0], 24 * b + 3 * wave + i, MG_DIM, lane);
             else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, a.layers[0].q8[0], 24 * b + 3 * wave + i, MG_DIM, lane); sc_a[i] = bf2f(a.layers[0].s8[0][24 * b + 3 * wave + i]); }
             else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave + i, MG_DIM, lane, a.ablate);
         }
-        nw_attn = load16(a.layers[0].attn_norm + ((wave * 64 + lane) & 255) * 8);
+        if (!MEGA_KV_AFTER_NORM) nw_attn = load16(a.layers[0].attn_norm + ((wave * 64 + lane) & 255) * 8);
     };
     issue_layer0(lane, wave);
 
@@ -395,11 +403,12 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         for (int q = 0; q < ATTN_U; ++q) kv[q] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int q = 0; q < ATTN_U; ++q) vv[q] = u32x4{0u, 0u, 0u, 0u};
-        if (first_att >= 0) issue_kv(first_att);
+        if (!MEGA_KV_AFTER_NORM && first_att >= 0) issue_kv(first_att);
         __builtin_amdgcn_sched_barrier(0);
         MG_STAMP(l, 11);  // K/V requested
         mega_norm<NU>(xs, nw_attn, red, a.eps);
         MG_STAMP(l, 12);  // norm done
+        if (MEGA_KV_AFTER_NORM && first_att >= 0) { issue_kv(first_att); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll 1
         for (int u = 0; u < NU; ++u) {
             float acc[3][2];
@@ -774,6 +783,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }
             __builtin_amdgcn_sched_barrier(0);
             // next: the following layer's wqkv rows, or the LM-head rows 11 b + wave + 8 i
+            if (MEGA_KV_AFTER_NORM) nw_attn = load16((l + 1 < a.n_layer ? a.layers[l + 1].attn_norm : a.final_norm) + (tid_o & 255) * 8);
             if (l + 1 < a.n_layer) {
                 const bf16_t* w = a.layers[l + 1].wqkv;
 #pragma unroll
@@ -795,7 +805,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                     else mega_issue_row<4>(wv + 4 * i, a.head, hn, MG_DIM, lane_o, a.ablate);
                 }
             }
-            nw_attn = load16((l + 1 < a.n_layer ? a.layers[l + 1].attn_norm : a.final_norm) + (tid_o & 255) * 8);
+            if (!MEGA_KV_AFTER_NORM) nw_attn = load16((l + 1 < a.n_layer ? a.layers[l + 1].attn_norm : a.final_norm) + (tid_o & 255) * 8);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
