@@ -127,6 +127,7 @@ struct mv_engine {
 
     // prefill workspace (M = 2 T rows of one utterance), allocated on the first batched prefill
     bf16_t *px = nullptr, *ph = nullptr, *pn = nullptr, *pq = nullptr, *pattn = nullptr, *pact = nullptr, *pvt = nullptr;
+    float* pslab = nullptr;              // split-K partial tiles of the prefill GEMMs (launch_gemm splits only grids below 1024 tiles)
 
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -301,6 +302,7 @@ int enqueue_prefill(mv_engine* e, int u, int T) {
         HIP_TRY(hipMalloc((void**)&e->pattn, rows * c.dim * 2));
         HIP_TRY(hipMalloc((void**)&e->pact, rows * c.intermediate * 2));
         HIP_TRY(hipMalloc((void**)&e->pvt, attn_rows_scratch_elems(2, c.n_head, 128, c.block_size) * 2));  // V transposed, for the MFMA attention
+        HIP_TRY(hipMalloc((void**)&e->pslab, (size_t)4 * 1024 * GEMM_TILE * GEMM_TILE * 2 * 4));  // 4 ranges x (< 1024 tiles of 64 x 64) x gated pair, fp32
     }
     HIP_TRY(launch_embed_rows(s, e->seq + (size_t)u * c.block_size, T, c.dim, e->tok_emb, e->pos_emb,
                               e->spk_proj + (size_t)u * c.dim, e->px));
@@ -316,6 +318,7 @@ int enqueue_prefill(mv_engine* e, int u, int T) {
         g.a = e->pn; g.w = w.wqkv; g.out_bf16 = e->pq; g.M = M; g.N = 3 * c.dim; g.K = c.dim; g.lda = c.dim; g.ldc = c.dim;
         g.qkv_dim = c.dim; g.seq_len = T; g.n_head = c.n_head; g.cache_len = c.block_size; g.kcache = kc; g.vcache = vc;
         g.scale = w.s8[0];  // null unless int8
+        g.slab = e->pslab;
         HIP_TRY(launch_gemm(s, g));
         AttnRowsArgs at;
         at.q = e->pq; at.k = kc; at.v = vc; at.out = e->pattn; at.k_batch_stride = (int64_t)c.n_head * c.block_size * 128;
@@ -325,16 +328,19 @@ int enqueue_prefill(mv_engine* e, int u, int T) {
         g = GemmArgs();
         g.a = e->pattn; g.w = w.wo; g.res_bf16 = e->px; g.out_bf16 = e->ph; g.M = M; g.N = c.dim; g.K = c.dim; g.lda = c.dim; g.ldc = c.dim;
         g.scale = w.s8[1];
+        g.slab = e->pslab;
         HIP_TRY(launch_gemm(s, g));
         n.x_bf16 = e->ph; n.w_bf16 = w.ffn_norm;
         HIP_TRY(launch_norm_rows(s, n));
         g = GemmArgs();
         g.a = e->pn; g.w = w.w1; g.w2 = w.w3; g.out_bf16 = e->pact; g.M = M; g.N = c.intermediate; g.K = c.dim; g.lda = c.dim;
         g.ldc = c.intermediate; g.scale = w.s8[2]; g.scale2 = w.s8[3];
+        g.slab = e->pslab;
         HIP_TRY(launch_gemm(s, g));
         g = GemmArgs();
         g.a = e->pact; g.w = w.w2; g.res_bf16 = e->ph; g.out_bf16 = e->px; g.M = M; g.N = c.dim; g.K = c.intermediate;
         g.lda = c.intermediate; g.ldc = c.dim; g.scale = w.s8[4];
+        g.slab = e->pslab;
         HIP_TRY(launch_gemm(s, g));
     }
     for (int r = 0; r < 2; ++r)
@@ -481,7 +487,7 @@ int mv_engine_destroy(mv_engine* e) {
     if (e->graph) hipGraphDestroy(e->graph);
     void* bufs[] = {e->q_arena, e->arena, e->x, e->h, e->q, e->attn, e->act, e->logits, e->kcache, e->vcache, e->partial, e->counters,
                     e->utt, e->pos_arr, e->seq, e->spk_emb, e->spk_proj, e->n_active, e->capture, e->px, e->ph, e->pn, e->pq,
-                    e->pattn, e->pact, e->pvt, e->mega_layers, e->granules, e->step_counter, e->abort_flag, e->dbg, e->stamps, e->utt_shadow,
+                    e->pattn, e->pact, e->pvt, e->pslab, e->mega_layers, e->granules, e->step_counter, e->abort_flag, e->dbg, e->stamps, e->utt_shadow,
                     e->pos_shadow};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -1070,7 +1076,13 @@ int mv_op_gemm(void* stream, int32_t M, int32_t N, int32_t K, const void* a, con
     g.a = (const bf16_t*)a; g.w = (const bf16_t*)w; g.w2 = (const bf16_t*)w2; g.bias = (const bf16_t*)bias; g.bias2 = (const bf16_t*)bias2;
     g.res_bf16 = (const bf16_t*)residual; g.out_bf16 = (bf16_t*)out; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N;
     g.act = gelu ? GEMM_ACT_GELU : GEMM_ACT_NONE;
-    if (launch_gemm((hipStream_t)stream, g) != hipSuccess) return fail(MV_ERR_INVALID, "gemm: unsupported shape M=%d N=%d K=%d (K %% 8 == 0)", M, N, K);
+    // the split-K path (few rows, deep K: the prefill shapes) needs scratch; this test entry allocates it per call, MV_GEMM_NO_SPLITK
+    // keeps the one-range kernel -- the parity test runs both
+    HIP_TRY(hipMalloc((void**)&g.slab, gemm_slab_elems(M, N, w2 != nullptr) * 4));
+    const hipError_t le = launch_gemm((hipStream_t)stream, g);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(g.slab);
+    if (le != hipSuccess) return fail(MV_ERR_INVALID, "gemm: unsupported shape M=%d N=%d K=%d (K %% 8 == 0)", M, N, K);
     return MV_OK;
 }
 

@@ -21,6 +21,36 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
+// The epilogue of one output element (m, n): v = the fp32 dot product x[m] . w[n], v2 = x[m] . w2[n] (gated pairs).
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, int m, int n, float v, float v2) {
+    const bool gated = a.w2 != nullptr;
+    float y = round_bf(v + (a.bias ? bf2f(a.bias[n]) : 0.f));  // the bf16 Linear output
+    if (a.scale) y = round_bf(y * bf2f(a.scale[n]));          // int8 weight-only: the codes were the GEMM operand, the row scale follows
+    if (gated) {  // bf16(bf16(silu(w1 x)) * bf16(w3 x))   (fast_model.py:237, layers.py:62-72)
+        float u = round_bf(v2 + (a.bias2 ? bf2f(a.bias2[n]) : 0.f));
+        if (a.scale2) u = round_bf(u * bf2f(a.scale2[n]));
+        y = round_bf(round_bf(y / (1.0f + __expf(-y))) * u);
+    } else if (a.act == GEMM_ACT_GELU) {
+        y = round_bf(gelu_erf(y));
+    }
+    if (a.qkv_dim > 0) {  // first-stage prefill: q -> out, k/v -> cache[row][head][t][128]  (fast_model.py:209-218)
+        const bf16_t o = f2bf(y);
+        const int dim = a.qkv_dim;
+        if (n < dim) {
+            a.out_bf16[(size_t)m * dim + n] = o;
+        } else {
+            const int which = (n - dim) / dim, hd = (n - dim) % dim;
+            const int row = m / a.seq_len, t = m % a.seq_len;
+            bf16_t* cache = which ? a.vcache : a.kcache;
+            cache[(((size_t)row * a.n_head + hd / 128) * a.cache_len + t) * 128 + hd % 128] = o;
+        }
+    } else if (a.out_f32) {  // second stage: fp32 residual stream, x = x + bf16(linear)  (combined.py:37-52)
+        a.out_f32[(size_t)m * a.ldc + n] = (a.res_f32 ? a.res_f32[(size_t)m * a.ldc + n] : 0.f) + y;
+    } else {  // first stage: bf16 residual stream (fast_model.py:179-180)
+        a.out_bf16[(size_t)m * a.ldc + n] = a.res_bf16 ? f2bf(bf2f(a.res_bf16[(size_t)m * a.ldc + n]) + y) : f2bf(y);
+    }
+}
+
 __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(16))) u32x4 lds[3][GT * 8];  // A, W, W2 tiles: [row][8 chunks of 16 B], chunk ^= row & 7
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -47,17 +77,20 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs a) {
 
     // K need only be a multiple of 8: 16-byte chunks past the end of a row are staged as zeros
     const u32x4 zero = {0u, 0u, 0u, 0u};
-    const bool in0 = sc * 8 < K;
-    u32x4 ra0 = in0 ? load16(ga0) : zero, ra1 = in0 ? load16(ga1) : zero, rw0 = in0 ? load16(gw0) : zero,
-          rw1 = in0 ? load16(gw1) : zero, rv0 = zero, rv1 = zero;
-    if (gated && in0) { rv0 = load16(gv0); rv1 = load16(gv1); }
-    for (int k0 = 0; k0 < K; k0 += GT) {
+    // split-K: this block covers [kb, ke) of K (whole 64-column steps; the last range takes the remainder)
+    const int ksteps = (K + GT - 1) / GT, per = (ksteps + a.splitk - 1) / a.splitk;
+    const int kb = (int)blockIdx.z * per * GT, ke = min(K, (int)(blockIdx.z + 1) * per * GT);
+    const bool in0 = kb + sc * 8 < ke;
+    u32x4 ra0 = in0 ? load16(ga0 + kb) : zero, ra1 = in0 ? load16(ga1 + kb) : zero, rw0 = in0 ? load16(gw0 + kb) : zero,
+          rw1 = in0 ? load16(gw1 + kb) : zero, rv0 = zero, rv1 = zero;
+    if (gated && in0) { rv0 = load16(gv0 + kb); rv1 = load16(gv1 + kb); }
+    for (int k0 = kb; k0 < ke; k0 += GT) {
         __syncthreads();  // everyone is done reading the previous tile
         lds[0][s0] = ra0; lds[0][s1] = ra1; lds[1][s0] = rw0; lds[1][s1] = rw1;
         if (gated) { lds[2][s0] = rv0; lds[2][s1] = rv1; }
         __syncthreads();
-        if (k0 + GT < K) {  // next tile's loads fly under this tile's MFMAs
-            const bool in = k0 + GT + sc * 8 < K;
+        if (k0 + GT < ke) {  // next tile's loads fly under this tile's MFMAs
+            const bool in = k0 + GT + sc * 8 < ke;
             ra0 = in ? load16(ga0 + k0 + GT) : zero; ra1 = in ? load16(ga1 + k0 + GT) : zero;
             rw0 = in ? load16(gw0 + k0 + GT) : zero; rw1 = in ? load16(gw1 + k0 + GT) : zero;
             if (gated) { rv0 = in ? load16(gv0 + k0 + GT) : zero; rv1 = in ? load16(gv1 + k0 + GT) : zero; }
@@ -87,52 +120,51 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs a) {
     }
 
     // ---- epilogue: C fragment (i, j): column lane & 15, rows (lane >> 4) * 4 + reg ---------------------------------
+    // split-K: this block's partial tile goes to the slab of its K range [range][M][N] (gated pairs: a second slab set behind it)
+    float* slab = a.splitk > 1 ? a.slab + (size_t)blockIdx.z * M * N : nullptr;
+    float* slab2 = a.splitk > 1 && gated ? a.slab + ((size_t)a.splitk + blockIdx.z) * M * N : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = tile_n + wn * 32 + j * 16 + (lane & 15);
             if (n >= N) continue;
-            const float b1 = a.bias ? bf2f(a.bias[n]) : 0.f;
-            const float b2 = (gated && a.bias2) ? bf2f(a.bias2[n]) : 0.f;
-            const float s1 = a.scale ? bf2f(a.scale[n]) : 0.f;
-            const float s2 = (gated && a.scale2) ? bf2f(a.scale2[n]) : 0.f;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int m = tile_m + wm * 32 + i * 16 + (lane >> 4) * 4 + reg;
                 if (m >= M) continue;
-                float y = round_bf(acc[i][j][reg] + b1);  // the bf16 Linear output
-                if (a.scale) y = round_bf(y * s1);        // int8 weight-only: the codes were the GEMM operand, the row scale follows
-                if (gated) {  // bf16(bf16(silu(w1 x)) * bf16(w3 x))   (fast_model.py:237, layers.py:62-72)
-                    float u = round_bf(acc2[i][j][reg] + b2);
-                    if (a.scale2) u = round_bf(u * s2);
-                    y = round_bf(round_bf(y / (1.0f + __expf(-y))) * u);
-                } else if (a.act == GEMM_ACT_GELU) {
-                    y = round_bf(gelu_erf(y));
-                }
-                if (a.qkv_dim > 0) {  // first-stage prefill: q -> out, k/v -> cache[row][head][t][128]  (fast_model.py:209-218)
-                    const bf16_t v = f2bf(y);
-                    const int dim = a.qkv_dim;
-                    if (n < dim) {
-                        a.out_bf16[(size_t)m * dim + n] = v;
-                    } else {
-                        const int which = (n - dim) / dim, hd = (n - dim) % dim;
-                        const int row = m / a.seq_len, t = m % a.seq_len;
-                        bf16_t* cache = which ? a.vcache : a.kcache;
-                        cache[(((size_t)row * a.n_head + hd / 128) * a.cache_len + t) * 128 + hd % 128] = v;
-                    }
-                } else if (a.out_f32) {  // second stage: fp32 residual stream, x = x + bf16(linear)  (combined.py:37-52)
-                    a.out_f32[(size_t)m * a.ldc + n] = (a.res_f32 ? a.res_f32[(size_t)m * a.ldc + n] : 0.f) + y;
-                } else {  // first stage: bf16 residual stream (fast_model.py:179-180)
-                    a.out_bf16[(size_t)m * a.ldc + n] = a.res_bf16 ? f2bf(bf2f(a.res_bf16[(size_t)m * a.ldc + n]) + y) : f2bf(y);
+                if (slab) {
+                    slab[(size_t)m * N + n] = acc[i][j][reg];
+                    if (slab2) slab2[(size_t)m * N + n] = acc2[i][j][reg];
+                } else {
+                    gemm_epilogue(a, m, n, acc[i][j][reg], acc2[i][j][reg]);
                 }
             }
         }
 }
 
-hipError_t launch_gemm(hipStream_t s, const GemmArgs& a) {
+// split-K tail: partial tiles added in range order (fixed: the result does not depend on which block finished first), then the epilogue
+__global__ void __launch_bounds__(256) gemm_combine_kernel(const GemmArgs a) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, MN = (size_t)a.M * a.N;
+    if (i >= MN) return;
+    float v = 0.f, v2 = 0.f;
+    for (int z = 0; z < a.splitk; ++z) v += a.slab[(size_t)z * MN + i];
+    if (a.w2)
+        for (int z = 0; z < a.splitk; ++z) v2 += a.slab[((size_t)a.splitk + z) * MN + i];
+    gemm_epilogue(a, (int)(i / a.N), (int)(i % a.N), v, v2);
+}
+
+hipError_t launch_gemm(hipStream_t s, const GemmArgs& a_in) {
+    GemmArgs a = a_in;
     if (a.M < 1 || a.N < 1 || a.K < 8 || a.K % 8 != 0 || a.lda % 8 != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gemm_bf16_kernel, dim3((a.N + GT - 1) / GT, (a.M + GT - 1) / GT), dim3(256), 0, s, a);
+    const int nt = (a.N + GT - 1) / GT, mt = (a.M + GT - 1) / GT, ksteps = (a.K + GT - 1) / GT;
+    // split K while the tile grid alone is below ~4 blocks per CU (1024) and every range keeps >= 8 steps: a block's K-loop is a
+    // chain of dependent load round trips, so what fills the memory system is the number of resident blocks
+    a.splitk = 1;
+    if (a.slab && !getenv("MV_GEMM_NO_SPLITK"))
+        while (a.splitk < 4 && (size_t)nt * mt * a.splitk < 1024 && ksteps / (a.splitk * 2) >= 8) a.splitk *= 2;
+    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(nt, mt, a.splitk), dim3(256), 0, s, a);
+    if (a.splitk > 1) hipLaunchKernelGGL(gemm_combine_kernel, dim3((unsigned)(((size_t)a.M * a.N + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

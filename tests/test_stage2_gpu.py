@@ -44,7 +44,12 @@ def close_bf16(got, ref, ulps, atol):
 
 @pytest.mark.parametrize("M,N_,K", [(256, 6144, 2048), (220, 2048, 2048), (256, 2048, 5632), (64, 1025, 384), (37, 100, 72), (2048, 384, 1024)])
 @pytest.mark.parametrize("mode", ["plain", "bias_resid", "gated", "gelu"])
-def test_gemm(M, N_, K, mode):
+@pytest.mark.parametrize("splitk", [True, False])
+def test_gemm(M, N_, K, mode, splitk, monkeypatch):
+    """`gemm_bf16_kernel` with every epilogue; `splitk`: few-row / deep-K shapes (the prefill's M = 256) run as up to four K ranges +
+    `gemm_combine_kernel` (the default when the caller hands in scratch), or as one range (MV_GEMM_NO_SPLITK)."""
+    if not splitk:
+        monkeypatch.setenv("MV_GEMM_NO_SPLITK", "1")
     g = torch.Generator().manual_seed(M + N_ + K)
     a = rb(torch.randn(M, K, generator=g))
     w = rb(torch.randn(N_, K, generator=g) * 0.05)
