@@ -302,7 +302,8 @@ int enqueue_prefill(mv_engine* e, int u, int T) {
         HIP_TRY(hipMalloc((void**)&e->pattn, rows * c.dim * 2));
         HIP_TRY(hipMalloc((void**)&e->pact, rows * c.intermediate * 2));
         HIP_TRY(hipMalloc((void**)&e->pvt, attn_rows_scratch_elems(2, c.n_head, 128, c.block_size) * 2));  // V transposed, for the MFMA attention
-        HIP_TRY(hipMalloc((void**)&e->pslab, (size_t)4 * 1024 * GEMM_TILE * GEMM_TILE * 2 * 4));  // 4 ranges x (< 1024 tiles of 64 x 64) x gated pair, fp32
+        // ranges x tiles < 2048 whenever launch_gemm splits (it doubles the ranges only while ranges x tiles < 1024), x gated pair, fp32
+        HIP_TRY(hipMalloc((void**)&e->pslab, (size_t)2048 * GEMM_TILE * GEMM_TILE * 2 * 4));
     }
     HIP_TRY(launch_embed_rows(s, e->seq + (size_t)u * c.block_size, T, c.dim, e->tok_emb, e->pos_emb,
                               e->spk_proj + (size_t)u * c.dim, e->px));

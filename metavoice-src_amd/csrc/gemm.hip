@@ -158,11 +158,11 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& a_in) {
     GemmArgs a = a_in;
     if (a.M < 1 || a.N < 1 || a.K < 8 || a.K % 8 != 0 || a.lda % 8 != 0) return hipErrorInvalidValue;
     const int nt = (a.N + GT - 1) / GT, mt = (a.M + GT - 1) / GT, ksteps = (a.K + GT - 1) / GT;
-    // split K while the tile grid alone is below ~4 blocks per CU (1024) and every range keeps >= 8 steps: a block's K-loop is a
+    // split K (2, 4 or 8 ranges) while the tile grid alone is below ~4 blocks per CU (1024) and every range keeps >= 4 steps: a block's K-loop is a
     // chain of dependent load round trips, so what fills the memory system is the number of resident blocks
     a.splitk = 1;
     if (a.slab && !getenv("MV_GEMM_NO_SPLITK"))
-        while (a.splitk < 4 && (size_t)nt * mt * a.splitk < 1024 && ksteps / (a.splitk * 2) >= 8) a.splitk *= 2;
+        while (a.splitk < 8 && (size_t)nt * mt * a.splitk < 1024 && ksteps / (a.splitk * 2) >= 4) a.splitk *= 2;
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3(nt, mt, a.splitk), dim3(256), 0, s, a);
     if (a.splitk > 1) hipLaunchKernelGGL(gemm_combine_kernel, dim3((unsigned)(((size_t)a.M * a.N + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();

@@ -167,14 +167,14 @@ struct GemmArgs {
     bf16_t* vcache = nullptr;
     // split-K (few rows, e.g. the M = 2T = 256 of a prefill: N / 64 x M / 64 tiles alone leave most CUs with one small block whose
     // every K-step is a dependent load round trip): `slab` = device scratch of gemm_slab_elems(M, N, gated) floats; launch_gemm then
-    // cuts K into up to 4 ranges (blockIdx.z), the blocks write fp32 partial tiles and gemm_combine_kernel adds them in range order
+    // cuts K into up to 8 ranges (blockIdx.z), the blocks write fp32 partial tiles and gemm_combine_kernel adds them in range order
     // and applies the epilogue.  Null: one range, epilogue in the GEMM kernel.
     float* slab = nullptr;
     int32_t splitk = 1;             // set by launch_gemm
 };
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& a);
 #define GEMM_TILE 64
-inline size_t gemm_slab_elems(int M, int N, bool gated) { return (size_t)4 * M * N * (gated ? 2 : 1); }
+inline size_t gemm_slab_elems(int M, int N, bool gated) { return (size_t)8 * M * N * (gated ? 2 : 1); }
 
 struct NormArgs {
     const bf16_t* x_bf16 = nullptr;
