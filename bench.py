@@ -196,7 +196,7 @@ def measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline):
             mbd_mod = importlib.import_module("metavoice-src_amd.mbd")
             shared[key] = mbd_mod.MultiBandDiffusionBands.from_package(mv.synthetic.mbd_package(seed=rank), seed=1234 + rank, precision=a.mbd_precision)
         diffusion = shared[key]
-    stage_ms = {"stage1_prefill+decode": 0.0, "stage1_decode_gpu": 0.0, "adapters+stage2": 0.0, "encodec_decode": 0.0, "multiband_diffusion": 0.0}
+    stage_ms = {"stage1_prefill+decode": 0.0, "stage1_begin(upload+prefill+first_token)": 0.0, "stage1_decode_gpu": 0.0, "adapters+stage2": 0.0, "encodec_decode": 0.0, "multiband_diffusion": 0.0}
 
     def fold_onto_codebooks(toks, n_prompt):
         """Random weights do not produce the cb0 / cb1 alternation a trained first stage does, and the adapter truncates both
@@ -216,6 +216,7 @@ def measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline):
             engine.begin(prompts, spk.expand(len(group), -1), [mv.SamplingParams(guidance_scale=3.0, temperature=1.0, top_p=0.95,
                                                                               seed=sp.seed + 7 * u) for u in range(len(group))],
                          max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
+            stage_ms["stage1_begin(upload+prefill+first_token)"] += (time.perf_counter() - t0) * 1e3   # mv_begin returns after a stream sync
             engine.run(poll_every=1 << 20)
             streams = [engine.tokens(u)[:len(prompts[u]) + caps[u]] for u in range(len(group))]
             t1 = time.perf_counter()
@@ -407,6 +408,17 @@ def measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline):
                               "algorithmic_bytes_per_step": total_bytes, "gpu_ms_per_step": round(gpu_ms / a.steps, 2)},
             "per_kernel": per_kernel,
         }
+        # the prefill (mv_begin: state upload, speaker projection, MFMA GEMMs over 2T rows + MFMA attention, LM head, first token):
+        # MFMA-bound by arithmetic intensity only from ~150 rows up; at the bench's 2T = 256 rows it is the 2.5 GB weight stream that
+        # prices it, so both fractions are printed
+        begin_s = stage_ms["stage1_begin(upload+prefill+first_token)"] / a.steps / len(work) * 1e-3
+        rows = sum(2 * len(p) for p, _ in work[0])
+        pf_flops = 2.0 * (weight_bytes(args, None) / 2) * rows
+        out["prefill_roofline"] = {"bound": "hbm (weights, below ~300 rows) / mfma", "rows": rows, "ms": round(begin_s * 1e3, 3),
+                                   "mfma_achieved_TFLOPs": round(pf_flops / begin_s / 1e12, 1), "mfma_frac": round(pf_flops / begin_s / 2.5e15, 4),
+                                   "weight_stream_GBs": round(weight_bytes(args, a.quantisation_mode) / begin_s / 1e9, 1),
+                                   "weight_stream_frac": round(weight_bytes(args, a.quantisation_mode) / begin_s / 1e9 / HBM_PEAK_GBS, 4),
+                                   "note": "whole mv_begin call per engine run, host-timed (it ends in a stream synchronisation)"}
         if diffusion is not None:
             # the vocoder's dominant kernel is MFMA-bound: algorithmic flops of the band UNets' convolutions (2 x MACs, x the MFMA terms
             # per product) over the whole multi-band-diffusion stage time (which also contains its element-wise kernels: a lower bound)

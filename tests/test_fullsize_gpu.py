@@ -3,11 +3,13 @@
 determinism, path equivalences that must hold bit for bit, quantiser idempotence, CFG identities -- while a short oracle
 comparison (first positions only) ties the full-size engine to the reference arithmetic."""
 import ctypes as C
+import os
 
+import numpy as np
 import pytest
 import torch
 
-from conftest import load_pkg
+from conftest import GOLDEN, load_pkg
 from oracle import stage1 as o_s1
 
 pytestmark = pytest.mark.gpu
@@ -59,10 +61,14 @@ def test_full_size_path_equivalences(full):
     # MFMA prefill vs the prompt teacher-forced through the decode kernels: same first-token logits to summation order
     d = run(engine, prompt, spk, sp, n_new, prefill_mode=0)
     ld = engine.captured_logits(T - 1, 1)
-    scale = float(la[0].std())
-    # two bf16 evaluations with different fp32 summation orders through 24 layers: the reference's own bf16-vs-fp32 noise on
-    # raw logits is max 0.094 at logit std ~0.9 (SURVEY.md 8c "noise floor"), i.e. ~0.1 sigma
-    assert float((la[0] - ld[0]).abs().max()) <= 0.15 * scale
+    # two bf16 evaluations with different fp32 summation orders through 24 layers (the prefill GEMMs also add their K ranges in
+    # another order than the decode kernels): the yardstick is what the REFERENCE loses between its own bf16 and fp32 evaluations
+    # at this size -- max 0.119 on raw logits over 64 steps, stored in the 24-layer golden -- with the factor the golden test allows
+    floor = float(np.load(os.path.join(GOLDEN, "stage1_full24.npz"))["noise_raw_refbf16"].max())
+    diff = float((la[0] - ld[0]).abs().max())
+    print(f"[full24] first-token logits, MFMA prefill vs the prompt teacher-forced through the decode kernels: max |d| {diff:.4f} "
+          f"(reference bf16-vs-fp32 floor {floor:.4f})")
+    assert diff <= 1.5 * floor
     assert len(a) == len(d) == T + n_new and a[:T] == prompt.tolist()
     assert run(engine, prompt, spk, mv.SamplingParams(top_p=0.95, seed=7), n_new, prefill_mode=1) != a  # the seed matters
 
