@@ -112,7 +112,8 @@ __device__ __forceinline__ void mega_issue_row(u32x4* wv, const bf16_t* w, int n
 #endif
 #define MEGA_EARLY_W2_BYTES (MG_WAVES * 5 * 1024)
 #define MEGA_EARLY_W1_BYTES (MG_WAVES * 6 * 1024)
-__device__ __forceinline__ void mega_row_to_lds(uint32_t lds, const bf16_t* g) {  // 64 lanes x 16 B -> 1 KB of LDS at `lds`
+__device__ __forceinline__ void mega_row_to_lds(uint32_t lds, const bf16_t* g, int ablate = 0) {  // 64 lanes x 16 B -> 1 KB of LDS at `lds`
+    if (ablate & 1) return;  // profiling only (mv_tune gemv_ablate bit 0): no weight requests at all, results are garbage
     uint32_t m0_save;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(m0_save) : "s"(lds), "v"(g) : "memory");
@@ -477,8 +478,8 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 else if (EARLY_W1) {
                     const bf16_t* row = L.w1 + (size_t)min(rb13 + i, MG_INTER - 1) * MG_DIM;
                     if (!w1_half_issued) {  // a workgroup that does not attend in this step (its key range is empty)
-                        mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + 0) * 64)), row + lane_o * 8);
-                        mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + 1) * 64)), row + 512 + lane_o * 8);
+                        mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + 0) * 64)), row + lane_o * 8, a.ablate);
+                        mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + 1) * 64)), row + 512 + lane_o * 8, a.ablate);
                     }
                     wv[4 * i + 2] = load_stream16(row + 2 * 512 + lane_o * 8);
                     wv[4 * i + 3] = load_stream16(row + 3 * 512 + lane_o * 8);
@@ -520,7 +521,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + j) * 64)),
-                                        L.w1 + (size_t)min(rb13 + i, MG_INTER - 1) * MG_DIM + j * 512 + lane_o * 8);
+                                        L.w1 + (size_t)min(rb13 + i, MG_INTER - 1) * MG_DIM + j * 512 + lane_o * 8, a.ablate);
                 w1_half_issued = true;
             }
             // One K/V register set.  After an utterance's partial has been merged and published (workgroup-wide
@@ -654,7 +655,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             if constexpr (EARLY_W2) {  // chunks 0..4 of the w2 row on their way while the norm, the w1|w3 dots and the act publish run
 #pragma unroll
                 for (int j = 0; j < 5; ++j)
-                    mega_row_to_lds(lds_addr(w2_lds + ((wave_o * 5 + j) * 64)), L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8);
+                    mega_row_to_lds(lds_addr(w2_lds + ((wave_o * 5 + j) * 64)), L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8, a.ablate);
             }
             mega_norm<NU>(xs, nw_ffn, red, a.eps);
             MG_STAMP(l, 18);  // norm done
@@ -748,7 +749,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                     for (int i = 0; i < 3; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + j) * 64)), w + (size_t)(24 * b + 3 * wave_o + i) * MG_DIM + j * 512 + lane_o * 8);
+                            mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + j) * 64)), w + (size_t)(24 * b + 3 * wave_o + i) * MG_DIM + j * 512 + lane_o * 8, a.ablate);
                 }
             }
 #pragma unroll 1
