@@ -1096,7 +1096,7 @@ int mv_op_attention_rows(void* stream, int32_t batch, int32_t T, int32_t n_head,
     a.k_batch_stride = (int64_t)T * 3 * C; a.k_head_stride = head_dim; a.k_key_stride = 3 * C; a.q_row_stride = 3 * C; a.out_row_stride = C;
     a.T = T; a.n_head = n_head; a.batch = batch; a.head_dim = head_dim; a.causal = causal;
     // the engines hand in their own scratch; this test entry allocates one per call (and runs the one-query-per-block VALU kernel too
-    // when MV_ATTN_VALU is set, so that both kernels stay covered by the same parity test)
+    // when MV_ATTN_VALU_OP is set, so that both kernels stay covered by the same parity test)
     const bool valu = getenv("MV_ATTN_VALU_OP") != nullptr;
     if (!valu) HIP_TRY(hipMalloc((void**)&a.vt_scratch, attn_rows_scratch_elems(batch, n_head, head_dim, T) * 2));
     const hipError_t le = launch_attn_rows((hipStream_t)stream, a);

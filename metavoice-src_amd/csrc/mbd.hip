@@ -371,6 +371,9 @@ constexpr int T256_STAGE_BYTES = 4 * 16 * 1024;   // a_hi | a_lo | w_hi | w_lo, 
 #ifndef T256_ABLATE
 #define T256_ABLATE 0
 #endif
+#ifndef T256_TERM_ORDER
+#define T256_TERM_ORDER 0
+#endif
 constexpr int T256_LDS_BYTES = 2 * T256_STAGE_BYTES + 8 * 256;   // + a 256-byte scratch slot per wave for the prefetch requests
 __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs a, int nt_m, int nt_n, int n_blocks) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char t256_lds[];   // [2 stages][4 halves][16 sub-tiles][1 KB]
@@ -487,6 +490,19 @@ __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs
                     stage_piece((kt + 1) & 1, (kt + 1) * 32, 2 * i + 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (T256_SPREAD == 2 && more) {   // one piece in front of each of the eight MFMA groups
+                    stage_piece((kt + 1) & 1, (kt + 1) * 32, half * 4 + i);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#if T256_TERM_ORDER == 1
+                // term-major: the four hi x hi products first (they need a_hi and w_hi only), then lo x hi, then hi x lo
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[i], bfh[j], acc[half * 4 + i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[i], bfh[j], acc[half * 4 + i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[i], bfl[j], acc[half * 4 + i][j], 0, 0, 0);
+#else
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4_t c = acc[half * 4 + i][j];
@@ -495,6 +511,7 @@ __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[i], bfh[j], c, 0, 0, 0);
                     acc[half * 4 + i][j] = c;
                 }
+#endif
             }
         }
     }
