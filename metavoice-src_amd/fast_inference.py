@@ -3,7 +3,9 @@
 Same constructor keywords and `synthesise(text, spk_ref_path, top_p, guidance_scale, temperature) -> str`.  Differences,
 all deliberate:
   * no telemetry (the reference posts the text of every request to PostHog, `:173-193`);
-  * no network: `model_name` may be a local directory holding first_stage.pt / second_stage.pt / speaker_encoder.pt; a hub id
+  * `spk_ref_path` may be a local path or a public http(s) URI (`get_cached_file`, fetched once) and its embedding is cached on
+    disk like the reference's (`get_cached_embedding`, `inference.py`);
+  * `model_name` may be a local directory holding first_stage.pt / second_stage.pt / speaker_encoder.pt; a hub id
     is resolved through huggingface_hub only if that package can reach the hub;
   * `spk_ref_path` may also be a tensor / `.pt` / `.npy` file holding a precomputed (1, 256) speaker embedding (the LSTM
     speaker encoder runs once per voice and is cached on disk by the reference, `fam/llm/inference.py:419-435`; it is outside
@@ -28,7 +30,7 @@ import torch
 from .adapters import FlattenedInterleavedEncodec2Codebook, TiltedEncodec
 from .decoders import EncodecDecoder
 from .fast_inference_utils import build_model, main
-from .inference import InferenceConfig, Model
+from .inference import InferenceConfig, Model, get_cached_embedding, get_cached_file
 from .longform import MAX_CHARS, split_text
 from .tokenise import TrainedBPETokeniser
 from .utils import check_audio_file, get_default_dtype, get_device, normalize_text
@@ -91,8 +93,9 @@ class TTS:
             return torch.from_numpy(np.load(p)).reshape(1, -1)
         if self.smodel is None:
             raise FileNotFoundError(f"no speaker encoder available to embed {p}; pass a precomputed (1, 256) embedding instead")
+        p = get_cached_file(p)  # fast_inference.py:122-127: fetch a URI once, length check, embedding cached per file
         check_audio_file(p)
-        return self.smodel.embed_utterance_from_file(p, numpy=False).unsqueeze(0)
+        return get_cached_embedding(p, self.smodel)
 
     def check_speaker_reference(self, spk_ref) -> None:
         """Raises what `synthesise` would raise for this speaker reference before any GPU work (serving.py validates requests with
@@ -107,7 +110,7 @@ class TTS:
             return
         if self.smodel is None:
             raise FileNotFoundError(f"no speaker encoder available to embed {p}; pass a precomputed (1, 256) embedding instead")
-        check_audio_file(p)
+        check_audio_file(get_cached_file(p))
 
     def synthesise(self, text: str, spk_ref_path, top_p=0.95, guidance_scale=3.0, temperature=1.0) -> str:
         """`fast_inference.py:111-195`: text -> path of the synthesised `.wav`."""

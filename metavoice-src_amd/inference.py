@@ -9,6 +9,11 @@ contract of `inference.py:53-156,248-377`.  The causal batched slow path (`causa
 from __future__ import annotations
 
 import dataclasses
+import hashlib
+import os
+import tempfile
+import urllib.parse
+import urllib.request
 from typing import Callable, List, Optional, Type
 
 import torch
@@ -33,6 +38,89 @@ class InferenceConfig:
 
     def __str__(self):
         return "InferenceConfig:\n" + "\n".join(f"  {f.name}: {getattr(self, f.name)}" for f in dataclasses.fields(self))
+
+
+def cache_root(kind: str) -> str:
+    """`~/.cache/metavoice` (downloaded speaker references) and `~/.cache/fam` (speaker embeddings) are the reference's
+    directories (`inference.py:403-404,426-427`), so a machine that ran the reference keeps its cache; `METAVOICE_CACHE_DIR`
+    moves both under one root (tests, read-only homes)."""
+    root = os.environ.get("METAVOICE_CACHE_DIR")
+    d = os.path.join(root, kind) if root else os.path.expanduser(f"~/.cache/{kind}")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+MAX_REFERENCE_BYTES = 256 << 20  # a speaker reference is a minute or two of audio; anything bigger is not one
+FETCH_TIMEOUT_S = 60.0
+
+
+def get_cached_file(file_or_uri: str) -> str:
+    """`fam/llm/inference.py:392-416`: an http(s) URI is fetched once into `~/.cache/metavoice/audio_<md5(uri)><ext>` and that
+    path is returned; anything else must be an existing local file (FileNotFoundError otherwise).  The reference shells out
+    (`curl -o <path> <uri>` through a shell); here the fetch is urllib with a time-out and a size cap, written to a temporary
+    name and renamed, so that an interrupted or concurrent fetch never leaves half a file under the cached name and the URI
+    never reaches a command line."""
+    file_or_uri = str(file_or_uri)
+    if not file_or_uri.startswith("http"):
+        if os.path.exists(file_or_uri):
+            return file_or_uri
+        raise FileNotFoundError(f"File {file_or_uri} not found!")
+    parts = urllib.parse.urlsplit(file_or_uri)
+    if parts.scheme not in ("http", "https") or not parts.netloc:
+        raise FileNotFoundError(f"File {file_or_uri} not found!")
+    ext = os.path.splitext(parts.path)[1]
+    if len(ext) > 8 or not ext[1:].isalnum():
+        ext = ""
+    d = cache_root("metavoice")
+    cache_path = os.path.join(d, "audio_" + hashlib.md5(file_or_uri.encode("utf-8")).hexdigest() + ext)
+    if os.path.exists(cache_path):
+        return cache_path
+    fd, tmp = tempfile.mkstemp(dir=d, prefix=".fetch_")
+    try:
+        with os.fdopen(fd, "wb") as out, urllib.request.urlopen(file_or_uri, timeout=FETCH_TIMEOUT_S) as src:
+            total = 0
+            while True:
+                block = src.read(1 << 20)
+                if not block:
+                    break
+                total += len(block)
+                if total > MAX_REFERENCE_BYTES:
+                    raise ValueError(f"{file_or_uri}: more than {MAX_REFERENCE_BYTES >> 20} MiB, not a speaker reference")
+                out.write(block)
+        os.replace(tmp, cache_path)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+    return cache_path
+
+
+def get_cached_embedding(local_file_path: str, spkemb_model) -> torch.Tensor:
+    """`fam/llm/inference.py:419-435`: the (1, 256) speaker embedding of an audio file, computed once and kept in
+    `~/.cache/fam/embedding_<md5(path)>.pt` (the reference's name, so its cache stays valid here).  One difference: a cache entry
+    older than the audio file is recomputed -- the reference keys on the path alone and would keep returning the embedding of
+    the file's previous contents."""
+    local_file_path = str(local_file_path)
+    if not os.path.exists(local_file_path):
+        raise FileNotFoundError(f"File {local_file_path} not found!")
+    d = cache_root("fam")
+    cache_path = os.path.join(d, "embedding_" + hashlib.md5(local_file_path.encode("utf-8")).hexdigest() + ".pt")
+    if os.path.exists(cache_path) and os.path.getmtime(cache_path) >= os.path.getmtime(local_file_path):
+        try:
+            emb = torch.load(cache_path, map_location="cpu")
+            if isinstance(emb, torch.Tensor) and emb.numel() and emb.dim() == 2 and emb.shape[0] == 1:
+                return emb
+        except Exception:
+            pass  # unreadable entry (interrupted writer of an older version): recompute below
+    emb = spkemb_model.embed_utterance_from_file(local_file_path, numpy=False).unsqueeze(0).detach().to("cpu")  # (b=1, c)
+    fd, tmp = tempfile.mkstemp(dir=d, prefix=".emb_")
+    try:
+        with os.fdopen(fd, "wb") as out:
+            torch.save(emb, out)
+        os.replace(tmp, cache_path)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+    return emb
 
 
 def pack_second_stage_input(text_tokens: List[int], codebooks: List[List[int]], ctx_window: int, pad_token: int = 1024) -> List[List[int]]:

@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the speaker-reference / embedding caches default to ~/.cache like the reference's; tests keep out of the home directory
+if "METAVOICE_CACHE_DIR" not in os.environ:
+    import tempfile
+
+    os.environ["METAVOICE_CACHE_DIR"] = tempfile.mkdtemp(prefix="mv_test_cache_")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

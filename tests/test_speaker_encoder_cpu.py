@@ -105,3 +105,82 @@ def test_load_audio_falls_back_to_an_installed_decoder_or_says_so(tmp_path, monk
     monkeypatch.setitem(sys.modules, "soundfile", fake)
     y = audio.load_audio(str(mp3))
     assert y.shape == (16000,) and abs(float(y[8000]) - 0.5) < 1e-3   # stereo -> mono, 32 kHz -> 16 kHz
+
+
+def test_get_cached_file_local_and_uri(tmp_path, monkeypatch):
+    """`fam/llm/inference.py:392-416`: local paths pass through (or FileNotFoundError); an http URI is fetched ONCE into the cache
+    directory under `audio_<md5(uri)><ext>`."""
+    import hashlib
+    import threading
+    from functools import partial
+    from http.server import HTTPServer, SimpleHTTPRequestHandler
+
+    inf = load_pkg("inference")
+    monkeypatch.setenv("METAVOICE_CACHE_DIR", str(tmp_path / "cache"))
+    local = tmp_path / "ref.wav"
+    local.write_bytes(b"RIFFxxxxWAVE" + bytes(range(200)))
+    assert inf.get_cached_file(str(local)) == str(local)
+    with pytest.raises(FileNotFoundError):
+        inf.get_cached_file(str(tmp_path / "nope.wav"))
+    with pytest.raises(FileNotFoundError):
+        inf.get_cached_file("httpfoo")  # starts with "http" (the reference's test), is no URI
+
+    hits = []
+
+    class H(SimpleHTTPRequestHandler):
+        def log_message(self, *a):
+            pass
+
+        def do_GET(self):
+            hits.append(self.path)
+            super().do_GET()
+
+    srv = HTTPServer(("127.0.0.1", 0), partial(H, directory=str(tmp_path)))
+    t = threading.Thread(target=srv.serve_forever, daemon=True)
+    t.start()
+    try:
+        uri = f"http://127.0.0.1:{srv.server_address[1]}/ref.wav"
+        got = inf.get_cached_file(uri)
+        assert os.path.basename(got) == "audio_" + hashlib.md5(uri.encode()).hexdigest() + ".wav"
+        assert os.path.dirname(got) == str(tmp_path / "cache" / "metavoice")
+        assert open(got, "rb").read() == local.read_bytes()
+        assert inf.get_cached_file(uri) == got and len(hits) == 1  # second call: no fetch
+        with pytest.raises(Exception):
+            inf.get_cached_file(uri.replace("ref.wav", "missing.wav"))
+        assert not [f for f in os.listdir(os.path.dirname(got)) if f.startswith(".fetch_")]  # no half files left behind
+        monkeypatch.setattr(inf, "MAX_REFERENCE_BYTES", 64)
+        with pytest.raises(ValueError):
+            inf.get_cached_file(uri + "?again=1")
+    finally:
+        srv.shutdown()
+
+
+def test_get_cached_embedding_is_computed_once_per_file(tmp_path, monkeypatch):
+    """`fam/llm/inference.py:419-435` (+ recomputed when the audio file is newer than the entry)."""
+    import hashlib
+
+    inf = load_pkg("inference")
+    monkeypatch.setenv("METAVOICE_CACHE_DIR", str(tmp_path / "cache"))
+
+    class Enc:
+        calls = 0
+
+        def embed_utterance_from_file(self, path, numpy):
+            Enc.calls += 1
+            return torch.full((256,), float(Enc.calls))
+
+    f = tmp_path / "a.wav"
+    f.write_bytes(b"x")
+    with pytest.raises(FileNotFoundError):
+        inf.get_cached_embedding(str(tmp_path / "b.wav"), Enc())
+    e1 = inf.get_cached_embedding(str(f), Enc())
+    e2 = inf.get_cached_embedding(str(f), Enc())
+    assert e1.shape == (1, 256) and torch.equal(e1, e2) and Enc.calls == 1
+    entry = tmp_path / "cache" / "fam" / ("embedding_" + hashlib.md5(str(f).encode()).hexdigest() + ".pt")
+    assert entry.exists()  # the reference's name for the same file
+    os.utime(f, (os.path.getmtime(entry) + 10, os.path.getmtime(entry) + 10))
+    e3 = inf.get_cached_embedding(str(f), Enc())
+    assert Enc.calls == 2 and float(e3[0, 0]) == 2.0
+    entry.write_bytes(b"garbage")
+    os.utime(entry, (os.path.getmtime(f) + 10, os.path.getmtime(f) + 10))
+    assert float(inf.get_cached_embedding(str(f), Enc())[0, 0]) == 3.0  # unreadable entry -> recomputed, not an error
