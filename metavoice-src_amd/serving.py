@@ -352,6 +352,9 @@ def text_to_speech(fields: Dict[str, str], files: Dict[str, bytes]) -> Tuple[int
             Path(wav_out_path).unlink(missing_ok=True)
 
 
+MAX_REQUEST_BYTES = 256 << 20  # text + an uploaded speaker reference (the reference's ffmpeg step keeps the first 2 minutes of it)
+
+
 class _Handler(BaseHTTPRequestHandler):
     protocol_version = "HTTP/1.1"  # chunked transfer for /tts_stream; every other response carries its Content-Length
 
@@ -385,9 +388,30 @@ class _Handler(BaseHTTPRequestHandler):
         else:
             self._send(404, "application/json", b'{"detail": "Not Found"}')
 
+    def do_OPTIONS(self):
+        """CORS preflight, answered the way the reference's CORSMiddleware is configured (`serving.py:138-144`: any origin, method
+        and header)."""
+        self.send_response(200)
+        self.send_header("Access-Control-Allow-Origin", self.headers.get("Origin", "*"))
+        self.send_header("Access-Control-Allow-Credentials", "true")
+        self.send_header("Access-Control-Allow-Methods", self.headers.get("Access-Control-Request-Method", "GET, POST, OPTIONS"))
+        self.send_header("Access-Control-Allow-Headers", self.headers.get("Access-Control-Request-Headers", "*"))
+        self.send_header("Access-Control-Max-Age", "600")
+        self.send_header("Vary", "Origin")
+        self.send_header("Content-Length", "0")
+        self.end_headers()
+
     def do_POST(self):
         route = self.path.split("?")[0]
-        body = self.rfile.read(int(self.headers.get("Content-Length", 0)))
+        try:
+            length = int(self.headers.get("Content-Length", 0))
+        except ValueError:
+            length = -1
+        if length < 0 or length > MAX_REQUEST_BYTES:  # the body is read into memory: refuse before reading, then drop the connection
+            self.close_connection = True
+            self._send(413 if length > 0 else 400, "application/json", b'{"detail": "Request body too large or of unknown length"}')
+            return
+        body = self.rfile.read(length)
         if route not in ("/tts", "/tts_stream"):
             self._send(404, "application/json", b'{"detail": "Not Found"}')
             return

@@ -313,3 +313,33 @@ def test_tts_stream_is_chunked_and_starts_with_an_open_ended_riff_header(server)
         got = e.partial
     assert got[:4] == b"RIFF" and len(got) == 44 + 2 * (10 + 20)
     conn.close()
+
+
+def test_cors_preflight_and_body_cap(server, monkeypatch):
+    """`serving.py:138-144` (CORSMiddleware: any origin / method / header) and a bound on what a request may make the server
+    read into memory."""
+    import http.client
+
+    base, tts = server
+    host, port = base[len("http://"):].split(":")
+    c = http.client.HTTPConnection(host, int(port), timeout=10)
+    c.request("OPTIONS", "/tts", headers={"Origin": "http://localhost:3000", "Access-Control-Request-Method": "POST",
+                                          "Access-Control-Request-Headers": "x-requested-with"})
+    r = c.getresponse()
+    r.read()
+    assert r.status == 200
+    assert r.getheader("Access-Control-Allow-Origin") == "http://localhost:3000"
+    assert r.getheader("Access-Control-Allow-Methods") == "POST"
+    assert r.getheader("Access-Control-Allow-Headers") == "x-requested-with"
+    # the same connection stays usable (HTTP/1.1 keep-alive, Content-Length: 0 on the preflight answer)
+    c.request("GET", "/health")
+    r = c.getresponse()
+    assert r.status == 200 and json.loads(r.read()) == {"status": "ok"}
+    c.close()
+
+    monkeypatch.setattr(serving, "MAX_REQUEST_BYTES", 1024)
+    n_before = len(tts.calls)
+    code, _, body = post(base + "/tts", urllib.parse.urlencode({"text": "x" * 4096, "speaker_ref_path": "a.wav"}).encode())
+    assert code == 413 and len(tts.calls) == n_before
+    code, _, _ = post(base + "/tts", urllib.parse.urlencode({"text": "ok", "speaker_ref_path": "a.wav"}).encode())
+    assert code == 200
