@@ -22,5 +22,7 @@ for precision in [int(x) for x in os.environ.get("MBD_PRECISIONS", "1,3").split(
         t0 = time.time()
         wav = eng.tokens_to_wav(lat, ref)
         dt = time.time() - t0
-        print(f"  tokens_to_wav({frames} frames): {dt * 1e3:.1f} ms, rms {float(wav.pow(2).mean().sqrt()):.4f}", flush=True)
+        import hashlib
+        digest = hashlib.sha1(wav.detach().float().cpu().contiguous().numpy().tobytes()).hexdigest()[:12]  # schedule variants must not change a bit
+        print(f"  tokens_to_wav({frames} frames): {dt * 1e3:.1f} ms, rms {float(wav.pow(2).mean().sqrt()):.4f}, sha1 {digest}", flush=True)
     eng.close()
