@@ -173,18 +173,58 @@ __device__ __forceinline__ bool lstm_poll(const gran_t* src, uint32_t tag, float
     return true;
 }
 
+// Two vectors of n <= 2 * LS_THREADS granules each in ONE wait: all loads of both are in flight together, so a vector that is already
+// there (layer 2's h1_t: layer 1 runs ahead) costs no load round trip of its own.
+__device__ __forceinline__ bool lstm_poll_pair(const gran_t* src_a, uint32_t tag_a, float* dst_a, const gran_t* src_b, uint32_t tag_b, float* dst_b,
+                                               int n, uint32_t* abort_flag, int tid) {
+    unsigned long long v[4];
+    bool need[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { need[k] = tid + (k & 1) * LS_THREADS < n; v[k] = 0; }
+    for (int tries = 0;; ++tries) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (need[k]) v[k] = __hip_atomic_load((k < 2 ? src_a : src_b) + tid + (k & 1) * LS_THREADS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool pending = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (need[k]) {
+                if ((uint32_t)(v[k] >> 32) == (k < 2 ? tag_a : tag_b)) {
+                    (k < 2 ? dst_a : dst_b)[tid + (k & 1) * LS_THREADS] = __uint_as_float((uint32_t)v[k]);
+                    need[k] = false;
+                } else pending = true;
+            }
+        if (!pending) return true;
+        if ((tries & 1023) == 1023) {
+            const bool peer = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (peer || tries >= LS_SPIN_LIMIT) {
+                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 // Two stacked layers, batch 1 (kernels.h: LstmSeq2Args).  Workgroups [0, H/8) are layer 1 -- exactly lstm_seq_kernel, plus a copy of
 // every h1_t into the [T][H] granule sequence --, workgroups [H/8, 2 H/8) are layer 2: they keep their 32 rows of W_ih2 AND of W_hh2
 // in LDS, and at step t wait for h1_t (sequence buffer: never overwritten, so layer 2 may lag by any number of steps) and h2_{t-1}
 // (their own two-slot ring).  Gate pre-activation of layer 2 = (W_hh2 h2_{t-1}) + ((W_ih2 h1_t) + b): both dot products per wave,
 // the same reduction as the single-layer kernel.
+//
+// HK > 0 (H = 64 HK, the codec's 512): the wave's 8 gate rows live in REGISTERS (8 HK floats per lane and matrix), lane l holding
+// columns l, l + 64, ...: a step reads its HK values of h from LDS once and runs 8 independent HK-long fma chains.  With the rows in
+// LDS (HK = 0, any H) every fma waits for its own two ds_reads: 3.0 us of a 4.7 us step were these 8 x 512 dot products
+// (profiles/r03n/lstm_stamps.txt).  Same products in the same order: the results do not change.
+template <int HK>
 __global__ void __launch_bounds__(LS_THREADS) lstm_seq2_kernel(const LstmSeq2Args a) {
     extern __shared__ float lds[];
     const int H = a.H, nwg = H / LS_UPW;
     const bool second = (int)blockIdx.x >= nwg;
-    float* w_s = lds;                               // [4 * LS_UPW][H]: W_hh rows of this workgroup's units
-    float* wi_s = w_s + 4 * LS_UPW * H;             // layer 2 only: [4 * LS_UPW][H] rows of W_ih2
-    float* h_s = wi_s + (second ? 4 * LS_UPW * H : 0);   // [H]: h_{t-1} of this layer
+    constexpr int NR = HK > 0 ? 8 * HK : 1;
+    float* w_s = lds;                               // HK = 0: [4 * LS_UPW][H]: W_hh rows of this workgroup's units
+    float* wi_s = w_s + (HK > 0 ? 0 : 4 * LS_UPW * H);             // HK = 0, layer 2 only: [4 * LS_UPW][H] rows of W_ih2
+    float* h_s = wi_s + (HK == 0 && second ? 4 * LS_UPW * H : 0);   // [H]: h_{t-1} of this layer
     float* x_s = h_s + H;                           // layer 2 only: [H]: h1_t
     float* c_s = x_s + H;                           // [LS_UPW]
     __shared__ int s_abort;
@@ -192,44 +232,130 @@ __global__ void __launch_bounds__(LS_THREADS) lstm_seq2_kernel(const LstmSeq2Arg
     const int u0 = ((int)blockIdx.x - (second ? nwg : 0)) * LS_UPW;
     const float* whh = second ? a.whh2 : a.whh1;
     if (tid == 0) s_abort = 0;
-    for (int i = tid; i < 4 * LS_UPW * H; i += LS_THREADS) {
-        const int r = i / H, k = i - r * H, q = r / LS_UPW, u = r - q * LS_UPW;
-        w_s[i] = whh[(size_t)(q * H + u0 + u) * H + k];
-        if (second) wi_s[i] = a.wih2[(size_t)k * a.wih2_ks + (q * H + u0 + u)];
+    float wh_r[NR], wi_r[NR];   // row j = uu * 4 + q of this wave (unit wave * 2 + uu, gate q), element i = column lane + 64 i
+    if constexpr (HK > 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const size_t grow = (size_t)((j & 3) * H + u0 + wave * 2 + (j >> 2));
+#pragma unroll
+            for (int i = 0; i < HK; ++i) {
+                wh_r[j * HK + i] = whh[grow * H + lane + 64 * i];
+                wi_r[j * HK + i] = second ? a.wih2[(size_t)(lane + 64 * i) * a.wih2_ks + grow] : 0.f;
+            }
+        }
+    } else {
+        wh_r[0] = wi_r[0] = 0.f;
+        for (int i = tid; i < 4 * LS_UPW * H; i += LS_THREADS) {
+            const int r = i / H, k = i - r * H, q = r / LS_UPW, u = r - q * LS_UPW;
+            w_s[i] = whh[(size_t)(q * H + u0 + u) * H + k];
+            if (second) wi_s[i] = a.wih2[(size_t)k * a.wih2_ks + (q * H + u0 + u)];
+        }
     }
     for (int i = tid; i < H; i += LS_THREADS) { h_s[i] = 0.f; x_s[i] = 0.f; }
     if (tid < LS_UPW) c_s[tid] = 0.f;
     __syncthreads();
     gran_t* ring = second ? a.hx2 : a.hx1;
+    // layer 2: the bias of the wave's 8 gate rows, once (read inside the step it was 8 global loads on every step's serial chain: the
+    // stores of the loop keep the compiler from hoisting them)
+    float bias_r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bias_r[j] = second ? a.bias2[(j & 3) * H + u0 + wave * 2 + (j >> 2)] : 0.f;
+#ifdef LSTM_STAMPS
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime(), t_start = t_prev;
+#define LS_STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[i] += now_ - t_prev; t_prev = now_; }
+#else
+#define LS_STAMP(i)
+#endif
     for (int t = 0; t < a.T; ++t) {
+        // layer 1: this step's input half of the gates, requested BEFORE the wait for h_{t-1} (it was a global load between the dot
+        // products and the non-linearities of every step)
+        float gin_v = 0.f;
+        if (!second && lane < 8)
+            gin_v = a.gin1[(size_t)t * a.gs_t + (size_t)((lane & 3) * H + u0 + wave * 2 + (lane >> 2)) * a.gs_r];
+        // layer 2: likewise the skip value added to this step's output (both loads land under the wait that follows)
+        float skip_v = 0.f;
+        if (second && a.skip && (lane == 0 || lane == 4)) skip_v = a.skip[(size_t)t * a.ys_t + (size_t)(u0 + wave * 2 + (lane >> 2)) * a.ys_u];
+        // layer 2, rows in registers: h1_t and h2_{t-1} in ONE wait -- h1_t is there early (layer 1 runs ahead), a wait of its own was a
+        // pure load round trip (0.85 us of a 3.5 us step, profiles/r03n/lstm_stamps2.txt), and with the rows in registers the 8 extra
+        // dot products behind the wait cost 0.1 us.  Rows in LDS: (W_ih2 h1_t) + b between two waits, overlapping h2_{t-1}'s flight.
+        float pre[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pre[j] = 0.f;
         bool ok = true;
-        if (second) ok = lstm_poll(a.seq1 + (size_t)t * H, a.tag_base + (uint32_t)t + 1u, x_s, H, a.abort_flag, tid);
-        if (ok && t > 0) ok = lstm_poll(ring + (size_t)(t & 1) * H, a.tag_base + (uint32_t)t, h_s, H, a.abort_flag, tid);
-        if (!ok) *(volatile int*)&s_abort = 1;
-        __syncthreads();
-        if (s_abort) return;
-        float mine = 0.f;
+        const bool one_wait = HK > 0 && HK <= 2 * LS_THREADS / 64 && second && t > 0;
+        if (second) {
+            if (one_wait)
+                ok = lstm_poll_pair(a.seq1 + (size_t)t * H, a.tag_base + (uint32_t)t + 1u, x_s, ring + (size_t)(t & 1) * H, a.tag_base + (uint32_t)t, h_s,
+                                    H, a.abort_flag, tid);
+            else ok = lstm_poll(a.seq1 + (size_t)t * H, a.tag_base + (uint32_t)t + 1u, x_s, H, a.abort_flag, tid);
+            if (!ok) *(volatile int*)&s_abort = 1;
+            __syncthreads();
+            if (s_abort) return;
+            LS_STAMP(0);
+            if constexpr (HK > 0) {
+                float xv[HK];
 #pragma unroll
-        for (int uu = 0; uu < 2; ++uu)
+                for (int i = 0; i < HK; ++i) xv[i] = x_s[lane + 64 * i];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = q * LS_UPW + wave * 2 + uu;
-                const float* w = w_s + (size_t)row * H;
-                float sh = 0.f;
-                for (int k = lane; k < H; k += 64) sh = fmaf(w[k], h_s[k], sh);
-                sh = wave_sum(sh);
-                if (second) {
-                    const float* wi = wi_s + (size_t)row * H;
+                for (int j = 0; j < 8; ++j) {
                     float sx = 0.f;
-                    for (int k = lane; k < H; k += 64) sx = fmaf(wi[k], x_s[k], sx);
-                    sh += wave_sum(sx) + a.bias2[q * H + u0 + wave * 2 + uu];
+#pragma unroll
+                    for (int i = 0; i < HK; ++i) sx = fmaf(wi_r[j * HK + i], xv[i], sx);
+                    pre[j] = wave_sum(sx) + bias_r[j];
                 }
-                if (lane == uu * 4 + q) mine = sh;
+            } else {
+#pragma unroll
+                for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float* wi = wi_s + (size_t)(q * LS_UPW + wave * 2 + uu) * H;
+                        float sx = 0.f;
+                        for (int k = lane; k < H; k += 64) sx = fmaf(wi[k], x_s[k], sx);
+                        pre[uu * 4 + q] = wave_sum(sx) + bias_r[uu * 4 + q];
+                    }
             }
+            LS_STAMP(1);
+        }
+        if (!one_wait) {
+            if (t > 0) ok = lstm_poll(ring + (size_t)(t & 1) * H, a.tag_base + (uint32_t)t, h_s, H, a.abort_flag, tid);
+            if (!ok) *(volatile int*)&s_abort = 1;
+            __syncthreads();
+            if (s_abort) return;
+        }
+        LS_STAMP(2);
+        float mine = 0.f;
+        if constexpr (HK > 0) {
+            float hv[HK];
+#pragma unroll
+            for (int i = 0; i < HK; ++i) hv[i] = h_s[lane + 64 * i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float sh = 0.f;
+#pragma unroll
+                for (int i = 0; i < HK; ++i) sh = fmaf(wh_r[j * HK + i], hv[i], sh);
+                sh = wave_sum(sh);
+                if (second) sh += pre[j];
+                if (lane == j) mine = sh;
+            }
+        } else {
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = q * LS_UPW + wave * 2 + uu;
+                    const float* w = w_s + (size_t)row * H;
+                    float sh = 0.f;
+                    for (int k = lane; k < H; k += 64) sh = fmaf(w[k], h_s[k], sh);
+                    sh = wave_sum(sh);
+                    if (second) sh += pre[uu * 4 + q];
+                    if (lane == uu * 4 + q) mine = sh;
+                }
+        }
+        LS_STAMP(3);
         float act = 0.f;
         if (lane < 8) {
-            const int u = wave * 2 + (lane >> 2), q = lane & 3;
-            const float g = second ? mine : mine + a.gin1[(size_t)t * a.gs_t + (size_t)(q * H + u0 + u) * a.gs_r];
+            const int q = lane & 3;
+            const float g = second ? mine : mine + gin_v;
             act = q == 2 ? tanhf(g) : sigmoidf_(g);
         }
         const int base = lane & 4;
@@ -244,11 +370,19 @@ __global__ void __launch_bounds__(LS_THREADS) lstm_seq2_kernel(const LstmSeq2Arg
             if (!second) __hip_atomic_store(a.seq1 + (size_t)t * H + u0 + u, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else {
                 const size_t o = (size_t)t * a.ys_t + (size_t)(u0 + u) * a.ys_u;
-                a.y[o] = h + (a.skip ? a.skip[o] : 0.f);
+                a.y[o] = h + skip_v;
             }
         }
+        LS_STAMP(4);
         __syncthreads();  // h_s / x_s are overwritten by the next polls
+        LS_STAMP(5);
     }
+#ifdef LSTM_STAMPS
+    if (tid == 0 && (blockIdx.x == 0 || (int)blockIdx.x == nwg || (int)blockIdx.x == nwg - 1 || (int)blockIdx.x == 2 * nwg - 1))
+        printf("lstm_seq2 stamps wg %d layer %d T %d: total %llu ticks; per step: x-wait %.0f ih-dots %.0f h-wait %.0f hh-dots %.0f act+publish %.0f end-barrier %.0f\n",
+               (int)blockIdx.x, second ? 2 : 1, a.T, t_prev - t_start, (double)ph[0] / a.T, (double)ph[1] / a.T, (double)ph[2] / a.T, (double)ph[3] / a.T,
+               (double)ph[4] / a.T, (double)ph[5] / a.T);
+#endif
 }
 
 // gin[b][t][row] = bias[row] + sum_k w[row][k] * x[b][t][k]      (the non-recurrent half of every gate, all time steps at once)
@@ -405,18 +539,24 @@ hipError_t launch_lstm_seq(hipStream_t s, const LstmSeqArgs& a) {
 
 hipError_t launch_lstm_seq2(hipStream_t s, const LstmSeq2Args& a) {
     if (a.H % LS_UPW != 0 || a.T < 1 || a.T > 65535) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)8 * LS_UPW * a.H + (size_t)2 * a.H + LS_UPW) * sizeof(float);
-    if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
-    static std::atomic<size_t> raised_on[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::atomic<size_t>& raised = raised_on[dev & 63];
-    if (lds > raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)lstm_seq2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        raised = lds;
+    static const bool rows_in_lds = getenv("MV_LSTM_ROWS_IN_LDS") != nullptr;   // A/B and tests: the general kernel at H = 512 too
+    if (a.H == 512 && !rows_in_lds) {   // EnCodec's size: gate rows in registers, LDS holds h, x, c only
+        const size_t lds = ((size_t)2 * a.H + LS_UPW) * sizeof(float);
+        hipLaunchKernelGGL(lstm_seq2_kernel<8>, dim3(2 * a.H / LS_UPW), dim3(LS_THREADS), lds, s, a);
+    } else {
+        const size_t lds = ((size_t)8 * LS_UPW * a.H + (size_t)2 * a.H + LS_UPW) * sizeof(float);
+        if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
+        static std::atomic<size_t> raised_on[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<size_t>& raised = raised_on[dev & 63];
+        if (lds > raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)lstm_seq2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            raised = lds;
+        }
+        hipLaunchKernelGGL(lstm_seq2_kernel<0>, dim3(2 * a.H / LS_UPW), dim3(LS_THREADS), lds, s, a);
     }
-    hipLaunchKernelGGL(lstm_seq2_kernel, dim3(2 * a.H / LS_UPW), dim3(LS_THREADS), lds, s, a);
     if (lstm_fault_pending()) (void)hipMemsetAsync(a.abort_flag, 1, 1, s);
     return hipGetLastError();
 }

@@ -91,3 +91,37 @@ print("FALLBACK_OK", d, d2)
     assert p.returncode == 0 and "FALLBACK_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
     if hook == "MV_LSTM_FAULT":
         assert "continue with one launch per time step" in p.stderr
+
+
+def test_lstm_rows_in_registers_equal_rows_in_lds():
+    """The fused two-layer LSTM keeps its gate rows in registers at EnCodec's size (H = 512, `lstm_seq2_kernel<8>`); with
+    `MV_LSTM_ROWS_IN_LDS` the general kernel (rows in LDS, any H) runs instead.  Same products in the same order: the decoded
+    waveform must be the same bits.  Child processes: the switch is read once per process."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = r'''
+import sys, hashlib, torch
+sys.path.insert(0, "tests")
+from conftest import load_pkg
+from test_codec_cpu import seeded_encodec
+codec = load_pkg("codec")
+dec = codec.EncodecDecoder.from_state_dict(seeded_encodec(2).state_dict(), n_q=8)
+tokens = torch.randint(0, 1024, (1, 8, 75), generator=torch.Generator().manual_seed(3))
+wav = dec.decode(tokens)
+print("DIGEST", hashlib.sha1(wav.detach().float().cpu().contiguous().numpy().tobytes()).hexdigest(), float(wav.abs().max()))
+'''
+    digests = []
+    for rows_in_lds in (False, True):
+        env = dict(os.environ)
+        env.pop("MV_LSTM_ROWS_IN_LDS", None)
+        if rows_in_lds:
+            env["MV_LSTM_ROWS_IN_LDS"] = "1"
+        p = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "DIGEST" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
+        digests.append(p.stdout.split("DIGEST")[1].split()[0])
+    assert digests[0] == digests[1]

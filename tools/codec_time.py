@@ -8,5 +8,7 @@ syn = importlib.import_module("metavoice-src_amd.synthetic")
 codec = importlib.import_module("metavoice-src_amd.codec")
 dec = codec.EncodecDecoder.from_state_dict(syn.encodec_state_dict(seed=0))
 tok = torch.randint(0, 1024, (1, 8, 960), generator=torch.Generator().manual_seed(0))
-for _ in range(3):
-    t0 = time.time(); w = dec.decode(tok); print(f"decode 960 frames: {(time.time() - t0) * 1e3:.2f} ms")
+import hashlib
+for _ in range(4):
+    t0 = time.time(); w = dec.decode(tok); dt = time.time() - t0
+    print(f"decode 960 frames: {dt * 1e3:.2f} ms, sha1 {hashlib.sha1(w.detach().float().cpu().contiguous().numpy().tobytes()).hexdigest()[:12]}")
