@@ -40,19 +40,32 @@ typedef unsigned long long gran_t;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// HK > 0 (H = 64 HK: 256 = the speaker encoder, 512): the wave's 8 gate rows in registers instead of LDS, as in lstm_seq2_kernel below
+// (where the measurement is: a dot product whose every fma waits for its own two ds_reads was 3.0 us of a 4.7 us step at H = 512).
+template <int HK>
 __global__ void __launch_bounds__(LS_THREADS) lstm_seq_kernel(const LstmSeqArgs a) {
     extern __shared__ float lds[];
     const int H = a.H, B = a.B;
-    float* w_s = lds;                       // [4 * LS_UPW][H]: row q * LS_UPW + u  <-  W_hh[q * H + u0 + u]
-    float* h_s = w_s + 4 * LS_UPW * H;      // [B][H]
+    float* w_s = lds;                       // HK = 0: [4 * LS_UPW][H]: row q * LS_UPW + u  <-  W_hh[q * H + u0 + u]
+    float* h_s = w_s + (HK > 0 ? 0 : 4 * LS_UPW * H);      // [B][H]
     float* c_s = h_s + (size_t)B * H;       // [B][LS_UPW]
     __shared__ int s_abort;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int u0 = blockIdx.x * LS_UPW;
     if (tid == 0) s_abort = 0;
-    for (int i = tid; i < 4 * LS_UPW * H; i += LS_THREADS) {
-        const int r = i / H, k = i - r * H, q = r / LS_UPW, u = r - q * LS_UPW;
-        w_s[i] = a.whh[(size_t)(q * H + u0 + u) * H + k];
+    constexpr int NR = HK > 0 ? 8 * HK : 1;
+    float wh_r[NR];   // row j = uu * 4 + q of this wave, element i = column lane + 64 i
+    if constexpr (HK > 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < HK; ++i) wh_r[j * HK + i] = a.whh[(size_t)((j & 3) * H + u0 + wave * 2 + (j >> 2)) * H + lane + 64 * i];
+    } else {
+        wh_r[0] = 0.f;
+        for (int i = tid; i < 4 * LS_UPW * H; i += LS_THREADS) {
+            const int r = i / H, k = i - r * H, q = r / LS_UPW, u = r - q * LS_UPW;
+            w_s[i] = a.whh[(size_t)(q * H + u0 + u) * H + k];
+        }
     }
     for (int i = tid; i < B * H; i += LS_THREADS) h_s[i] = 0.f;
     for (int i = tid; i < B * LS_UPW; i += LS_THREADS) c_s[i] = 0.f;
@@ -97,32 +110,50 @@ __global__ void __launch_bounds__(LS_THREADS) lstm_seq_kernel(const LstmSeqArgs 
         }
         // wave w owns units 2w, 2w+1: all four gates of a unit stay in one wave, so the cell update needs no exchange
         gran_t* dst = a.hx + (size_t)((t + 1) & 1) * B * H;
-        for (int b = 0; b < B; ++b) {
-            const float* hb = h_s + (size_t)b * H;
-            // the wave's 8 gate rows (2 units x i, f, g, o): row totals are wave-uniform after wave_sum; lane l < 8 keeps the total of
-            // (unit l >> 2, gate l & 3) and evaluates that gate's non-linearity -- the eight expf / tanhf run in parallel lanes
-            // instead of one after the other in lane 0 (they were ~0.5 us of every step's serial chain)
+        // Batch rows in groups of 8: the 8 gate-row totals of row b0 + bb land in lanes 8 bb .. 8 bb + 7, then ONE pass of the gate
+        // non-linearities and ONE cell update serve 8 rows (64 live lanes instead of 8: with one pass per row the expf / tanhf bodies
+        // were ~0.9 us per row and step, 33 of a 62 us step at the speaker encoder's 37 partials)
+        for (int b0 = 0; b0 < B; b0 += 8) {
+            const int nb = min(8, B - b0);
             float mine = 0.f;
+            for (int bb = 0; bb < nb; ++bb) {
+                const float* hb = h_s + (size_t)(b0 + bb) * H;
+                // the wave's 8 gate rows (2 units x i, f, g, o): row totals are wave-uniform after wave_sum; lane 8 bb + j keeps the
+                // total of (unit j >> 2, gate j & 3)
+                if constexpr (HK > 0) {
+                    float hv[HK];
 #pragma unroll
-            for (int uu = 0; uu < 2; ++uu)
+                    for (int i = 0; i < HK; ++i) hv[i] = hb[lane + 64 * i];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float* w = w_s + (size_t)(q * LS_UPW + wave * 2 + uu) * H;
-                    float s = 0.f;
-                    for (int k = lane; k < H; k += 64) s = fmaf(w[k], hb[k], s);
-                    s = wave_sum(s);
-                    if (lane == uu * 4 + q) mine = s;
+                    for (int j = 0; j < 8; ++j) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int i = 0; i < HK; ++i) s = fmaf(wh_r[j * HK + i], hv[i], s);
+                        s = wave_sum(s);
+                        if (lane == bb * 8 + j) mine = s;
+                    }
+                } else {
+#pragma unroll
+                    for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float* w = w_s + (size_t)(q * LS_UPW + wave * 2 + uu) * H;
+                            float s = 0.f;
+                            for (int k = lane; k < H; k += 64) s = fmaf(w[k], hb[k], s);
+                            s = wave_sum(s);
+                            if (lane == bb * 8 + uu * 4 + q) mine = s;
+                        }
                 }
+            }
+            const int bl = lane >> 3, b = b0 + bl, u = wave * 2 + ((lane >> 2) & 1), q = lane & 3;
             float act = 0.f;
-            if (lane < 8) {
-                const int u = wave * 2 + (lane >> 2), q = lane & 3;
+            if (bl < nb) {
                 const float g = mine + a.gin[(size_t)b * a.gs_b + (size_t)t * a.gs_t + (size_t)(q * H + u0 + u) * a.gs_r];
                 act = q == 2 ? tanhf(g) : sigmoidf_(g);
             }
-            const int base = lane & 4;  // lanes 0 and 4 gather their unit's i, f, g, o
+            const int base = lane & ~3;  // lanes 8 bl and 8 bl + 4 gather their unit's i, f, g, o
             const float ig = __shfl(act, base + 0, 64), fg = __shfl(act, base + 1, 64), gg = __shfl(act, base + 2, 64), og = __shfl(act, base + 3, 64);
-            if (lane == 0 || lane == 4) {
-                const int u = wave * 2 + (lane >> 2);
+            if (q == 0 && bl < nb) {
                 const float c = fmaf(fg, c_s[b * LS_UPW + u], ig * gg);
                 const float h = og * tanhf(c);
                 c_s[b * LS_UPW + u] = c;
@@ -521,18 +552,24 @@ hipError_t launch_lstm_seq(hipStream_t s, const LstmSeqArgs& a) {
         e = hipMemsetAsync(a.hx, 0, (size_t)2 * a.B * a.H * 8, s);   // leave no float that could pass for a tagged granule
         return e != hipSuccess ? e : hipGetLastError();
     }
-    const size_t lds = lstm_seq_lds_bytes(a.B, a.H);
+    static const bool rows_in_lds = getenv("MV_LSTM_ROWS_IN_LDS") != nullptr;   // A/B and tests: the general kernel everywhere
+    const int hk = rows_in_lds ? 0 : a.H == 256 ? 4 : a.H == 512 ? 8 : 0;
+    // LDS: [B][H] of h and [B][8] of c, plus the 32 gate rows when they are not in registers
+    const size_t lds = lstm_seq_lds_bytes(a.B, a.H) - (hk ? (size_t)4 * LS_UPW * a.H * sizeof(float) : 0);
     if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;  // the kernel also has a few static words
-    static std::atomic<size_t> raised_on[64];   // per device: the attribute belongs to the device's copy of the function
+    const void* fn = hk == 4 ? (const void*)lstm_seq_kernel<4> : hk == 8 ? (const void*)lstm_seq_kernel<8> : (const void*)lstm_seq_kernel<0>;
+    static std::atomic<size_t> raised_on[64][3];   // per device and instance: the attribute belongs to the device's copy of the function
     int dev = 0;
     (void)hipGetDevice(&dev);
-    std::atomic<size_t>& raised = raised_on[dev & 63];
-    if (lds > raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)lstm_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    std::atomic<size_t>& raised = raised_on[dev & 63][hk == 4 ? 1 : hk == 8 ? 2 : 0];
+    if (lds > 64 * 1024 && lds > raised) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         raised = lds;
     }
-    hipLaunchKernelGGL(lstm_seq_kernel, dim3(a.H / LS_UPW), dim3(LS_THREADS), lds, s, a);
+    if (hk == 4) hipLaunchKernelGGL(lstm_seq_kernel<4>, dim3(a.H / LS_UPW), dim3(LS_THREADS), lds, s, a);
+    else if (hk == 8) hipLaunchKernelGGL(lstm_seq_kernel<8>, dim3(a.H / LS_UPW), dim3(LS_THREADS), lds, s, a);
+    else hipLaunchKernelGGL(lstm_seq_kernel<0>, dim3(a.H / LS_UPW), dim3(LS_THREADS), lds, s, a);
     if (lstm_fault_pending()) (void)hipMemsetAsync(a.abort_flag, 1, 1, s);
     return hipGetLastError();
 }

@@ -94,9 +94,10 @@ print("FALLBACK_OK", d, d2)
 
 
 def test_lstm_rows_in_registers_equal_rows_in_lds():
-    """The fused two-layer LSTM keeps its gate rows in registers at EnCodec's size (H = 512, `lstm_seq2_kernel<8>`); with
-    `MV_LSTM_ROWS_IN_LDS` the general kernel (rows in LDS, any H) runs instead.  Same products in the same order: the decoded
-    waveform must be the same bits.  Child processes: the switch is read once per process."""
+    """The persistent LSTM kernels keep their gate rows in registers at EnCodec's size (H = 512, `lstm_seq2_kernel<8>`) and the speaker
+    encoder's (H = 256, `lstm_seq_kernel<4>`); with `MV_LSTM_ROWS_IN_LDS` the general kernels (rows in LDS, any H) run instead.  Same
+    products in the same order: the decoded waveform and the speaker embedding must be the same bits.  Child processes: the switch is
+    read once per process."""
     import hashlib
     import os
     import subprocess
@@ -113,7 +114,12 @@ codec = load_pkg("codec")
 dec = codec.EncodecDecoder.from_state_dict(seeded_encodec(2).state_dict(), n_q=8)
 tokens = torch.randint(0, 1024, (1, 8, 75), generator=torch.Generator().manual_seed(3))
 wav = dec.decode(tokens)
-print("DIGEST", hashlib.sha1(wav.detach().float().cpu().contiguous().numpy().tobytes()).hexdigest(), float(wav.abs().max()))
+spk, synthetic = load_pkg("speaker_encoder.model"), load_pkg("synthetic")
+enc = spk.SpeakerEncoder(state_dict=synthetic.speaker_encoder_state_dict(seed=4), verbose=False)   # H = 256: lstm_seq_kernel<4>
+emb = enc(torch.rand(5, 160, 40, generator=torch.Generator().manual_seed(12)) * 3.0)
+h = hashlib.sha1(wav.detach().float().cpu().contiguous().numpy().tobytes())
+h.update(emb.detach().float().cpu().contiguous().numpy().tobytes())
+print("DIGEST", h.hexdigest(), float(wav.abs().max()), float(emb.abs().max()))
 '''
     digests = []
     for rows_in_lds in (False, True):
