@@ -72,6 +72,11 @@ struct MbdGemmArgs {   // the band models run the same shapes: grid.z = band
     const float* residual = nullptr;  // band 0: [M][ldr] or null
     int64_t ldr = 0, res_band = 0;
     PF col_add;            // [N] per band or null (step embedding row)
+    // GroupNorm statistics of the OUTPUT from the epilogue (256 x 256 and three-term 128 x 128 kernels; null = off): every tile writes
+    // the sum and the sum of squares of its share of each of the gn_G channel groups (gn_cg = N / gn_G channels each, a multiple of 16)
+    // to gn_part[band][tile][group][2] (double), gn_final_kernel adds the tiles in index order -- the output is not read again.
+    double* gn_part = nullptr;
+    int gn_cg = 0, gn_G = 0;
 };
 
 // C = A W^T on BM x 128 x 128 tiles (BM = 128 or 64), 256 threads = 4 waves (2 x 2), each wave (BM / 2) x 64 = MI x 4 MFMA 16x16x32
@@ -251,6 +256,34 @@ __global__ void __launch_bounds__(256, 4) mbd_gemm_glds_kernel(const MbdGemmArgs
         }
 }
 
+// GroupNorm partials of one output tile (MbdGemmArgs::gn_part).  gs / gs2: this thread's sum and sum of squares (fp32, in the fixed
+// order of the epilogue loops) over its rows of the four 16-column blocks j of its wave; a block lies inside one group (gn_cg is a
+// multiple of 16).  Lanes are added in double in a fixed order, then thread (g, which) adds the (wave, j) entries of group g in
+// index order: the same bits on every run.
+template <int NW>
+__device__ __forceinline__ void gn_tile_partials(const MbdGemmArgs& a, const float (&gs)[4], const float (&gs2)[4], int wave_col0, int wave, int lane,
+                                                 int tid, double* dst, double (*red)[4][2], int* grp) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double s = gs[j], s2 = gs2[j];
+        for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); s2 += __shfl_down(s2, off, 64); }
+        if (lane == 0) {
+            red[wave][j][0] = s;
+            red[wave][j][1] = s2;
+            grp[wave * 4 + j] = wave_col0 + j * 16 < a.N ? (wave_col0 + j * 16) / a.gn_cg : -1;
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * a.gn_G) {
+        const int g = tid >> 1, which = tid & 1;
+        double t = 0.0;
+        for (int w = 0; w < NW; ++w)
+            for (int j = 0; j < 4; ++j)
+                if (grp[w * 4 + j] == g) t += red[w][j][which];
+        dst[g * 2 + which] = t;
+    }
+}
+
 // Three-term products in ONE pass: per K-step the hi AND lo tiles of both operands are loaded (2 A + 2 W tiles instead of the
 // 3 A + 3 W of three separate segments) and every fragment pair feeds three MFMAs (a_hi w_hi + a_hi w_lo + a_lo w_hi): a third
 // fewer operand bytes and three times the MFMA work per barrier pair.  64 KB of LDS, two blocks per CU; segment 0 carries a_hi,
@@ -320,6 +353,7 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_glds3_kernel(const MbdGemmArg
         }
         __syncthreads();
     }
+    float gs[4] = {0.f, 0.f, 0.f, 0.f}, gs2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -334,8 +368,16 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_glds3_kernel(const MbdGemmArg
                 float y = acc[i][j][reg] + add;
                 if (a.residual) y += a.residual[(size_t)band * a.res_band + (size_t)m * a.ldr + n];
                 a.out[(size_t)band * a.out_band + (size_t)m * a.ldc + n] = y;
+                gs[j] += y;
+                gs2[j] = fmaf(y, y, gs2[j]);
             }
         }
+    if (a.gn_part) {   // the operand tiles are dead (the K loop ended with a barrier): their LDS carries the reduction
+        double (*gn_red)[4][2] = reinterpret_cast<double (*)[4][2]>(lds_ah);
+        int* gn_grp = reinterpret_cast<int*>(lds_al);
+        const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x, tiles = (size_t)gridDim.x * gridDim.y;
+        gn_tile_partials<4>(a, gs, gs2, tile_n + wn * 64, wave, lane, tid, a.gn_part + ((size_t)band * tiles + tile) * a.gn_G * 2, gn_red, gn_grp);
+    }
 }
 
 // Three-term products on 256 x 256 tiles (the 768- and 3072-channel layers: 94 % of an evaluation's FLOPs).
@@ -515,6 +557,7 @@ __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs
             }
         }
     }
+    float gs[4] = {0.f, 0.f, 0.f, 0.f}, gs2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -529,8 +572,16 @@ __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs
                 float y = acc[i][j][reg] + add;
                 if (a.residual) y += a.residual[(size_t)band * a.res_band + (size_t)m * a.ldr + n];
                 a.out[(size_t)band * a.out_band + (size_t)m * a.ldc + n] = y;
+                gs[j] += y;
+                gs2[j] = fmaf(y, y, gs2[j]);
             }
         }
+    if (a.gn_part) {
+        __shared__ double gn_red[8][4][2];
+        __shared__ int gn_grp[32];
+        const size_t tile = (size_t)tm * nt_n + tn, tiles = (size_t)nt_m * nt_n;
+        gn_tile_partials<8>(a, gs, gs2, tile_n + wn * 64, wave, lane, tid, a.gn_part + ((size_t)band * tiles + tile) * a.gn_G * 2, gn_red, gn_grp);
+    }
 }
 
 // ---- GroupNorm statistics: deterministic two stages ------------------------------------------------------------------------
@@ -1228,9 +1279,21 @@ template <typename F> PF pf_of(int nb, F f) { PF r{}; for (int b = 0; b < nb; ++
 template <typename F> PH ph_of(int nb, F f) { PH r{}; for (int b = 0; b < nb; ++b) r.p[b] = f(b); return r; }
 
 // cw(b): the band's ConvW.  taps > 1 only when the taps are not contiguous in memory (dilation).
+// GroupNorm statistics of a GEMM's output from its epilogue: `G` groups over the N output channels, partials into `part`; launch_gemm
+// sets `tiles` to the number of partial records per band it will have written, or to 0 when the kernel it picked does not do it (the
+// caller then runs the two-pass group_stats on the output).
+struct GnFuse {
+    int G = 0;
+    double* part = nullptr;
+    int tiles = 0;
+};
 template <typename CW>
 hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, const bf16_t* a_hi, const bf16_t* a_lo, CW cw, int taps, int64_t tap_stride,
-                       int k_per_tap) {
+                       int k_per_tap, GnFuse* gf = nullptr) {
+    const bool gn_fused = !getenv("MV_MBD_NO_GN_FUSE");   // read per call: the tests compare both ways in one process
+    const bool gn_ok = gf && gn_fused && gf->G > 0 && g.N % gf->G == 0 && (g.N / gf->G) % 16 == 0 && 2 * gf->G <= 256;
+    g.gn_part = nullptr;
+    if (gf) gf->tiles = 0;
     g.n_seg = 0;
     g.ldw = cw(0).Ktot;
     g.w_hi = ph_of(nb, [&](int b) { return (const bf16_t*)cw(b).hi; });
@@ -1263,9 +1326,12 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
             t256_raised = true;
         }
         const int n_blocks = nt_m256 * nt_n256 * nb;
+        if (gn_ok) { g.gn_part = gf->part; g.gn_G = gf->G; g.gn_cg = g.N / gf->G; gf->tiles = nt_m256 * nt_n256; }
         hipLaunchKernelGGL(mbd_gemm_t256_kernel, dim3(n_blocks), dim3(512), T256_LDS_BYTES, s, g, nt_m256, nt_n256, n_blocks);
-    } else if (glds_mode == 2 && k64 && prec == 3 && taps == 1 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400)
+    } else if (glds_mode == 2 && k64 && prec == 3 && taps == 1 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400) {
+        if (gn_ok) { g.gn_part = gf->part; g.gn_G = gf->G; g.gn_cg = g.N / gf->G; gf->tiles = nt * ((g.M + 127) / 128); }
         hipLaunchKernelGGL(mbd_gemm_glds3_kernel, dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
+    }
     else if (glds_mode >= 1 && k64 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400)
         hipLaunchKernelGGL(mbd_gemm_glds_kernel, dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
     else if ((size_t)nt * ((g.M + 127) / 128) * nb >= 400) hipLaunchKernelGGL(mbd_gemm_kernel<128>, dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
@@ -1273,9 +1339,10 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
     return hipGetLastError();
 }
 
-size_t gn_blocks(int T, int C, int G) {
+size_t gn_blocks(int T, int C, int G) {   // partial records x G of a [T][C] tensor: the two-pass kernels, or the tiles of a GEMM epilogue
     const int rows_per = std::max(1, (int)((size_t)16384 * G / C));
-    return (size_t)((T + rows_per - 1) / rows_per) * G;
+    const size_t two_pass = (size_t)((T + rows_per - 1) / rows_per), tiles = (size_t)((T + 127) / 128) * ((C + BN - 1) / BN);
+    return std::max(two_pass, tiles) * G;
 }
 hipError_t group_stats(hipStream_t s, const float* x, int64_t x_band, int T, int C, int G, UnetBuffers& ub) {
     // ~16 K elements per block whatever the [T][C] aspect ratio: rows_per rows of one group
@@ -1283,6 +1350,13 @@ hipError_t group_stats(hipStream_t s, const float* x, int64_t x_band, int T, int
     const int chunks = (T + rows_per - 1) / rows_per;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, G, ub.NB), dim3(256), 0, s, x, x_band, T, C, G, rows_per, ub.part);
     hipLaunchKernelGGL(gn_final_kernel, dim3(ub.NB), dim3(256), 0, s, ub.part, chunks, G, (double)T * (C / G), 1e-5f, ub.stats);
+    return hipGetLastError();
+}
+
+// the statistics of a GEMM's output: from the partials its epilogue left (gf.tiles records per band), or the two passes over the output
+hipError_t stats_of_gemm_output(hipStream_t s, const GnFuse& gf, const float* x, int64_t x_band, int T, int C, int G, UnetBuffers& ub) {
+    if (gf.tiles == 0) return group_stats(s, x, x_band, T, C, G, ub);
+    hipLaunchKernelGGL(gn_final_kernel, dim3(ub.NB), dim3(256), 0, s, ub.part, gf.tiles, G, (double)T * (C / G), 1e-5f, ub.stats);
     return hipGetLastError();
 }
 
@@ -1294,16 +1368,18 @@ void launch_norm_act(hipStream_t s, const UnetBuffers& ub, const float* x, int64
 }
 
 // x [band][T][C] fp32 -> ResBlock(x) into `out` (may alias x): x + conv2(act(gn2(conv1(act(gn1(x))))))  (+ col_add); rw(b) = band b's weights
+// out_gf (optional): also leave the GroupNorm partials of the block's OUTPUT (stats_of_gemm_output turns them into statistics)
 template <typename RW>
 hipError_t res_block(hipStream_t s, const mv_mbd* m, RW rw, const float* x, int64_t x_band, float* out, int64_t out_band, int T, int C, int dilation, PF col_add,
-                     UnetBuffers& ub) {
+                     UnetBuffers& ub, GnFuse* out_gf = nullptr) {
     const int G = m->cfg.norm_groups, act = m->cfg.act, nb = ub.NB;
     const int pad = dilation;  // kernel 3
     hipError_t e;
+    GnFuse mid{G, ub.part, 0};   // conv1's output is only ever read through its GroupNorm: statistics from conv1's epilogue
     for (int half = 0; half < 2; ++half) {
         const float* in = half == 0 ? x : ub.b32;
         const int64_t in_band = half == 0 ? x_band : (int64_t)ub.widest;
-        if ((e = group_stats(s, in, in_band, T, C, G, ub)) != hipSuccess) return e;
+        if ((e = half == 0 ? group_stats(s, in, in_band, T, C, G, ub) : stats_of_gemm_output(s, mid, in, in_band, T, C, G, ub)) != hipSuccess) return e;
         launch_norm_act(s, ub, in, in_band, T, C, G, ub.stats, pf_of(nb, [&](int b) { return (const float*)(half == 0 ? rw(b).n1.g : rw(b).n2.g); }),
                         pf_of(nb, [&](int b) { return (const float*)(half == 0 ? rw(b).n1.b : rw(b).n2.b); }), act, nullptr, 0, ub.hi,
                         m->cfg.precision > 2 ? ub.lo : nullptr, pad, pad);
@@ -1315,8 +1391,9 @@ hipError_t res_block(hipStream_t s, const mv_mbd* m, RW rw, const float* x, int6
         if (half == 1) { g.residual = x; g.ldr = C; g.res_band = x_band; g.col_add = col_add; }
         auto cw = [&](int b) -> const ConvW& { return half == 0 ? rw(b).c1 : rw(b).c2; };
         // window of output row t: rows t - pad + j * dilation, j = 0..2; contiguous (one segment per term) when dilation == 1
-        if (dilation == 1) e = launch_gemm(s, m, nb, g, ub.hi, ub.lo, cw, 1, 0, 3 * C);
-        else e = launch_gemm(s, m, nb, g, ub.hi, ub.lo, cw, 3, (int64_t)dilation * C, C);
+        GnFuse* gf = half == 0 ? &mid : out_gf;
+        if (dilation == 1) e = launch_gemm(s, m, nb, g, ub.hi, ub.lo, cw, 1, 0, 3 * C, gf);
+        else e = launch_gemm(s, m, nb, g, ub.hi, ub.lo, cw, 3, (int64_t)dilation * C, C, gf);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -1441,6 +1518,7 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
         for (int i = 0; i < D; ++i) {
             const int Cin = i == 0 ? 1 : m->ch[i - 1], Cout = m->ch[i], To = ub.T[i];
             auto E = [&](int b) -> const EncW& { return m->band[b].enc[i]; };
+            GnFuse enc_gf{G, ub.part, 0};   // stays at 0 tiles for the first level (no GEMM): two-pass statistics
             if (i == 0) {
                 hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)(((size_t)To * (Cout / 4) + 255) / 256), NB), dim3(256), (size_t)Cout * k * 4, s, zin, Tin,
                                    pf_of(NB, [&](int b) { return (const float*)E(b).conv_in_w; }), Cout, k, st, pad, ub.a32, WB, To);
@@ -1451,9 +1529,9 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
                 MbdGemmArgs ga;
                 ga.M = To; ga.N = Cout; ga.lda = (int64_t)st * Cin; ga.a_band = OB; ga.out = ub.a32; ga.ldc = Cout; ga.out_band = WB;
                 ga.bias = PF{}; ga.col_add = PF{};
-                MG_TRY(launch_gemm(s, m, NB, ga, ub.hi, ub.lo, [&](int b) -> const ConvW& { return E(b).conv; }, 1, 0, k * Cin));
+                MG_TRY(launch_gemm(s, m, NB, ga, ub.hi, ub.lo, [&](int b) -> const ConvW& { return E(b).conv; }, 1, 0, k * Cin, &enc_gf));
             }
-            MG_TRY(group_stats(s, ub.a32, WB, To, Cout, G, ub));
+            MG_TRY(stats_of_gemm_output(s, enc_gf, ub.a32, WB, To, Cout, G, ub));
             const bool has_emb = i == 0 || g.emb_all_layers;
             const PF emb = has_emb ? pf_of(NB, [&](int b) { return (const float*)(E(b).emb + (size_t)m->band[b].steps[ev] * Cout); }) : PF{};
             if (g.res_blocks == 0) return mv_fail(MV_ERR_INVALID, "res_blocks = 0 is not supported");
@@ -1512,9 +1590,11 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
             // z = z[:, :, :skip.T] + skip   (z rows beyond skip.T are dropped; z never is shorter)
             const size_t n = (size_t)Ts * C;
             hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256), NB), dim3(256), 0, s, ub.skip[lvl], (int64_t)ub.skip_band[lvl], z, z_band, ub.c32, WB, n);
+            GnFuse dec_gf{G, ub.part, 0};
             for (int r = 0; r < g.res_blocks; ++r)
-                MG_TRY(res_block(s, m, [&](int b) -> const ResW& { return Dw(b).res[r]; }, ub.c32, WB, ub.c32, WB, Ts, C, 1 << r, PF{}, ub));
-            MG_TRY(group_stats(s, ub.c32, WB, Ts, C, G, ub));
+                MG_TRY(res_block(s, m, [&](int b) -> const ResW& { return Dw(b).res[r]; }, ub.c32, WB, ub.c32, WB, Ts, C, 1 << r, PF{}, ub,
+                                 r == g.res_blocks - 1 ? &dec_gf : nullptr));
+            MG_TRY(stats_of_gemm_output(s, dec_gf, ub.c32, WB, Ts, C, G, ub));
             const PF ng = pf_of(NB, [&](int b) { return (const float*)Dw(b).norm.g; }), nbias = pf_of(NB, [&](int b) { return (const float*)Dw(b).norm.b; });
             if (lvl == 0) {
                 launch_norm_act(s, ub, ub.c32, WB, Ts, C, G, ub.stats, ng, nbias, g.act, ub.a32, WB, nullptr, nullptr, 0, 0);

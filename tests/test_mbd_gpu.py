@@ -85,6 +85,37 @@ def test_unet_forward_on_the_256x256_tile_gemm(kw, T, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("kw,T,t256", [
+    (dict(hidden=64, depth=2, growth=4.0, codec_dim=None), 205003, False),   # 256 channels on the three-term 128 x 128 kernel (>= 400 tiles)
+    (dict(hidden=96, depth=2, growth=4.0, codec_dim=None), 9000, True),      # 384 channels, 256 x 256 tiles: a group (96 channels) inside a tile,
+                                                                             # a ragged second column tile
+    (dict(hidden=32, depth=3, growth=4.0, codec_dim=24), 16000, True),       # 512 channels: a tile spans two groups of 128
+])
+def test_group_norm_statistics_from_the_gemm_epilogue(kw, T, t256, monkeypatch):
+    """The GEMMs whose output is only read through a GroupNorm leave the norm's partial sums from their epilogue (`MbdGemmArgs::gn_part`)
+    instead of `gn_partial_kernel` reading the output again.  Against the two-pass statistics (`MV_MBD_NO_GN_FUSE`) the result may differ
+    in the last bits of the statistics only."""
+    pkg = synthetic.mbd_package(seed=5, n_bands=2, proc_bands=1, **kw)
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(T, generator=g)
+    lat = torch.randn(1, kw["codec_dim"], 11, generator=g) if kw.get("codec_dim") else None
+    band = oracle_bands(pkg)[0]
+    ref = o_mbd.unet_forward(band.sd, band.cfg, x.view(1, 1, -1), 90, lat).reshape(-1)
+    eng = mbd.MultiBandDiffusionBands.from_package(pkg, precision=3, eq_bands=1)
+    if t256:
+        monkeypatch.setenv("MV_MBD_T256_MIN_BLOCKS", "1")
+    fused = eng.unet_forward(0, x, 90, lat)
+    again = eng.unet_forward(0, x, 90, lat)
+    monkeypatch.setenv("MV_MBD_NO_GN_FUSE", "1")
+    two_pass = eng.unet_forward(0, x, 90, lat)
+    s_f, s_t, s_pair = snr_db(fused, ref), snr_db(two_pass, ref), snr_db(fused, two_pass)
+    print(f"[mbd gn fuse {kw} T={T}] SNR vs oracle: fused {s_f:.1f} dB, two-pass {s_t:.1f} dB; between the two {s_pair:.1f} dB")
+    assert torch.equal(fused, again)          # fixed-order partials: the same bits on every run
+    assert s_f >= 60.0 and s_t >= 60.0 and s_pair >= 100.0
+    assert not torch.equal(fused, two_pass) or s_pair == float("inf")   # (identical would mean the switch did nothing)
+    eng.close()
+
+
 def test_unet_with_bilstm_bottleneck():
     """BiLSTM bottleneck (codec conditioning reaches the output only through it): the HIP persistent LSTM kernel in both directions
     against the oracle's explicit-gate restatement and against torch.nn.LSTM on the same weights."""
