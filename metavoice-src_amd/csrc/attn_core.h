@@ -214,8 +214,14 @@ __device__ __forceinline__ bool attn_publish_combine(AttnAcc& b, float* pbase, u
 // a stale line harmless (the poll just retries).
 __device__ __forceinline__ void attn_publish_tagged(const AttnAcc& b, u64* slot, uint32_t tag, int lane) {
     const int g = lane >> 4, dl = lane & 15;
-    const float lo = g == 0 ? b.o[0] : g == 1 ? b.o[2] : g == 2 ? b.o[4] : b.o[6];
-    const float hi = g == 0 ? b.o[1] : g == 1 ? b.o[3] : g == 2 ? b.o[5] : b.o[7];
+    // The eight values are pinned in registers before lane group g picks its pair.  Written as a plain chain of selects over b.o[...]
+    // hipcc turned "select of loads" into ONE load through a selected ADDRESS: the accumulator went to scratch memory (44 bytes per
+    // lane in every instance of the persistent kernel), and the publish of every split partial waited for two scratch stores, two
+    // dynamically addressed scratch loads and -- `s_waitcnt vmcnt(0)` -- every weight row the wave had in flight.
+    float o0 = b.o[0], o1 = b.o[1], o2 = b.o[2], o3 = b.o[3], o4 = b.o[4], o5 = b.o[5], o6 = b.o[6], o7 = b.o[7];
+    asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "+v"(o4), "+v"(o5), "+v"(o6), "+v"(o7));
+    const float lo = g == 0 ? o0 : g == 1 ? o2 : g == 2 ? o4 : o6;
+    const float hi = g == 0 ? o1 : g == 1 ? o3 : g == 2 ? o5 : o7;
     const u32x4 v = {__float_as_uint(lo), tag, __float_as_uint(hi), tag};
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slot + dl * 8 + 2 * g), "v"(v) : "memory");
     if (lane == 0) {
@@ -250,6 +256,9 @@ __device__ __forceinline__ bool attn_combine_tagged(AttnAcc& b, const u64* slots
               "=&v"(v[1][3]), "=&v"(v[1][4])
             : "v"(p0), "v"(p0d), "v"(p1), "v"(p1d)
             : "memory");
+#if !defined(MEGA_POLL_SCOREBOARD) || MEGA_POLL_SCOREBOARD
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // compiler-visible vmcnt(0) behind the asm's own: see mega_core.h, mega_loads_have_landed
+#endif
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll

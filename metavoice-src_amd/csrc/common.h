@@ -43,6 +43,9 @@ __device__ __forceinline__ float dot8_bf16(const u32x4& w, const u32x4& x, float
 typedef const __attribute__((address_space(1))) u32x4* mv_gptr16_t;
 __device__ __forceinline__ u32x4 load_stream16(const void* p) { return __builtin_nontemporal_load((mv_gptr16_t)p); }
 __device__ __forceinline__ u32x4 load16(const void* p) { return *(mv_gptr16_t)p; }
+// scalars through global-address-space pointers for the same reason (scale / zero words of the quantised formats)
+__device__ __forceinline__ uint32_t load_global_u32(const uint32_t* p) { return *(const __attribute__((address_space(1))) uint32_t*)p; }
+__device__ __forceinline__ uint16_t load_global_u16(const uint16_t* p) { return *(const __attribute__((address_space(1))) uint16_t*)p; }
 
 // ---- cross-lane sums over a 64-lane wave; every lane ends up with the total -------------------------------
 template <int CTRL>

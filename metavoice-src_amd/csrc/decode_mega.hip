@@ -129,7 +129,7 @@ __device__ __forceinline__ void mega_issue_row_i4(u32x4* cq, uint32_t* cz, const
     for (int j = 0; j < KCH; ++j) {
         const int c = min(j * 2048 + lane * 32, K - 32);
         cq[j] = load_stream16(codes + ((size_t)n * K + c) / 2);
-        cz[j] = sz[(size_t)n * (K / 128) + c / 128];
+        cz[j] = load_global_u32(sz + (size_t)n * (K / 128) + c / 128);
     }
 }
 template <int KCH, int NR, int KP>
@@ -280,8 +280,17 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     if (tid < NU) { pos_s[tid] = a.pos[tid]; done_s[tid] = fold ? a.utt[tid].done : 0; }
     if (fold && b < NU && tid == 0) st_s = a.utt[b];
     __syncthreads();
+    // NOTE: this read compiles to flat_load_dword (the address escapes into the poll helpers as a generic pointer), whose wait is
+    // `vmcnt(0) lgkmcnt(0)`.  Reading it through an LDS-typed pointer (ds_read_b32, lgkmcnt only) measured SLOWER for bf16: 720.5 vs
+    // 687.6 us/step for one utterance, 1054 vs 1027 for two, 1587 vs 1573 for four (profiles/r03q, same box, identical tokens) -- kept
+#ifndef MEGA_ABORT_LDS
+#define MEGA_ABORT_LDS 0
+#endif
+#if MEGA_ABORT_LDS
+#define MG_ABORTED() (*(volatile __attribute__((address_space(3))) int*)(__attribute__((address_space(3))) int*)&s_abort != 0)
+#else
 #define MG_ABORTED() (*(volatile int*)&s_abort != 0)
-    // leaving early: first drain this wave's LDS-direct requests (they write into LDS this workgroup is about to give back)
+#endif
 #define MG_ABORT_RETURN() do { if (MG_ABORTED()) { if (EARLY_ANY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; } } while (0)
     if (fold) {  // a launch queued behind the one in which the last utterance ended: nothing to do
         bool all_done = true;
@@ -317,7 +326,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             if (I4) mega_issue_row_i4<1>(cq + i, cz + i, a.layers[0].q[0], a.layers[0].sz[0], 24 * b + 3 * wave + i, MG_DIM, lane);
-            else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, a.layers[0].q8[0], 24 * b + 3 * wave + i, MG_DIM, lane); sc_a[i] = bf2f(a.layers[0].s8[0][24 * b + 3 * wave + i]); }
+            else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, a.layers[0].q8[0], 24 * b + 3 * wave + i, MG_DIM, lane); sc_a[i] = bf2f(load_global_u16(a.layers[0].s8[0] + (24 * b + 3 * wave + i))); }
             else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave + i, MG_DIM, lane, a.ablate);
         }
         if (!MEGA_KV_AFTER_NORM) nw_attn = load16(a.layers[0].attn_norm + ((wave * 64 + lane) & 255) * 8);
@@ -467,14 +476,14 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         const int rb13 = 22 * b + (wave_o < 6 ? 3 * wave_o : 18 + 2 * (wave_o - 6));
         auto request_wo = [&]() {
             if (I4) mega_issue_row_i4<1>(cq + 6, cz + 6, L.q[1], L.sz[1], 8 * b + wave_o, MG_DIM, lane_o);
-            else if (I8) { mega_issue_row_i8<2>(cq + 12, L.q8[1], 8 * b + wave_o, MG_DIM, lane_o); sc_c = bf2f(L.s8[1][8 * b + wave_o]); }
+            else if (I8) { mega_issue_row_i8<2>(cq + 12, L.q8[1], 8 * b + wave_o, MG_DIM, lane_o); sc_c = bf2f(load_global_u16(L.s8[1] + (8 * b + wave_o))); }
             else mega_issue_row<4>(wv + 12, L.wo, 8 * b + wave_o, MG_DIM, lane_o, a.ablate);
         };
         auto request_w1 = [&]() {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 if (I4) mega_issue_row_i4<1>(cq + i, cz + i, L.q[2], L.sz[2], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
-                else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, L.q8[2], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o); sc_a[i] = bf2f(L.s8[2][min(rb13 + i, MG_INTER - 1)]); }
+                else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, L.q8[2], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o); sc_a[i] = bf2f(load_global_u16(L.s8[2] + (min(rb13 + i, MG_INTER - 1)))); }
                 else if (EARLY_W1) {
                     const bf16_t* row = L.w1 + (size_t)min(rb13 + i, MG_INTER - 1) * MG_DIM;
                     if (!w1_half_issued) {  // a workgroup that does not attend in this step (its key range is empty)
@@ -638,7 +647,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 if (I4) mega_issue_row_i4<1>(cq + 3 + i, cz + 3 + i, L.q[3], L.sz[3], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
-                else if (I8) { mega_issue_row_i8<2>(cq + 6 + 2 * i, L.q8[3], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o); sc_b[i] = bf2f(L.s8[3][min(rb13 + i, MG_INTER - 1)]); }
+                else if (I8) { mega_issue_row_i8<2>(cq + 6 + 2 * i, L.q8[3], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o); sc_b[i] = bf2f(load_global_u16(L.s8[3] + (min(rb13 + i, MG_INTER - 1)))); }
                 else mega_issue_row<4>(wv + 12 + 4 * i, L.w3, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o, a.ablate);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -708,7 +717,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             MG_STAMP(l, 20);  // act published
             // next: w2 row 8 b + wave (K = 5632: 11 chunks)
             if (I4) mega_issue_row_i4<3>(cq + 6, cz + 6, L.q[4], L.sz[4], 8 * b + wave_o, MG_INTER, lane_o);
-            else if (I8) { mega_issue_row_i8<6>(cq, L.q8[4], 8 * b + wave_o, MG_INTER, lane_o); sc_c = bf2f(L.s8[4][8 * b + wave_o]); }
+            else if (I8) { mega_issue_row_i8<6>(cq, L.q8[4], 8 * b + wave_o, MG_INTER, lane_o); sc_c = bf2f(load_global_u16(L.s8[4] + (8 * b + wave_o))); }
             else if (EARLY_W2) {
 #pragma unroll
                 for (int j = 5; j < 11; ++j) wv[j] = load_stream16(L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8);
@@ -790,7 +799,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     if (I4) mega_issue_row_i4<1>(cq + i, cz + i, a.layers[l + 1].q[0], a.layers[l + 1].sz[0], 24 * b + 3 * wave_o + i, MG_DIM, lane_o);
-                    else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, a.layers[l + 1].q8[0], 24 * b + 3 * wave_o + i, MG_DIM, lane_o); sc_a[i] = bf2f(a.layers[l + 1].s8[0][24 * b + 3 * wave_o + i]); }
+                    else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, a.layers[l + 1].q8[0], 24 * b + 3 * wave_o + i, MG_DIM, lane_o); sc_a[i] = bf2f(load_global_u16(a.layers[l + 1].s8[0] + (24 * b + 3 * wave_o + i))); }
                     else if (EARLY_QKV) {
                         const bf16_t* row = w + (size_t)(24 * b + 3 * wave_o + i) * MG_DIM;
                         wv[4 * i + 2] = load_stream16(row + 2 * 512 + lane_o * 8);
@@ -802,7 +811,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int hn = min(11 * b + wave_o + 8 * i, a.vocab - 1);
-                    if (I8) { mega_issue_row_i8<2>(cq + 2 * i, a.head_q8, hn, MG_DIM, lane_o); sc_a[i] = bf2f(a.head_s8[hn]); }
+                    if (I8) { mega_issue_row_i8<2>(cq + 2 * i, a.head_q8, hn, MG_DIM, lane_o); sc_a[i] = bf2f(load_global_u16(a.head_s8 + hn)); }
                     else mega_issue_row<4>(wv + 4 * i, a.head, hn, MG_DIM, lane_o, a.ablate);
                 }
             }

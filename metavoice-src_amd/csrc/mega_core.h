@@ -41,6 +41,18 @@ __device__ __forceinline__ void mega_report_timeout(uint32_t* abort_flag, uint32
     }
 }
 
+// The poll loads are inline asm ending in `s_waitcnt vmcnt(0)`: every load the wave issued before them has landed when the statement
+// ends (loads retire in order) -- but hipcc does not look inside asm statements, keeps the weight / K/V loads it issued itself on its
+// scoreboard and puts a counted `s_waitcnt vmcnt(N)` in front of their first use, where N no longer means what it assumed (LDS-direct
+// requests and the next poll's loads were issued in between): a wait for traffic the use does not depend on.  This compiler-visible
+// wait right behind the poll costs nothing (nothing is outstanding) and clears the scoreboard.
+#ifndef MEGA_POLL_SCOREBOARD
+#define MEGA_POLL_SCOREBOARD 1
+#endif
+__device__ __forceinline__ void mega_loads_have_landed() {
+    if (MEGA_POLL_SCOREBOARD) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+}
+
 // One wave waits until all of ITS granules carry `tag` (no block barrier inside: the loaders only mirror the barrier after).
 template <int PER, typename Fetch, typename Sink>
 __device__ __forceinline__ void wave_poll(uint32_t tag, uint32_t* abort_flag, int* s_abort, Fetch fetch, Sink sink) {
@@ -173,6 +185,7 @@ __device__ __forceinline__ void wave_poll16(const gran_t* g, uint32_t tag, uint3
             p[k] = g + 2 * max(n[k], 0);
         }
         poll16_loads<PER>(v, p);
+        mega_loads_have_landed();
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < PER; ++k) ok = ok && (n[k] < 0 || (v[k].y == tag && v[k].w == tag));
