@@ -283,6 +283,10 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     // NOTE: this read compiles to flat_load_dword (the address escapes into the poll helpers as a generic pointer), whose wait is
     // `vmcnt(0) lgkmcnt(0)`.  Reading it through an LDS-typed pointer (ds_read_b32, lgkmcnt only) measured SLOWER for bf16: 720.5 vs
     // 687.6 us/step for one utterance, 1054 vs 1027 for two, 1587 vs 1573 for four (profiles/r03q, same box, identical tokens) -- kept
+    // The per-layer pointer table is read through a CONSTANT-address-space pointer: scalar loads (s_load, lgkmcnt).  Through the plain
+    // pointer hipcc fetched the pointers with vector loads next to their uses (global_load_dwordx2 + v_readfirstlane) and waited for them
+    // with `s_waitcnt vmcnt(0)` -- i.e. for every weight row in flight -- in front of the address arithmetic of the next requests.
+#define MG_LAYER(i) (*((const __attribute__((address_space(4))) MegaLayer*)(a.layers) + (i)))
 #ifndef MEGA_ABORT_LDS
 #define MEGA_ABORT_LDS 0
 #endif
@@ -321,15 +325,15 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     // of every step -- before the wait for the next token.
     u32x4 nw_attn, nw_ffn = u32x4{0u, 0u, 0u, 0u};
     auto issue_layer0 = [&](int lane, int wave) {  // (lane, wave): the caller's ids, opaque to the optimiser inside the step loop
-        const bf16_t* w = a.layers[0].wqkv;
-        if (MEGA_KV_AFTER_NORM) nw_attn = load16(a.layers[0].attn_norm + ((wave * 64 + lane) & 255) * 8);
+        const bf16_t* w = MG_LAYER(0).wqkv;
+        if (MEGA_KV_AFTER_NORM) nw_attn = load16(MG_LAYER(0).attn_norm + ((wave * 64 + lane) & 255) * 8);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            if (I4) mega_issue_row_i4<1>(cq + i, cz + i, a.layers[0].q[0], a.layers[0].sz[0], 24 * b + 3 * wave + i, MG_DIM, lane);
-            else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, a.layers[0].q8[0], 24 * b + 3 * wave + i, MG_DIM, lane); sc_a[i] = bf2f(load_global_u16(a.layers[0].s8[0] + (24 * b + 3 * wave + i))); }
+            if (I4) mega_issue_row_i4<1>(cq + i, cz + i, MG_LAYER(0).q[0], MG_LAYER(0).sz[0], 24 * b + 3 * wave + i, MG_DIM, lane);
+            else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, MG_LAYER(0).q8[0], 24 * b + 3 * wave + i, MG_DIM, lane); sc_a[i] = bf2f(load_global_u16(MG_LAYER(0).s8[0] + (24 * b + 3 * wave + i))); }
             else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave + i, MG_DIM, lane, a.ablate);
         }
-        if (!MEGA_KV_AFTER_NORM) nw_attn = load16(a.layers[0].attn_norm + ((wave * 64 + lane) & 255) * 8);
+        if (!MEGA_KV_AFTER_NORM) nw_attn = load16(MG_LAYER(0).attn_norm + ((wave * 64 + lane) & 255) * 8);
     };
     issue_layer0(lane, wave);
 
@@ -367,7 +371,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         int lane_o = lane, wave_o = wave;
         asm volatile("" : "+v"(lane_o), "+v"(wave_o));
         const int tid_o = wave_o * 64 + lane_o;
-        const MegaLayer L = a.layers[l];
+        const __attribute__((address_space(4))) MegaLayer& L = MG_LAYER(l);   // fields are fetched with scalar loads where they are used
         const uint32_t tag0 = epoch + (uint32_t)l * 8u + 1u;  // + phase index
         bf16_t* kc = a.kcache + (size_t)l * a.kv_layer_elems;
         bf16_t* vc = a.vcache + (size_t)l * a.kv_layer_elems;
@@ -753,7 +757,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             MG_STAMP(l, 9);
             if constexpr (EARLY_QKV) {  // chunks 0, 1 of the next layer's three wqkv rows on their way while the w2 dots and the x publish run
                 if (l + 1 < a.n_layer) {
-                    const bf16_t* w = a.layers[l + 1].wqkv;
+                    const bf16_t* w = MG_LAYER(l + 1).wqkv;
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -793,13 +797,13 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }
             __builtin_amdgcn_sched_barrier(0);
             // next: the following layer's wqkv rows, or the LM-head rows 11 b + wave + 8 i
-            if (MEGA_KV_AFTER_NORM) nw_attn = load16((l + 1 < a.n_layer ? a.layers[l + 1].attn_norm : a.final_norm) + (tid_o & 255) * 8);
+            if (MEGA_KV_AFTER_NORM) nw_attn = load16((l + 1 < a.n_layer ? MG_LAYER(l + 1).attn_norm : a.final_norm) + (tid_o & 255) * 8);
             if (l + 1 < a.n_layer) {
-                const bf16_t* w = a.layers[l + 1].wqkv;
+                const bf16_t* w = MG_LAYER(l + 1).wqkv;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    if (I4) mega_issue_row_i4<1>(cq + i, cz + i, a.layers[l + 1].q[0], a.layers[l + 1].sz[0], 24 * b + 3 * wave_o + i, MG_DIM, lane_o);
-                    else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, a.layers[l + 1].q8[0], 24 * b + 3 * wave_o + i, MG_DIM, lane_o); sc_a[i] = bf2f(load_global_u16(a.layers[l + 1].s8[0] + (24 * b + 3 * wave_o + i))); }
+                    if (I4) mega_issue_row_i4<1>(cq + i, cz + i, MG_LAYER(l + 1).q[0], MG_LAYER(l + 1).sz[0], 24 * b + 3 * wave_o + i, MG_DIM, lane_o);
+                    else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, MG_LAYER(l + 1).q8[0], 24 * b + 3 * wave_o + i, MG_DIM, lane_o); sc_a[i] = bf2f(load_global_u16(MG_LAYER(l + 1).s8[0] + (24 * b + 3 * wave_o + i))); }
                     else if (EARLY_QKV) {
                         const bf16_t* row = w + (size_t)(24 * b + 3 * wave_o + i) * MG_DIM;
                         wv[4 * i + 2] = load_stream16(row + 2 * 512 + lane_o * 8);
@@ -815,7 +819,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                     else mega_issue_row<4>(wv + 4 * i, a.head, hn, MG_DIM, lane_o, a.ablate);
                 }
             }
-            if (!MEGA_KV_AFTER_NORM) nw_attn = load16((l + 1 < a.n_layer ? a.layers[l + 1].attn_norm : a.final_norm) + (tid_o & 255) * 8);
+            if (!MEGA_KV_AFTER_NORM) nw_attn = load16((l + 1 < a.n_layer ? MG_LAYER(l + 1).attn_norm : a.final_norm) + (tid_o & 255) * 8);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
