@@ -13,7 +13,7 @@ for line in p.stderr.split("\n"):
     m = re.search(r"Function Name: (\S+)", line)
     if m:
         cur, vals = m.group(1), {}
-    for k, label in (("VGPRs", "vgpr"), (r"ScratchSize \[bytes/lane\]", "scratch"), ("VGPRs Spill", "spill"), ("Occupancy \[waves/SIMD\]", "occ")):
+    for k, label in (("VGPRs", "vgpr"), (r"ScratchSize \[bytes/lane\]", "scratch"), ("VGPRs Spill", "spill"), ("SGPRs Spill", "sgpr_spill"), ("Occupancy \[waves/SIMD\]", "occ")):
         m = re.search(r"remark:\s+" + k + r": (\d+)", line)
         if m:
             vals[label] = int(m.group(1))
