@@ -955,9 +955,14 @@ bool mega_supported(const mv_config& c, int rows, int n_cus) {
 }
 
 // One utterance per engine (the rolled utterance loops of the 2 / 4-utterance instances spill inside the layer loop once the sampler
-// tail is compiled in), bf16 or int4: the int8 instance measured SLOWER with the tail (1426 vs 1452 tok/s on the same box; bf16
-// +1.4 %, int4 +2.2 %), so int8 engines keep one step per launch + sample_kernel.
-bool mega_folds(const mv_config& c) { return c.max_utterances <= MEGA_FOLD_MAX_UTT && c.weight_format != MV_W_INT8; }
+// tail is compiled in).
+// int8 engines draw their tokens inside the launch like bf16 / int4 ones: 647 vs 655 us/step (profiles/r03w; in round 2, with the
+// accumulator of the split-partial publish in scratch, the instance was the slower one and int8 kept sample_kernel).
+// -DMEGA_FOLD_INT8=0 restores that.
+#ifndef MEGA_FOLD_INT8
+#define MEGA_FOLD_INT8 1
+#endif
+bool mega_folds(const mv_config& c) { return c.max_utterances <= MEGA_FOLD_MAX_UTT && (MEGA_FOLD_INT8 || c.weight_format != MV_W_INT8); }
 
 __global__ void bump_counter_kernel(uint32_t* c) { c[0] += 1u; }
 hipError_t launch_bump_counter(hipStream_t s, uint32_t* c) {
@@ -985,7 +990,8 @@ static hipError_t launch_mega_instance(hipStream_t s, const MegaArgs& a) {
 template <int WF>
 static hipError_t launch_mega_format(hipStream_t s, const MegaArgs& a) {
     switch (a.n_utt) {
-        case 1: return a.n_steps > 0 ? (WF == MV_W_INT8 ? hipErrorInvalidValue : launch_mega_instance<WF, 1, WF != MV_W_INT8>(s, a)) : launch_mega_instance<WF, 1, false>(s, a);
+        case 1: return a.n_steps > 0 ? (WF == MV_W_INT8 && !MEGA_FOLD_INT8 ? hipErrorInvalidValue : launch_mega_instance<WF, 1, MEGA_FOLD_INT8 || WF != MV_W_INT8>(s, a))
+                                     : launch_mega_instance<WF, 1, false>(s, a);
         case 2: return a.n_steps > 0 ? hipErrorInvalidValue : launch_mega_instance<WF, 2, false>(s, a);
         case 4: return a.n_steps > 0 ? hipErrorInvalidValue : launch_mega_instance<WF, 4, false>(s, a);
         default: return hipErrorInvalidValue;

@@ -6,8 +6,8 @@
 
 typedef uint16_t bf16_t;
 
-// Engines of more utterances keep sample_kernel behind every step, and so do int8 engines: with the token draw compiled in (inlined
-// or out of line) those instances measured slower (r02: int8 1426 vs 1452 tok/s; r03a out of line: see decode_mega.hip)
+// Engines of more utterances keep sample_kernel behind every step: with the token draw compiled in (inlined or out of line) those
+// instances measured slower (r03a: see decode_mega.hip).  One-utterance engines of every format draw inside the launch.
 #define MEGA_FOLD_MAX_UTT 1
 
 // ---- tuning knobs (mv_tune): defaults are the measured best for MetaVoice-1B on MI355X (DESIGN.md "Tuning") ------
@@ -22,7 +22,7 @@ struct MvTune {
                                          // (MetaVoice-1B shape, >= 256 CUs); 0: per-layer launches
     int mega_steps = 512;                // decode steps per launch of the folding persistent kernel
     int mega_fold = 1;                   // 1: the persistent kernel also draws the token and runs several steps per launch (engines
-                                         // of up to MEGA_FOLD_MAX_UTT utterances, bf16 / int4); 0: one step per launch + sample_kernel
+                                         // of up to MEGA_FOLD_MAX_UTT utterances); 0: one step per launch + sample_kernel
 };
 extern MvTune g_tune;
 

@@ -54,7 +54,7 @@ def test_full_size_path_equivalences(full):
     lc = engine.captured_logits(T - 1, n_new)
     assert engine.decode_path() == (2, 0), "a persistent launch was abandoned: the comparison would be launches against launches"
     assert a == c and torch.equal(la, lc)
-    engine.tune(mega_fold=0)  # one step per launch + sample_kernel (what engines of several utterances and int8 engines run)
+    engine.tune(mega_fold=0)  # one step per launch + sample_kernel (what engines of several utterances run)
     assert run(engine, prompt, spk, sp, n_new, prefill_mode=1) == a and torch.equal(la, engine.captured_logits(T - 1, n_new))
     assert engine.decode_path() == (1, 0)
     engine.tune(mega_fold=1)

@@ -55,7 +55,7 @@ def test_persistent_decode_kernel_has_no_scratch_and_no_flat_loads(tmp_path):
             assert "scratch_" not in body
         # the layer pointer table comes through scalar loads: no vector load whose result is only read back with v_readfirstlane
         assert not re.search(r"global_load_dwordx2 v\[(\d+):\d+\], v\d+, s\[\d+:\d+\][^\n]*\n(?:[^\n]*\n){0,6}?\s*v_readfirstlane_b32 s\d+, v\1\b", body), name
-    assert seen == 11   # 3 formats x (1 utterance one-step, 2, 4) + the two instances that draw their own tokens (bf16, int4)
+    assert seen == 12   # 3 formats x (1 utterance one-step, 2, 4) + the three one-utterance instances that draw their own tokens
 
 
 def test_fused_lstm_keeps_its_rows_in_registers(tmp_path):
