@@ -992,7 +992,9 @@ static hipError_t launch_mega_format(hipStream_t s, const MegaArgs& a) {
     switch (a.n_utt) {
         case 1: return a.n_steps > 0 ? (WF == MV_W_INT8 && !MEGA_FOLD_INT8 ? hipErrorInvalidValue : launch_mega_instance<WF, 1, MEGA_FOLD_INT8 || WF != MV_W_INT8>(s, a))
                                      : launch_mega_instance<WF, 1, false>(s, a);
-        case 2: return a.n_steps > 0 ? hipErrorInvalidValue : launch_mega_instance<WF, 2, false>(s, a);
+        case 2:
+            if constexpr (MEGA_FOLD_MAX_UTT >= 2) { if (a.n_steps > 0) return launch_mega_instance<WF, 2, true>(s, a); }
+            return a.n_steps > 0 ? hipErrorInvalidValue : launch_mega_instance<WF, 2, false>(s, a);
         case 4: return a.n_steps > 0 ? hipErrorInvalidValue : launch_mega_instance<WF, 4, false>(s, a);
         default: return hipErrorInvalidValue;
     }

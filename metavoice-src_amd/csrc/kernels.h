@@ -8,7 +8,9 @@ typedef uint16_t bf16_t;
 
 // Engines of more utterances keep sample_kernel behind every step: with the token draw compiled in (inlined or out of line) those
 // instances measured slower (r03a: see decode_mega.hip).  One-utterance engines of every format draw inside the launch.
-#define MEGA_FOLD_MAX_UTT 1
+#ifndef MEGA_FOLD_MAX_UTT
+#define MEGA_FOLD_MAX_UTT 1   // -DMEGA_FOLD_MAX_UTT=2 (decode_mega.hip only): A/B build with the two-utterance instances drawing inside the launch
+#endif
 
 // ---- tuning knobs (mv_tune): defaults are the measured best for MetaVoice-1B on MI355X (DESIGN.md "Tuning") ------
 struct MvTune {
