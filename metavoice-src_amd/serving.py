@@ -19,7 +19,8 @@ GPU this degenerates to the reference's behaviour.  Launch: `python -m torch.dis
 The reference builds this on FastAPI + python-multipart + tyro + ffmpeg; of those only FastAPI is in this image and its
 `Form(...)` needs python-multipart, so the same surface is served here with the standard library (`http.server` + `email`
 for multipart bodies).  Uploaded `audiodata` is written to a temp file and handed to `TTS.synthesise` as the speaker
-reference; transcoding arbitrary formats through ffmpeg (`:112-124`) is out of scope.
+reference (RIFF/WAVE uploads cut to the reference's two minutes); transcoding arbitrary formats through ffmpeg (`:112-124`) is out
+of scope.
 """
 from __future__ import annotations
 
@@ -273,6 +274,28 @@ STREAM_WAV_HEADER = (b"RIFF" + b"\xff\xff\xff\xff" + b"WAVE" + b"fmt " + (16).to
                      (16).to_bytes(2, "little") + b"data" + b"\xff\xff\xff\xff")  # 24 kHz mono PCM16, sizes unknown (streamed)
 
 
+UPLOAD_MAX_SECONDS = 120.0   # `_convert_audiodata_to_wav_path` (serving.py:112-124): `ffmpeg -t 120`, "arbitrary 2 minute cutoff"
+
+
+def _store_upload(audiodata: bytes, wav_tmp) -> str:
+    """The uploaded speaker reference as a temp file for `TTS.synthesise`.  The reference transcodes every upload through ffmpeg and keeps
+    its first two minutes; there is no ffmpeg here, uploads are handed on in the format they came in (speaker_encoder/audio.py sniffs
+    it) -- but a RIFF/WAVE upload longer than two minutes is cut like the reference's."""
+    wav_tmp.write(audiodata)
+    wav_tmp.flush()
+    if audiodata[:4] in (b"RIFF", b"RIFX") and audiodata[8:12] == b"WAVE":
+        try:
+            from scipy.io import wavfile
+
+            rate, data = wavfile.read(wav_tmp.name)
+            keep = int(UPLOAD_MAX_SECONDS * rate)
+            if len(data) > keep:
+                wavfile.write(wav_tmp.name, rate, data[:keep])
+        except Exception:   # an odd header: leave the file to load_audio, which reports what it cannot read
+            pass
+    return wav_tmp.name
+
+
 def text_to_speech_stream(fields: Dict[str, str], files: Dict[str, bytes]):
     """`POST /tts_stream` (no counterpart in the reference, which stops at 220 characters: BASELINE configs[4] "streaming decode"):
     the same form as `/tts`, any text length.  Returns (refusal, None) or (None, generator of body pieces): the RIFF header with
@@ -287,9 +310,7 @@ def text_to_speech_stream(fields: Dict[str, str], files: Dict[str, bytes]):
     def pieces():
         with tempfile.NamedTemporaryFile(suffix=".wav") as wav_tmp:
             if fields.get("speaker_ref_path") is None:
-                wav_tmp.write(files["audiodata"])
-                wav_tmp.flush()
-                spk = wav_tmp.name
+                spk = _store_upload(files["audiodata"], wav_tmp)
             else:
                 spk = fields["speaker_ref_path"]
             gen = GlobalState.tts.synthesise_long_stream(text, spk, top_p=top_p, guidance_scale=guidance, temperature=GlobalState.config.temperature)
@@ -332,9 +353,7 @@ def text_to_speech(fields: Dict[str, str], files: Dict[str, bytes]) -> Tuple[int
     try:
         with tempfile.NamedTemporaryFile(suffix=".wav") as wav_tmp:
             if speaker_ref_path is None:
-                wav_tmp.write(audiodata)
-                wav_tmp.flush()
-                wav_path = wav_tmp.name
+                wav_path = _store_upload(audiodata, wav_tmp)
             else:
                 wav_path = speaker_ref_path
             if GlobalState.dispatcher is not None:  # queued, batched, sharded over the GPUs; the waveform never touches the disk

@@ -343,3 +343,28 @@ def test_cors_preflight_and_body_cap(server, monkeypatch):
     assert code == 413 and len(tts.calls) == n_before
     code, _, _ = post(base + "/tts", urllib.parse.urlencode({"text": "ok", "speaker_ref_path": "a.wav"}).encode())
     assert code == 200
+
+
+def test_uploaded_wave_reference_is_cut_to_two_minutes(server):
+    """`serving.py:112-124`: the reference keeps the first 120 s of an uploaded speaker reference (`ffmpeg -t 120`)."""
+    import io
+
+    import numpy as np
+    from scipy.io import wavfile
+
+    base, tts = server
+    rate = 8000
+    long_ref = io.BytesIO()
+    wavfile.write(long_ref, rate, (np.arange(130 * rate) % 256).astype(np.int16))
+    short_ref = io.BytesIO()
+    wavfile.write(short_ref, rate, (np.arange(40 * rate) % 256).astype(np.int16))
+    for payload, seconds in ((long_ref.getvalue(), 120), (short_ref.getvalue(), 40)):
+        boundary = "----mvtest"
+        body = (f"--{boundary}\r\nContent-Disposition: form-data; name=\"text\"\r\n\r\nhello\r\n"
+                f"--{boundary}\r\nContent-Disposition: form-data; name=\"audiodata\"; filename=\"ref.wav\"\r\nContent-Type: audio/wav\r\n\r\n").encode() \
+            + payload + f"\r\n--{boundary}--\r\n".encode()
+        code, ctype, _ = post(base + "/tts", body, {"Content-Type": f"multipart/form-data; boundary={boundary}"})
+        assert code == 200 and ctype == "audio/wav"
+        got_rate, got = wavfile.read(io.BytesIO(tts.calls[-1]["ref_bytes"]))
+        assert got_rate == rate and len(got) == seconds * rate
+        assert np.array_equal(got, (np.arange(seconds * rate) % 256).astype(np.int16))   # the FIRST two minutes, untouched
