@@ -269,3 +269,34 @@ class TTS:
         print(f"\nSaved audio to {name}.wav ({len(chunks)} chunks, {dur:.1f} s)")
         print(f"Real-time factor: {(time.time() - start) / max(dur, 1e-9):.2f}")
         return str(name) + ".wav"
+
+
+def _parse_cli(argv=None):
+    """`fast_inference.py:198-199` builds a `TTS` from the command line (`tyro.cli(TTS)`): the same constructor keywords here, plus an
+    optional one-shot synthesis (`--text` with `--spk_ref_path`) so that the module is usable as a command."""
+    import argparse
+
+    ap = argparse.ArgumentParser(description="MetaVoice-1B text to speech on MI355X")
+    ap.add_argument("--model_name", default="metavoiceio/metavoice-1B-v0.1", help="hub id or a local directory with the checkpoints")
+    ap.add_argument("--seed", type=int, default=1337)
+    ap.add_argument("--output_dir", default="outputs")
+    ap.add_argument("--quantisation_mode", choices=["int4", "int8"], default=None)
+    ap.add_argument("--first_stage_path", default=None)
+    ap.add_argument("--telemetry_origin", default=None, help="accepted for compatibility; nothing is sent anywhere")
+    ap.add_argument("--text", default=None, help="synthesise this text once and print the path of the .wav")
+    ap.add_argument("--spk_ref_path", default=None, help="speaker reference (path, http(s) URI or a precomputed .pt / .npy embedding)")
+    ap.add_argument("--top_p", type=float, default=0.95)
+    ap.add_argument("--guidance_scale", type=float, default=3.0)
+    ap.add_argument("--temperature", type=float, default=1.0)
+    a = ap.parse_args(argv)
+    if (a.text is None) != (a.spk_ref_path is None):
+        ap.error("--text and --spk_ref_path go together")
+    return a
+
+
+if __name__ == "__main__":
+    _a = _parse_cli()
+    tts = TTS(model_name=_a.model_name, seed=_a.seed, output_dir=_a.output_dir, quantisation_mode=_a.quantisation_mode,
+              first_stage_path=_a.first_stage_path, telemetry_origin=_a.telemetry_origin)
+    if _a.text is not None:
+        print(tts.synthesise(_a.text, _a.spk_ref_path, top_p=_a.top_p, guidance_scale=_a.guidance_scale, temperature=_a.temperature))

@@ -191,3 +191,14 @@ def test_split_text_keeps_closing_quotes_and_brackets_with_their_sentence():
             assert " ".join(ch) == norm, (t, mc, ch)   # nothing dropped, nothing reordered; only hard cuts of over-long words add spaces
         else:
             assert "".join(ch).replace(" ", "") == norm.replace(" ", "")
+
+
+def test_fast_inference_command_line():
+    """`fast_inference.py:198-199`: the module builds a TTS from the command line; here with the constructor's keywords as flags."""
+    fi = load_pkg("fast_inference")
+    a = fi._parse_cli(["--model_name", "/models/mv", "--quantisation_mode", "int8", "--seed", "7"])
+    assert (a.model_name, a.quantisation_mode, a.seed, a.output_dir, a.text) == ("/models/mv", "int8", 7, "outputs", None)
+    a = fi._parse_cli(["--text", "hello", "--spk_ref_path", "ref.wav", "--top_p", "0.9"])
+    assert (a.text, a.spk_ref_path, a.top_p, a.guidance_scale, a.temperature) == ("hello", "ref.wav", 0.9, 3.0, 1.0)
+    with pytest.raises(SystemExit):
+        fi._parse_cli(["--text", "no speaker"])
