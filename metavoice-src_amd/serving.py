@@ -58,6 +58,7 @@ class _GlobalState:
     config: ServingConfig
     tts = None
     dispatcher = None
+    engine_lock = threading.Lock()   # without a dispatcher: serialises the handler threads on the one engine
 
 
 class BatchingDispatcher:
@@ -305,7 +306,7 @@ def text_to_speech_stream(fields: Dict[str, str], files: Dict[str, bytes]):
     if refusal is not None:
         return refusal, None
     text, guidance, top_p = fields["text"], float(fields.get("guidance", 3.0)), float(fields.get("top_p", 0.95))
-    lock = GlobalState.dispatcher.engine_lock if GlobalState.dispatcher is not None else threading.Lock()
+    lock = _engine_lock()
 
     def pieces():
         with tempfile.NamedTemporaryFile(suffix=".wav") as wav_tmp:
@@ -328,9 +329,9 @@ def text_to_speech_stream(fields: Dict[str, str], files: Dict[str, bytes]):
     try:
         head = next(it)
         first = next(it, b"")
-    except Exception:
+    except Exception as e:
         logger.exception(f"Error processing streaming request. text: {text[:80]!r}")
-        return (500, "text/plain", ERROR_TEXT.encode()), None
+        return _error_response(e), None
 
     def body():
         yield head
@@ -358,17 +359,29 @@ def text_to_speech(fields: Dict[str, str], files: Dict[str, bytes]) -> Tuple[int
                 wav_path = speaker_ref_path
             if GlobalState.dispatcher is not None:  # queued, batched, sharded over the GPUs; the waveform never touches the disk
                 return 200, "audio/wav", GlobalState.dispatcher.submit(text, wav_path, top_p, guidance)
-            wav_out_path = GlobalState.tts.synthesise(text=text, spk_ref_path=wav_path, top_p=top_p, guidance_scale=guidance)
+            with _engine_lock():  # handler threads are concurrent (keep-alive clients must not block each other); the engine is not re-entrant
+                wav_out_path = GlobalState.tts.synthesise(text=text, spk_ref_path=wav_path, top_p=top_p, guidance_scale=guidance)
         with open(wav_out_path, "rb") as f:
             return 200, "audio/wav", f.read()
     except Exception as e:
-        if type(e).__name__ == "UnsupportedAudioFormat":  # the speaker reference is in a format nothing here can decode: the client's to fix
-            return 415, "application/json", json.dumps({"detail": str(e)}).encode()
         logger.exception(f"Error processing request. text: {text}, speaker_ref_path: {speaker_ref_path}, guidance: {guidance}, top_p: {top_p}")
-        return 500, "text/plain", ERROR_TEXT.encode()
+        return _error_response(e)
     finally:
         if wav_out_path is not None:
             Path(wav_out_path).unlink(missing_ok=True)
+
+
+def _engine_lock():
+    """The one lock around the engine: the dispatcher's when there is one, else the server's own."""
+    return GlobalState.dispatcher.engine_lock if GlobalState.dispatcher is not None else GlobalState.engine_lock
+
+
+def _error_response(e: Exception) -> Tuple[int, str, bytes]:
+    """Exception -> (status, content type, body), shared by `/tts` and `/tts_stream`: a speaker reference in a format nothing here can
+    decode is the client's to fix (415), everything else is the reference's fixed 500 text (`serving.py:101-105`)."""
+    if type(e).__name__ == "UnsupportedAudioFormat" or "UnsupportedAudioFormat" in str(e)[:64]:
+        return 415, "application/json", json.dumps({"detail": str(e)}).encode()
+    return 500, "text/plain", ERROR_TEXT.encode()
 
 
 MAX_REQUEST_BYTES = 256 << 20  # text + an uploaded speaker reference (the reference's ffmpeg step keeps the first 2 minutes of it)
@@ -376,6 +389,7 @@ MAX_REQUEST_BYTES = 256 << 20  # text + an uploaded speaker reference (the refer
 
 class _Handler(BaseHTTPRequestHandler):
     protocol_version = "HTTP/1.1"  # chunked transfer for /tts_stream; every other response carries its Content-Length
+    timeout = 30                   # an idle keep-alive socket gives its handler thread back after 30 s (StreamRequestHandler.timeout)
 
     def _send_chunked(self, ctype: str, pieces):
         self.send_response(200)
@@ -454,8 +468,10 @@ def make_server(tts, config: Optional[ServingConfig] = None, host: str = "0.0.0.
     GlobalState.config = config or ServingConfig()
     GlobalState.tts = tts
     GlobalState.dispatcher = dispatcher
-    cls = ThreadingHTTPServer if dispatcher is not None else HTTPServer
-    return cls((host, GlobalState.config.port), _Handler)
+    GlobalState.engine_lock = threading.Lock()
+    # one thread per connection in BOTH modes: HTTP/1.1 keeps connections open, and with a single-threaded server one idle persistent
+    # client (a browser tab, a load-balancer probe) would block every other client, /health included
+    return ThreadingHTTPServer((host, GlobalState.config.port), _Handler)
 
 
 def main(argv=None):

@@ -368,3 +368,39 @@ def test_uploaded_wave_reference_is_cut_to_two_minutes(server):
         got_rate, got = wavfile.read(io.BytesIO(tts.calls[-1]["ref_bytes"]))
         assert got_rate == rate and len(got) == seconds * rate
         assert np.array_equal(got, (np.arange(seconds * rate) % 256).astype(np.int16))   # the FIRST two minutes, untouched
+
+
+def test_an_idle_keep_alive_client_does_not_block_other_clients(server):
+    """HTTP/1.1 keeps connections open; with a single-threaded server one idle persistent client blocked every
+    other client, /health included.  One thread per connection now, the engine behind one lock."""
+    import http.client
+
+    base, tts = server
+    host, port = base[len("http://"):].split(":")
+    c1 = http.client.HTTPConnection(host, int(port), timeout=10)
+    c1.request("GET", "/health")
+    r1 = c1.getresponse()
+    assert r1.status == 200 and json.loads(r1.read()) == {"status": "ok"}
+    # c1 stays open and idle; a second client must be served
+    c2 = http.client.HTTPConnection(host, int(port), timeout=5)
+    c2.request("GET", "/health")
+    assert c2.getresponse().status == 200
+    code, ctype, body = post(base + "/tts", urllib.parse.urlencode({"text": "hello", "speaker_ref_path": "/refs/a.wav"}).encode())
+    assert code == 200 and body.startswith(b"RIFF")
+    # and the first connection is still usable (keep-alive)
+    c1.request("GET", "/health")
+    assert c1.getresponse().status == 200
+    c1.close(); c2.close()
+    assert serving._Handler.timeout and serving._Handler.timeout <= 60   # an idle socket cannot hold a thread forever
+
+
+def test_stream_maps_errors_like_tts(server):
+    base, _ = server
+
+    class Unsupported(ValueError):
+        pass
+    Unsupported.__name__ = "UnsupportedAudioFormat"
+    assert serving._error_response(Unsupported("no decoder"))[0] == 415
+    assert serving._error_response(RuntimeError("x")) == (500, "text/plain", serving.ERROR_TEXT.encode())
+    code, _, body = post(base + "/tts_stream", urllib.parse.urlencode({"text": "boom", "speaker_ref_path": "x"}).encode())
+    assert code == 500 and body.decode() == serving.ERROR_TEXT

@@ -4,6 +4,7 @@ how long wave 0 waited for each hand-off and how long it computed.  Slots: 0 lay
 3 q/k/v ready, 4 attention done (P2 start), 5 attn vector ready, 6 P3 start, 7 h ready, 8 P4 start, 9 act ready, 10 x published."""
 import ctypes as C, importlib, os, sys
 os.environ["MV_MEGA_STAMPS"] = "1"
+os.environ.setdefault("MV_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "metavoice-src_amd", "lib", "libmetavoice_hip_instr.so"))  # stamps live in the instrumented build (make -C csrc instr)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
