@@ -202,3 +202,85 @@ def test_fast_inference_command_line():
     assert (a.text, a.spk_ref_path, a.top_p, a.guidance_scale, a.temperature) == ("hello", "ref.wav", 0.9, 3.0, 1.0)
     with pytest.raises(SystemExit):
         fi._parse_cli(["--text", "no speaker"])
+
+
+def test_bpe_matches_independent_formulations_on_random_vocabularies():
+    """tokenise.py restates tiktoken 0.5.1's `_byte_pair_merge` (fam/quantiser/text/tokenise.py:5-12; tiktoken is not in the image, the
+    real ranks live in the unreachable checkpoint).  Pinned here against two formulations written independently of it, on random
+    TRAINED-LIKE vocabularies (every merge joins two existing tokens, ranks in creation order -- the only kind BPE training emits):
+      (a) the incremental form tiktoken 0.5.1 itself uses (`_byte_pair_merge`: a vector of (start, rank of the pair starting here),
+          only the two ranks next to a merge are recomputed);
+      (b) a span-based brute force of "fuse the adjacent pair of lowest rank, leftmost first" that never builds byte strings for the
+          parts (boundaries into the original piece + a rank lookup on slices).
+    All three must give the same segmentation; a bug in the merge loop (wrong tie order, stale pair after a
+    merge, off-by-one at the ends) separates them on random byte strings."""
+    import random
+
+    tok_mod = load_pkg("tokenise")
+    rng = random.Random(1234)
+
+    def random_vocab(alphabet, n_merges):
+        toks = [bytes([c]) for c in alphabet]
+        ranks = {bytes([c]): c for c in range(256)}
+        merges = []
+        nxt = 256
+        while len(merges) < n_merges:
+            a, b = rng.choice(toks), rng.choice(toks)
+            if a + b in ranks or len(a + b) > 6:
+                continue
+            ranks[a + b] = nxt
+            merges.append((a, b))
+            toks.append(a + b)
+            nxt += 1
+        return ranks, merges
+
+    def incremental(ranks, piece):
+        MAX = 1 << 60
+        parts = [[i, MAX] for i in range(len(piece) + 1)]
+
+        def get_rank(start_idx, skip):
+            if start_idx + skip + 2 < len(parts):
+                return ranks.get(piece[parts[start_idx][0]:parts[start_idx + skip + 2][0]], MAX)
+            return MAX
+
+        for i in range(len(parts) - 2):
+            parts[i][1] = get_rank(i, 0)
+        while len(parts) > 1:
+            best_rank, best_i = MAX, -1
+            for i in range(len(parts) - 1):
+                if parts[i][1] < best_rank:
+                    best_rank, best_i = parts[i][1], i
+            if best_rank == MAX:
+                break
+            i = best_i
+            parts[i][1] = get_rank(i, 1)
+            if i > 0:
+                parts[i - 1][1] = get_rank(i - 1, 1)
+            parts.pop(i + 1)
+        return [piece[parts[k][0]:parts[k + 1][0]] for k in range(len(parts) - 1)]
+
+    def span_brute_force(ranks, piece):
+        cuts = list(range(len(piece) + 1))   # boundaries: part k = piece[cuts[k]:cuts[k+1]]
+        while len(cuts) > 2:
+            best = min(((ranks.get(piece[cuts[k]:cuts[k + 2]], 1 << 60), k) for k in range(len(cuts) - 2)))
+            if best[0] == 1 << 60:
+                break
+            del cuts[best[1] + 1]
+        return [piece[cuts[k]:cuts[k + 1]] for k in range(len(cuts) - 1)]
+
+    checked = 0
+    for trial in range(60):
+        alphabet = rng.sample(range(97, 123), rng.randint(2, 5))
+        ranks, merges = random_vocab(alphabet, rng.randint(3, 40))
+        for _ in range(40):
+            piece = bytes(rng.choice(alphabet) for _ in range(rng.randint(1, 24)))
+            got = tok_mod._bpe(ranks, piece)
+            # tiktoken's `_encode_native` looks the whole piece up before it merges anything (src/lib.rs: `if let Some(token) = encoder.get(piece)`)
+            want_a = [ranks[piece]] if piece in ranks else [ranks[p] for p in incremental(ranks, piece)]
+            want_b = [ranks[piece]] if piece in ranks else [ranks[p] for p in span_brute_force(ranks, piece)]
+            assert got == want_b, (piece, got, want_b)
+            assert got == want_a, (piece, got, want_a)
+            checked += 1
+    assert checked == 2400
+    # the classic overlap case: "aaa" with the merge (a, a) fuses the LEFT pair
+    assert tok_mod._bpe({b"a": 0, b"aa": 1}, b"aaa") == [1, 0]

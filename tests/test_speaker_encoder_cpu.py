@@ -184,3 +184,27 @@ def test_get_cached_embedding_is_computed_once_per_file(tmp_path, monkeypatch):
     entry.write_bytes(b"garbage")
     os.utime(entry, (os.path.getmtime(f) + 10, os.path.getmtime(f) + 10))
     assert float(inf.get_cached_embedding(str(f), Enc())[0, 0]) == 3.0  # unreadable entry -> recomputed, not an error
+
+
+def test_mel_front_end_matches_the_independent_implementation_in_the_image():
+    """`fam/quantiser/audio/speaker_encoder/audio.py:15-21` is one librosa call.  librosa is not in the image; `transformers.audio_utils`
+    (its numpy equivalent: `mel_filter_bank(norm="slaney", mel_scale="slaney")`, `spectrogram(center=True, pad_mode="constant",
+    power=2.0)`, periodic Hann 400 / hop 160) is, and minted `tests/golden/mel_frontend.npz` (`make_frontend_golden.py`, committed).
+    The product's restated front end reproduces the filter bank exactly and the mel power spectrogram to float32 rounding."""
+    import importlib.util
+
+    g = np.load(os.path.join(GOLDEN, "mel_frontend.npz"))
+    spec = importlib.util.spec_from_file_location("make_frontend_golden", os.path.join(GOLDEN, "make_frontend_golden.py"))
+    # the waveform recipe is pure integer / closed-form arithmetic: re-create it without importing transformers
+    src = open(spec.origin).read()
+    ns = {"np": np}
+    exec(compile(src[src.index("SR, N_FFT"):src.index("def main")], spec.origin, "exec"), ns)
+    wav = ns["test_waveform"](int(g["seed"]), float(g["seconds"]))
+    fb = audio.mel_filterbank(16000, 400, 40)
+    assert fb.shape == g["filter_bank"].shape == (40, 201)
+    assert float(np.abs(fb - g["filter_bank"]).max()) <= 1e-9
+    mel = audio.wav_to_mel_spectrogram(wav)
+    assert mel.shape == g["mel"].shape == (151, 40)
+    assert float(np.abs(mel - g["mel"]).max()) <= 2e-6 * float(np.abs(g["mel"]).max())
+    rel = np.abs(mel - g["mel"]) / (np.abs(g["mel"]) + 1e-6)
+    assert float(np.percentile(rel, 99)) < 1e-4
