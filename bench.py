@@ -307,6 +307,7 @@ def measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline):
         else:
             N.check(N.lib().mv_probe_kernel(engine._h, 3, 24 * 20, C.byref(ms), C.byref(nbytes)))
             kname = "gemv_kernel<SWIGLU> (RMSNorm + w1|w3 + SiLU gate; per-layer launches)"
+        engine.tune(mega_fold=1)                # mv_tune settings are process-wide: the legs that follow draw their tokens in the launch again
         ach = nbytes.value / (ms.value * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": kname,
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -450,6 +451,98 @@ def measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline):
     return None
 
 
+BOUNDARY_TEXT = ("The quick brown fox jumps over the lazy dog while seven silver swans glide across a quiet lake, and far away a single "
+                 "church bell counts the hours of an ordinary afternoon in late summer; nobody hurries, nothing changes, and yet the light "
+                 "keeps moving on the water.")[:256]
+
+
+def boundary_leg(rank: int, composed: dict, steps: int = 3):
+    """The headline THROUGH the drop-in boundary: `TTS(model_dir).synthesise(text_256_chars, spk)` on a full-size synthetic model
+    directory (`synthetic.write_model_dir`: 24 layers x 2048, the reference's checkpoint layout, written once under /tmp), timed
+    with the reference's timer scope -- text normalisation, tokenise, first stage, adapters, second stage, EnCodec + multi-band
+    diffusion, loudness normalisation, the `.wav` on disk (`fam/llm/fast_inference.py:129-166`, `decoders.py:40-47`).  `bench.py`'s
+    main line composes the engine / second stage / codec / diffusion calls itself; this leg says what the boundary adds on top.
+    The same two accommodations for random weights as the composed line, both outside the timed arithmetic: end-of-audio cannot end
+    the utterance (the stream runs to the context limit, as `generate()` does without an EOA), and the stream is folded onto
+    alternating codebooks before the adapter (random weights do not alternate; the adapter would truncate to the shorter one)."""
+    import shutil
+    import wave
+
+    mv = importlib.import_module("metavoice-src_amd")
+    fi = importlib.import_module("metavoice-src_amd.fast_inference")
+    model_dir = os.environ.get("MV_BENCH_MODEL_DIR", "/tmp/mv_bench_fullsize_model")
+    t_dir = time.perf_counter()
+    if not os.path.exists(os.path.join(model_dir, ".complete")):
+        shutil.rmtree(model_dir, ignore_errors=True)
+        args = mv.ModelArgs.from_name("metavoice-1B")
+        mv.synthetic.write_model_dir(model_dir, stage1=dict(n_layer=args.n_layer, n_head=args.n_head, dim=args.dim, vocab_size=args.vocab_size,
+                                                            block_size=args.block_size),
+                                     stage2_args=mv.synthetic.stage2_model_args(block_size=2048), seed=rank, mbd={})
+        open(os.path.join(model_dir, ".complete"), "w").close()
+    t_load = time.perf_counter()
+    out_dir = os.path.join(model_dir, "outputs")
+    with contextlib.redirect_stdout(io.StringIO()):
+        tts = fi.TTS(model_dir, seed=1337 + rank, output_dir=out_dir)
+    t_ready = time.perf_counter()
+    engine = tts.model.engine
+    real_begin = engine.begin
+
+    def begin_without_eoa(*args, **kw):
+        kw["end_of_audio_token"] = 9999
+        return real_begin(*args, **kw)
+
+    engine.begin = begin_without_eoa
+    real_decode = tts.first_stage_adapter.decode
+    n_prompt = len(tts.tokenizer.encode(fi.normalize_text(BOUNDARY_TEXT)))
+
+    def folded_decode(tokens):
+        toks = tokens[0]
+        return real_decode([toks[:n_prompt] + [(t % 1024) + 1024 * (i & 1) for i, t in enumerate(toks[n_prompt:])]])
+
+    tts.first_stage_adapter.decode = folded_decode
+    spk = mv.synthetic.speaker_embedding(rank)
+    walls, decode_ms, begin_ms, audio_s, paths = [], [], [], [], []
+    for it in range(steps + 1):   # one warm-up call
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            path = tts.synthesise(BOUNDARY_TEXT, spk)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        with wave.open(path, "rb") as w:
+            secs = w.getnframes() / float(w.getframerate())
+        os.unlink(path)
+        if it:
+            walls.append(wall * 1e3); decode_ms.append(engine.last_run_ms); audio_s.append(secs)
+    path_now, timeouts = engine.decode_path()
+    wall_ms, dec_ms, secs = sum(walls) / len(walls), sum(decode_ms) / len(decode_ms), sum(audio_s) / len(audio_s)
+    comp_rest = composed["ms_per_step"] - composed["step_roofline"]["gpu_ms_per_step"]
+    comp_per_tok = composed["step_roofline"]["gpu_ms_per_step"] / (composed["config"]["tokens_per_step"] - 1)
+    n_tok = int(round(secs * TOKENS_PER_AUDIO_SECOND))
+    leg = {"value": round(secs / (wall_ms * 1e-3), 4), "unit": "audio-s/s", "steps": steps, "warmup": 1, "ms_per_step": round(wall_ms, 2),
+           "audio_s_per_step": round(secs, 3), "prompt_tokens": n_prompt, "generated_tokens": n_tok,
+           "stage1_decode_gpu_ms": round(dec_ms, 2), "rest_ms": round(wall_ms - dec_ms, 2),
+           "composed_rest_ms": round(comp_rest, 2),
+           "host_overhead_ms": round((wall_ms - dec_ms) - comp_rest, 2),
+           "decode_us_per_token": round(dec_ms * 1e3 / max(n_tok - 1, 1), 2), "composed_decode_us_per_token": round(comp_per_tok * 1e3, 2),
+           "gap_vs_composed_pct": round(100.0 * (composed["value"] - secs / (wall_ms * 1e-3)) / composed["value"], 2),
+           "decode_fallbacks": timeouts, "decode_path": path_now,
+           "model_dir_write_s": round(t_load - t_dir, 1), "tts_load_s": round(t_ready - t_load, 1),
+           "workload": ("TTS(model_dir).synthesise(256 characters, speaker embedding) on a full-size synthetic model directory, the reference's timer scope "
+                        "(normalise + tokenise -> first stage -> adapters -> second stage -> EnCodec + multi-band diffusion -> loudness -> .wav on disk); "
+                        f"{n_prompt} prompt tokens (synthetic 512-rank BPE), generation to the context limit; rest_ms = wall - first-stage decode "
+                        "(HIP events); host_overhead_ms = rest_ms - the composed line's non-decode time (prefill, second stage, codec, diffusion)")}
+    tts.first_stage_adapter.decode = real_decode
+    engine.begin = real_begin
+    for closer in (getattr(tts.vocoder, "close", None), getattr(engine, "close", None)):
+        try:
+            if closer:
+                closer()
+        except Exception:
+            pass
+    return leg
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -556,6 +649,12 @@ def main():
                 except Exception as e:  # a leg that fails must not take the headline line with it: say so in its place
                     extras[name] = {"error": f"{type(e).__name__}: {e}"[:500]}
                 extras[name]["leg_wall_s"] = round(time.perf_counter() - t0, 1)   # incl. weight generation, quantisation and warm-up
+            t0 = time.perf_counter()
+            try:   # the headline through the drop-in boundary
+                extras["configs[1] through TTS.synthesise (the drop-in boundary)"] = boundary_leg(rank, out)
+            except Exception as e:
+                extras["configs[1] through TTS.synthesise (the drop-in boundary)"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+            extras["configs[1] through TTS.synthesise (the drop-in boundary)"]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
             out["extra_configs"] = extras
         print(json.dumps(out))
     if world > 1:

@@ -20,19 +20,65 @@
 #include "gemv_i4_core.h"
 #include "gemv_i8_core.h"
 
+// MEGA_INSTR = 1 (libmetavoice_hip_instr.so, `make instr`): phase stamps (MV_MEGA_STAMPS), per-layer debug vectors (MV_DEBUG_VECTORS) and
+// the no-weights ablation (mv_tune gemv_ablate) are compiled in.  The product library carries none of them: every one was a runtime
+// branch (and a live pointer) at 20-odd places of the layer loop.
+#ifndef MEGA_INSTR
+#define MEGA_INSTR 0
+#endif
+
+// The launch arguments.  MegaArgs travels by value in the kernarg segment (~400 bytes); hipcc loads every field the kernel names at
+// the top of the kernel and keeps it live: 80-odd SGPRs for the whole launch, i.e. (round 3) 175-241 SGPRs spilled into VGPR lanes and
+// 319 v_readlane + 225 s_nop per layer iteration to get them back.  Now:
+//  * HOT fields -- what the layer loop needs at its publishes and requests: the granule slab (one pointer: the six vectors sit at
+//    compile-time offsets from it), the layer table, K/V cache, partial slab, a few scalars -- are read by value (`a.field`): they live
+//    in SGPRs for the whole launch, there are 16 of them;
+//  * COLD fields -- everything the step prologue, the token draw, the time-out path and the test hooks need -- are read through
+//    `KC(i)`: the kernarg pointer plus `(i >> 30)` elements, i being the step or layer counter: the optimiser cannot prove the offset
+//    zero, so it can neither hoist those s_loads out of the loop nor keep their results live across it.
+// (Tried first: a VOLATILE view of the whole struct, every access an s_load at its use.  The publishes then waited for a scalar load
+// each -- 683-690 vs 678 us/step -- and in the one-step instances hipcc moved the kernarg pointer into a VGPR pair and fetched every
+// field with `global_load ... sc0 sc1`: 790 vs 691 us/step, profiles/r04a.  An empty asm with a "+s" operand on the pointer does not
+// compile inside divergent regions: "illegal VGPR to SGPR copy".)
+typedef const __attribute__((address_space(4))) MegaArgs* mega_kargs_t;
+#define KC(i) ((mega_kargs_t)__builtin_amdgcn_kernarg_segment_ptr() + ((uint32_t)(i) >> 30))
+
+#undef MG_STAMP
+#if MEGA_INSTR
+#define MG_STAMP(l, k) do { if (stamping && lane == 0) (a.stamps + (size_t)(b == 0 ? 0 : 1) * n_layer * MG_STAMP_SLOTS)[(l) * MG_STAMP_SLOTS + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MG_DBG_ON() (a.dbg != nullptr)
+#define MG_ABLATE (a.ablate)
+#else
+#define MG_ABLATE 0
+#define MG_STAMP(l, k) do { } while (0)
+#define MG_DBG_ON() false
+#endif
+bool mega_instrumented() { return MEGA_INSTR != 0; }
+
 // RMSNorm of the NU row pairs xs[u][2][2048], IN PLACE, bit-identical to gemv.hip's prologue (threads 0..255 own 8 columns
 // each, of both rows of every utterance; every thread holds its columns in registers across the two barriers).
 // The norm weights `nw` (columns 8 tid .. 8 tid + 7) are requested by the caller a phase ahead: loaded here, their load would
 // return in order behind the K/V and weight requests already in flight and the norm would wait ~2 us for data it does not need.
+#ifndef MEGA_NORM_STATS8
+#define MEGA_NORM_STATS8 0   // 1: one utterance, statistics on all 8 waves (one row each).  A/B on one box: 678.5 / 677.6 vs 672.7 / 676.9 us/step with 0 (profiles/r04d)
+#endif
+#ifndef MEGA_NORM_DIRECT_TOTAL
+#define MEGA_NORM_DIRECT_TOTAL 1
+#endif
 template <int NU>
-__device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x4& nw, float* red, float eps) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x4& nw, float* red, float eps, const int tid) {
+    const int lane = tid & 63, wave = tid >> 6;   // tid: the caller's (possibly opaque) thread id -- see the layer loop
     // statistics: lane l of "column wave" q sums the squares of columns 8 (64 q + l) .. + 7, the 64 lanes are added with wave_sum -- the
     // summation order of gemv.hip's prologue.  One utterance: waves 0..3 ARE the column waves, each does both rows.  Several utterances:
     // (utterance, row) pair p is done by wave p, which plays the four column waves one after the other with the four chains unrolled
     // -- all 8 waves busy and no serial walk over the utterances (rolled, each row waited for its own ds_read and wave_sum:
     // 2.5 us per norm at four utterances against 0.7 at one, profiles/r03u).
-    if constexpr (NU == 1) {
+    if constexpr (NU == 1 && MEGA_NORM_STATS8) {
+        // all 8 waves: wave w plays column wave w & 3 for row w >> 2 (round 3: waves 0..3 did both rows one after the other)
+        const int r = wave >> 2, q = wave & 3;
+        const float s = wave_sum(sumsq8(*(const u32x4*)(xs[0] + r * MG_DIM + (q * 64 + lane) * 8)));
+        if (lane == 0) red[q * 2 + r] = s;
+    } else if constexpr (NU == 1) {
         if (tid < MG_DIM / 8) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -65,7 +111,11 @@ __device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x
     for (int u = 0; u < NU; ++u) xv[u] = *(const u32x4*)(xs[u] + r * MG_DIM + c);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        const float tot = wave_sum(lane < MG_DIM / 8 / 64 ? red[u * 2 * MG_WAVES + lane * 2 + r] : 0.f);  // == block_total over the 4 waves that hold columns
+        // == block_total over the 4 column waves: wave_sum over lanes {v0, v1, v2, v3, 0, ...} is (v0 + v1) + (v2 + v3) plus exact zeros
+        // (common.h: xor-1, xor-2, then mirrors and row broadcasts that only add zeros) -- the same bits without the 7-deep DPP chain
+        const float* rd = red + u * 2 * MG_WAVES + r;
+        const float tot = MEGA_NORM_DIRECT_TOTAL ? (rd[0] + rd[2]) + (rd[4] + rd[6])
+                                                 : wave_sum(lane < MG_DIM / 8 / 64 ? red[u * 2 * MG_WAVES + lane * 2 + r] : 0.f);
         rstd[u] = rms_rstd(tot, MG_DIM, eps);
     }
 #pragma unroll
@@ -133,6 +183,45 @@ __device__ __forceinline__ void mega_issue_row(u32x4* wv, const bf16_t* w, int n
 #ifndef MEGA_KV_AFTER_NORM
 #define MEGA_KV_AFTER_NORM 0
 #endif
+// MEGA_W3_EARLY (bf16, one utterance, with MEGA_EARLY_W1): the w3 rows are requested together with the register half of w1 -- after the
+// workgroup's attention partial / output has been published -- instead of after the h publish.  From there to "h published" a layer
+// spends ~5 us (split-partial exchange, combine, attention-vector exchange, wo dots) in which only w1's 12 MB per chip were in
+// flight, and the w3 requests then stalled for 2.25 us in front of the h poll (profiles/r04a/stamps_1utt.txt).  Registers: with the
+// first two chunks of every w1 row in LDS, wv[0], [1], [4], [5], [8], [9] are unused; the wo row moves there (wv[0], [1], [4], [5]) and
+// wv[12..23] are free for w3 a whole phase earlier.
+#ifndef MEGA_W3_EARLY
+#define MEGA_W3_EARLY 0
+#endif
+// MEGA_KV_EARLY: the first attention slice's K/V rows of layer l + 1 (rows of EARLIER steps: independent of this step) are requested
+// right behind the h publish of layer l -- the kv / vv registers are free from the end of layer l's attention on -- instead of at the top
+// of layer l + 1, where they queued behind the 25 MB of wqkv rows and stalled the wave for 2.4 us in front of the norm.  With
+// MEGA_W3_EARLY the hand-off of h has nothing else in flight.  Layer 0's slice is requested where it always was.
+#ifndef MEGA_KV_EARLY
+#define MEGA_KV_EARLY 0
+#endif
+// Two more placements, both about keeping the memory system quiet while a hand-off is in the air (one utterance, experiments):
+//   MEGA_W1_AFTER_ATTN: the register half of w1 (+ the ffn norm weights) is requested when the attention vector HAS ARRIVED (in front of the
+//                       wo dots) instead of behind the workgroup's attention partial -- nothing streams during the split-partial and the
+//                       attention-vector hops;
+//   MEGA_WO_AFTER_QKV:  the wo row is requested when q / k / v have arrived instead of in front of their poll.
+#ifndef MEGA_W1_AFTER_ATTN
+#define MEGA_W1_AFTER_ATTN 0
+#endif
+#ifndef MEGA_WO_AFTER_QKV
+#define MEGA_WO_AFTER_QKV 0
+#endif
+// MEGA_ATTN_V2 (engines of 2 / 4 utterances).  Round 3 gave every workgroup one key range of (row, head) of EVERY utterance and walked
+// the utterances one after the other: K/V slice requested, landed, scored, merged, published, the next slice requested -- 16.6 us of a
+// 60 us layer at four utterances, with the memory system idle for most of it (profiles/r04a/stamps_4utt.txt).  Now a workgroup belongs
+// to ONE (utterance, row, head) and owns NU consecutive key ranges of it (8 / NU workgroups per (utterance, row, head)): the ranges are
+// the same 8 splits of cs keys with the same 8 x kw wave slices, scored, merged and combined by the same functions in the same order --
+// the bits do not change -- but the NU slices of a workgroup are one contiguous stretch of the cache, streamed through TWO register
+// sets (kv / vv, and the weight registers wv[0..7] / wv[16..23], idle between the wqkv dots and the w1 request): the next range's rows
+// are in flight while the current one is scored, the wave partials of all ranges wait in LDS for ONE merge (wave j merges range j) and
+// ONE publish, and each (utterance, row, head) is combined once, by the workgroup of its first ranges.
+#ifndef MEGA_ATTN_V2
+#define MEGA_ATTN_V2 1
+#endif
 #define MEGA_EARLY_W2_BYTES (MG_WAVES * 5 * 1024)
 #define MEGA_EARLY_W1_BYTES (MG_WAVES * 6 * 1024)
 __device__ __forceinline__ void mega_row_to_lds(uint32_t lds, const bf16_t* g, int ablate = 0) {  // 64 lanes x 16 B -> 1 KB of LDS at `lds`
@@ -186,8 +275,8 @@ __device__ __forceinline__ float i8_out(float wave_total, float scale) { return 
 
 // 16-byte polls of a row-paired 2048-column vector of every utterance ([NU][2048] granules): pair n = granules 2n, 2n+1 =
 // columns 2n, 2n+1 of both rows.  ONE poll loop for all utterances: a loop per utterance would pay a round trip each.
-template <int NU>
-__device__ __forceinline__ void mega_poll_rowpairs(const gran_t* g, uint32_t tag, bf16_t (*xs)[2 * MG_INTER], uint32_t* abort_flag, int* s_abort,
+template <int NU, typename AF>
+__device__ __forceinline__ void mega_poll_rowpairs(const gran_t* g, uint32_t tag, bf16_t (*xs)[2 * MG_INTER], AF abort_flag, int* s_abort,
                                                    int tid) {
     wave_poll16<2 * NU>(g, tag, abort_flag, s_abort, [&](int k) { return (k >> 1) * (MG_DIM / 2) + tid + (k & 1) * MG_THREADS; },
                         [&](int n, uint32_t p0, uint32_t p1) {
@@ -197,8 +286,8 @@ __device__ __forceinline__ void mega_poll_rowpairs(const gran_t* g, uint32_t tag
                         });
 }
 
-__host__ __device__ constexpr size_t mega_lds_bytes(int n_utt) {  // dynamic LDS of the kernel below: xs, qkv_s, sm, red
-    return (size_t)n_utt * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2) + ATTN_WAVES * 16 * 12 * 4 + (size_t)n_utt * MG_WAVES * 2 * 4;
+__host__ __device__ constexpr size_t mega_lds_bytes(int n_utt) {  // dynamic LDS of the kernel below: xs, qkv_s, sm (one per key range of the workgroup), red
+    return (size_t)n_utt * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2) + (size_t)(MEGA_ATTN_V2 ? n_utt : 1) * ATTN_WAVES * 16 * 12 * 4 + (size_t)n_utt * MG_WAVES * 2 * 4;
 }
 
 // sample() + the bookkeeping of decode_n_tokens + (last step of a launch) the next launch's input rows, by the workgroup of
@@ -208,7 +297,7 @@ __host__ __device__ constexpr size_t mega_lds_bytes(int n_utt) {  // dynamic LDS
 // SLOWER by 100-220 us/step (bf16 866 vs 722, int8 792 vs 680, 2 / 4 utterances 1211 / 1863 vs 1092 / 1643; profiles/r03a) -- the
 // call site saves and restores the kernel's live registers through scratch (368 B/lane) and the allocation around it degraded.
 template <int NU>
-__device__ __forceinline__ void mega_draw_and_publish(const MegaArgs& a, const int u, const bf16_t* lg, UttState* st_p, SampleScratch* sc_p,
+__device__ __forceinline__ void mega_draw_and_publish(const mega_kargs_t a, gran_t* const g_ctl, const int u, const bf16_t* lg, UttState* st_p, SampleScratch* sc_p,
                                                                 const int VP, const uint32_t tag_next, const bool last_step, const int tid_t) {
     UttState& st_s = *st_p;
     SampleScratch& smp_sc = *sc_p;
@@ -217,13 +306,13 @@ __device__ __forceinline__ void mega_draw_and_publish(const MegaArgs& a, const i
         if (!was_done) {
             const int pos = st_s.pos, next_index = pos + 1;     // sequence index of the token decided now
             const bool forced = next_index < st_s.prompt_len;   // teacher-forced prompt token (prefill by decode steps)
-            const int V = a.vocab;
-            if (a.capture != nullptr && pos < a.capture_max) {
-                float* cap = a.capture + ((size_t)pos * (2 * NU) + 2 * u) * V;
+            const int V = a->vocab;
+            if (a->capture != nullptr && pos < a->capture_max) {
+                float* cap = a->capture + ((size_t)pos * (2 * NU) + 2 * u) * V;
                 for (int i = tid_t; i < V; i += MG_THREADS) { cap[i] = bf2f(lg[i]); cap[V + i] = bf2f(lg[VP + i]); }
             }
             int tok;
-            if (forced) tok = a.seq[(size_t)u * a.block_size + next_index];
+            if (forced) tok = a->seq[(size_t)u * a->block_size + next_index];
             else {
                 int par = 0;
                 const mv_sampling sp = st_s.s;
@@ -231,30 +320,30 @@ __device__ __forceinline__ void mega_draw_and_publish(const MegaArgs& a, const i
             }
             done_now = (!forced && tok == st_s.eoa_token) || (next_index + 1 >= st_s.max_len);
             // the control word first: it is what the other 255 workgroups are waiting for
-            if (tid_t == 0 && !last_step) gran_store(a.g_ctl + u, (uint32_t)tok | ((uint32_t)next_index << 12) | ((uint32_t)done_now << 31), tag_next);
+            if (tid_t == 0 && !last_step) gran_store(g_ctl + u, (uint32_t)tok | ((uint32_t)next_index << 12) | ((uint32_t)done_now << 31), tag_next);
             __syncthreads();  // every thread has read st_s
             if (tid_t == 0) {
-                if (!forced) a.seq[(size_t)u * a.block_size + next_index] = tok;
-                UttState* gs = a.utt + u;
+                if (!forced) a->seq[(size_t)u * a->block_size + next_index] = tok;
+                UttState* gs = a->utt + u;
                 gs->n_tokens = next_index + 1;
                 gs->pos = next_index;
-                a.pos_out[u] = next_index;
+                a->pos_out[u] = next_index;
                 st_s.pos = next_index;
                 st_s.n_tokens = next_index + 1;
                 if (done_now) {
                     gs->done = 1;
                     st_s.done = 1;
-                    atomicSub(a.n_active, 1);
+                    atomicSub(a->n_active, 1);
                 }
             }
             if (!done_now && last_step) {
                 // the next LAUNCH's (or the per-layer launches') input rows, as sample_kernel leaves them:
                 // bf16(bf16(tok_emb[tok] + pos_emb[pos]) + spk_proj * mask).  Between the steps of one launch every workgroup
                 // builds them itself from the control word (below).
-                const bf16_t* te = a.tok_emb + (size_t)tok * MG_DIM;
-                const bf16_t* pe = a.pos_emb + (size_t)next_index * MG_DIM;
-                const bf16_t* sp = a.spk_proj + (size_t)u * MG_DIM;
-                bf16_t* x0 = a.x_out + (size_t)(2 * u) * MG_DIM;
+                const bf16_t* te = a->tok_emb + (size_t)tok * MG_DIM;
+                const bf16_t* pe = a->pos_emb + (size_t)next_index * MG_DIM;
+                const bf16_t* sp = a->spk_proj + (size_t)u * MG_DIM;
+                bf16_t* x0 = a->x_out + (size_t)(2 * u) * MG_DIM;
                 for (int i = tid_t; i < MG_DIM; i += MG_THREADS) {
                     const float base = round_bf(bf2f(te[i]) + bf2f(pe[i]));
                     x0[i] = f2bf(base + bf2f(sp[i]));
@@ -263,22 +352,23 @@ __device__ __forceinline__ void mega_draw_and_publish(const MegaArgs& a, const i
             }
         } else if (tid_t == 0 && !last_step) {
             // a finished (or unused) utterance keeps its last input rows, as with sample_kernel: same token, same position
-            gran_store(a.g_ctl + u, (uint32_t)a.seq[(size_t)u * a.block_size + st_s.pos] | ((uint32_t)st_s.pos << 12) | (1u << 31), tag_next);
+            gran_store(g_ctl + u, (uint32_t)a->seq[(size_t)u * a->block_size + st_s.pos] | ((uint32_t)st_s.pos << 12) | (1u << 31), tag_next);
         }
 }
 
 template <int WF, int NU, bool FOLD>  // WF: MV_W_BF16, MV_W_INT4_G128 (LM head bf16) or MV_W_INT8 (LM head int8 too); NU utterances;
                                       // FOLD: a.n_steps decode steps per launch, the token drawn inside (else one step, logits only)
-__global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_kernel(const MegaArgs a) {
+__global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_kernel(const MegaArgs a) {   // hot fields by name, cold ones through KC()
     extern __shared__ __attribute__((aligned(16))) unsigned char mg_lds[];
     // the GEMV operand of the current phase, per utterance; the residual stream is NOT kept here: a wave produces exactly the
     // columns (8 b + wave) whose residual it needs two phases later, so those ride in registers (xres / hres)
     bf16_t (*xs)[2 * MG_INTER] = (bf16_t(*)[2 * MG_INTER])mg_lds;
     bf16_t (*qkv_s)[3 * 2 * 128] = (bf16_t(*)[3 * 2 * 128])(mg_lds + (size_t)NU * 2 * MG_INTER * 2);  // q, k_new, v_new of this block's head
-    float (*sm)[16][12] = (float(*)[16][12])(mg_lds + (size_t)NU * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2));
-    float* red = (float*)(sm + ATTN_WAVES);  // [NU][MG_WAVES * 2]
+    float (*sm)[16][12] = (float(*)[16][12])(mg_lds + (size_t)NU * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2));  // [ranges of this workgroup][ATTN_WAVES][16][12]
+    float* red = (float*)(sm + (MEGA_ATTN_V2 ? NU : 1) * ATTN_WAVES);  // [NU][MG_WAVES * 2]
     constexpr bool EARLY_ANY = mega_early_rows(WF, NU);
     constexpr bool EARLY_W2 = EARLY_ANY && MEGA_EARLY_W2, EARLY_W1 = EARLY_ANY && MEGA_EARLY_W1, EARLY_QKV = EARLY_ANY && MEGA_EARLY_QKV;
+    constexpr bool W3_EARLY = EARLY_W1 && MEGA_W3_EARLY;
     u32x4* w2_lds = (u32x4*)(mg_lds + mega_lds_bytes(1));                        // [MG_WAVES][5 chunks][64 lanes]
     u32x4* w1_lds = (u32x4*)(mg_lds + mega_lds_bytes(1) + MEGA_EARLY_W2_BYTES);  // [MG_WAVES][3 rows x 2 chunks][64 lanes]; wqkv rows of the next layer between P4 and P0
     bool w1_half_issued = false;
@@ -298,10 +388,10 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     constexpr bool fold = FOLD;  // compile time: the one-step instance carries no sampler code (and shows up under its own name in rocprofv3)
-    const int n_steps = fold ? a.n_steps : 1;
+    const int n_steps = fold ? KC(b)->n_steps : 1;
     if (tid == 0) s_abort = 0;
-    if (tid < NU) { pos_s[tid] = a.pos[tid]; done_s[tid] = fold ? a.utt[tid].done : 0; }
-    if (fold && b < NU && tid == 0) st_s = a.utt[b];
+    if (tid < NU) { pos_s[tid] = KC(b)->pos[tid]; done_s[tid] = fold ? KC(b)->utt[tid].done : 0; }
+    if (fold && b < NU && tid == 0) st_s = KC(b)->utt[b];
     __syncthreads();
     // NOTE: this read compiles to flat_load_dword (the address escapes into the poll helpers as a generic pointer), whose wait is
     // `vmcnt(0) lgkmcnt(0)`.  Reading it through an LDS-typed pointer (ds_read_b32, lgkmcnt only) measured SLOWER for bf16: 720.5 vs
@@ -325,17 +415,23 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         for (int u = 0; u < NU; ++u) all_done = all_done && done_s[u] != 0;
         if (all_done) return;
     }
-    const uint32_t counter0 = a.step_counter[0];
+    const uint32_t counter0 = KC(b)->step_counter[0];
     const int VP = (a.vocab + 1) & ~1;  // logits travel as row-paired granules, polled two at a time
 
     // attention geometry: block (r, h, s) = one of the (up to) 8 even key ranges of (row r, head h) of EVERY utterance; 8 waves x 32 keys
-    const int at_r = b >> 7, at_h = (b >> 3) & 15, at_s = b & 7, at_w = wave;
+    // ATTN_V2: block = (utterance, row, head, part): SPB = NU consecutive key ranges starting at at_s, 8 / NU blocks per (utterance, row, head)
+    constexpr bool ATTN_V2 = NU > 1 && MEGA_ATTN_V2;
+    constexpr int BPH = ATTN_V2 ? 8 / NU : 8, SPB = ATTN_V2 ? NU : 1;
+    constexpr bool ATTN_DB = ATTN_V2 && WF == MV_W_BF16;   // two register sets: the quantised instances have no idle weight registers to lend (one set, ranges back to back)
+    const int at_u = ATTN_V2 ? b / (32 * BPH) : 0;
+    const int at_r = (b / (16 * BPH)) & 1, at_h = (b / BPH) & 15, at_s = (b % BPH) * SPB, at_w = wave;
     const int g = lane >> 4, dl = lane & 15;
 #define GEO(k, u) __builtin_amdgcn_readfirstlane(geo[k][u])
 
     // optional phase stamps (blocks 0 and 255, wave 0): poll-wait vs compute per phase, for profiles/
+#if MEGA_INSTR
     const bool stamping = a.stamps != nullptr && (b == 0 || b == 255) && wave == 0;
-    unsigned long long* stamp_base = a.stamps ? a.stamps + (size_t)(b == 0 ? 0 : 1) * a.n_layer * MG_STAMP_SLOTS : nullptr;
+#endif
 
     u32x4 wv[24];  // the weight working set of the current GEMV phase (next phase's rows are issued into it after the dots)
     // int4: codes / (scale, zero) words.  Slots: wqkv rows 0..2 | w1 rows 0..2, w3 rows 3..5, wo 6 | w2 (3 chunks) 6..8
@@ -354,7 +450,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         for (int i = 0; i < 3; ++i) {
             if (I4) mega_issue_row_i4<1>(cq + i, cz + i, MG_LAYER(0).q[0], MG_LAYER(0).sz[0], 24 * b + 3 * wave + i, MG_DIM, lane);
             else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, MG_LAYER(0).q8[0], 24 * b + 3 * wave + i, MG_DIM, lane); sc_a[i] = bf2f(load_global_u16(MG_LAYER(0).s8[0] + (24 * b + 3 * wave + i))); }
-            else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave + i, MG_DIM, lane, a.ablate);
+            else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave + i, MG_DIM, lane, MG_ABLATE);
         }
         if (!MEGA_KV_AFTER_NORM) nw_attn = load16(MG_LAYER(0).attn_norm + ((wave * 64 + lane) & 255) * 8);
     };
@@ -372,7 +468,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         const int Pu = pos_s[u] + 1;  // keys [0, P): the cache holds [0, P-1), key P-1 is produced by this step's QKV phase
         const int csu = attn_keys_per_split(Pu), nactu = (Pu + csu - 1) / csu;
         if (tid == 0) { geo[0][u] = Pu; geo[1][u] = csu; geo[2][u] = nactu; geo[3][u] = attn_keys_per_wave(csu); }
-        if (at_s < nactu) { any_att = true; first_att = u; }
+        if (at_s < nactu && (!ATTN_V2 || u == at_u)) { any_att = true; first_att = u; }
     }
     // residual values of this wave's own column n = 8 b + wave, both rows packed (row 0 | row 1 << 16): x entering the layer
     // (layer 0: the sampler's / prefill's output -- in xs already after the first step; later: what this wave published in P4) and
@@ -380,46 +476,65 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
 #pragma unroll 1
     for (int u = 0; u < NU; ++u) {
         if (step == 0) {
-            const bf16_t* xi = a.x_in + (size_t)u * 2 * MG_DIM + 8 * b + wave;
+            const bf16_t* xi = KC(step)->x_in + (size_t)u * 2 * MG_DIM + 8 * b + wave;
             if (lane == 0) res_s[0][u][wave] = (uint32_t)xi[0] | ((uint32_t)xi[MG_DIM] << 16);
         } else if (lane == 0) {
             res_s[0][u][wave] = (uint32_t)xs[u][8 * b + wave] | ((uint32_t)xs[u][MG_DIM + 8 * b + wave] << 16);
         }
     }
     __syncthreads();
-    for (int l = 0; l < a.n_layer; ++l) {
+    const int n_layer = a.n_layer;
+    // the six exchanged vectors of every utterance sit in ONE slab at compile-time offsets (engine.hip: mega_args): one live pointer
+    gran_t* const g_x = a.g_x;
+    gran_t* const g_qkv = g_x + (size_t)NU * MG_DIM;
+    gran_t* const g_attn = g_qkv + (size_t)NU * 3 * MG_DIM;
+    gran_t* const g_h = g_attn + (size_t)NU * MG_DIM;
+    gran_t* const g_act = g_h + (size_t)NU * MG_DIM;
+    gran_t* const g_logits = g_act + (size_t)NU * MG_INTER;   // [NU][VP], then g_ctl [NU]
+    for (int l = 0; l < n_layer; ++l) {
         // Address arithmetic below is a function of (lane, wave): left alone, the compiler hoists ~60 loop-invariant 64-bit
         // addresses out of the layer loop and spills them.  Making the two ids opaque once per layer keeps every address
         // computation next to its load (a handful of VALU ops) and the kernel spill-free.
         int lane_o = lane, wave_o = wave;
         asm volatile("" : "+v"(lane_o), "+v"(wave_o));
         const int tid_o = wave_o * 64 + lane_o;
+        auto abort_flag_of = [&]() { return KC(l)->abort_flag; };   // read only when a wait runs out
+        // engines of several utterances run at the 256-VGPR limit: there every LDS / granule address the optimiser hoists out of the layer
+        // loop (functions of lane / wave) is a spilled register, reloaded behind `s_waitcnt vmcnt(0)` -- i.e. behind every weight row in
+        // flight.  Their dots, norms and epilogues therefore use the opaque ids too; the one-utterance instances keep the plain ones.
+        const int lane_p = NU > 1 ? lane_o : lane, wave_p = NU > 1 ? wave_o : wave, tid_p = NU > 1 ? tid_o : tid;
         const __attribute__((address_space(4))) MegaLayer& L = MG_LAYER(l);   // fields are fetched with scalar loads where they are used
         const uint32_t tag0 = epoch + (uint32_t)l * 8u + 1u;  // + phase index
-        bf16_t* kc = a.kcache + (size_t)l * a.kv_layer_elems;
-        bf16_t* vc = a.vcache + (size_t)l * a.kv_layer_elems;
         // This block's K/V slice of utterance u (rows of EARLIER steps: independent of this step), into the kv / vv registers.
         // Addresses are clamped to the newest row an EARLIER launch wrote (P-2): row P-1 is being written by this launch and
         // is taken from the hand-off -- it must not even be touched here (a line fetched before its producer's store could be
         // served stale to the next launch).
-        auto issue_kv = [&](int u) {  // u: runtime, block-uniform
+        // SET 0: kv / vv.  SET 1 (ATTN_V2): wv[0..7] / wv[16..23], idle between the wqkv dots and the w1 request.  `split`: the key range.
+        auto issue_kv_set = [&](auto set_tag, int u, int kv_layer, int split) {  // u, split: runtime, block-uniform
+            constexpr int SET = decltype(set_tag)::value;
+            u32x4* const kd = SET == 0 ? kv : wv;
+            u32x4* const vd = SET == 0 ? vv : wv + 16;
 #pragma unroll
-            for (int q = 0; q < ATTN_U; ++q) kv[q] = u32x4{0u, 0u, 0u, 0u};
+            for (int q = 0; q < ATTN_U; ++q) kd[q] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int q = 0; q < ATTN_U; ++q) vv[q] = u32x4{0u, 0u, 0u, 0u};
+            for (int q = 0; q < ATTN_U; ++q) vd[q] = u32x4{0u, 0u, 0u, 0u};
             const int Pu = GEO(0, u), csu = GEO(1, u), nactu = GEO(2, u), kwu = GEO(3, u);
-            const int go = lane_o >> 4, dlo = lane_o & 15, s0o = at_s * csu + wave_o * kwu;
+            const int go = lane_o >> 4, dlo = lane_o & 15, s0o = split * csu + wave_o * kwu;
+            const size_t layer_off = (size_t)kv_layer * a.kv_layer_elems;
+            const bf16_t* kc = a.kcache + layer_off;
+            const bf16_t* vc = a.vcache + layer_off;
             const size_t head_base = ((size_t)(2 * u + at_r) * MG_HEADS + at_h) * (size_t)a.cache_len * 128 + dlo * 8;
             const int last_old = max(Pu - 2, 0);
-            if (Pu > 1 && at_s < nactu) {
+            if (Pu > 1 && split < nactu) {
 #pragma unroll
                 for (int q = 0; q < ATTN_U; ++q)
-                    if (q * 4 < kwu) kv[q] = load_stream16(kc + head_base + (size_t)min(s0o + q * 4 + go, last_old) * 128);
+                    if (q * 4 < kwu) kd[q] = load_stream16(kc + head_base + (size_t)min(s0o + q * 4 + go, last_old) * 128);
 #pragma unroll
                 for (int q = 0; q < ATTN_U; ++q)
-                    if (q * 4 < kwu) vv[q] = load_stream16(vc + head_base + (size_t)min(s0o + q * 4 + go, last_old) * 128);
+                    if (q * 4 < kwu) vd[q] = load_stream16(vc + head_base + (size_t)min(s0o + q * 4 + go, last_old) * 128);
             }
         };
+        auto issue_kv = [&](int u, int kv_layer) { issue_kv_set(std::integral_constant<int, 0>{}, u, kv_layer, at_s); };
 
         // ================= P0: RMSNorm + wqkv (+ KV-cache write)        fast_model.py:179,209,218 ====================
         __syncthreads();
@@ -428,29 +543,32 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             if (step == 0) {
 #pragma unroll
                 for (int u = 0; u < NU; ++u)
-                    *(u32x4*)(xs[u] + tid * 8) = load16(a.x_in + (size_t)u * 2 * MG_DIM + tid * 8);  // written by the sampler in the previous launch
+                    *(u32x4*)(xs[u] + tid * 8) = load16(KC(step)->x_in + (size_t)u * 2 * MG_DIM + tid * 8);  // written by the sampler in the previous launch
             }  // later steps: built at the end of the previous step from the control word
-        } else mega_poll_rowpairs<NU>(a.g_x, tag0 - 8u + 4u, xs, a.abort_flag, &s_abort, tid_o);
+        } else mega_poll_rowpairs<NU>(g_x, tag0 - 8u + 4u, xs, abort_flag_of, &s_abort, tid_o);
         __syncthreads();
         MG_ABORT_RETURN();
         MG_STAMP(l, 1);
         // The K/V stream of the first attention slice is requested here, before the norm and the wqkv dots: it lands while they
         // run.  (Requested after the q/k/v publish instead it sits in front of the q/k/v poll: 831 vs 794 us/step.)
+        const bool kv_here = !MEGA_KV_EARLY || l == 0;   // else: requested behind the previous layer's h publish
+        if (kv_here) {
 #pragma unroll
-        for (int q = 0; q < ATTN_U; ++q) kv[q] = u32x4{0u, 0u, 0u, 0u};
+            for (int q = 0; q < ATTN_U; ++q) kv[q] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int q = 0; q < ATTN_U; ++q) vv[q] = u32x4{0u, 0u, 0u, 0u};
-        if (!MEGA_KV_AFTER_NORM && first_att >= 0) issue_kv(first_att);
+            for (int q = 0; q < ATTN_U; ++q) vv[q] = u32x4{0u, 0u, 0u, 0u};
+        }
+        if (!MEGA_KV_AFTER_NORM && first_att >= 0 && kv_here) issue_kv(first_att, l);
         __builtin_amdgcn_sched_barrier(0);
         MG_STAMP(l, 11);  // K/V requested
-        mega_norm<NU>(xs, nw_attn, red, a.eps);
+        mega_norm<NU>(xs, nw_attn, red, a.eps, tid_p);
         MG_STAMP(l, 12);  // norm done
-        if (MEGA_KV_AFTER_NORM && first_att >= 0) { issue_kv(first_att); __builtin_amdgcn_sched_barrier(0); }
+        if (MEGA_KV_AFTER_NORM && first_att >= 0 && kv_here) { issue_kv(first_att, l); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll 1
         for (int u = 0; u < NU; ++u) {
             float acc[3][2];
-            if (I4) mega_dots_i4<1, 3, MG_DIM>(cq, cz, xs[u], MG_DIM, lane, acc);
-            else if (I8) mega_dots_i8<2, 3, MG_DIM>(cq, xs[u], MG_DIM, lane, acc);
+            if (I4) mega_dots_i4<1, 3, MG_DIM>(cq, cz, xs[u], MG_DIM, lane_p, acc);
+            else if (I8) mega_dots_i8<2, 3, MG_DIM>(cq, xs[u], MG_DIM, lane_p, acc);
             else if (EARLY_QKV && l > 0) {  // layer 0's rows come whole, in registers (issue_layer0); same order as mega_dots
 #pragma unroll
                 for (int i = 0; i < 3; ++i) acc[i][0] = acc[i][1] = 0.f;
@@ -466,7 +584,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                         }
                     }
             }
-            else mega_dots<4, 3, MG_DIM>(wv, xs[u], lane, acc);
+            else mega_dots<4, 3, MG_DIM>(wv, xs[u], lane_p, acc);
             __builtin_amdgcn_sched_barrier(0);
             if (u == 0) MG_STAMP(l, 13);  // wqkv dots done
             float v0 = 0.f, v1 = 0.f;
@@ -474,26 +592,31 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             for (int i = 0; i < 3; ++i) {
                 float t0 = wave_sum(acc[i][0]), t1 = wave_sum(acc[i][1]);
                 if (I8) { t0 = i8_out(t0, sc_a[i]); t1 = i8_out(t1, sc_a[i]); }
-                if (lane == i) { v0 = t0; v1 = t1; }
+                if (lane_p == i) { v0 = t0; v1 = t1; }
             }
-            if (lane < 3) {
-                const int n = 24 * b + 3 * wave + lane;
+            if (lane_p < 3) {
+                const int n = 24 * b + 3 * wave_p + lane_p;
                 const bf16_t y0 = f2bf(v0), y1 = f2bf(v1);
-                gran_store(a.g_qkv + (size_t)u * 3 * MG_DIM + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 0u);
-                if (a.dbg && u == 0 && n < MG_DIM) { bf16_t* d = a.dbg + ((size_t)l * 5 + 0) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
+                gran_store(g_qkv + (size_t)u * 3 * MG_DIM + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 0u);
+                if (MG_DBG_ON() && u == 0 && n < MG_DIM) { bf16_t* d = a.dbg + ((size_t)l * 5 + 0) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
                 if (n >= MG_DIM) {  // K / V rows also go to the cache for the FUTURE steps (this step reads them from the granules)
                     const int which = (n - MG_DIM) / MG_DIM, hd = (n - MG_DIM) % MG_DIM;
-                    bf16_t* cache = (which ? vc : kc) + (size_t)2 * u * MG_HEADS * a.cache_len * 128;
-                    const size_t off = ((size_t)(hd / 128) * a.cache_len + (GEO(0, u) - 1)) * 128 + hd % 128;
+                    const size_t cache_len = (size_t)a.cache_len;
+                    bf16_t* cache = (which ? a.vcache : a.kcache) + (size_t)l * a.kv_layer_elems + (size_t)2 * u * MG_HEADS * cache_len * 128;
+                    const size_t off = ((size_t)(hd / 128) * cache_len + (GEO(0, u) - 1)) * 128 + hd % 128;
                     // agent-scope (write-through) stores: with several steps per launch the row is read by other CUs -- other XCDs,
                     // other L2s -- in the next step, with no kernel boundary in between
                     __hip_atomic_store(cache + off, y0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(cache + (size_t)MG_HEADS * a.cache_len * 128 + off, y1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cache + (size_t)MG_HEADS * cache_len * 128 + off, y1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         MG_STAMP(l, 2);
+        if constexpr (ATTN_DB) {
+            if (any_att && at_s + 1 < GEO(2, at_u)) issue_kv_set(std::integral_constant<int, 1>{}, at_u, l, at_s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 
         // next: wo row 8 b + wave.  Publish-before-prefetch (profiles/r01g_handoff/NOTES.md): a wave that still has something to
         // publish does so BEFORE it queues its next weight loads -- the memory pipeline accepts loads only as fast as it
@@ -504,7 +627,20 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         auto request_wo = [&]() {
             if (I4) mega_issue_row_i4<1>(cq + 6, cz + 6, L.q[1], L.sz[1], 8 * b + wave_o, MG_DIM, lane_o);
             else if (I8) { mega_issue_row_i8<2>(cq + 12, L.q8[1], 8 * b + wave_o, MG_DIM, lane_o); sc_c = bf2f(load_global_u16(L.s8[1] + (8 * b + wave_o))); }
-            else mega_issue_row<4>(wv + 12, L.wo, 8 * b + wave_o, MG_DIM, lane_o, a.ablate);
+            else if (W3_EARLY) {  // chunks 0..3 -> wv[0], [1], [4], [5]: the slots the LDS half of w1 leaves unused
+                const bf16_t* row = L.wo + (size_t)(8 * b + wave_o) * MG_DIM + lane_o * 8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wv[(j >> 1) * 4 + (j & 1)] = load_stream16(row + j * 512);
+            }
+            else mega_issue_row<4>(wv + 12, L.wo, 8 * b + wave_o, MG_DIM, lane_o, MG_ABLATE);
+        };
+        auto request_w3 = [&]() {  // 22 rows per block: waves 0..5 take 3, waves 6, 7 take 2 (third slot clamped, masked)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (I4) mega_issue_row_i4<1>(cq + 3 + i, cz + 3 + i, L.q[3], L.sz[3], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
+                else if (I8) { mega_issue_row_i8<2>(cq + 6 + 2 * i, L.q8[3], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o); sc_b[i] = bf2f(load_global_u16(L.s8[3] + (min(rb13 + i, MG_INTER - 1)))); }
+                else mega_issue_row<4>(wv + 12 + 4 * i, L.w3, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o, MG_ABLATE);
+            }
         };
         auto request_w1 = [&]() {
 #pragma unroll
@@ -514,16 +650,17 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 else if (EARLY_W1) {
                     const bf16_t* row = L.w1 + (size_t)min(rb13 + i, MG_INTER - 1) * MG_DIM;
                     if (!w1_half_issued) {  // a workgroup that does not attend in this step (its key range is empty)
-                        mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + 0) * 64)), row + lane_o * 8, a.ablate);
-                        mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + 1) * 64)), row + 512 + lane_o * 8, a.ablate);
+                        mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + 0) * 64)), row + lane_o * 8, MG_ABLATE);
+                        mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + 1) * 64)), row + 512 + lane_o * 8, MG_ABLATE);
                     }
                     wv[4 * i + 2] = load_stream16(row + 2 * 512 + lane_o * 8);
                     wv[4 * i + 3] = load_stream16(row + 3 * 512 + lane_o * 8);
                 }
-                else mega_issue_row<4>(wv + 4 * i, L.w1, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o, a.ablate);
+                else mega_issue_row<4>(wv + 4 * i, L.w1, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o, MG_ABLATE);
             }
             w1_half_issued = false;  // next layer
             nw_ffn = load16(L.ffn_norm + (tid_o & 255) * 8);
+            if (W3_EARLY && MEGA_W3_EARLY != 2) request_w3();
         };
         auto request_wo_w1 = [&]() { request_wo(); request_w1(); };
 
@@ -532,18 +669,29 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         // the workgroup of split 0, the combined output) to publish, and a store queued behind 112 KB of the other waves' bulk
         // requests in this CU's memory pipeline reaches the combiner -- on everybody's critical path -- microseconds late.  So the
         // other waves of an attending workgroup hold their requests (the next utterance's K/V, then wo | w1) until wave 0 is through.
-        if (!any_att) request_wo_w1();
+        constexpr bool W1_LATE = NU == 1 && MEGA_W1_AFTER_ATTN, WO_LATE = NU == 1 && MEGA_WO_AFTER_QKV;
+        if (!any_att) { request_wo(); if (!W1_LATE) request_w1(); }
         if (any_att) {
             __syncthreads();
             // every wave of the block has published its q/k/v rows: the wo row (8 MB chip-wide, ~1 us of stream) is requested HERE, under
             // the q/k/v hand-off, which costs its ~1.7 us of latency whatever is queued behind it; w1 follows after the attention
-            request_wo();
+            if (!WO_LATE) request_wo();
             {   // q, k_new, v_new of head at_h of every utterance this block attends for: 3 x 128 row-paired granules each
                 const int sec = tid_o >> 7, c = tid_o & 127;
-                wave_poll<NU>(tag0 + 0u, a.abort_flag, &s_abort,
+                const gran_t* gq = g_qkv;
+                if constexpr (ATTN_V2)
+                    wave_poll<1>(tag0 + 0u, abort_flag_of, &s_abort,
+                                 [&](int, u64& v) {
+                                     if (tid_o >= 384) return false;
+                                     v = gran_load(gq + (size_t)at_u * 3 * MG_DIM + sec * MG_DIM + at_h * 128 + c);
+                                     return true;
+                                 },
+                                 [&](int, uint32_t p) { qkv_s[0][(sec * 2 + 0) * 128 + c] = (bf16_t)p; qkv_s[0][(sec * 2 + 1) * 128 + c] = (bf16_t)(p >> 16); });
+                else
+                wave_poll<NU>(tag0 + 0u, abort_flag_of, &s_abort,
                               [&](int k, u64& v) {
                                   if (tid_o >= 384 || !(at_s < GEO(2, k))) return false;
-                                  v = gran_load(a.g_qkv + (size_t)k * 3 * MG_DIM + sec * MG_DIM + at_h * 128 + c);
+                                  v = gran_load(gq + (size_t)k * 3 * MG_DIM + sec * MG_DIM + at_h * 128 + c);
                                   return true;
                               },
                               [&](int k, uint32_t p) { qkv_s[k][(sec * 2 + 0) * 128 + c] = (bf16_t)p; qkv_s[k][(sec * 2 + 1) * 128 + c] = (bf16_t)(p >> 16); });
@@ -551,15 +699,90 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             __syncthreads();
             MG_ABORT_RETURN();
             MG_STAMP(l, 3);
+            if (WO_LATE) request_wo();
             if constexpr (EARLY_W1) {  // half of w1 on its way while the partial is computed, merged and published
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + j) * 64)),
-                                        L.w1 + (size_t)min(rb13 + i, MG_INTER - 1) * MG_DIM + j * 512 + lane_o * 8, a.ablate);
+                                        L.w1 + (size_t)min(rb13 + i, MG_INTER - 1) * MG_DIM + j * 512 + lane_o * 8, MG_ABLATE);
                 w1_half_issued = true;
             }
+            if constexpr (ATTN_V2) {
+                // ---- this workgroup's key ranges at_s .. at_s + SPB - 1 of (at_u, at_r, at_h), two register sets in flight ----
+                const int u = at_u;
+                // opaque ids: the publish / poll addresses below are functions of the lane -- hoisted out of the layer loop they are spilled, and a
+                // scratch reload in front of a publish waits for every K/V row in flight
+                const int g = lane_o >> 4, dl = lane_o & 15, at_w = wave_o, lane = lane_o;
+                const int Pu = GEO(0, u), csu = GEO(1, u), nactu = GEO(2, u), kwu = GEO(3, u);
+                const int n_my = min(SPB, nactu - at_s);   // >= 1: this workgroup attends
+                const u32x4 qv = *(const u32x4*)(qkv_s[0] + (0 * 2 + at_r) * 128 + dl * 8);
+                auto& kvB = *reinterpret_cast<u32x4(*)[ATTN_U]>(&wv[0]);   // second register set (ATTN_DB): see issue_kv_set
+                auto& vvB = *reinterpret_cast<u32x4(*)[ATTN_U]>(&wv[ATTN_DB ? 16 : 0]);
+#pragma unroll
+                for (int j = 0; j < SPB; ++j) {
+                    if (j < n_my) {   // block-uniform
+                        const int split = at_s + j;
+                        const int s0 = split * csu + at_w * kwu, s1 = min(min(Pu, split * csu + csu), s0 + kwu);
+                        u32x4 (&kx)[ATTN_U] = (ATTN_DB && (j & 1)) ? kvB : kv;
+                        u32x4 (&vx)[ATTN_U] = (ATTN_DB && (j & 1)) ? vvB : vv;
+#pragma unroll
+                        for (int q = 0; q < ATTN_U; ++q) {
+                            if (s0 + q * 4 + g == Pu - 1) {  // the key produced by this step: not in the cache yet for this launch
+                                kx[q] = *(const u32x4*)(qkv_s[0] + (1 * 2 + at_r) * 128 + dl * 8);
+                                vx[q] = *(const u32x4*)(qkv_s[0] + (2 * 2 + at_r) * 128 + dl * 8);
+                            }
+                        }
+                        const AttnAcc w = attn_wave_partial(kx, vx, qv, s0, s1, g);
+                        if (j == 0) MG_STAMP(l, 14);  // first wave partial done
+                        // this set's registers are free: the range after next is requested into them while the other set is scored
+                        if constexpr (ATTN_DB) {
+                            if (j + 2 < SPB && j + 2 < n_my) {
+                                if (j & 1) issue_kv_set(std::integral_constant<int, 1>{}, u, l, split + 2);
+                                else issue_kv_set(std::integral_constant<int, 0>{}, u, l, split + 2);
+                            }
+                        } else if (j + 1 < SPB && j + 1 < n_my) issue_kv_set(std::integral_constant<int, 0>{}, u, l, split + 1);
+                        if (g == 0) {
+                            float (*smj)[16][12] = sm + j * ATTN_WAVES;
+                            smj[at_w][dl][0] = w.m;
+                            smj[at_w][dl][1] = w.l;
+#pragma unroll
+                            for (int d = 0; d < 8; ++d) smj[at_w][dl][2 + d] = w.o[d];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+                // wave j merges range j and publishes its partial; with a single range (<= 256 keys) the merged result is the output
+                u64* slots = (u64*)a.partial + ((size_t)(2 * u + at_r) * MG_HEADS + at_h) * ATTN_NSPLIT * ATTN_TPART_STRIDE;
+                AttnAcc bb;
+                if (at_w < n_my) {
+                    bb = attn_merge_waves(sm + at_w * ATTN_WAVES, g, dl);
+                    if (nactu > 1) attn_publish_tagged(bb, slots + (size_t)(at_s + at_w) * ATTN_TPART_STRIDE, tag0 + 5u, lane);
+                }
+                if (at_w == 0 && at_s == 0) {   // the workgroup of the first ranges combines (utterance, row, head) and publishes its output
+                    bool last = true;
+                    if (nactu > 1 && !attn_combine_tagged(bb, slots, tag0 + 5u, nactu, lane, MG_SPIN_LIMIT)) {
+                        uint32_t* af = abort_flag_of();
+                        mega_report_timeout(af, tag0 + 5u);
+                        __hip_atomic_store(af, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *(volatile int*)&s_abort = 1;
+                        last = false;
+                    }
+                    if (last && g == 0) {  // 8 dims per lane = 4 column-paired granules
+                        const u32x4 y = attn_normalise(bb);
+                        gran_t* gp = g_attn + (size_t)u * MG_DIM + at_r * (MG_DIM / 2) + (at_h * 128 + dl * 8) / 2;
+                        gran_store(gp + 0, y.x, tag0 + 1u);
+                        gran_store(gp + 1, y.y, tag0 + 1u);
+                        gran_store(gp + 2, y.z, tag0 + 1u);
+                        gran_store(gp + 3, y.w, tag0 + 1u);
+                        if (MG_DBG_ON() && u == 0) *(u32x4*)(a.dbg + ((size_t)l * 5 + 1) * 2 * MG_INTER + at_r * MG_INTER + at_h * 128 + dl * 8) = y;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else
             // One K/V register set.  After an utterance's partial has been merged and published (workgroup-wide
             // publish-before-prefetch) EVERY wave requests its slice of the next attending utterance -- wave 0 too, before the
             // combine polls it may owe.  The split partials of utterance u are combined by the workgroup of split u % nact (not
@@ -585,7 +808,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 if (u == 0) MG_STAMP(l, 14);  // wave partial done
                 // MEGA_NU_EARLY_KV: the K/V registers are free from here on -- the next attending utterance's slice is requested NOW, so
                 // it streams while this utterance's partial is merged and published (instead of after the publish)
-                if (MEGA_NU_EARLY_KV && NU > 1 && next_att >= 0) issue_kv(next_att);
+                if (MEGA_NU_EARLY_KV && NU > 1 && next_att >= 0) issue_kv(next_att, l);
                 if (g == 0) {
                     sm[at_w][dl][0] = w.m;
                     sm[at_w][dl][1] = w.l;
@@ -604,34 +827,35 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 }
                 if (next_att >= 0) {
                     __syncthreads();  // the partial has left, `sm` has been consumed
-                    if (!(MEGA_NU_EARLY_KV && NU > 1)) issue_kv(next_att);
+                    if (!(MEGA_NU_EARLY_KV && NU > 1)) issue_kv(next_att, l);
                 }
                 if (at_w == 0) {
                     bool last = true;
                     if (nactu > 1) {
                         last = at_s == (NU == 1 ? 0 : u % nactu);
                         if (last && !attn_combine_tagged(bb, slots, tag0 + 5u, nactu, lane, MG_SPIN_LIMIT)) {
-                            mega_report_timeout(a.abort_flag, tag0 + 5u);
-                            __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            uint32_t* af = abort_flag_of();
+                            mega_report_timeout(af, tag0 + 5u);
+                            __hip_atomic_store(af, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             *(volatile int*)&s_abort = 1;
                             last = false;
                         }
                     }
                     if (last && g == 0) {  // 8 dims per lane = 4 column-paired granules
                         const u32x4 y = attn_normalise(bb);
-                        gran_t* gp = a.g_attn + (size_t)u * MG_DIM + at_r * (MG_DIM / 2) + (at_h * 128 + dl * 8) / 2;
+                        gran_t* gp = g_attn + (size_t)u * MG_DIM + at_r * (MG_DIM / 2) + (at_h * 128 + dl * 8) / 2;
                         gran_store(gp + 0, y.x, tag0 + 1u);
                         gran_store(gp + 1, y.y, tag0 + 1u);
                         gran_store(gp + 2, y.z, tag0 + 1u);
                         gran_store(gp + 3, y.w, tag0 + 1u);
-                        if (a.dbg && u == 0) *(u32x4*)(a.dbg + ((size_t)l * 5 + 1) * 2 * MG_INTER + at_r * MG_INTER + at_h * 128 + dl * 8) = y;
+                        if (MG_DBG_ON() && u == 0) *(u32x4*)(a.dbg + ((size_t)l * 5 + 1) * 2 * MG_INTER + at_r * MG_INTER + at_h * 128 + dl * 8) = y;
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             MG_STAMP(l, 15);  // wave 0: attention output (or partial) published
             __syncthreads();
-            request_w1();
+            if (!W1_LATE) request_w1();
         }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -640,43 +864,50 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         MG_STAMP(l, 4);
         {
             // granule i of utterance u = elements 2i, 2i+1 of its [2][2048] attention output
-            wave_poll16<2 * NU>(a.g_attn, tag0 + 1u, a.abort_flag, &s_abort, [&](int k) { return (k >> 1) * (MG_DIM / 2) * 2 / 2 + tid_o + (k & 1) * MG_THREADS; },
+            wave_poll16<2 * NU>(g_attn, tag0 + 1u, abort_flag_of, &s_abort, [&](int k) { return (k >> 1) * (MG_DIM / 2) * 2 / 2 + tid_o + (k & 1) * MG_THREADS; },
                                 [&](int n, uint32_t p0, uint32_t p1) { ((uint2*)xs[n / (MG_DIM / 2)])[n % (MG_DIM / 2)] = make_uint2(p0, p1); });
             __syncthreads();
             MG_ABORT_RETURN();
             MG_STAMP(l, 5);
+            if (W1_LATE) { request_w1(); __builtin_amdgcn_sched_barrier(0); }
+            if (W3_EARLY && MEGA_W3_EARLY == 2) { request_w3(); __builtin_amdgcn_sched_barrier(0); }  // experiment: behind the attention vector, in front of the h publish
 #pragma unroll 1
             for (int u = 0; u < NU; ++u) {
                 float acc[1][2];
-                if (I4) mega_dots_i4<1, 1, MG_DIM>(cq + 6, cz + 6, xs[u], MG_DIM, lane, acc);
-                else if (I8) mega_dots_i8<2, 1, MG_DIM>(cq + 12, xs[u], MG_DIM, lane, acc);
-                else mega_dots<4, 1, MG_DIM>(wv + 12, xs[u], lane, acc);
+                if (I4) mega_dots_i4<1, 1, MG_DIM>(cq + 6, cz + 6, xs[u], MG_DIM, lane_p, acc);
+                else if (I8) mega_dots_i8<2, 1, MG_DIM>(cq + 12, xs[u], MG_DIM, lane_p, acc);
+                else if (W3_EARLY) {  // same order as mega_dots: chunk j ascending, row r
+                    acc[0][0] = acc[0][1] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r)
+                            acc[0][r] = dot8_bf16(wv[(j >> 1) * 4 + (j & 1)], *(const u32x4*)(xs[u] + r * MG_DIM + j * 512 + lane * 8), acc[0][r]);
+                }
+                else mega_dots<4, 1, MG_DIM>(wv + 12, xs[u], lane_p, acc);
                 __builtin_amdgcn_sched_barrier(0);
                 if (u == 0) MG_STAMP(l, 16);  // wo dots done
                 float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
                 if (I8) { t0 = i8_out(t0, sc_c); t1 = i8_out(t1, sc_c); }
-                const uint32_t xr = res_s[0][u][wave];
+                const uint32_t xr = res_s[0][u][wave_p];
                 const bf16_t y0 = epi_resid((bf16_t)xr, t0), y1 = epi_resid((bf16_t)(xr >> 16), t1);
                 const uint32_t hr = (uint32_t)y0 | ((uint32_t)y1 << 16);
-                if (lane == 0) res_s[1][u][wave] = hr;
+                if (lane_p == 0) res_s[1][u][wave_p] = hr;
                 // test hook (mv_tune "mega_fault"): one workgroup withholds this publish -> every peer's wait has to time out, raise the
                 // abort flag and leave the kernel; mv_run then reports the error (tests/test_engine_gpu.py)
-                if (lane == 0 && !(a.fault != 0 && b == ((a.fault - 1) & 255) && l == 1)) {
-                    const int n = 8 * b + wave;
-                    gran_store(a.g_h + (size_t)u * MG_DIM + n, hr, tag0 + 2u);
-                    if (a.dbg && u == 0) { bf16_t* d = a.dbg + ((size_t)l * 5 + 2) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
+                bool withhold = false;
+                if (l == 1) { const int fault = a.fault; withhold = fault != 0 && b == ((fault - 1) & 255); }
+                if (lane_p == 0 && !withhold) {
+                    const int n = 8 * b + wave_p;
+                    gran_store(g_h + (size_t)u * MG_DIM + n, hr, tag0 + 2u);
+                    if (MG_DBG_ON() && u == 0) { bf16_t* d = a.dbg + ((size_t)l * 5 + 2) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 17);  // h published
-            // next: the w3 rows (w1 is already in flight).  22 rows per block: waves 0..5 take 3, waves 6,7 take 2 (third slot
-            // clamped, masked)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                if (I4) mega_issue_row_i4<1>(cq + 3 + i, cz + 3 + i, L.q[3], L.sz[3], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
-                else if (I8) { mega_issue_row_i8<2>(cq + 6 + 2 * i, L.q8[3], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o); sc_b[i] = bf2f(load_global_u16(L.s8[3] + (min(rb13 + i, MG_INTER - 1)))); }
-                else mega_issue_row<4>(wv + 12 + 4 * i, L.w3, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o, a.ablate);
-            }
+            // next: the w3 rows (w1 is already in flight) -- unless they went out with w1 (MEGA_W3_EARLY)
+            if (!W3_EARLY) request_w3();
+            if (MEGA_KV_EARLY && first_att >= 0 && l + 1 < n_layer) issue_kv(first_att, l + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -684,28 +915,28 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         __syncthreads();
         MG_STAMP(l, 6);
         {
-            mega_poll_rowpairs<NU>(a.g_h, tag0 + 2u, xs, a.abort_flag, &s_abort, tid_o);
+            mega_poll_rowpairs<NU>(g_h, tag0 + 2u, xs, abort_flag_of, &s_abort, tid_o);
             __syncthreads();
             MG_ABORT_RETURN();
             MG_STAMP(l, 7);
             if constexpr (EARLY_W2) {  // chunks 0..4 of the w2 row on their way while the norm, the w1|w3 dots and the act publish run
 #pragma unroll
                 for (int j = 0; j < 5; ++j)
-                    mega_row_to_lds(lds_addr(w2_lds + ((wave_o * 5 + j) * 64)), L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8, a.ablate);
+                    mega_row_to_lds(lds_addr(w2_lds + ((wave_o * 5 + j) * 64)), L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8, MG_ABLATE);
             }
-            mega_norm<NU>(xs, nw_ffn, red, a.eps);
+            mega_norm<NU>(xs, nw_ffn, red, a.eps, tid_p);
             MG_STAMP(l, 18);  // norm done
-            const int nrows = wave < 6 ? 3 : 2;
-            const int rb = 22 * b + (wave < 6 ? 3 * wave : 18 + 2 * (wave - 6));
+            const int nrows = wave_p < 6 ? 3 : 2;
+            const int rb = 22 * b + (wave_p < 6 ? 3 * wave_p : 18 + 2 * (wave_p - 6));
 #pragma unroll 1
             for (int u = 0; u < NU; ++u) {
                 float acc1[3][2], acc3[3][2];
                 if (I4) {
-                    mega_dots_i4<1, 3, MG_DIM>(cq, cz, xs[u], MG_DIM, lane, acc1);
-                    mega_dots_i4<1, 3, MG_DIM>(cq + 3, cz + 3, xs[u], MG_DIM, lane, acc3);
+                    mega_dots_i4<1, 3, MG_DIM>(cq, cz, xs[u], MG_DIM, lane_p, acc1);
+                    mega_dots_i4<1, 3, MG_DIM>(cq + 3, cz + 3, xs[u], MG_DIM, lane_p, acc3);
                 } else if (I8) {
-                    mega_dots_i8<2, 3, MG_DIM>(cq, xs[u], MG_DIM, lane, acc1);
-                    mega_dots_i8<2, 3, MG_DIM>(cq + 6, xs[u], MG_DIM, lane, acc3);
+                    mega_dots_i8<2, 3, MG_DIM>(cq, xs[u], MG_DIM, lane_p, acc1);
+                    mega_dots_i8<2, 3, MG_DIM>(cq + 6, xs[u], MG_DIM, lane_p, acc3);
                 } else {
                     if constexpr (EARLY_W1) {  // same order as mega_dots: chunk j ascending, row r, weight row i
 #pragma unroll
@@ -722,8 +953,8 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                                 }
                             }
                     } else
-                    mega_dots<4, 3, MG_DIM>(wv, xs[u], lane, acc1);
-                    mega_dots<4, 3, MG_DIM>(wv + 12, xs[u], lane, acc3);
+                    mega_dots<4, 3, MG_DIM>(wv, xs[u], lane_p, acc1);
+                    mega_dots<4, 3, MG_DIM>(wv + 12, xs[u], lane_p, acc3);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (u == 0) MG_STAMP(l, 19);  // w1|w3 dots done
@@ -732,12 +963,12 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 for (int i = 0; i < 3; ++i) {
                     float a0 = wave_sum(acc1[i][0]), a1 = wave_sum(acc1[i][1]), c0 = wave_sum(acc3[i][0]), c1 = wave_sum(acc3[i][1]);
                     if (I8) { a0 = i8_out(a0, sc_a[i]); a1 = i8_out(a1, sc_a[i]); c0 = i8_out(c0, sc_b[i]); c1 = i8_out(c1, sc_b[i]); }
-                    if (lane == i) { g0 = a0; g1 = a1; u0 = c0; u1 = c1; }
+                    if (lane_p == i) { g0 = a0; g1 = a1; u0 = c0; u1 = c1; }
                 }
-                if (lane < nrows) {
+                if (lane_p < nrows) {
                     const bf16_t y0 = epi_swiglu(g0, u0), y1 = epi_swiglu(g1, u1);
-                    gran_store(a.g_act + (size_t)u * MG_INTER + rb + lane, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 3u);
-                    if (a.dbg && u == 0) { bf16_t* d = a.dbg + ((size_t)l * 5 + 3) * 2 * MG_INTER; d[rb + lane] = y0; d[MG_INTER + rb + lane] = y1; }
+                    gran_store(g_act + (size_t)u * MG_INTER + rb + lane_p, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 3u);
+                    if (MG_DBG_ON() && u == 0) { bf16_t* d = a.dbg + ((size_t)l * 5 + 3) * 2 * MG_INTER; d[rb + lane_p] = y0; d[MG_INTER + rb + lane_p] = y1; }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -749,7 +980,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
 #pragma unroll
                 for (int j = 5; j < 11; ++j) wv[j] = load_stream16(L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8);
             }
-            else mega_issue_row<11>(wv, L.w2, 8 * b + wave_o, MG_INTER, lane_o, a.ablate);
+            else mega_issue_row<11>(wv, L.w2, 8 * b + wave_o, MG_INTER, lane_o, MG_ABLATE);
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -763,7 +994,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             constexpr int PPT = (MG_INTER / 2 + MG_THREADS - 1) / MG_THREADS;  // pairs per thread and utterance
 #pragma unroll
             for (int u0 = 0; u0 < NU; u0 += UPP) {
-                wave_poll16<PPT * UPP>(a.g_act + (size_t)u0 * MG_INTER, tag0 + 3u, a.abort_flag, &s_abort,
+                wave_poll16<PPT * UPP>(g_act + (size_t)u0 * MG_INTER, tag0 + 3u, abort_flag_of, &s_abort,
                                        [&](int k) {
                                            const int n = tid_o + (k % PPT) * MG_THREADS;
                                            return n < MG_INTER / 2 ? (k / PPT) * (MG_INTER / 2) + n : -1;
@@ -779,20 +1010,20 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             MG_ABORT_RETURN();
             MG_STAMP(l, 9);
             if constexpr (EARLY_QKV) {  // chunks 0, 1 of the next layer's three wqkv rows on their way while the w2 dots and the x publish run
-                if (l + 1 < a.n_layer) {
+                if (l + 1 < n_layer) {
                     const bf16_t* w = MG_LAYER(l + 1).wqkv;
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + j) * 64)), w + (size_t)(24 * b + 3 * wave_o + i) * MG_DIM + j * 512 + lane_o * 8, a.ablate);
+                            mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + j) * 64)), w + (size_t)(24 * b + 3 * wave_o + i) * MG_DIM + j * 512 + lane_o * 8, MG_ABLATE);
                 }
             }
 #pragma unroll 1
             for (int u = 0; u < NU; ++u) {
                 float acc[1][2];
-                if (I4) mega_dots_i4<3, 1, MG_INTER>(cq + 6, cz + 6, xs[u], MG_INTER, lane, acc);
-                else if (I8) mega_dots_i8<6, 1, MG_INTER>(cq, xs[u], MG_INTER, lane, acc);
+                if (I4) mega_dots_i4<3, 1, MG_INTER>(cq + 6, cz + 6, xs[u], MG_INTER, lane_p, acc);
+                else if (I8) mega_dots_i8<6, 1, MG_INTER>(cq, xs[u], MG_INTER, lane_p, acc);
                 else if (EARLY_W2) {  // same order as mega_dots: chunk j ascending, row r
                     acc[0][0] = acc[0][1] = 0.f;
 #pragma unroll
@@ -802,26 +1033,26 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                         for (int r = 0; r < 2; ++r) acc[0][r] = dot8_bf16(w, *(const u32x4*)(xs[u] + r * MG_INTER + j * 512 + lane * 8), acc[0][r]);
                     }
                 }
-                else mega_dots<11, 1, MG_INTER>(wv, xs[u], lane, acc);
+                else mega_dots<11, 1, MG_INTER>(wv, xs[u], lane_p, acc);
                 __builtin_amdgcn_sched_barrier(0);
                 if (u == 0) MG_STAMP(l, 21);  // w2 dots done
                 float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
                 if (I8) { t0 = i8_out(t0, sc_c); t1 = i8_out(t1, sc_c); }
-                const uint32_t hr = res_s[1][u][wave];
+                const uint32_t hr = res_s[1][u][wave_p];
                 const bf16_t y0 = epi_resid((bf16_t)hr, t0), y1 = epi_resid((bf16_t)(hr >> 16), t1);
                 const uint32_t xr = (uint32_t)y0 | ((uint32_t)y1 << 16);
-                if (lane == 0) {
-                    const int n = 8 * b + wave;
-                    res_s[0][u][wave] = xr;
-                    gran_store(a.g_x + (size_t)u * MG_DIM + n, xr, tag0 + 4u);
+                if (lane_p == 0) {
+                    const int n = 8 * b + wave_p;
+                    res_s[0][u][wave_p] = xr;
+                    gran_store(g_x + (size_t)u * MG_DIM + n, xr, tag0 + 4u);
                     if (u == 0) MG_STAMP(l, 10);
-                    if (a.dbg && u == 0) { bf16_t* d = a.dbg + ((size_t)l * 5 + 4) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
+                    if (MG_DBG_ON() && u == 0) { bf16_t* d = a.dbg + ((size_t)l * 5 + 4) * 2 * MG_INTER; d[n] = y0; d[MG_INTER + n] = y1; }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             // next: the following layer's wqkv rows, or the LM-head rows 11 b + wave + 8 i
-            if (MEGA_KV_AFTER_NORM) nw_attn = load16((l + 1 < a.n_layer ? MG_LAYER(l + 1).attn_norm : a.final_norm) + (tid_o & 255) * 8);
-            if (l + 1 < a.n_layer) {
+            if (MEGA_KV_AFTER_NORM) nw_attn = load16((l + 1 < n_layer ? MG_LAYER(l + 1).attn_norm : KC(l)->final_norm) + (tid_o & 255) * 8);
+            if (l + 1 < n_layer) {
                 const bf16_t* w = MG_LAYER(l + 1).wqkv;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -832,28 +1063,29 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                         wv[4 * i + 2] = load_stream16(row + 2 * 512 + lane_o * 8);
                         wv[4 * i + 3] = load_stream16(row + 3 * 512 + lane_o * 8);
                     }
-                    else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave_o + i, MG_DIM, lane_o, a.ablate);
+                    else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave_o + i, MG_DIM, lane_o, MG_ABLATE);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
+                    const mega_kargs_t A = KC(l);
                     const int hn = min(11 * b + wave_o + 8 * i, a.vocab - 1);
-                    if (I8) { mega_issue_row_i8<2>(cq + 2 * i, a.head_q8, hn, MG_DIM, lane_o); sc_a[i] = bf2f(load_global_u16(a.head_s8 + hn)); }
-                    else mega_issue_row<4>(wv + 4 * i, a.head, hn, MG_DIM, lane_o, a.ablate);
+                    if (I8) { mega_issue_row_i8<2>(cq + 2 * i, A->head_q8, hn, MG_DIM, lane_o); sc_a[i] = bf2f(load_global_u16(A->head_s8 + hn)); }
+                    else mega_issue_row<4>(wv + 4 * i, A->head, hn, MG_DIM, lane_o, MG_ABLATE);
                 }
             }
-            if (!MEGA_KV_AFTER_NORM) nw_attn = load16((l + 1 < a.n_layer ? MG_LAYER(l + 1).attn_norm : a.final_norm) + (tid_o & 255) * 8);
+            if (!MEGA_KV_AFTER_NORM) nw_attn = load16((l + 1 < n_layer ? MG_LAYER(l + 1).attn_norm : KC(l)->final_norm) + (tid_o & 255) * 8);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 
     // ================= LM head on the last position: logits = head(norm(x))     fast_model.py:161-162 =================
-    const uint32_t tag_head = epoch + (uint32_t)a.n_layer * 8u + 1u;
+    const uint32_t tag_head = epoch + (uint32_t)n_layer * 8u + 1u;
     __syncthreads();
-    mega_poll_rowpairs<NU>(a.g_x, epoch + (uint32_t)(a.n_layer - 1) * 8u + 1u + 4u, xs, a.abort_flag, &s_abort, tid);
+    mega_poll_rowpairs<NU>(g_x, epoch + (uint32_t)(n_layer - 1) * 8u + 1u + 4u, xs, [&]() { return KC(step)->abort_flag; }, &s_abort, tid);
     __syncthreads();
     MG_ABORT_RETURN();
-    mega_norm<NU>(xs, nw_attn, red, a.eps);
+    mega_norm<NU>(xs, nw_attn, red, a.eps, tid);
 #pragma unroll 1
     for (int u = 0; u < NU; ++u) {
         float acc[2][2];
@@ -869,11 +1101,14 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         if (lane < 2) {
             const int slot = wave + 8 * lane, n = 11 * b + slot;
             const bf16_t y0 = f2bf(v0), y1 = f2bf(v1);
-            if (slot < 11 && n < a.vocab) {
-                a.logits[(size_t)(2 * u) * a.vocab + n] = y0;
-                a.logits[(size_t)(2 * u + 1) * a.vocab + n] = y1;
+            const mega_kargs_t A = KC(step);
+            const int vocab = a.vocab;
+            if (fold && slot < 11 && n < VP) gran_store(g_logits + (size_t)u * VP + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag_head);
+            if (slot < 11 && n < vocab) {
+                bf16_t* lo = A->logits;
+                lo[(size_t)(2 * u) * vocab + n] = y0;
+                lo[(size_t)(2 * u + 1) * vocab + n] = y1;
             }
-            if (fold && slot < 11 && n < VP) gran_store(a.g_logits + (size_t)u * VP + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag_head);
         }
     }
     if constexpr (fold) {
@@ -894,7 +1129,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         __syncthreads();     // every wave is through with the head's operand in xs
         const bool was_done = st_s.done != 0;
         if (!was_done) {
-            wave_poll16<3>(a.g_logits + (size_t)u * VP, tag_head, a.abort_flag, &s_abort,
+            wave_poll16<3>(g_logits + (size_t)u * VP, tag_head, [&]() { return KC(step)->abort_flag; }, &s_abort,
                            [&](int k) { const int n = tid_t + k * MG_THREADS; return n < VP / 2 ? n : -1; },
                            [&](int n, uint32_t p0, uint32_t p1) {
                                *(uint32_t*)(lg + 2 * n) = (p0 & 0xFFFFu) | (p1 << 16);
@@ -905,8 +1140,8 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         if (!last_step) issue_layer0(lane_t, wave_t);
         __syncthreads();
         MG_ABORT_RETURN();
-        mega_draw_and_publish<NU>(a, u, lg, &st_s, &smp_sc, VP, tag_next, last_step, tid_t);
-        if (tid_t == 0 && u == 0) a.step_counter_out[0] = counter0 + (uint32_t)step + 1u;  // the next launch's first epoch
+        mega_draw_and_publish<NU>(KC(step), g_logits + (size_t)NU * VP, u, lg, &st_s, &smp_sc, VP, tag_next, last_step, tid_t);
+        if (tid_t == 0 && u == 0) KC(step)->step_counter_out[0] = counter0 + (uint32_t)step + 1u;  // the next launch's first epoch
     } else if (!last_step) {
         issue_layer0(lane_t, wave_t);
     }
@@ -915,10 +1150,12 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     // Every workgroup: wait for the control words {token | position << 12 | done << 31} -- ONE wave polls, one granule per utterance,
     // instead of 2048 waves spinning on a 16 KB vector of input rows for the ~10 us of a draw -- then build the next input rows from
     // the embedding tables (three 16-byte loads per thread; the token's row is shared by all 256 workgroups, i.e. L2 / MALL hits).
-    if (wave_t == 0)
-        wave_poll<1>(tag_next, a.abort_flag, &s_abort,
-                     [&](int, u64& v) { if (lane_t >= NU) return false; v = gran_load(a.g_ctl + lane_t); return true; },
+    if (wave_t == 0) {
+        const gran_t* gc = g_logits + (size_t)NU * VP;   // g_ctl
+        wave_poll<1>(tag_next, [&]() { return KC(step)->abort_flag; }, &s_abort,
+                     [&](int, u64& v) { if (lane_t >= NU) return false; v = gran_load(gc + lane_t); return true; },
                      [&](int, uint32_t p) { tok_s[lane_t] = (int)(p & 0xFFFu); pos_s[lane_t] = (int)((p >> 12) & 0x7FFFFu); done_s[lane_t] = (int)(p >> 31); });
+    }
     __syncthreads();  // also: block u has read `lg`, xs may be overwritten
     MG_ABORT_RETURN();
     {
@@ -929,8 +1166,9 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     }
     for (int t = tid_t; t < 256 * NU; t += MG_THREADS) {  // fast_model.py:152-157; item t: columns 8 (t & 255) .. of both rows of utterance t >> 8
         const int u = t >> 8, c = (t & 255) * 8;
-        const u32x4 te = load16(a.tok_emb + (size_t)tok_s[u] * MG_DIM + c), pe = load16(a.pos_emb + (size_t)pos_s[u] * MG_DIM + c);
-        const u32x4 sp = load16(a.spk_proj + (size_t)u * MG_DIM + c);
+        const mega_kargs_t A = KC(step);
+        const u32x4 te = load16(A->tok_emb + (size_t)tok_s[u] * MG_DIM + c), pe = load16(A->pos_emb + (size_t)pos_s[u] * MG_DIM + c);
+        const u32x4 sp = load16(A->spk_proj + (size_t)u * MG_DIM + c);
         u32x4 r0, r1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

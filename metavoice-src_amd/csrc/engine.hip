@@ -383,6 +383,8 @@ int mv_debug_stamps(mv_engine* e, uint64_t* out, int64_t cap_elems) {
 
 int mv_debug_vectors(mv_engine* e, uint16_t* out, int64_t cap_elems) {
     if (!e || !e->dbg || !out) return fail(MV_ERR_STATE, "debug vectors are not enabled (MV_DEBUG_VECTORS=1 before mv_finalize)");
+    if (e->mega_ok && g_tune.mega && !e->mega_failed && !mega_instrumented())
+        return fail(MV_ERR_STATE, "the persistent kernel writes debug vectors only in the instrumented library (libmetavoice_hip_instr.so); use it or mv_tune(\"mega\", 0)");
     const size_t n = (size_t)e->cfg.n_layer * 5 * 2 * 5632;
     if ((size_t)cap_elems < n) return fail(MV_ERR_INVALID, "buffer too small");
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -639,6 +641,9 @@ int mv_finalize(mv_engine* e) {
         HIP_TRY(hipMemset(e->dbg, 0, (size_t)c.n_layer * 5 * 2 * 5632 * 2));
     }
     if (getenv("MV_MEGA_STAMPS")) {
+        // the persistent kernel carries its stamps / debug vectors / ablation hook only in the instrumented build (`make instr`,
+        // MV_HIP_LIB=.../libmetavoice_hip_instr.so): asking for them from the product library is an error, not a silent no-op
+        if (!mega_instrumented()) return fail(MV_ERR_STATE, "MV_MEGA_STAMPS needs the instrumented library (make -C csrc instr; MV_HIP_LIB=.../libmetavoice_hip_instr.so)");
         HIP_TRY(hipMalloc((void**)&e->stamps, (size_t)2 * c.n_layer * 24 * 8));
         HIP_TRY(hipMemset(e->stamps, 0, (size_t)2 * c.n_layer * 24 * 8));
     }

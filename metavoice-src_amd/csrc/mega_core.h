@@ -11,6 +11,8 @@
 // Every wait is bounded; a timeout raises a device flag that the host turns into an error (a plain launch gives no
 // residency guarantee: if another kernel occupies CUs the grid may not be co-resident).
 #pragma once
+#include <type_traits>
+
 #include "attn_core.h"
 #include "gemv_core.h"
 
@@ -53,9 +55,17 @@ __device__ __forceinline__ void mega_loads_have_landed() {
     if (MEGA_POLL_SCOREBOARD) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
 }
 
+// The abort flag as the polls take it: a pointer, or a callable returning it that is evaluated only when a wait runs out (the persistent
+// kernel reads the pointer from its launch arguments there instead of keeping it live in two SGPRs through every layer).
+template <typename AF>
+__device__ __forceinline__ uint32_t* mega_abort_ptr(AF af) {
+    if constexpr (std::is_pointer_v<AF>) return af;
+    else return af();
+}
+
 // One wave waits until all of ITS granules carry `tag` (no block barrier inside: the loaders only mirror the barrier after).
-template <int PER, typename Fetch, typename Sink>
-__device__ __forceinline__ void wave_poll(uint32_t tag, uint32_t* abort_flag, int* s_abort, Fetch fetch, Sink sink) {
+template <int PER, typename AF, typename Fetch, typename Sink>
+__device__ __forceinline__ void wave_poll(uint32_t tag, AF abort_flag_of, int* s_abort, Fetch fetch, Sink sink) {
     for (int tries = 0;; ++tries) {
         u64 v[PER];
         bool have[PER];
@@ -71,6 +81,7 @@ __device__ __forceinline__ void wave_poll(uint32_t tag, uint32_t* abort_flag, in
             return;
         }
         if ((tries & 1023) == 1023) {  // a peer is missing (grid not co-resident?) or already gave up
+            uint32_t* abort_flag = mega_abort_ptr(abort_flag_of);
             const bool peer = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
             if (peer || tries >= MG_SPIN_LIMIT) {
                 if (!peer) mega_report_timeout(abort_flag, tag);
@@ -82,8 +93,8 @@ __device__ __forceinline__ void wave_poll(uint32_t tag, uint32_t* abort_flag, in
         __builtin_amdgcn_s_sleep(2);
     }
 }
-template <int NCOL>
-__device__ __forceinline__ void wave_poll_rowpair(const gran_t* g, uint32_t tag, bf16_t* raw, uint32_t* abort_flag, int* s_abort, int tid) {
+template <int NCOL, typename AF>
+__device__ __forceinline__ void wave_poll_rowpair(const gran_t* g, uint32_t tag, bf16_t* raw, AF abort_flag, int* s_abort, int tid) {
     constexpr int PER = (NCOL + MG_THREADS - 1) / MG_THREADS;
     wave_poll<PER>(
         tag, abort_flag, s_abort,
@@ -173,8 +184,8 @@ __device__ __forceinline__ void poll16_loads(u32x4 (&v)[PER], const gran_t* cons
 
 // The same with 16-byte agent-scope loads: two granules per lane per request, each 8-byte half validated by its own tag
 // (profiles/r01g_handoff: 2.0 vs 2.3 us per idle 2048-granule hand-off).  index(k) = pair index of the lane's k-th request or -1.
-template <int PER, typename Index, typename Sink>
-__device__ __forceinline__ void wave_poll16(const gran_t* g, uint32_t tag, uint32_t* abort_flag, int* s_abort, Index index, Sink sink) {
+template <int PER, typename AF, typename Index, typename Sink>
+__device__ __forceinline__ void wave_poll16(const gran_t* g, uint32_t tag, AF abort_flag_of, int* s_abort, Index index, Sink sink) {
     for (int tries = 0;; ++tries) {
         u32x4 v[PER];
         int n[PER];
@@ -196,6 +207,7 @@ __device__ __forceinline__ void wave_poll16(const gran_t* g, uint32_t tag, uint3
             return;
         }
         if ((tries & 1023) == 1023) {
+            uint32_t* abort_flag = mega_abort_ptr(abort_flag_of);
             const bool peer = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
             if (peer || tries >= MG_SPIN_LIMIT) {
                 if (!peer) mega_report_timeout(abort_flag, tag);
@@ -208,7 +220,8 @@ __device__ __forceinline__ void wave_poll16(const gran_t* g, uint32_t tag, uint3
     }
 }
 // row-paired vector of 2048 columns: pair n = granules 2n, 2n+1 = columns 2n, 2n+1 of both rows
-__device__ __forceinline__ void wave_poll_rowpair16(const gran_t* g, uint32_t tag, bf16_t* raw, uint32_t* abort_flag, int* s_abort, int tid) {
+template <typename AF>
+__device__ __forceinline__ void wave_poll_rowpair16(const gran_t* g, uint32_t tag, bf16_t* raw, AF abort_flag, int* s_abort, int tid) {
     wave_poll16<2>(g, tag, abort_flag, s_abort, [&](int k) { return tid + k * MG_THREADS; },
                    [&](int n, uint32_t p0, uint32_t p1) {
                        *(uint32_t*)(raw + 2 * n) = (p0 & 0xFFFFu) | (p1 << 16);

@@ -28,7 +28,7 @@ def compile_to_asm(source: str, tmp_path):
         if m:
             cur = m.group(1)
             usage[cur] = {}
-        for key, label in ((r"ScratchSize \[bytes/lane\]", "scratch"), ("VGPRs Spill", "spill"), ("VGPRs", "vgpr")):
+        for key, label in ((r"ScratchSize \[bytes/lane\]", "scratch"), ("VGPRs Spill", "spill"), ("SGPRs Spill", "sgpr_spill"), ("VGPRs", "vgpr")):
             m = re.search(r"remark:\s+" + key + r": (\d+)", line)
             if m and cur:
                 usage[cur].setdefault(label, int(m.group(1)))
@@ -50,9 +50,20 @@ def test_persistent_decode_kernel_has_no_scratch_and_no_flat_loads(tmp_path):
         # the one flat load that stays is the volatile read of the abort word behind the barriers (kept on purpose: DESIGN 3.1 (ii))
         others = [l for l in body.split("\n") if "flat_load" in l and not re.search(r"flat_load_dword v\d+, v\[\d+:\d+\] sc0 sc1", l)]
         assert not others, f"{name}: a flat_load counts in vmcnt AND lgkmcnt (generic pointer where a global / LDS one was meant?): {others[:3]}"
-        if n_utt == "1":   # the multi-utterance bf16 / int4 instances are at the 256-VGPR limit and spill a few registers
+        # round 4: no instance but the int4 ones of 2 / 4 utterances (a footprint mode) may touch scratch memory -- a scratch reload waits,
+        # in order, behind every weight row in flight.  Round 3's bf16 / int8 engines of 2 / 4 utterances spilled 12-29 VGPRs.
+        if not (fmt == "1" and n_utt != "1"):
             assert usage[name]["scratch"] == 0, f"{name}: {usage[name]} -- scratch without spills means a dynamically indexed local array"
             assert "scratch_" not in body
+        else:
+            assert usage[name]["spill"] <= 8, f"{name}: {usage[name]}"
+        # SGPR spills (values parked in VGPR lanes, v_readlane + s_nop to get them back): the launch arguments used to be loaded whole at the
+        # top of the kernel and kept live -- 175-241 spilled SGPRs in the instances that draw their own tokens, 47-135 in the others.  Now
+        # only the hot fields are read by value, the cold ones through KC() (decode_mega.hip).
+        bound = 160 if fold == "1" else 100
+        assert usage[name]["sgpr_spill"] <= bound, f"{name}: {usage[name]['sgpr_spill']} spilled SGPRs (bound {bound})"
+        # the launch arguments never travel through vector memory (r04a: a volatile view of the kernarg segment ended up in a VGPR pair)
+        assert not re.search(r"global_load_dword(x2)? v[\[\d:\]]+, v\[\d+:\d+\], off[^\n]*sc0 sc1", body), name
         # the layer pointer table comes through scalar loads: no vector load whose result is only read back with v_readfirstlane
         assert not re.search(r"global_load_dwordx2 v\[(\d+):\d+\], v\d+, s\[\d+:\d+\][^\n]*\n(?:[^\n]*\n){0,6}?\s*v_readfirstlane_b32 s\d+, v\1\b", body), name
     assert seen == 12   # 3 formats x (1 utterance one-step, 2, 4) + the three one-utterance instances that draw their own tokens
