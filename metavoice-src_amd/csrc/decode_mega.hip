@@ -204,6 +204,19 @@ __device__ __forceinline__ void mega_issue_row(u32x4* wv, const bf16_t* w, int n
 //                       wo dots) instead of behind the workgroup's attention partial -- nothing streams during the split-partial and the
 //                       attention-vector hops;
 //   MEGA_WO_AFTER_QKV:  the wo row is requested when q / k / v have arrived instead of in front of their poll.
+// how far the loops over the utterances of an engine of 2 / 4 are unrolled in the wqkv (P0) and w1|w3 (P3) phases: 1 = rolled (round 2:
+// unrolled they interleaved the utterances' temporaries and spilled 60-190 VGPRs; with the launch arguments out of the way 2 fits)
+#ifndef MEGA_NU_UNROLL_P0
+#define MEGA_NU_UNROLL_P0 1
+#endif
+#ifndef MEGA_NU_UNROLL_P3
+#define MEGA_NU_UNROLL_P3 1
+#endif
+// MEGA_W3_QKV_ROWS (one utterance, bf16): that many of the wave's three w3 rows are requested together with the wo row, under the q / k / v
+// hand-off (8 MB of wo in a ~2 us hop leave room), the rest behind the h publish as before (23 MB there: the hop is stream-bound).
+#ifndef MEGA_W3_QKV_ROWS
+#define MEGA_W3_QKV_ROWS 0
+#endif
 #ifndef MEGA_W1_AFTER_ATTN
 #define MEGA_W1_AFTER_ATTN 0
 #endif
@@ -564,7 +577,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         mega_norm<NU>(xs, nw_attn, red, a.eps, tid_p);
         MG_STAMP(l, 12);  // norm done
         if (MEGA_KV_AFTER_NORM && first_att >= 0 && kv_here) { issue_kv(first_att, l); __builtin_amdgcn_sched_barrier(0); }
-#pragma unroll 1
+#pragma unroll MEGA_NU_UNROLL_P0
         for (int u = 0; u < NU; ++u) {
             float acc[3][2];
             if (I4) mega_dots_i4<1, 3, MG_DIM>(cq, cz, xs[u], MG_DIM, lane_p, acc);
@@ -613,11 +626,6 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         }
         __builtin_amdgcn_sched_barrier(0);
         MG_STAMP(l, 2);
-        if constexpr (ATTN_DB) {
-            if (any_att && at_s + 1 < GEO(2, at_u)) issue_kv_set(std::integral_constant<int, 1>{}, at_u, l, at_s + 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-
         // next: wo row 8 b + wave.  Publish-before-prefetch (profiles/r01g_handoff/NOTES.md): a wave that still has something to
         // publish does so BEFORE it queues its next weight loads -- the memory pipeline accepts loads only as fast as it
         // drains them, so a publish behind 100-200 KB of requests reaches its consumers microseconds late.
@@ -634,9 +642,11 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }
             else mega_issue_row<4>(wv + 12, L.wo, 8 * b + wave_o, MG_DIM, lane_o, MG_ABLATE);
         };
-        auto request_w3 = [&]() {  // 22 rows per block: waves 0..5 take 3, waves 6, 7 take 2 (third slot clamped, masked)
+        constexpr int W3_AT_QKV = (NU == 1 && WF == MV_W_BF16 && !(EARLY_ANY && MEGA_EARLY_W1 && MEGA_W3_EARLY)) ? MEGA_W3_QKV_ROWS : 0;
+        auto request_w3 = [&](int i0 = 0, int i1 = 3) {  // 22 rows per block: waves 0..5 take 3, waves 6, 7 take 2 (third slot clamped, masked)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
+                if (i < i0 || i >= i1) continue;
                 if (I4) mega_issue_row_i4<1>(cq + 3 + i, cz + 3 + i, L.q[3], L.sz[3], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
                 else if (I8) { mega_issue_row_i8<2>(cq + 6 + 2 * i, L.q8[3], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o); sc_b[i] = bf2f(load_global_u16(L.s8[3] + (min(rb13 + i, MG_INTER - 1)))); }
                 else mega_issue_row<4>(wv + 12 + 4 * i, L.w3, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o, MG_ABLATE);
@@ -670,12 +680,13 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         // requests in this CU's memory pipeline reaches the combiner -- on everybody's critical path -- microseconds late.  So the
         // other waves of an attending workgroup hold their requests (the next utterance's K/V, then wo | w1) until wave 0 is through.
         constexpr bool W1_LATE = NU == 1 && MEGA_W1_AFTER_ATTN, WO_LATE = NU == 1 && MEGA_WO_AFTER_QKV;
-        if (!any_att) { request_wo(); if (!W1_LATE) request_w1(); }
+        if (!any_att) { request_wo(); if (W3_AT_QKV > 0) request_w3(3 - W3_AT_QKV, 3); if (!W1_LATE) request_w1(); }
         if (any_att) {
             __syncthreads();
             // every wave of the block has published its q/k/v rows: the wo row (8 MB chip-wide, ~1 us of stream) is requested HERE, under
             // the q/k/v hand-off, which costs its ~1.7 us of latency whatever is queued behind it; w1 follows after the attention
             if (!WO_LATE) request_wo();
+            if (W3_AT_QKV > 0) request_w3(3 - W3_AT_QKV, 3);   // the LAST rows: wv[16..23] / wv[20..23], idle until the h publish
             {   // q, k_new, v_new of head at_h of every utterance this block attends for: 3 x 128 row-paired granules each
                 const int sec = tid_o >> 7, c = tid_o & 127;
                 const gran_t* gq = g_qkv;
@@ -711,6 +722,12 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }
             if constexpr (ATTN_V2) {
                 // ---- this workgroup's key ranges at_s .. at_s + SPB - 1 of (at_u, at_r, at_h), two register sets in flight ----
+                // The second range goes out HERE, behind the q / k / v poll: every poll ends in `s_waitcnt vmcnt(0)`, and loads retire in
+                // order -- requested in front of the poll (r04g: "q/k/v ready" 4.7 us) the poll waited for the whole second range.
+                if constexpr (ATTN_DB) {
+                    if (at_s + 1 < GEO(2, at_u)) issue_kv_set(std::integral_constant<int, 1>{}, at_u, l, at_s + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 const int u = at_u;
                 // opaque ids: the publish / poll addresses below are functions of the lane -- hoisted out of the layer loop they are spilled, and a
                 // scratch reload in front of a publish waits for every K/V row in flight
@@ -906,7 +923,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 17);  // h published
             // next: the w3 rows (w1 is already in flight) -- unless they went out with w1 (MEGA_W3_EARLY)
-            if (!W3_EARLY) request_w3();
+            if (!W3_EARLY) request_w3(0, 3 - W3_AT_QKV);
             if (MEGA_KV_EARLY && first_att >= 0 && l + 1 < n_layer) issue_kv(first_att, l + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -928,7 +945,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             MG_STAMP(l, 18);  // norm done
             const int nrows = wave_p < 6 ? 3 : 2;
             const int rb = 22 * b + (wave_p < 6 ? 3 * wave_p : 18 + 2 * (wave_p - 6));
-#pragma unroll 1
+#pragma unroll MEGA_NU_UNROLL_P3
             for (int u = 0; u < NU; ++u) {
                 float acc1[3][2], acc3[3][2];
                 if (I4) {

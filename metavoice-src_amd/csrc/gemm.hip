@@ -143,6 +143,117 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs a) {
         }
 }
 
+// ---- few rows (a prefill: M = 2T ~ 256), big matrices: 64 columns x ALL rows per block -------------------------------------------
+// With 64 x 64 tiles a prefill re-reads every weight tile M / 64 times through L2 and leaves each block a chain of short dependent
+// K-steps: mv_begin spent 4.0 ms on 2.5 GB of weights (0.62 TB/s, round 3).  Here (cdna_hip_programming.md section 5, "M = 256
+// projection GEMM") a block owns 64 output columns for a whole 256-row tile: the W tile is streamed once and shared by the block's 8
+// waves (wave w: rows 32 w .. 32 w + 31, 2 x 4 MFMA tiles), the activations (1 MB at K = 2048: L2-resident, re-read by every column
+// block) go through LDS in full 128-byte lines, two LDS buffers so that a K-step costs one barrier, the next step's global loads in
+// flight under the current step's 16 MFMAs per wave; K is split over blockIdx.z until ~one block per CU is resident.  Same fragment
+// mapping, same epilogues (gemm_epilogue) and the same fixed-order split-K combine as gemm_bf16_kernel.
+#define SK_BM 256
+#define SK_LDS_BYTES (2 * (SK_BM * 8 + 2 * GT * 8) * 16)   // two buffers of A [256][8 chunks] + W [64][8] + W2 [64][8], 16-byte chunks
+__global__ void __launch_bounds__(512) gemm_skinny_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 sk_lds[];
+    constexpr int BUF = SK_BM * 8 + 2 * GT * 8;   // chunks per buffer
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile_m = blockIdx.y * SK_BM, tile_n = blockIdx.x * GT;
+    const bool gated = a.w2 != nullptr;
+    const int M = a.M, N = a.N, K = a.K;
+    // staging: thread owns chunk (tid & 7) of A rows (tid >> 3) + 64 i (i < 4) and of W row (tid >> 3)
+    const int sr = tid >> 3, sc = tid & 7;
+    const bf16_t* ga[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ga[i] = a.a + (size_t)min(tile_m + sr + 64 * i, M - 1) * a.lda + sc * 8;
+    const bf16_t* gw = a.w + (size_t)min(tile_n + sr, N - 1) * K + sc * 8;
+    const bf16_t* gv = gated ? a.w2 + (size_t)min(tile_n + sr, N - 1) * K + sc * 8 : nullptr;
+    int sa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sa[i] = (sr + 64 * i) * 8 + (sc ^ ((sr + 64 * i) & 7));
+    const int sw = SK_BM * 8 + sr * 8 + (sc ^ (sr & 7)), sv = sw + GT * 8;
+
+    f32x4_t acc[2][4], acc2[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[i][j] = f32x4_t{0, 0, 0, 0}; acc2[i][j] = f32x4_t{0, 0, 0, 0}; }
+
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    const int ksteps = (K + GT - 1) / GT, per = (ksteps + a.splitk - 1) / a.splitk;
+    const int kb = (int)blockIdx.z * per * GT, ke = min(K, (int)(blockIdx.z + 1) * per * GT);
+    u32x4 ra[4], rw = zero, rv = zero;
+    auto fetch = [&](int k0) {
+        const bool in = k0 + sc * 8 < ke;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = in ? load16(ga[i] + k0) : zero;
+        rw = in ? load16(gw + k0) : zero;
+        if (gated) rv = in ? load16(gv + k0) : zero;
+    };
+    auto stage = [&](int buf) {
+        u32x4* L = sk_lds + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) L[sa[i]] = ra[i];
+        L[sw] = rw;
+        if (gated) L[sv] = rv;
+    };
+    if (kb < ke) {
+        fetch(kb);
+        stage(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kb; k0 < ke; k0 += GT) {
+        const bool more = k0 + GT < ke;
+        if (more) fetch(k0 + GT);   // next step's loads fly under this step's MFMAs
+        const u32x4* L = sk_lds + buf * BUF;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t af[2], bf[4], cf[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = wave * 32 + i * 16 + (lane & 15);
+                af[i] = __builtin_bit_cast(bf16x8_t, L[r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = j * 16 + (lane & 15);
+                bf[j] = __builtin_bit_cast(bf16x8_t, L[SK_BM * 8 + r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
+                if (gated) cf[j] = __builtin_bit_cast(bf16x8_t, L[SK_BM * 8 + GT * 8 + r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    if (gated) acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], cf[j], acc2[i][j], 0, 0, 0);
+                }
+        }
+        if (more) stage(buf ^ 1);   // the other buffer: last read before the barrier that ended the previous step
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* slab = a.splitk > 1 ? a.slab + (size_t)blockIdx.z * M * N : nullptr;
+    float* slab2 = a.splitk > 1 && gated ? a.slab + ((size_t)a.splitk + blockIdx.z) * M * N : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = tile_n + j * 16 + (lane & 15);
+            if (n >= N) continue;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int m = tile_m + wave * 32 + i * 16 + (lane >> 4) * 4 + reg;
+                if (m >= M) continue;
+                if (slab) {
+                    slab[(size_t)m * N + n] = acc[i][j][reg];
+                    if (slab2) slab2[(size_t)m * N + n] = acc2[i][j][reg];
+                } else {
+                    gemm_epilogue(a, m, n, acc[i][j][reg], acc2[i][j][reg]);
+                }
+            }
+        }
+}
+
 // split-K tail: partial tiles added in range order (fixed: the result does not depend on which block finished first), then the epilogue
 __global__ void __launch_bounds__(256) gemm_combine_kernel(const GemmArgs a) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, MN = (size_t)a.M * a.N;
@@ -161,6 +272,22 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& a_in) {
     // split K (2, 4 or 8 ranges) while the tile grid alone is below ~4 blocks per CU (1024) and every range keeps >= 4 steps: a block's K-loop is a
     // chain of dependent load round trips, so what fills the memory system is the number of resident blocks
     a.splitk = 1;
+    // few rows, big matrix (a prefill): 64 columns x all rows per block, K split until ~one block per CU is resident.  MV_GEMM_NO_SKINNY=1
+    // keeps the 64 x 64 tiles (A/B runs, tests).
+    if (a.M >= 96 && a.K >= 512 && a.N >= 512 && a.M <= 8 * SK_BM && !getenv("MV_GEMM_NO_SKINNY")) {
+        const int mt256 = (a.M + SK_BM - 1) / SK_BM;
+        if (a.slab && !getenv("MV_GEMM_NO_SPLITK"))
+            while (a.splitk < 8 && (size_t)nt * mt256 * a.splitk * 2 <= 320 && ksteps / (a.splitk * 2) >= 4) a.splitk *= 2;
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_skinny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES);
+            if (e != hipSuccess) return e;
+            raised = true;
+        }
+        hipLaunchKernelGGL(gemm_skinny_kernel, dim3(nt, mt256, a.splitk), dim3(512), SK_LDS_BYTES, s, a);
+        if (a.splitk > 1) hipLaunchKernelGGL(gemm_combine_kernel, dim3((unsigned)(((size_t)a.M * a.N + 255) / 256)), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     if (a.slab && !getenv("MV_GEMM_NO_SPLITK"))
         while (a.splitk < 8 && (size_t)nt * mt * a.splitk < 1024 && ksteps / (a.splitk * 2) >= 4) a.splitk *= 2;
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3(nt, mt, a.splitk), dim3(256), 0, s, a);
