@@ -439,6 +439,15 @@ def measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline):
                                        "note": f"hardware: {flops / 1e12:.0f} TFLOP of bf16 MFMA work per utterance ({a.mbd_precision} terms per product); useful: {useful / 1e12:.0f} TFLOP "
                                                "of fp32-class multiply-accumulates (for scale: gfx950's exact-fp32 MFMA peaks at 157 TFLOP/s); both over the WHOLE stage time, "
                                                "which also holds its element-wise / GroupNorm / FIR kernels (a lower bound for the GEMM kernels themselves: profiles/)"}
+            # the stage's HBM-bound kernels as achieved GB/s (north_star): from the rocprofv3 --stats summary of one default bench step,
+            # reduced by tools/vocoder_hbm.py (a process cannot profile itself; the committed summary is quoted with its source)
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "vocoder_hbm_kernels.json")) as f:
+                    hk = json.load(f)
+                out["vocoder_roofline"]["hbm_kernels"] = {k: {x: v[x] for x in ("achieved_GBs", "frac_of_8TBs", "avg_us", "calls")} for k, v in hk["kernels"].items()}
+                out["vocoder_roofline"]["hbm_kernels_source"] = hk["source"]
+            except (OSError, KeyError, ValueError):
+                pass
         if with_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(mv, cfgk)

@@ -1254,6 +1254,32 @@ static hipError_t launch_mega_format(hipStream_t s, const MegaArgs& a) {
         default: return hipErrorInvalidValue;
     }
 }
+// Residency check in front of the first launch (instead of finding out by a time-out): the hand-offs need all 256 workgroups resident at once,
+// i.e. >= 1 workgroup of this instance per CU by the occupancy query (registers, LDS) and >= 256 CUs.  What the query cannot see -- another
+// process or stream holding CUs -- is still caught by the bounded waits (mv_run then redoes the launch with per-layer launches).
+template <int WF, int NU, bool FOLD>
+static bool mega_instance_fits(int n_cus) {
+    const size_t lds = mega_lds_bytes(NU) + (mega_early_rows(WF, NU) ? MEGA_EARLY_W2_BYTES + MEGA_EARLY_W1_BYTES : 0);
+    if (hipFuncSetAttribute((const void*)decode_mega_kernel<WF, NU, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)decode_mega_kernel<WF, NU, FOLD>, MG_THREADS, lds) != hipSuccess) return false;
+    return per_cu >= 1 && (long)per_cu * n_cus >= 256;
+}
+template <int WF>
+static bool mega_format_fits(int n_utt, int n_cus) {
+    switch (n_utt) {
+        case 1: return mega_instance_fits<WF, 1, false>(n_cus) && (WF == MV_W_INT8 && !MEGA_FOLD_INT8 ? true : mega_instance_fits<WF, 1, MEGA_FOLD_INT8 || WF != MV_W_INT8>(n_cus));
+        case 2: return mega_instance_fits<WF, 2, false>(n_cus);
+        case 4: return mega_instance_fits<WF, 4, false>(n_cus);
+        default: return false;
+    }
+}
+bool mega_fits(int weight_format, int n_utt, int n_cus) {
+    if (weight_format == MV_W_INT4_G128) return mega_format_fits<MV_W_INT4_G128>(n_utt, n_cus);
+    if (weight_format == MV_W_INT8) return mega_format_fits<MV_W_INT8>(n_utt, n_cus);
+    return mega_format_fits<MV_W_BF16>(n_utt, n_cus);
+}
+
 hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a, int weight_format) {
     if (weight_format == MV_W_INT4_G128) return launch_mega_format<MV_W_INT4_G128>(s, a);
     if (weight_format == MV_W_INT8) return launch_mega_format<MV_W_INT8>(s, a);

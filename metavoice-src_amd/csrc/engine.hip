@@ -659,7 +659,9 @@ int mv_finalize(mv_engine* e) {
         int dev = 0, n_cus = 0;
         HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev));
-        e->mega_ok = mega_supported(c, R, n_cus);  // every weight format has an instance of the persistent kernel
+        // every weight format has an instance of the persistent kernel; whether its 256 workgroups can be resident together is asked
+        // here (occupancy query), not discovered by a time-out in the first mv_run
+        e->mega_ok = mega_supported(c, R, n_cus) && mega_fits(c.weight_format, c.max_utterances, n_cus);
         if (e->mega_ok) {
             std::vector<MegaLayer> ml(c.n_layer);
             for (int l = 0; l < c.n_layer; ++l) {

@@ -152,49 +152,64 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs a) {
 // flight under the current step's 16 MFMAs per wave; K is split over blockIdx.z until ~one block per CU is resident.  Same fragment
 // mapping, same epilogues (gemm_epilogue) and the same fixed-order split-K combine as gemm_bf16_kernel.
 #define SK_BM 256
-#define SK_LDS_BYTES (2 * (SK_BM * 8 + 2 * GT * 8) * 16)   // two buffers of A [256][8 chunks] + W [64][8] + W2 [64][8], 16-byte chunks
+// NT = 16-column MFMA tiles per wave = block columns / 16: 4 (64 columns) or 8 (128 columns: half the activation bytes per weight byte --
+// the activation tile, re-read from L2 by every column block, is what bounds this shape: r04k, both tile shapes at 1.2 TB/s of weights)
+template <int NT>
 __global__ void __launch_bounds__(512) gemm_skinny_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 sk_lds[];
-    constexpr int BUF = SK_BM * 8 + 2 * GT * 8;   // chunks per buffer
+    constexpr int BNS = NT * 16, WCH = BNS * 8;        // block columns; chunks of one W tile
+    constexpr int BUF = SK_BM * 8 + 2 * WCH;           // chunks per buffer: A [256][8] + W [BNS][8] + W2 [BNS][8]
+    constexpr int WPT = BNS / 64;                      // W rows staged per thread
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile_m = blockIdx.y * SK_BM, tile_n = blockIdx.x * GT;
+    const int tile_m = blockIdx.y * SK_BM, tile_n = blockIdx.x * BNS;
     const bool gated = a.w2 != nullptr;
     const int M = a.M, N = a.N, K = a.K;
-    // staging: thread owns chunk (tid & 7) of A rows (tid >> 3) + 64 i (i < 4) and of W row (tid >> 3)
+    // staging: thread owns chunk (tid & 7) of A rows (tid >> 3) + 64 i (i < 4) and of W rows (tid >> 3) + 64 j (j < WPT)
     const int sr = tid >> 3, sc = tid & 7;
     const bf16_t* ga[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) ga[i] = a.a + (size_t)min(tile_m + sr + 64 * i, M - 1) * a.lda + sc * 8;
-    const bf16_t* gw = a.w + (size_t)min(tile_n + sr, N - 1) * K + sc * 8;
-    const bf16_t* gv = gated ? a.w2 + (size_t)min(tile_n + sr, N - 1) * K + sc * 8 : nullptr;
-    int sa[4];
+    const bf16_t *gw[WPT], *gv[WPT];
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        gw[j] = a.w + (size_t)min(tile_n + sr + 64 * j, N - 1) * K + sc * 8;
+        gv[j] = gated ? a.w2 + (size_t)min(tile_n + sr + 64 * j, N - 1) * K + sc * 8 : nullptr;
+    }
+    int sa[4], sw[WPT];
 #pragma unroll
     for (int i = 0; i < 4; ++i) sa[i] = (sr + 64 * i) * 8 + (sc ^ ((sr + 64 * i) & 7));
-    const int sw = SK_BM * 8 + sr * 8 + (sc ^ (sr & 7)), sv = sw + GT * 8;
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) sw[j] = SK_BM * 8 + (sr + 64 * j) * 8 + (sc ^ ((sr + 64 * j) & 7));
 
-    f32x4_t acc[2][4], acc2[2][4];
+    f32x4_t acc[2][NT], acc2[2][NT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { acc[i][j] = f32x4_t{0, 0, 0, 0}; acc2[i][j] = f32x4_t{0, 0, 0, 0}; }
+        for (int j = 0; j < NT; ++j) { acc[i][j] = f32x4_t{0, 0, 0, 0}; acc2[i][j] = f32x4_t{0, 0, 0, 0}; }
 
     const u32x4 zero = {0u, 0u, 0u, 0u};
     const int ksteps = (K + GT - 1) / GT, per = (ksteps + a.splitk - 1) / a.splitk;
     const int kb = (int)blockIdx.z * per * GT, ke = min(K, (int)(blockIdx.z + 1) * per * GT);
-    u32x4 ra[4], rw = zero, rv = zero;
+    u32x4 ra[4], rw[WPT], rv[WPT];
     auto fetch = [&](int k0) {
         const bool in = k0 + sc * 8 < ke;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[i] = in ? load16(ga[i] + k0) : zero;
-        rw = in ? load16(gw + k0) : zero;
-        if (gated) rv = in ? load16(gv + k0) : zero;
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            rw[j] = in ? load16(gw[j] + k0) : zero;
+            rv[j] = gated && in ? load16(gv[j] + k0) : zero;
+        }
     };
     auto stage = [&](int buf) {
         u32x4* L = sk_lds + buf * BUF;
 #pragma unroll
         for (int i = 0; i < 4; ++i) L[sa[i]] = ra[i];
-        L[sw] = rw;
-        if (gated) L[sv] = rv;
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            L[sw[j]] = rw[j];
+            if (gated) L[sw[j] + WCH] = rv[j];
+        }
     };
     if (kb < ke) {
         fetch(kb);
@@ -208,43 +223,46 @@ __global__ void __launch_bounds__(512) gemm_skinny_kernel(const GemmArgs a) {
         const u32x4* L = sk_lds + buf * BUF;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t af[2], bf[4], cf[4];
+            bf16x8_t af[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int r = wave * 32 + i * 16 + (lane & 15);
                 af[i] = __builtin_bit_cast(bf16x8_t, L[r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = j * 16 + (lane & 15);
-                bf[j] = __builtin_bit_cast(bf16x8_t, L[SK_BM * 8 + r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
-                if (gated) cf[j] = __builtin_bit_cast(bf16x8_t, L[SK_BM * 8 + GT * 8 + r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7))]);
-            }
+            for (int j = 0; j < NT; ++j) {
+                const int r = j * 16 + (lane & 15), idx = SK_BM * 8 + r * 8 + ((kk * 4 + (lane >> 4)) ^ (r & 7));
+                const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, L[idx]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+                if (gated) {
+                    const bf16x8_t cf = __builtin_bit_cast(bf16x8_t, L[idx + WCH]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-                    if (gated) acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], cf[j], acc2[i][j], 0, 0, 0);
+                    for (int i = 0; i < 2; ++i) acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], cf, acc2[i][j], 0, 0, 0);
                 }
+            }
         }
         if (more) stage(buf ^ 1);   // the other buffer: last read before the barrier that ended the previous step
         __syncthreads();
         buf ^= 1;
     }
-    float* slab = a.splitk > 1 ? a.slab + (size_t)blockIdx.z * M * N : nullptr;
-    float* slab2 = a.splitk > 1 && gated ? a.slab + ((size_t)a.splitk + blockIdx.z) * M * N : nullptr;
+    // NT = 8 always leaves fp32 partial tiles (launch_gemm runs the combine kernel behind it even for one K range): 64 inlined copies of
+    // the epilogue are past hipcc's full-unroll budget, and a loop it does not unroll indexes the accumulators dynamically -- they went
+    // to scratch memory (528 bytes per lane)
+    const bool to_slab = a.splitk > 1 || NT == 8;
+    float* slab = to_slab ? a.slab + (size_t)blockIdx.z * M * N : nullptr;
+    float* slab2 = to_slab && gated ? a.slab + ((size_t)a.splitk + blockIdx.z) * M * N : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NT; ++j) {
             const int n = tile_n + j * 16 + (lane & 15);
             if (n >= N) continue;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int m = tile_m + wave * 32 + i * 16 + (lane >> 4) * 4 + reg;
                 if (m >= M) continue;
-                if (slab) {
+                if (NT == 8 || slab) {
                     slab[(size_t)m * N + n] = acc[i][j][reg];
                     if (slab2) slab2[(size_t)m * N + n] = acc2[i][j][reg];
                 } else {
@@ -253,6 +271,7 @@ __global__ void __launch_bounds__(512) gemm_skinny_kernel(const GemmArgs a) {
             }
         }
 }
+template <int NT> constexpr int sk_lds_bytes() { return 2 * (SK_BM * 8 + 2 * NT * 16 * 8) * 16; }
 
 // split-K tail: partial tiles added in range order (fixed: the result does not depend on which block finished first), then the epilogue
 __global__ void __launch_bounds__(256) gemm_combine_kernel(const GemmArgs a) {
@@ -272,20 +291,27 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& a_in) {
     // split K (2, 4 or 8 ranges) while the tile grid alone is below ~4 blocks per CU (1024) and every range keeps >= 4 steps: a block's K-loop is a
     // chain of dependent load round trips, so what fills the memory system is the number of resident blocks
     a.splitk = 1;
-    // few rows, big matrix (a prefill): 64 columns x all rows per block, K split until ~one block per CU is resident.  MV_GEMM_NO_SKINNY=1
-    // keeps the 64 x 64 tiles (A/B runs, tests).
-    if (a.M >= 96 && a.K >= 512 && a.N >= 512 && a.M <= 8 * SK_BM && !getenv("MV_GEMM_NO_SKINNY")) {
+    // few rows, big matrix (a prefill): 64 / 128 columns x all rows per block, K split until ~one block per CU is resident -- behind
+    // MV_GEMM_SKINNY=1 (tests, A/B runs): measured on the prefill it is NOT faster than the 64 x 64 tiles (r04j-r04l: mv_begin 3.7-3.9 ms
+    // at T = 128 with either, every GEMM launch ~21.6 us = 1.2 TB/s of weights whatever the tiling -- with one K-step of prefetch distance a
+    // block is a chain of dependent load round trips and the resident blocks hold too few bytes in flight; 8.4 vs 7.9 ms at T = 512).
+    if (a.M >= 96 && a.K >= 512 && a.N >= 512 && a.M <= 8 * SK_BM && getenv("MV_GEMM_SKINNY") && !getenv("MV_GEMM_NO_SKINNY")) {
         const int mt256 = (a.M + SK_BM - 1) / SK_BM;
+        const char* cols_env = getenv("MV_GEMM_SKINNY_COLS");   // A/B: 64 or 128 columns per block (default 128)
+        const int cols = (cols_env ? atoi(cols_env) : 128) == 64 || !a.slab ? 64 : 128;   // the 128-column instance needs the partial-tile slab
+        const int ntc = (a.N + cols - 1) / cols;
         if (a.slab && !getenv("MV_GEMM_NO_SPLITK"))
-            while (a.splitk < 8 && (size_t)nt * mt256 * a.splitk * 2 <= 320 && ksteps / (a.splitk * 2) >= 4) a.splitk *= 2;
+            while (a.splitk < 8 && (size_t)ntc * mt256 * a.splitk * 2 <= 320 && ksteps / (a.splitk * 2) >= 4) a.splitk *= 2;
         static bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_skinny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES);
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_skinny_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, sk_lds_bytes<4>());
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_skinny_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, sk_lds_bytes<8>());
             if (e != hipSuccess) return e;
             raised = true;
         }
-        hipLaunchKernelGGL(gemm_skinny_kernel, dim3(nt, mt256, a.splitk), dim3(512), SK_LDS_BYTES, s, a);
-        if (a.splitk > 1) hipLaunchKernelGGL(gemm_combine_kernel, dim3((unsigned)(((size_t)a.M * a.N + 255) / 256)), dim3(256), 0, s, a);
+        if (cols == 64) hipLaunchKernelGGL(gemm_skinny_kernel<4>, dim3(ntc, mt256, a.splitk), dim3(512), sk_lds_bytes<4>(), s, a);
+        else hipLaunchKernelGGL(gemm_skinny_kernel<8>, dim3(ntc, mt256, a.splitk), dim3(512), sk_lds_bytes<8>(), s, a);
+        if (a.splitk > 1 || cols == 128) hipLaunchKernelGGL(gemm_combine_kernel, dim3((unsigned)(((size_t)a.M * a.N + 255) / 256)), dim3(256), 0, s, a);
         return hipGetLastError();
     }
     if (a.slab && !getenv("MV_GEMM_NO_SPLITK"))

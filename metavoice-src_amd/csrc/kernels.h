@@ -296,6 +296,7 @@ struct MegaArgs {
     uint32_t* step_counter_out = nullptr;  // = step_counter: advanced once per step by block 0
 };
 bool mega_supported(const mv_config& c, int rows, int n_cus);
+bool mega_fits(int weight_format, int n_utt, int n_cus);  // occupancy query: one workgroup of the instance per CU, 256 resident (asked once, at mv_finalize)
 bool mega_instrumented();  // decode_mega.hip was built with -DMEGA_INSTR=1 (phase stamps, debug vectors, the no-weights ablation)
 bool mega_folds(const mv_config& c);  // the persistent kernel of this configuration draws its own tokens (several steps per launch)
 hipError_t launch_decode_mega(hipStream_t s, const MegaArgs& a, int weight_format);  // every wave prefetches its weight rows into registers; bf16 or int4

@@ -1368,10 +1368,12 @@ void launch_norm_act(hipStream_t s, const UnetBuffers& ub, const float* x, int64
 }
 
 // x [band][T][C] fp32 -> ResBlock(x) into `out` (may alias x): x + conv2(act(gn2(conv1(act(gn1(x))))))  (+ col_add); rw(b) = band b's weights
-// out_gf (optional): also leave the GroupNorm partials of the block's OUTPUT (stats_of_gemm_output turns them into statistics)
+// out_gf (optional): also leave the GroupNorm partials of the block's OUTPUT (stats_of_gemm_output turns them into statistics);
+// in_gf (optional): the partials of the block's INPUT, left by the GEMM that produced it (the previous ResBlock's conv2, round 4: the
+// two-pass statistics of that tensor -- one more read of 59 MB per ResBlock -- are gone)
 template <typename RW>
 hipError_t res_block(hipStream_t s, const mv_mbd* m, RW rw, const float* x, int64_t x_band, float* out, int64_t out_band, int T, int C, int dilation, PF col_add,
-                     UnetBuffers& ub, GnFuse* out_gf = nullptr) {
+                     UnetBuffers& ub, GnFuse* out_gf = nullptr, const GnFuse* in_gf = nullptr) {
     const int G = m->cfg.norm_groups, act = m->cfg.act, nb = ub.NB;
     const int pad = dilation;  // kernel 3
     hipError_t e;
@@ -1379,7 +1381,8 @@ hipError_t res_block(hipStream_t s, const mv_mbd* m, RW rw, const float* x, int6
     for (int half = 0; half < 2; ++half) {
         const float* in = half == 0 ? x : ub.b32;
         const int64_t in_band = half == 0 ? x_band : (int64_t)ub.widest;
-        if ((e = half == 0 ? group_stats(s, in, in_band, T, C, G, ub) : stats_of_gemm_output(s, mid, in, in_band, T, C, G, ub)) != hipSuccess) return e;
+        if ((e = half == 0 ? (in_gf ? stats_of_gemm_output(s, *in_gf, in, in_band, T, C, G, ub) : group_stats(s, in, in_band, T, C, G, ub))
+                           : stats_of_gemm_output(s, mid, in, in_band, T, C, G, ub)) != hipSuccess) return e;
         launch_norm_act(s, ub, in, in_band, T, C, G, ub.stats, pf_of(nb, [&](int b) { return (const float*)(half == 0 ? rw(b).n1.g : rw(b).n2.g); }),
                         pf_of(nb, [&](int b) { return (const float*)(half == 0 ? rw(b).n1.b : rw(b).n2.b); }), act, nullptr, 0, ub.hi,
                         m->cfg.precision > 2 ? ub.lo : nullptr, pad, pad);
@@ -1537,10 +1540,13 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
             if (g.res_blocks == 0) return mv_fail(MV_ERR_INVALID, "res_blocks = 0 is not supported");
             launch_norm_act(s, ub, ub.a32, WB, To, Cout, G, ub.stats, pf_of(NB, [&](int b) { return (const float*)E(b).norm.g; }),
                             pf_of(NB, [&](int b) { return (const float*)E(b).norm.b; }), g.act, ub.c32, WB, nullptr, nullptr, 0, 0);
+            GnFuse chain{G, ub.part, 0};   // ResBlock r's output partials = ResBlock r + 1's input statistics
             for (int r = 0; r < g.res_blocks; ++r) {
                 const bool lastr = r == g.res_blocks - 1;
+                const GnFuse in_gf = chain;
                 MG_TRY(res_block(s, m, [&](int b) -> const ResW& { return E(b).res[r]; }, ub.c32, WB, lastr ? ub.skip[i] : ub.c32,
-                                 lastr ? (int64_t)ub.skip_band[i] : WB, To, Cout, 1 << r, lastr ? emb : PF{}, ub));
+                                 lastr ? (int64_t)ub.skip_band[i] : WB, To, Cout, 1 << r, lastr ? emb : PF{}, ub, lastr ? nullptr : &chain,
+                                 r > 0 && in_gf.tiles > 0 ? &in_gf : nullptr));
             }
             zin = ub.skip[i];
             zin_band = (int64_t)ub.skip_band[i];
@@ -1590,10 +1596,12 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
             // z = z[:, :, :skip.T] + skip   (z rows beyond skip.T are dropped; z never is shorter)
             const size_t n = (size_t)Ts * C;
             hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256), NB), dim3(256), 0, s, ub.skip[lvl], (int64_t)ub.skip_band[lvl], z, z_band, ub.c32, WB, n);
-            GnFuse dec_gf{G, ub.part, 0};
-            for (int r = 0; r < g.res_blocks; ++r)
+            GnFuse dec_gf{G, ub.part, 0};   // every ResBlock leaves its output partials: the next one's input statistics, then the decoder norm's
+            for (int r = 0; r < g.res_blocks; ++r) {
+                const GnFuse in_gf = dec_gf;
                 MG_TRY(res_block(s, m, [&](int b) -> const ResW& { return Dw(b).res[r]; }, ub.c32, WB, ub.c32, WB, Ts, C, 1 << r, PF{}, ub,
-                                 r == g.res_blocks - 1 ? &dec_gf : nullptr));
+                                 &dec_gf, r > 0 && in_gf.tiles > 0 ? &in_gf : nullptr));
+            }
             MG_TRY(stats_of_gemm_output(s, dec_gf, ub.c32, WB, Ts, C, G, ub));
             const PF ng = pf_of(NB, [&](int b) { return (const float*)Dw(b).norm.g; }), nbias = pf_of(NB, [&](int b) { return (const float*)Dw(b).norm.b; });
             if (lvl == 0) {

@@ -45,16 +45,18 @@ def close_bf16(got, ref, ulps, atol):
 @pytest.mark.parametrize("M,N_,K", [(256, 6144, 2048), (220, 2048, 2048), (256, 2048, 5632), (64, 1025, 384), (37, 100, 72), (2048, 384, 1024),
                                     (600, 1090, 2048), (2200, 640, 1032)])
 @pytest.mark.parametrize("mode", ["plain", "bias_resid", "gated", "gelu"])
-@pytest.mark.parametrize("splitk,tiles", [(True, "auto"), (False, "auto"), (True, "64x64")])
+@pytest.mark.parametrize("splitk,tiles", [(True, "auto"), (False, "auto"), (True, "64x64"), (True, "skinny64")])
 def test_gemm(M, N_, K, mode, splitk, tiles, monkeypatch):
-    """The MFMA GEMMs with every epilogue.  `tiles`: "auto" = what `launch_gemm` picks -- `gemm_skinny_kernel` (64 columns x a whole
-    256-row tile per block, round 4: the prefill shapes, M >= 96 and K, N >= 512; ragged M and N, K not a multiple of 64 included),
-    else `gemm_bf16_kernel` (64 x 64 tiles); "64x64" forces the latter (MV_GEMM_NO_SKINNY).  `splitk`: few-row / deep-K shapes run as
+    """The MFMA GEMMs with every epilogue.  `tiles`: "64x64" = `gemm_bf16_kernel`, what the engines run; "auto" / "skinny64" =
+    `gemm_skinny_kernel` (128 / 64 columns x a whole 256-row tile per block, round 4, opt-in through MV_GEMM_SKINNY: the prefill
+    shapes, M >= 96 and K, N >= 512; ragged M and N, K not a multiple of 64 included), else the 64 x 64 tiles.  `splitk`: few-row / deep-K shapes run as
     up to eight K ranges + `gemm_combine_kernel` (the default when the caller hands in scratch), or as one range (MV_GEMM_NO_SPLITK)."""
     if not splitk:
         monkeypatch.setenv("MV_GEMM_NO_SPLITK", "1")
-    if tiles == "64x64":
-        monkeypatch.setenv("MV_GEMM_NO_SKINNY", "1")
+    if tiles != "64x64":      # gemm_skinny_kernel is opt-in (measured no faster than the 64 x 64 tiles on the prefill: profiles/r04j-r04l)
+        monkeypatch.setenv("MV_GEMM_SKINNY", "1")
+    if tiles == "skinny64":   # its 64-column instance (128 columns per block otherwise)
+        monkeypatch.setenv("MV_GEMM_SKINNY_COLS", "64")
     g = torch.Generator().manual_seed(M + N_ + K)
     a = rb(torch.randn(M, K, generator=g))
     w = rb(torch.randn(N_, K, generator=g) * 0.05)

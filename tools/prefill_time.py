@@ -19,9 +19,10 @@ spk, sp = mv.synthetic.speaker_embedding(0), mv.SamplingParams(top_k=1, guidance
 for T in [int(x) for x in os.environ.get("PREFILL_T", "50,128,256,512,1100,2016").split(",")]:
     prompt = mv.synthetic.prompt_tokens(T, seed=0)
     row = []
-    for tiles in ("skinny", "64x64"):
-        if tiles == "64x64": os.environ["MV_GEMM_NO_SKINNY"] = "1"
-        else: os.environ.pop("MV_GEMM_NO_SKINNY", None)
+    for tiles in os.environ.get("PREFILL_MODES", "skinny,skinny64,64x64").split(","):
+        os.environ.pop("MV_GEMM_SKINNY", None); os.environ.pop("MV_GEMM_SKINNY_COLS", None)
+        if tiles != "64x64": os.environ["MV_GEMM_SKINNY"] = "1"
+        if tiles == "skinny64": os.environ["MV_GEMM_SKINNY_COLS"] = "64"
         best = 1e9
         for _ in range(reps):
             torch.cuda.synchronize()
@@ -30,5 +31,5 @@ for T in [int(x) for x in os.environ.get("PREFILL_T", "50,128,256,512,1100,2016"
             best = min(best, (time.perf_counter() - t0) * 1e3)
         e.run(max_steps=1)
         row.append((tiles, best, e.tokens(0)[T]))
-    os.environ.pop("MV_GEMM_NO_SKINNY", None)
+    os.environ.pop("MV_GEMM_SKINNY", None); os.environ.pop("MV_GEMM_SKINNY_COLS", None)
     print(f"T = {T:5d} ({2 * T} rows): " + "; ".join(f"{n} {ms:6.2f} ms (first token {tok})" for n, ms, tok in row), flush=True)
