@@ -235,7 +235,13 @@ __device__ __forceinline__ void mega_issue_row(u32x4* wv, const bf16_t* w, int n
 #ifndef MEGA_ATTN_V2
 #define MEGA_ATTN_V2 1
 #endif
-#define MEGA_EARLY_W2_BYTES (MG_WAVES * 5 * 1024)
+// Engines of 2 / 4 utterances (round 4, MEGA_EARLY_NU): two utterances have the LDS for both (62 + 88 KB); four only for FOUR chunks of
+// the w2 row (121 + 32 KB of 160) -- "P4 top (w2 requested)" was a 3.1 us issue stall per layer there (profiles/r04h).
+#ifndef MEGA_EARLY_NU
+#define MEGA_EARLY_NU 0   // measured: 4 utterances 1375 vs 1339 us/step, 2 utterances 956 vs 926 (profiles/r04m) -- off
+#endif
+__host__ __device__ constexpr int mega_early_w2_chunks(int nu) { return nu == 4 ? 4 : 5; }
+__host__ __device__ constexpr bool mega_early_w1(int nu) { return MEGA_EARLY_W1 && nu <= 2; }
 #define MEGA_EARLY_W1_BYTES (MG_WAVES * 6 * 1024)
 __device__ __forceinline__ void mega_row_to_lds(uint32_t lds, const bf16_t* g, int ablate = 0) {  // 64 lanes x 16 B -> 1 KB of LDS at `lds`
     if (ablate & 1) return;  // profiling only (mv_tune gemv_ablate bit 0): no weight requests at all, results are garbage
@@ -243,7 +249,12 @@ __device__ __forceinline__ void mega_row_to_lds(uint32_t lds, const bf16_t* g, i
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(m0_save) : "s"(lds), "v"(g) : "memory");
 }
-__host__ __device__ constexpr bool mega_early_rows(int wf, int nu) { return wf == MV_W_BF16 && nu == 1 && (MEGA_EARLY_W1 || MEGA_EARLY_W2 || MEGA_EARLY_QKV); }
+__host__ __device__ constexpr bool mega_early_rows(int wf, int nu) {
+    return wf == MV_W_BF16 && (nu == 1 || (MEGA_EARLY_NU && (nu == 2 || nu == 4))) && (MEGA_EARLY_W1 || MEGA_EARLY_W2 || MEGA_EARLY_QKV);
+}
+__host__ __device__ constexpr size_t mega_early_lds_bytes(int wf, int nu) {   // the LDS slots of the early rows, behind mega_lds_bytes(nu)
+    return !mega_early_rows(wf, nu) ? 0 : (size_t)(MEGA_EARLY_W2 ? MG_WAVES * mega_early_w2_chunks(nu) * 1024 : 0) + (mega_early_w1(nu) || MEGA_EARLY_QKV ? MEGA_EARLY_W1_BYTES : 0);
+}
 
 // int4 (group-128) weight rows: per 2048-column chunk a lane requests 16 B of codes (32 columns) and the (scale, zero) word of
 // their 128-column group -- the same loads, and through i4_dots the same arithmetic, as gemv_i4.hip.
@@ -380,10 +391,11 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     float (*sm)[16][12] = (float(*)[16][12])(mg_lds + (size_t)NU * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2));  // [ranges of this workgroup][ATTN_WAVES][16][12]
     float* red = (float*)(sm + (MEGA_ATTN_V2 ? NU : 1) * ATTN_WAVES);  // [NU][MG_WAVES * 2]
     constexpr bool EARLY_ANY = mega_early_rows(WF, NU);
-    constexpr bool EARLY_W2 = EARLY_ANY && MEGA_EARLY_W2, EARLY_W1 = EARLY_ANY && MEGA_EARLY_W1, EARLY_QKV = EARLY_ANY && MEGA_EARLY_QKV;
-    constexpr bool W3_EARLY = EARLY_W1 && MEGA_W3_EARLY;
-    u32x4* w2_lds = (u32x4*)(mg_lds + mega_lds_bytes(1));                        // [MG_WAVES][5 chunks][64 lanes]
-    u32x4* w1_lds = (u32x4*)(mg_lds + mega_lds_bytes(1) + MEGA_EARLY_W2_BYTES);  // [MG_WAVES][3 rows x 2 chunks][64 lanes]; wqkv rows of the next layer between P4 and P0
+    constexpr bool EARLY_W2 = EARLY_ANY && MEGA_EARLY_W2, EARLY_W1 = EARLY_ANY && mega_early_w1(NU), EARLY_QKV = EARLY_ANY && MEGA_EARLY_QKV && NU == 1;
+    constexpr bool W3_EARLY = EARLY_W1 && MEGA_W3_EARLY && NU == 1;
+    constexpr int EW2 = mega_early_w2_chunks(NU);   // chunks of the w2 row that go to LDS early
+    u32x4* w2_lds = (u32x4*)(mg_lds + mega_lds_bytes(NU));                                                        // [MG_WAVES][EW2 chunks][64 lanes]
+    u32x4* w1_lds = (u32x4*)(mg_lds + mega_lds_bytes(NU) + (MEGA_EARLY_W2 ? MG_WAVES * EW2 * 1024 : 0));  // [MG_WAVES][3 rows x 2 chunks][64 lanes]; wqkv rows of the next layer between P4 and P0
     bool w1_half_issued = false;
     auto lds_addr = [&](const u32x4* p) { return __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p); };
     __shared__ int s_abort;
@@ -936,10 +948,10 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             __syncthreads();
             MG_ABORT_RETURN();
             MG_STAMP(l, 7);
-            if constexpr (EARLY_W2) {  // chunks 0..4 of the w2 row on their way while the norm, the w1|w3 dots and the act publish run
+            if constexpr (EARLY_W2) {  // chunks 0..EW2-1 of the w2 row on their way while the norm, the w1|w3 dots and the act publish run
 #pragma unroll
-                for (int j = 0; j < 5; ++j)
-                    mega_row_to_lds(lds_addr(w2_lds + ((wave_o * 5 + j) * 64)), L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8, MG_ABLATE);
+                for (int j = 0; j < EW2; ++j)
+                    mega_row_to_lds(lds_addr(w2_lds + ((wave_o * EW2 + j) * 64)), L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8, MG_ABLATE);
             }
             mega_norm<NU>(xs, nw_ffn, red, a.eps, tid_p);
             MG_STAMP(l, 18);  // norm done
@@ -962,10 +974,10 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
                             for (int r = 0; r < 2; ++r) {
-                                const u32x4 xv = *(const u32x4*)(xs[u] + r * MG_DIM + j * 512 + lane * 8);
+                                const u32x4 xv = *(const u32x4*)(xs[u] + r * MG_DIM + j * 512 + lane_p * 8);
 #pragma unroll
                                 for (int i = 0; i < 3; ++i) {
-                                    const u32x4 w = j < 2 ? w1_lds[(wave * 6 + i * 2 + j) * 64 + lane] : wv[4 * i + j];
+                                    const u32x4 w = j < 2 ? w1_lds[(wave_p * 6 + i * 2 + j) * 64 + lane_p] : wv[4 * i + j];
                                     acc1[i][r] = dot8_bf16(w, xv, acc1[i][r]);
                                 }
                             }
@@ -995,7 +1007,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             else if (I8) { mega_issue_row_i8<6>(cq, L.q8[4], 8 * b + wave_o, MG_INTER, lane_o); sc_c = bf2f(load_global_u16(L.s8[4] + (8 * b + wave_o))); }
             else if (EARLY_W2) {
 #pragma unroll
-                for (int j = 5; j < 11; ++j) wv[j] = load_stream16(L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8);
+                for (int j = EW2; j < 11; ++j) wv[j] = load_stream16(L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8);
             }
             else mega_issue_row<11>(wv, L.w2, 8 * b + wave_o, MG_INTER, lane_o, MG_ABLATE);
             __builtin_amdgcn_sched_barrier(0);
@@ -1045,9 +1057,9 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                     acc[0][0] = acc[0][1] = 0.f;
 #pragma unroll
                     for (int j = 0; j < 11; ++j) {
-                        const u32x4 w = j < 5 ? w2_lds[(wave * 5 + j) * 64 + lane] : wv[j];
+                        const u32x4 w = j < EW2 ? w2_lds[(wave_p * EW2 + j) * 64 + lane_p] : wv[j];
 #pragma unroll
-                        for (int r = 0; r < 2; ++r) acc[0][r] = dot8_bf16(w, *(const u32x4*)(xs[u] + r * MG_INTER + j * 512 + lane * 8), acc[0][r]);
+                        for (int r = 0; r < 2; ++r) acc[0][r] = dot8_bf16(w, *(const u32x4*)(xs[u] + r * MG_INTER + j * 512 + lane_p * 8), acc[0][r]);
                     }
                 }
                 else mega_dots<11, 1, MG_INTER>(wv, xs[u], lane_p, acc);
@@ -1233,7 +1245,7 @@ static hipError_t launch_mega_instance(hipStream_t s, const MegaArgs& a) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::atomic<bool>& raised = raised_on[dev & 63];
-    const size_t lds = mega_lds_bytes(NU) + (mega_early_rows(WF, NU) ? MEGA_EARLY_W2_BYTES + MEGA_EARLY_W1_BYTES : 0);
+    const size_t lds = mega_lds_bytes(NU) + mega_early_lds_bytes(WF, NU);
     if (!raised) {
         hipError_t e = hipFuncSetAttribute((const void*)decode_mega_kernel<WF, NU, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1259,7 +1271,7 @@ static hipError_t launch_mega_format(hipStream_t s, const MegaArgs& a) {
 // process or stream holding CUs -- is still caught by the bounded waits (mv_run then redoes the launch with per-layer launches).
 template <int WF, int NU, bool FOLD>
 static bool mega_instance_fits(int n_cus) {
-    const size_t lds = mega_lds_bytes(NU) + (mega_early_rows(WF, NU) ? MEGA_EARLY_W2_BYTES + MEGA_EARLY_W1_BYTES : 0);
+    const size_t lds = mega_lds_bytes(NU) + mega_early_lds_bytes(WF, NU);
     if (hipFuncSetAttribute((const void*)decode_mega_kernel<WF, NU, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)decode_mega_kernel<WF, NU, FOLD>, MG_THREADS, lds) != hipSuccess) return false;
