@@ -175,6 +175,75 @@ __global__ void __launch_bounds__(256, 3) mbd_gemm_kernel(const MbdGemmArgs a) {
         }
 }
 
+// Thin layers (round 4): N <= 64 output channels, one contiguous K <= 160 window per term -- the 48-channel ResBlock convolutions of the
+// outermost level (M = 76 800 rows per band, K = 3 x 48).  On the 128-column tiles above 62 % of every MFMA and of every staged W tile was
+// padding (79 us per call, 80 calls per utterance: profiles/r03_final).  Here the WHOLE weight matrix of a band (hi and lo halves) lives in
+// registers as B fragments -- NTN x 5 x 2 fragments of 4 VGPRs -- and a wave walks 16-row tiles of A, whose fragments come straight from
+// global memory (16 B per lane; the windows of consecutive rows overlap by 2/3, so the 64-byte pieces hit in L1): no LDS, no barrier, no
+// padding columns; three MFMAs (a_hi w_hi + a_hi w_lo + a_lo w_hi) per fragment pair as in the fused three-term kernels.  K is walked in
+// steps of 32 with the tail zeroed on the A side (144 = 4 x 32 + 16).  Bound by its bytes: A hi | lo, the residual and the fp32 output.
+template <int NTN>
+__global__ void __launch_bounds__(256) mbd_gemm_thin_kernel(const MbdGemmArgs a) {
+    constexpr int KS = 5, MT = 4;   // K-steps of 32 (K <= 160); 16-row tiles per wave and loop trip
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, band = blockIdx.y;
+    const int M = a.M, N = a.N, K = a.seg[0].K;
+    const int col = lane & 15, kg = lane >> 4;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    bf16x8_t wh[NTN][KS], wl[NTN][KS];
+#pragma unroll
+    for (int j = 0; j < NTN; ++j) {
+        const size_t row = (size_t)min(j * 16 + col, N - 1) * a.ldw + a.seg[0].w_off;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = ks * 32 + kg * 8;
+            wh[j][ks] = __builtin_bit_cast(bf16x8_t, k < K ? load16(a.w_hi.p[band] + row + k) : zero);
+            wl[j][ks] = __builtin_bit_cast(bf16x8_t, k < K ? load16(a.w_lo.p[band] + row + k) : zero);
+        }
+    }
+    const bf16_t* ah = a.seg[0].a + (size_t)band * a.a_band;   // segment 0: a_hi x w_hi, segment 2: a_lo x w_hi (launch_gemm's order)
+    const bf16_t* al = a.seg[2].a + (size_t)band * a.a_band;
+    const int tile0 = (blockIdx.x * 4 + wave) * (16 * MT);
+#pragma unroll 1
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m0 = tile0 + mt * 16;
+        if (m0 >= M) break;
+        const size_t arow = (size_t)min(m0 + col, M - 1) * a.lda;
+        f32x4_t acc[NTN];
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) acc[j] = f32x4_t{0, 0, 0, 0};
+        bf16x8_t fh[KS], fl[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = ks * 32 + kg * 8;
+            fh[ks] = __builtin_bit_cast(bf16x8_t, k < K ? load16(ah + arow + k) : zero);
+            fl[ks] = __builtin_bit_cast(bf16x8_t, k < K ? load16(al + arow + k) : zero);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < NTN; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[ks], wh[j][ks], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[ks], wl[j][ks], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[ks], wh[j][ks], acc[j], 0, 0, 0);
+            }
+        // C fragment j: column lane & 15, rows (lane >> 4) * 4 + reg
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) {
+            const int n = j * 16 + col;
+            if (n >= N) continue;
+            const float add = (a.bias.p[band] ? a.bias.p[band][n] : 0.f) + (a.col_add.p[band] ? a.col_add.p[band][n] : 0.f);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int m = m0 + kg * 4 + reg;
+                if (m >= M) continue;
+                float y = acc[j][reg] + add;
+                if (a.residual) y += a.residual[(size_t)band * a.res_band + (size_t)m * a.ldr + n];
+                a.out[(size_t)band * a.out_band + (size_t)m * a.ldc + n] = y;
+            }
+        }
+    }
+}
+
 // The same GEMM with DIRECT global -> LDS loads (`global_load_lds_dwordx4`, gfx950): no staging registers and no ds_write pass, so a
 // block needs ~110 VGPRs and 32 KB of LDS and FOUR blocks share a CU; one block's load round trip is covered by the MFMAs of the
 // other three (two barriers per K-step, no software pipeline inside a block).  A wave instruction writes 1 KB of LDS linearly
@@ -260,17 +329,17 @@ __global__ void __launch_bounds__(256, 4) mbd_gemm_glds_kernel(const MbdGemmArgs
 // order of the epilogue loops) over its rows of the four 16-column blocks j of its wave; a block lies inside one group (gn_cg is a
 // multiple of 16).  Lanes are added in double in a fixed order, then thread (g, which) adds the (wave, j) entries of group g in
 // index order: the same bits on every run.
-template <int NW>
+template <int NW, int NJ = 4>   // NJ: 16-column tiles a wave holds (<= 4)
 __device__ __forceinline__ void gn_tile_partials(const MbdGemmArgs& a, const float (&gs)[4], const float (&gs2)[4], int wave_col0, int wave, int lane,
                                                  int tid, double* dst, double (*red)[4][2], int* grp) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        double s = gs[j], s2 = gs2[j];
+        double s = j < NJ ? gs[j] : 0.f, s2 = j < NJ ? gs2[j] : 0.f;
         for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); s2 += __shfl_down(s2, off, 64); }
         if (lane == 0) {
             red[wave][j][0] = s;
             red[wave][j][1] = s2;
-            grp[wave * 4 + j] = wave_col0 + j * 16 < a.N ? (wave_col0 + j * 16) / a.gn_cg : -1;
+            grp[wave * 4 + j] = j < NJ && wave_col0 + j * 16 < a.N ? (wave_col0 + j * 16) / a.gn_cg : -1;
         }
     }
     __syncthreads();
@@ -288,40 +357,49 @@ __device__ __forceinline__ void gn_tile_partials(const MbdGemmArgs& a, const flo
 // 3 A + 3 W of three separate segments) and every fragment pair feeds three MFMAs (a_hi w_hi + a_hi w_lo + a_lo w_hi): a third
 // fewer operand bytes and three times the MFMA work per barrier pair.  64 KB of LDS, two blocks per CU; segment 0 carries a_hi,
 // segment 2 a_lo (launch_gemm's order), one tap.
+// Tile shapes: <128, 128> (2 x 2 waves of 64 x 64) and, round 4, <64, 192> (1 x 4 waves of 64 x 48) for the 192-channel layers: on 128-column
+// tiles their second column tile was half padding (25 % of the MFMAs and of the W bytes; 13 ms per utterance at 0.39 of the peak).
+template <int BMR, int BNR>
 __global__ void __launch_bounds__(256, 2) mbd_gemm_glds3_kernel(const MbdGemmArgs a) {
-    constexpr int BM = 128, CH = 8;   // BK = 64
-    __shared__ __attribute__((aligned(1024))) u32x4 lds_ah[BM * CH];
-    __shared__ __attribute__((aligned(1024))) u32x4 lds_al[BM * CH];
-    __shared__ __attribute__((aligned(1024))) u32x4 lds_wh[BN * CH];
-    __shared__ __attribute__((aligned(1024))) u32x4 lds_wl[BN * CH];
+    constexpr int CH = 8;   // BK = 64
+    constexpr int WM = BMR / 64, WN = 4 / WM, NI = BNR / WN / 16;   // waves along M / N; 16-column MFMA tiles per wave (4 row tiles always)
+    constexpr int AI = BMR / 32, WI = BNR / 32;                     // 8-row wave loads per operand half and wave
+    static_assert(NI <= 4 && NI * 16 * WN == BNR && WM * 64 == BMR, "tile shape");
+    __shared__ __attribute__((aligned(1024))) u32x4 lds_ah[BMR * CH];
+    __shared__ __attribute__((aligned(1024))) u32x4 lds_al[BMR * CH];
+    __shared__ __attribute__((aligned(1024))) u32x4 lds_wh[BNR * CH];
+    __shared__ __attribute__((aligned(1024))) u32x4 lds_wl[BNR * CH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tile_m = blockIdx.y * BM, tile_n = blockIdx.x * BN, band = blockIdx.z;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile_m = blockIdx.y * BMR, tile_n = blockIdx.x * BNR, band = blockIdx.z;
     const int M = a.M, N = a.N, K = a.seg[0].K;
     const int lr = lane >> 3, lc = (lane & 7) ^ (lr & 7);
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[4][NI];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
 
     const bf16_t* ah = a.seg[0].a + (size_t)band * a.a_band + lc * 8;
     const bf16_t* al = a.seg[2].a + (size_t)band * a.a_band + lc * 8;
     const bf16_t* wh = a.w_hi.p[band] + a.seg[0].w_off + lc * 8;
     const bf16_t* wl = a.w_lo.p[band] + a.seg[0].w_off + lc * 8;
-    uint32_t oa[4], ow[4];
+    uint32_t oa[AI], ow[WI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        oa[i] = (uint32_t)((size_t)min(tile_m + (wave * 4 + i) * 8 + lr, M - 1) * a.lda);
-        ow[i] = (uint32_t)((size_t)min(tile_n + (wave * 4 + i) * 8 + lr, N - 1) * a.ldw);
-    }
+    for (int i = 0; i < AI; ++i) oa[i] = (uint32_t)((size_t)min(tile_m + (wave * AI + i) * 8 + lr, M - 1) * a.lda);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) ow[i] = (uint32_t)((size_t)min(tile_n + (wave * WI + i) * 8 + lr, N - 1) * a.ldw);
     for (int k0 = 0; k0 < K; k0 += 64) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int slot = (wave * 4 + i) * 64;
+        for (int i = 0; i < AI; ++i) {
+            const int slot = (wave * AI + i) * 64;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(ah + oa[i] + k0), (lds_ptr_t)(lds_ah + slot), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(al + oa[i] + k0), (lds_ptr_t)(lds_al + slot), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int slot = (wave * WI + i) * 64;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(wh + ow[i] + k0), (lds_ptr_t)(lds_wh + slot), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(wl + ow[i] + k0), (lds_ptr_t)(lds_wl + slot), 16, 0, 0);
         }
@@ -329,7 +407,7 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_glds3_kernel(const MbdGemmArg
         __syncthreads();
 #pragma unroll 1
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t afh[4], afl[4], bfh[4], bfl[4];
+            bf16x8_t afh[4], afl[4], bfh[NI], bfl[NI];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = wm * 64 + i * 16 + (lane & 15), idx = r * CH + ((kk * 4 + (lane >> 4)) ^ (r & 7));
@@ -337,15 +415,15 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_glds3_kernel(const MbdGemmArg
                 afl[i] = __builtin_bit_cast(bf16x8_t, lds_al[idx]);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = wn * 64 + j * 16 + (lane & 15), idx = r * CH + ((kk * 4 + (lane >> 4)) ^ (r & 7));
+            for (int j = 0; j < NI; ++j) {
+                const int r = wn * (NI * 16) + j * 16 + (lane & 15), idx = r * CH + ((kk * 4 + (lane >> 4)) ^ (r & 7));
                 bfh[j] = __builtin_bit_cast(bf16x8_t, lds_wh[idx]);
                 bfl[j] = __builtin_bit_cast(bf16x8_t, lds_wl[idx]);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NI; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[i], bfh[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[i], bfl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[i], bfh[j], acc[i][j], 0, 0, 0);
@@ -357,8 +435,8 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_glds3_kernel(const MbdGemmArg
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = tile_n + wn * 64 + j * 16 + (lane & 15);
+        for (int j = 0; j < NI; ++j) {
+            const int n = tile_n + wn * (NI * 16) + j * 16 + (lane & 15);
             if (n >= N) continue;
             const float add = (a.bias.p[band] ? a.bias.p[band][n] : 0.f) + (a.col_add.p[band] ? a.col_add.p[band][n] : 0.f);
 #pragma unroll
@@ -373,10 +451,10 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_glds3_kernel(const MbdGemmArg
             }
         }
     if (a.gn_part) {   // the operand tiles are dead (the K loop ended with a barrier): their LDS carries the reduction
-        double (*gn_red)[4][2] = reinterpret_cast<double (*)[4][2]>(lds_ah);
-        int* gn_grp = reinterpret_cast<int*>(lds_al);
+        double (*gn_red)[4][2] = reinterpret_cast<double (*)[4][2]>(lds_wh);
+        int* gn_grp = reinterpret_cast<int*>(lds_wl);
         const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x, tiles = (size_t)gridDim.x * gridDim.y;
-        gn_tile_partials<4>(a, gs, gs2, tile_n + wn * 64, wave, lane, tid, a.gn_part + ((size_t)band * tiles + tile) * a.gn_G * 2, gn_red, gn_grp);
+        gn_tile_partials<4, NI>(a, gs, gs2, tile_n + wn * (NI * 16), wave, lane, tid, a.gn_part + ((size_t)band * tiles + tile) * a.gn_G * 2, gn_red, gn_grp);
     }
 }
 
@@ -833,6 +911,59 @@ __global__ void __launch_bounds__(256) fir_bank_kernel(const float* __restrict__
     if (t + 3 < T) { dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3; }
     else { if (t < T) dst[0] = a0; if (t + 1 < T) dst[1] = a1; if (t + 2 < T) dst[2] = a2; }
 }
+// The same filter bank on the fp32 matrix cores (round 4): low[f][t] = sum_j bank[f][j] x[t + j - half] is a GEMM with a Toeplitz operand --
+// A = the bank, 32 filter rows (zero rows beyond the real ones) x taps, B[j][t] = x[t + j - half] -- on v_mfma_f32_32x32x2_f32: exact
+// fp32 products, fp32 accumulation, 64 FLOP per cycle and SIMD against the 8 of the VALU form above (which ran at 27 TFLOP/s: 4.4 ms per
+// utterance for the 8-band and the two 32-band splits, 121 GFLOP).  A wave owns 32 filters x 128 outputs (four 32 x 32 accumulators): per
+// pair of taps ONE coalesced 256-byte load of the transposed bank [taps][32] (L1 / L2 resident, eight pairs requested ahead) feeds four
+// MFMAs whose B operands are single-dword LDS reads of the input tile (lane l: sample t + (l & 31) + (l >> 5): consecutive addresses,
+// the second half-wave re-reads the first one's shifted by one: no bank conflicts).  Output columns are time: stores are 128-byte runs.
+constexpr int FIRM_TILE = 512;   // outputs per workgroup: 4 waves x 128
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256) fir_bank_mfma_kernel(const float* __restrict__ x, int T, const float* __restrict__ bank_t, int taps2, int half,
+                                                            int n_filters, float* __restrict__ low) {
+    extern __shared__ __attribute__((aligned(16))) float fsh[];   // [FIRM_TILE + taps2 + 2]: the input tile with its halo (replicate padding)
+    const int t0 = blockIdx.x * FIRM_TILE, nx = FIRM_TILE + taps2 + 2;
+    for (int i = threadIdx.x; i < nx; i += 256) fsh[i] = x[min(max(t0 + i - half, 0), T - 1)];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, kh = lane >> 5;
+    f32x16_t acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+    const float* ap = bank_t + lane;                 // pair p: bank_t[(2 p + kh) * 32 + col] = (2 p) * 32 + lane
+    const float* bp = fsh + wave * 128 + col + kh;   // + 2 p (+ 32 q)
+    constexpr int PF = 8;
+    float areg[PF];
+    const int npairs = taps2 / 2;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) areg[i] = i < npairs ? ap[(size_t)i * 64] : 0.f;
+    for (int p0 = 0; p0 < npairs; p0 += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int p = p0 + i;
+            const float a = areg[i];
+            areg[i] = p + PF < npairs ? ap[(size_t)(p + PF) * 64] : 0.f;   // the coefficient PF pairs ahead (zero past the end: its MFMAs add nothing)
+            if (p < npairs) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[2 * p + 32 * q], acc[q], 0, 0, 0);
+            }
+        }
+    }
+    // C layout of the 32 x 32 tile: lane -> column l & 31; register i -> row 8 (i >> 2) + 4 (l >> 5) + (i & 3)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int t = t0 + wave * 128 + q * 32 + col;
+        if (t >= T) continue;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int f = 8 * (i >> 2) + 4 * kh + (i & 3);
+            if (f < n_filters) low[(size_t)f * T + t] = acc[q][i];
+        }
+    }
+}
 // bands from the low-passes in place: band[0] = low[0], band[i] = low[i] - low[i-1], band[n-1] = x - low[n-2]   (SplitBands.forward)
 __global__ void bands_kernel(const float* __restrict__ x, const float* __restrict__ low, int T, int n_bands, float* __restrict__ bands) {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -939,6 +1070,7 @@ struct mv_mbd {
     std::vector<BandW> band;
     std::vector<int> ch;                     // channels per encoder level
     float *proc_bank = nullptr, *eq_bank = nullptr;  // device FIR banks [n-1][taps]
+    float *proc_bank_t = nullptr, *eq_bank_t = nullptr;  // the same banks transposed and zero padded [taps + 1][32]: the A operand of fir_bank_mfma_kernel
     int proc_taps = 0, eq_taps = 0;
     bool finalized = false;
     // LSTM scratch (bottleneck BiLSTM)
@@ -1204,6 +1336,15 @@ int mv_mbd_set_filterbank(mv_mbd* m, int32_t which, int32_t n_filters, int32_t t
     const int rc = upload_f32(m, dst, coeffs, (size_t)n_filters * taps);
     if (rc != MV_OK) return rc;
     (which == 0 ? m->proc_taps : m->eq_taps) = taps;
+    if (n_filters <= 32) {   // [taps + 1][32], zero rows / columns beyond the real filters and taps
+        std::vector<float> t((size_t)(taps + 1) * 32, 0.f);
+        for (int f = 0; f < n_filters; ++f)
+            for (int j = 0; j < taps; ++j) t[(size_t)j * 32 + f] = coeffs[(size_t)f * taps + j];
+        float** dt = which == 0 ? &m->proc_bank_t : &m->eq_bank_t;
+        *dt = nullptr;
+        const int rt = upload_f32(m, dt, t.data(), t.size());
+        if (rt != MV_OK) return rt;
+    }
     return MV_OK;
 }
 
@@ -1328,9 +1469,25 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
         const int n_blocks = nt_m256 * nt_n256 * nb;
         if (gn_ok) { g.gn_part = gf->part; g.gn_G = gf->G; g.gn_cg = g.N / gf->G; gf->tiles = nt_m256 * nt_n256; }
         hipLaunchKernelGGL(mbd_gemm_t256_kernel, dim3(n_blocks), dim3(512), T256_LDS_BYTES, s, g, nt_m256, nt_n256, n_blocks);
+    } else if (glds_mode == 2 && k64 && prec == 3 && taps == 1 && g.N % 192 == 0 && g.N % 128 != 0 && !getenv("MV_MBD_NO_N192") &&
+               (size_t)(g.N / 192) * ((g.M + 63) / 64) * nb >= (getenv("MV_MBD_N192_MIN_BLOCKS") ? (size_t)atoi(getenv("MV_MBD_N192_MIN_BLOCKS")) : 400)) {
+        // 192-channel layers: 64 x 192 tiles, no padding columns (MV_MBD_N192_MIN_BLOCKS: tests lower the threshold for small shapes)
+        const int nt192 = g.N / 192, mt64 = (g.M + 63) / 64;
+        if (gn_ok) { g.gn_part = gf->part; g.gn_G = gf->G; g.gn_cg = g.N / gf->G; gf->tiles = nt192 * mt64; }
+        hipLaunchKernelGGL((mbd_gemm_glds3_kernel<64, 192>), dim3(nt192, mt64, nb), dim3(256), 0, s, g);
     } else if (glds_mode == 2 && k64 && prec == 3 && taps == 1 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400) {
         if (gn_ok) { g.gn_part = gf->part; g.gn_G = gf->G; g.gn_cg = g.N / gf->G; gf->tiles = nt * ((g.M + 127) / 128); }
-        hipLaunchKernelGGL(mbd_gemm_glds3_kernel, dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
+        hipLaunchKernelGGL((mbd_gemm_glds3_kernel<128, 128>), dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
+    }
+    else if (prec == 3 && taps == 1 && g.N <= 64 && g.N % 16 == 0 && g.seg[0].K <= 160 && g.seg[0].K % 8 == 0 && !getenv("MV_MBD_NO_THIN")) {
+        // thin layers: the whole W in registers, A fragments straight from global memory (MV_MBD_NO_THIN=1: the 128-column tiles; tests, A/B)
+        const dim3 grid((unsigned)((g.M + 255) / 256), nb);
+        switch (g.N / 16) {
+            case 1: hipLaunchKernelGGL(mbd_gemm_thin_kernel<1>, grid, dim3(256), 0, s, g); break;
+            case 2: hipLaunchKernelGGL(mbd_gemm_thin_kernel<2>, grid, dim3(256), 0, s, g); break;
+            case 3: hipLaunchKernelGGL(mbd_gemm_thin_kernel<3>, grid, dim3(256), 0, s, g); break;
+            default: hipLaunchKernelGGL(mbd_gemm_thin_kernel<4>, grid, dim3(256), 0, s, g); break;
+        }
     }
     else if (glds_mode >= 1 && k64 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400)
         hipLaunchKernelGGL(mbd_gemm_glds_kernel, dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
@@ -1341,8 +1498,9 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
 
 size_t gn_blocks(int T, int C, int G) {   // partial records x G of a [T][C] tensor: the two-pass kernels, or the tiles of a GEMM epilogue
     const int rows_per = std::max(1, (int)((size_t)16384 * G / C));
-    const size_t two_pass = (size_t)((T + rows_per - 1) / rows_per), tiles = (size_t)((T + 127) / 128) * ((C + BN - 1) / BN);
-    return std::max(two_pass, tiles) * G;
+    const size_t two_pass = (size_t)((T + rows_per - 1) / rows_per), tiles = (size_t)((T + 127) / 128) * ((C + BN - 1) / BN),
+                 tiles192 = (size_t)((T + 63) / 64) * ((C + 191) / 192);   // the 64 x 192 tiles of the 192-channel layers
+    return std::max(std::max(two_pass, tiles), tiles192) * G;
 }
 hipError_t group_stats(hipStream_t s, const float* x, int64_t x_band, int T, int C, int G, UnetBuffers& ub) {
     // ~16 K elements per block whatever the [T][C] aspect ratio: rows_per rows of one group
@@ -1490,6 +1648,12 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
         MG_TRY(wk.get(&lstm_rev, (size_t)lstm_band * NB, false));
     }
     auto split = [&](const float* x, int n_bands, const float* bank, int taps, float* lowbuf, float* out_bands) -> hipError_t {
+        const float* bank_t = bank == m->proc_bank ? m->proc_bank_t : m->eq_bank_t;
+        if (bank_t && !getenv("MV_MBD_FIR_VALU")) {   // the Toeplitz product on the fp32 matrix cores; MV_MBD_FIR_VALU=1: the VALU kernel (A/B, tests)
+            const int taps2 = taps + 1;   // even: the transposed bank carries one zero row
+            hipLaunchKernelGGL(fir_bank_mfma_kernel, dim3((T + FIRM_TILE - 1) / FIRM_TILE), dim3(256), (size_t)(FIRM_TILE + taps2 + 2) * 4, s, x, T, bank_t, taps2,
+                               (taps - 1) / 2, n_bands - 1, lowbuf);
+        } else
         hipLaunchKernelGGL(fir_bank_kernel, dim3((T + FIR_TILE - 1) / FIR_TILE, n_bands - 1), dim3(256), (size_t)(FIR_TILE + 2 * ((taps + 3) & ~3) + 4) * 4, s, x, T, bank, taps, lowbuf);
         hipLaunchKernelGGL(bands_kernel, dim3((T + 255) / 256), dim3(256), 0, s, x, lowbuf, T, n_bands, out_bands);
         return hipGetLastError();

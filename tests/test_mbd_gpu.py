@@ -85,6 +85,55 @@ def test_unet_forward_on_the_256x256_tile_gemm(kw, T, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("kw,T", [
+    (dict(hidden=48, depth=2, growth=4.0, codec_dim=None), 40003),   # the bench's two outer levels: 48 channels (thin kernel) and 192 (64 x 192 tiles)
+    (dict(hidden=16, depth=3, growth=2.0, codec_dim=32), 9001),      # 16 / 32 / 64 channels: every instance of the thin kernel, K = 48 / 96 (two K-steps and a tail)
+])
+def test_thin_and_192_column_gemm_tiles(kw, T, monkeypatch):
+    """Round 4: `mbd_gemm_thin_kernel` (N <= 64: the whole W in registers, A fragments straight from global memory) and
+    `mbd_gemm_glds3_kernel<64, 192>` (the 192-channel layers without padding columns) against the oracle and against the 128-column
+    tiles they replace (MV_MBD_NO_THIN / MV_MBD_NO_N192)."""
+    pkg = synthetic.mbd_package(seed=13, n_bands=2, proc_bands=1, **kw)
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(T, generator=g)
+    lat = torch.randn(1, kw["codec_dim"], 9, generator=g) if kw.get("codec_dim") else None
+    band = oracle_bands(pkg)[1]
+    ref = o_mbd.unet_forward(band.sd, band.cfg, x.view(1, 1, -1), 250, lat).reshape(-1)
+    eng = mbd.MultiBandDiffusionBands.from_package(pkg, precision=3, eq_bands=1)
+    monkeypatch.setenv("MV_MBD_N192_MIN_BLOCKS", "1")
+    new = eng.unet_forward(1, x, 250, lat)
+    monkeypatch.setenv("MV_MBD_NO_THIN", "1")
+    monkeypatch.setenv("MV_MBD_NO_N192", "1")
+    old = eng.unet_forward(1, x, 250, lat)
+    s_new, s_old, s_pair = snr_db(new, ref), snr_db(old, ref), snr_db(new, old)
+    print(f"[mbd thin / 64x192 {kw} T={T}] SNR vs oracle: new tiles {s_new:.1f} dB, 128-column tiles {s_old:.1f} dB; between the two {s_pair:.1f} dB")
+    assert s_new >= 60.0 and s_old >= 60.0 and s_pair >= 80.0
+    assert not torch.equal(new, old) or s_pair == float("inf")   # (identical would mean the switches did nothing)
+    eng.close()
+
+
+def test_fir_bank_on_the_fp32_matrix_cores_equals_the_valu_kernel(monkeypatch):
+    """`fir_bank_mfma_kernel` (the julius low-pass bank as a Toeplitz product on v_mfma_f32_32x32x2_f32: exact fp32 products, fp32
+    accumulation in tap order) against `fir_bank_kernel` (fmaf chain in tap order): the whole `tokens_to_wav` -- processor band split,
+    band statistics, re_eq -- must agree to fp32 rounding."""
+    kw = dict(hidden=16, depth=3, growth=2.0, codec_dim=32)
+    pkg = synthetic.mbd_package(seed=7, n_bands=2, proc_bands=4, **kw)
+    step_list = [999, 666, 333, 0]
+    T, frames = 6400, 20
+    g = torch.Generator().manual_seed(1)
+    lat = torch.randn(1, 32, frames, generator=g)
+    wav_ref = 0.3 * torch.randn(1, 1, T, generator=g).cumsum(-1) / 20.0
+    noise = torch.randn(2, len(step_list), T, generator=g)
+    eng = mbd.MultiBandDiffusionBands.from_package(pkg, precision=3, step_list=step_list, eq_bands=8)
+    a = eng.tokens_to_wav(lat, wav_ref, noise=noise).reshape(-1)
+    monkeypatch.setenv("MV_MBD_FIR_VALU", "1")
+    b = eng.tokens_to_wav(lat, wav_ref, noise=noise).reshape(-1)
+    s = snr_db(a, b)
+    print(f"[mbd fir] matrix-core bank vs VALU bank: SNR {s:.1f} dB (inf = identical bits)")
+    assert s >= 110.0
+    eng.close()
+
+
 @pytest.mark.parametrize("kw,T,t256", [
     (dict(hidden=64, depth=2, growth=4.0, codec_dim=None), 205003, False),   # 256 channels on the three-term 128 x 128 kernel (>= 400 tiles)
     (dict(hidden=96, depth=2, growth=4.0, codec_dim=None), 9000, True),      # 384 channels, 256 x 256 tiles: a group (96 channels) inside a tile,
