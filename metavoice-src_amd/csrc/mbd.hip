@@ -665,21 +665,47 @@ __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs
 // ---- GroupNorm statistics: deterministic two stages ------------------------------------------------------------------------
 // stage 1: block (c, g) sums x and x^2 of group g over rows [c * rows_per, ...) -> part[c][g][2] (double).  A thread walks the
 // (rows x C / G) sub-matrix in float4 steps (C / G is a multiple of 4 whenever C is a multiple of 16; otherwise scalar steps).
+// Round 4: (i) four float4 loads of a thread are in flight at once -- the sums still run in the old order (one accumulator, ascending i), so
+// the bits are unchanged; with one load per loop trip the kernel ran at 0.37 of the HBM rate (profiles/vocoder_hbm_kernels.json);
+// (ii) optional second input and output: y = x + x2 is written to `sum_out` and the statistics are those of y -- the decoder's skip
+// addition no longer is a pass of its own in front of this one.
 __global__ void __launch_bounds__(256) gn_partial_kernel(const float* __restrict__ x, int64_t x_band, int T, int C, int G, int rows_per,
-                                                         double* __restrict__ part) {
+                                                         double* __restrict__ part, const float* __restrict__ x2 = nullptr, int64_t x2_band = 0,
+                                                         float* __restrict__ sum_out = nullptr, int64_t out_band = 0) {
     __shared__ double red[4][2];
     const int c = blockIdx.x, g = blockIdx.y, cg = C / G;
     const int t0 = c * rows_per, t1 = min(T, t0 + rows_per);
-    const float* base = x + (size_t)blockIdx.z * x_band + (size_t)t0 * C + (size_t)g * cg;
+    const size_t off0 = (size_t)t0 * C + (size_t)g * cg;
+    const float* base = x + (size_t)blockIdx.z * x_band + off0;
+    const float* base2 = x2 ? x2 + (size_t)blockIdx.z * x2_band + off0 : nullptr;
+    float* obase = sum_out ? sum_out + (size_t)blockIdx.z * out_band + off0 : nullptr;
     part += (size_t)blockIdx.z * gridDim.x * G * 2;
     float s = 0.f, s2 = 0.f;
     if ((cg & 3) == 0) {
         const int q4 = cg >> 2, n = (t1 - t0) * q4;
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const int r = i / q4, k = i - r * q4;
-            const float4 v = *(const float4*)(base + (size_t)r * C + 4 * k);
-            s += (v.x + v.y) + (v.z + v.w);
-            s2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, s2))));
+        for (int i0 = threadIdx.x; i0 < n; i0 += 1024) {
+            float4 v[4];
+            size_t o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + 256 * u, n - 1), r = i / q4, k = i - r * q4;
+                o[u] = (size_t)r * C + 4 * k;
+                v[u] = *(const float4*)(base + o[u]);
+            }
+            if (base2) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 w = *(const float4*)(base2 + o[u]);
+                    v[u].x += w.x; v[u].y += w.y; v[u].z += w.z; v[u].w += w.w;
+                    if (i0 + 256 * u < n) *(float4*)(obase + o[u]) = v[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + 256 * u < n) {
+                    s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+                    s2 = fmaf(v[u].x, v[u].x, fmaf(v[u].y, v[u].y, fmaf(v[u].z, v[u].z, fmaf(v[u].w, v[u].w, s2))));
+                }
         }
     } else {
         const int n = (t1 - t0) * cg;
@@ -1511,6 +1537,17 @@ hipError_t group_stats(hipStream_t s, const float* x, int64_t x_band, int T, int
     return hipGetLastError();
 }
 
+// z = a + b written to `out`, and the GroupNorm statistics of z, in ONE pass (the decoder's skip addition in front of its first ResBlock);
+// falls back to the separate add + two passes when the channel groups are not float4-aligned
+hipError_t add_and_group_stats(hipStream_t s, const float* a, int64_t a_band, const float* b, int64_t b_band, float* out, int64_t out_band, int T, int C, int G,
+                               UnetBuffers& ub) {
+    const int rows_per = std::max(1, (int)((size_t)16384 * G / C));
+    const int chunks = (T + rows_per - 1) / rows_per;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, G, ub.NB), dim3(256), 0, s, a, a_band, T, C, G, rows_per, ub.part, b, b_band, out, out_band);
+    hipLaunchKernelGGL(gn_final_kernel, dim3(ub.NB), dim3(256), 0, s, ub.part, chunks, G, (double)T * (C / G), 1e-5f, ub.stats);
+    return hipGetLastError();
+}
+
 // the statistics of a GEMM's output: from the partials its epilogue left (gf.tiles records per band), or the two passes over the output
 hipError_t stats_of_gemm_output(hipStream_t s, const GnFuse& gf, const float* x, int64_t x_band, int T, int C, int G, UnetBuffers& ub) {
     if (gf.tiles == 0) return group_stats(s, x, x_band, T, C, G, ub);
@@ -1531,7 +1568,7 @@ void launch_norm_act(hipStream_t s, const UnetBuffers& ub, const float* x, int64
 // two-pass statistics of that tensor -- one more read of 59 MB per ResBlock -- are gone)
 template <typename RW>
 hipError_t res_block(hipStream_t s, const mv_mbd* m, RW rw, const float* x, int64_t x_band, float* out, int64_t out_band, int T, int C, int dilation, PF col_add,
-                     UnetBuffers& ub, GnFuse* out_gf = nullptr, const GnFuse* in_gf = nullptr) {
+                     UnetBuffers& ub, GnFuse* out_gf = nullptr, const GnFuse* in_gf = nullptr, bool in_stats_ready = false) {
     const int G = m->cfg.norm_groups, act = m->cfg.act, nb = ub.NB;
     const int pad = dilation;  // kernel 3
     hipError_t e;
@@ -1539,7 +1576,7 @@ hipError_t res_block(hipStream_t s, const mv_mbd* m, RW rw, const float* x, int6
     for (int half = 0; half < 2; ++half) {
         const float* in = half == 0 ? x : ub.b32;
         const int64_t in_band = half == 0 ? x_band : (int64_t)ub.widest;
-        if ((e = half == 0 ? (in_gf ? stats_of_gemm_output(s, *in_gf, in, in_band, T, C, G, ub) : group_stats(s, in, in_band, T, C, G, ub))
+        if ((e = half == 0 ? (in_stats_ready ? hipSuccess : in_gf ? stats_of_gemm_output(s, *in_gf, in, in_band, T, C, G, ub) : group_stats(s, in, in_band, T, C, G, ub))
                            : stats_of_gemm_output(s, mid, in, in_band, T, C, G, ub)) != hipSuccess) return e;
         launch_norm_act(s, ub, in, in_band, T, C, G, ub.stats, pf_of(nb, [&](int b) { return (const float*)(half == 0 ? rw(b).n1.g : rw(b).n2.g); }),
                         pf_of(nb, [&](int b) { return (const float*)(half == 0 ? rw(b).n1.b : rw(b).n2.b); }), act, nullptr, 0, ub.hi,
@@ -1759,12 +1796,16 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
             auto Dw = [&](int b) -> const DecW& { return m->band[b].dec[i]; };
             // z = z[:, :, :skip.T] + skip   (z rows beyond skip.T are dropped; z never is shorter)
             const size_t n = (size_t)Ts * C;
-            hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256), NB), dim3(256), 0, s, ub.skip[lvl], (int64_t)ub.skip_band[lvl], z, z_band, ub.c32, WB, n);
+            // the skip addition and the statistics of its result (the first ResBlock's GroupNorm input) in one pass when the groups are
+            // float4-aligned and there is something to add (z == nullptr: the bottleneck without a BiLSTM is zeros -- add_kernel copies)
+            const bool fused_add = z != nullptr && ((C / G) & 3) == 0 && !getenv("MV_MBD_NO_ADD_FUSE");
+            if (fused_add) MG_TRY(add_and_group_stats(s, ub.skip[lvl], (int64_t)ub.skip_band[lvl], z, z_band, ub.c32, WB, Ts, C, G, ub));
+            else hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256), NB), dim3(256), 0, s, ub.skip[lvl], (int64_t)ub.skip_band[lvl], z, z_band, ub.c32, WB, n);
             GnFuse dec_gf{G, ub.part, 0};   // every ResBlock leaves its output partials: the next one's input statistics, then the decoder norm's
             for (int r = 0; r < g.res_blocks; ++r) {
                 const GnFuse in_gf = dec_gf;
                 MG_TRY(res_block(s, m, [&](int b) -> const ResW& { return Dw(b).res[r]; }, ub.c32, WB, ub.c32, WB, Ts, C, 1 << r, PF{}, ub,
-                                 &dec_gf, r > 0 && in_gf.tiles > 0 ? &in_gf : nullptr));
+                                 &dec_gf, r > 0 && in_gf.tiles > 0 ? &in_gf : nullptr, r == 0 && fused_add));
             }
             MG_TRY(stats_of_gemm_output(s, dec_gf, ub.c32, WB, Ts, C, G, ub));
             const PF ng = pf_of(NB, [&](int b) { return (const float*)Dw(b).norm.g; }), nbias = pf_of(NB, [&](int b) { return (const float*)Dw(b).norm.b; });

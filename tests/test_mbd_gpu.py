@@ -112,6 +112,25 @@ def test_thin_and_192_column_gemm_tiles(kw, T, monkeypatch):
     eng.close()
 
 
+def test_skip_addition_fused_into_the_group_norm_statistics(monkeypatch):
+    """The decoder's `z + skip` is written by the statistics pass of the GroupNorm that reads it (`gn_partial_kernel` with a second input):
+    same sums in the same order as the separate `add_kernel` + two-pass statistics => identical bits."""
+    kw = dict(hidden=16, depth=3, growth=2.0, codec_dim=32)
+    pkg = synthetic.mbd_package(seed=21, n_bands=2, proc_bands=1, **kw)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(7001, generator=g)
+    lat = torch.randn(1, 32, 9, generator=g)
+    band = oracle_bands(pkg)[0]
+    ref = o_mbd.unet_forward(band.sd, band.cfg, x.view(1, 1, -1), 600, lat).reshape(-1)
+    eng = mbd.MultiBandDiffusionBands.from_package(pkg, precision=3, eq_bands=1)
+    fused = eng.unet_forward(0, x, 600, lat)
+    monkeypatch.setenv("MV_MBD_NO_ADD_FUSE", "1")
+    separate = eng.unet_forward(0, x, 600, lat)
+    assert snr_db(fused, ref) >= 60.0
+    assert torch.equal(fused, separate)
+    eng.close()
+
+
 def test_fir_bank_on_the_fp32_matrix_cores_equals_the_valu_kernel(monkeypatch):
     """`fir_bank_mfma_kernel` (the julius low-pass bank as a Toeplitz product on v_mfma_f32_32x32x2_f32: exact fp32 products, fp32
     accumulation in tap order) against `fir_bank_kernel` (fmaf chain in tap order): the whole `tokens_to_wav` -- processor band split,
