@@ -128,6 +128,132 @@ __global__ void __launch_bounds__(256) convt1d_kernel(const ConvArgs a) {
     }
 }
 
+// ---- the same convolutions on the fp32 matrix cores (round 4) ---------------------------------------------------------------------------
+// A Conv1d is the GEMM out[co][t] = sum_kk W[kk][co] X[kk][t] with kk = (ci, k) flattened and X[kk][t] = in[ci][reflect(t + k dil - P)]: on
+// v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation, 64 FLOP per cycle and SIMD against the VALU's 8) lane l supplies
+// A = W[kk + (l >> 5)][co0 + (l & 31)] -- the [Cin][K][CoutP] layout makes that one coalesced 256-byte load per pair of kk -- and
+// B = X[kk + (l >> 5)][t0 + (l & 31)], a 128-byte run of one input row per half-wave.  A wave owns CT x TT tiles of 32 x 32 (CT TT = 4: 64
+// accumulator registers); the loads of the next PF pairs are in flight under the current pair's four MFMAs.  The VALU kernels above ran the
+// decoder's ~25 GFLOP at 9 TFLOP/s (3.2 ms per utterance, profiles/r03_final); MV_CODEC_VALU=1 keeps them (A/B, tests).
+typedef float cd_f32x16_t __attribute__((ext_vector_type(16)));
+template <int CT, int TT>
+__global__ void __launch_bounds__(256) conv1d_mfma_kernel(const ConvArgs a) {
+    constexpr int PF = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, kh = lane >> 5;
+    const int t0 = (blockIdx.x * 4 + wave) * (32 * TT), co0 = blockIdx.y * (32 * CT);
+    const int P = (a.K - 1) * a.dil, npairs = a.Cin * a.K / 2;
+    cd_f32x16_t acc[CT][TT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int q = 0; q < TT; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[c][q][i] = 0.f;
+    if (t0 >= a.T) return;
+    float ra[PF][CT], rb[PF][TT];
+    auto fetch = [&](int p, float (&fa)[CT], float (&fb)[TT]) {
+        const int kk = min(2 * p + kh, a.Cin * a.K - 1), ci = kk / a.K, k = kk - ci * a.K;
+        const float* wr = a.w + (size_t)kk * a.CoutP + co0 + col;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) fa[c] = co0 + 32 * c < a.CoutP ? wr[32 * c] : 0.f;
+        const float* row = a.in + (size_t)ci * a.T;
+#pragma unroll
+        for (int q = 0; q < TT; ++q) {
+            int i = min(t0 + 32 * q + col, a.T - 1) + k * a.dil - P;
+            i = i < 0 ? -i : i;   // reflect (no edge repeat); T > P is checked on the host
+            fb[q] = row[i];
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) fetch(min(i, npairs - 1), ra[i], rb[i]);
+    for (int p0 = 0; p0 < npairs; p0 += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int p = p0 + i;
+            float fa[CT], fb[TT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) fa[c] = ra[i][c];
+#pragma unroll
+            for (int q = 0; q < TT; ++q) fb[q] = rb[i][q];
+            fetch(min(p + PF, npairs - 1), ra[i], rb[i]);
+            if (p < npairs) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int q = 0; q < TT; ++q) acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c], fb[q], acc[c][q], 0, 0, 0);
+            }
+        }
+    }
+    // C layout of a 32 x 32 tile: lane -> column l & 31 (time); register i -> row 8 (i >> 2) + 4 (l >> 5) + (i & 3) (output channel)
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int q = 0; q < TT; ++q) {
+            const int t = t0 + 32 * q + col;
+            if (t >= a.T) continue;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = co0 + 32 * c + 8 * (i >> 2) + 4 * kh + (i & 3);
+                if (co < a.Cout) {
+                    float* o = a.out + (size_t)co * a.T + t;
+                    const float y = acc[c][q][i] + a.bias[co];
+                    *o = a.accumulate ? *o + y : y;
+                }
+            }
+        }
+}
+// ConvTranspose1d (kernel 2 S, stride S, right-trimmed): per output phase p a GEMM over kk = (ci, j), j = 0: tap p on in[ci][i], j = 1: tap p + S
+// on in[ci][i - 1].  A wave owns one 32-channel tile x 32 input steps and ALL S phases (S accumulators): the B operand (lane l: in[ci][i0 +
+// (l & 31) - (l >> 5)]) is shared by the S MFMAs of a channel pair; a lane ends up with the S consecutive output samples of its input step.
+template <int S>
+__global__ void __launch_bounds__(256) convt1d_mfma_kernel(const ConvArgs a) {
+    constexpr int PF = 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, kh = lane >> 5;
+    const int i0 = (blockIdx.x * 4 + wave) * 32, co0 = blockIdx.y * 32;
+    cd_f32x16_t acc[S];
+#pragma unroll
+    for (int p = 0; p < S; ++p)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[p][i] = 0.f;
+    if (i0 >= a.T) return;
+    const int ii = min(i0 + col, a.T - 1) - kh;   // kh = 1: the previous input step (zero in front of the first one)
+    float ra[PF][S], rb[PF];
+    auto fetch = [&](int ci, float (&fa)[S], float& fb) {
+        const float* wr = a.w + ((size_t)ci * 2 * S + (size_t)kh * S) * a.CoutP + co0 + col;
+#pragma unroll
+        for (int p = 0; p < S; ++p) fa[p] = wr[(size_t)p * a.CoutP];
+        fb = ii >= 0 ? a.in[(size_t)ci * a.T + ii] : 0.f;
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) fetch(min(i, a.Cin - 1), ra[i], rb[i]);
+    for (int c0 = 0; c0 < a.Cin; c0 += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int ci = c0 + i;
+            float fa[S];
+#pragma unroll
+            for (int p = 0; p < S; ++p) fa[p] = ra[i][p];
+            const float fb = rb[i];
+            fetch(min(ci + PF, a.Cin - 1), ra[i], rb[i]);
+            if (ci < a.Cin) {
+#pragma unroll
+                for (int p = 0; p < S; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p], fb, acc[p], 0, 0, 0);
+            }
+        }
+    }
+    const int step = i0 + col;
+    if (step >= a.T) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int co = co0 + 8 * (i >> 2) + 4 * kh + (i & 3);
+        if (co >= a.Cout) continue;
+        float* o = a.out + (size_t)co * a.T * S + (size_t)step * S;
+        const float bco = a.bias[co];
+#pragma unroll
+        for (int p = 0; p < S; ++p) o[p] = acc[p][i] + bco;
+    }
+}
+
 struct Conv {
     float *w = nullptr, *b = nullptr;  // device, re-laid out
     int cin = 0, cout = 0, coutp = 0, k = 0, dil = 1, stride = 1;
@@ -164,7 +290,7 @@ namespace {
 
 int alloc_conv(mv_codec* c, Conv& cv, int cin, int cout, int k, int dil, bool transposed, int stride) {
     cv.cin = cin; cv.cout = cout; cv.k = k; cv.dil = dil; cv.transposed = transposed; cv.stride = stride;
-    cv.coutp = (cout + CO_T - 1) / CO_T * CO_T;
+    cv.coutp = (cout + 31) / 32 * 32;   // zero-padded to the 32-row tiles of the matrix-core kernels (a multiple of the VALU kernels' CO_T too)
     CD_TRY(hipMalloc((void**)&cv.w, (size_t)cin * k * cv.coutp * 4));
     CD_TRY(hipMalloc((void**)&cv.b, (size_t)cv.coutp * 4));
     c->allocs.push_back(cv.w);
@@ -190,6 +316,21 @@ int upload_conv_weight(Conv& cv, const float* w) {
 
 hipError_t run_conv(hipStream_t s, const Conv& cv, const float* in, float* out, int T, bool accumulate) {
     ConvArgs a{in, cv.w, cv.b, out, cv.cin, cv.cout, cv.coutp, cv.k, cv.dil, T, accumulate ? 1 : 0};
+    if (!getenv("MV_CODEC_VALU") && (cv.cin * cv.k) % 2 == 0) {   // fp32 matrix cores
+        if (!cv.transposed) {
+            if (cv.coutp >= 64) hipLaunchKernelGGL((conv1d_mfma_kernel<2, 2>), dim3((T + 255) / 256, (cv.coutp + 63) / 64), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv1d_mfma_kernel<1, 4>), dim3((T + 511) / 512, cv.coutp / 32), dim3(256), 0, s, a);
+            return hipGetLastError();
+        }
+        const dim3 gt((T + 127) / 128, cv.coutp / 32);
+        switch (cv.stride) {
+            case 2: hipLaunchKernelGGL(convt1d_mfma_kernel<2>, gt, dim3(256), 0, s, a); return hipGetLastError();
+            case 4: hipLaunchKernelGGL(convt1d_mfma_kernel<4>, gt, dim3(256), 0, s, a); return hipGetLastError();
+            case 5: hipLaunchKernelGGL(convt1d_mfma_kernel<5>, gt, dim3(256), 0, s, a); return hipGetLastError();
+            case 8: hipLaunchKernelGGL(convt1d_mfma_kernel<8>, gt, dim3(256), 0, s, a); return hipGetLastError();
+            default: break;
+        }
+    }
     const dim3 grid((T + 255) / 256, cv.coutp / CO_T);
     if (!cv.transposed) {
         hipLaunchKernelGGL(conv1d_kernel, grid, dim3(256), 0, s, a);
