@@ -73,6 +73,62 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_bcast_f<0x143, 0xC>(v);  // row_bcast31
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// N independent wave sums, level by level.  Same tree per value as wave_sum (so the same bits) -- but written one value after the other
+// hipcc ran every chain through the same two registers at the 240-VGPR kernels' register pressure: 17 dependent instructions with an
+// `s_nop 1` behind every DPP add (a VALU write needs two wait states before a DPP read of it), ~100 cycles per sum, 22 sums per layer of the
+// persistent decode kernel = 0.8 us per layer (profiles/r04t: 678 -> 658 us/step with the sums removed).  Level by level the N chains are
+// independent neighbours, in place in the registers the accumulators already occupy: no wait states, ~4 cycles per instruction.
+// The two row-broadcast levels as ONE instruction per value: `v_add_f32_dpp v, v, v row_bcast:15 row_mask:0xa` adds lane 15 of the row
+// below into rows 1 and 3 and leaves rows 0 and 2 alone (a masked-off row keeps the destination = the tied input).  From C the compiler
+// builds v_mov_b32 0 / v_mov_b32_dpp / v_add_f32 (its DPP combiner folds a masked mov only into integer ops), three instructions per
+// value and level.  Lane 63 -- the only lane read -- gets the same bits (rows 1,3 then 2,3 are the enabled ones on its path).
+// Inline assembly is invisible to the compiler's hazard recogniser, so each statement opens with its own `s_nop 1`: a VALU write
+// needs two wait states before a DPP read of the register; within a statement the values are independent.
+#define MV_BC(k, C) "v_add_f32_dpp %" #k ", %" #k ", %" #k " " C "\n"
+#define MV_BCAST15 "row_bcast:15 row_mask:0xa bank_mask:0xf"
+#define MV_BCAST31 "row_bcast:31 row_mask:0xc bank_mask:0xf"
+template <int N>
+__device__ __forceinline__ void wave_bcast_levels(float (&v)[N]) {
+    static_assert(N % 2 == 0, "pairs");
+    if constexpr (N % 6 == 0) {
+#pragma unroll
+        for (int j = 0; j < N; j += 6)
+            asm("s_nop 1\n" MV_BC(0, MV_BCAST15) MV_BC(1, MV_BCAST15) MV_BC(2, MV_BCAST15) MV_BC(3, MV_BCAST15) MV_BC(4, MV_BCAST15) MV_BC(5, MV_BCAST15)
+                : "+v"(v[j]), "+v"(v[j + 1]), "+v"(v[j + 2]), "+v"(v[j + 3]), "+v"(v[j + 4]), "+v"(v[j + 5]));
+#pragma unroll
+        for (int j = 0; j < N; j += 6)
+            asm("s_nop 1\n" MV_BC(0, MV_BCAST31) MV_BC(1, MV_BCAST31) MV_BC(2, MV_BCAST31) MV_BC(3, MV_BCAST31) MV_BC(4, MV_BCAST31) MV_BC(5, MV_BCAST31)
+                : "+v"(v[j]), "+v"(v[j + 1]), "+v"(v[j + 2]), "+v"(v[j + 3]), "+v"(v[j + 4]), "+v"(v[j + 5]));
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; j += 2) asm("s_nop 1\n" MV_BC(0, MV_BCAST15) MV_BC(1, MV_BCAST15) : "+v"(v[j]), "+v"(v[j + 1]));
+#pragma unroll
+        for (int j = 0; j < N; j += 2) asm("s_nop 1\n" MV_BC(0, MV_BCAST31) MV_BC(1, MV_BCAST31) : "+v"(v[j]), "+v"(v[j + 1]));
+    }
+}
+#ifndef MV_WAVE_SUM_ASM_BCAST
+#define MV_WAVE_SUM_ASM_BCAST 1
+#endif
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] += dpp_f<0xB1>(v[j]);   // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] += dpp_f<0x4E>(v[j]);   // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] += dpp_f<0x141>(v[j]);  // row_half_mirror
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] += dpp_f<0x140>(v[j]);  // row_mirror
+    if constexpr (MV_WAVE_SUM_ASM_BCAST && N % 2 == 0) wave_bcast_levels<N>(v);
+    else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] += dpp_bcast_f<0x142, 0xA>(v[j]);  // row_bcast15
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] += dpp_bcast_f<0x143, 0xC>(v[j]);  // row_bcast31
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[j]), 63));
+}
 __device__ __forceinline__ float max_across16(float v) {
     v = fmaxf(v, dpp_f<0xB1>(v));
     v = fmaxf(v, dpp_f<0x4E>(v));

@@ -59,6 +59,26 @@ bool mega_instrumented() { return MEGA_INSTR != 0; }
 // each, of both rows of every utterance; every thread holds its columns in registers across the two barriers).
 // The norm weights `nw` (columns 8 tid .. 8 tid + 7) are requested by the caller a phase ahead: loaded here, their load would
 // return in order behind the K/V and weight requests already in flight and the norm would wait ~2 us for data it does not need.
+// profiling only (results are garbage): MEGA_FAKE_REDUCE = 1: the 64-lane sums of the GEMV epilogues (wqkv, wo, w1|w3, w2, head) cost one
+// v_readlane instead of six DPP adds + one; 2: additionally the RMSNorm apply is skipped.  Upper bounds for what a cheaper reduction / norm
+// could give (profiles/r04t).
+#ifndef MEGA_FAKE_REDUCE
+#define MEGA_FAKE_REDUCE 0
+#endif
+#ifndef MEGA_SUMS_INTERLEAVED
+#define MEGA_SUMS_INTERLEAVED 1   // 0: one wave_sum after the other (round 3)
+#endif
+template <int N>
+__device__ __forceinline__ void mega_wave_sums(float (&v)[N]) {
+    if (MEGA_FAKE_REDUCE) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[j]), 63));
+    } else if (MEGA_SUMS_INTERLEAVED) wave_sum_n<N>(v);
+    else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = wave_sum(v[j]);
+    }
+}
 #ifndef MEGA_NORM_STATS8
 #define MEGA_NORM_STATS8 0   // 1: one utterance, statistics on all 8 waves (one row each).  A/B on one box: 678.5 / 677.6 vs 672.7 / 676.9 us/step with 0 (profiles/r04d)
 #endif
@@ -80,11 +100,11 @@ __device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x
         if (lane == 0) red[q * 2 + r] = s;
     } else if constexpr (NU == 1) {
         if (tid < MG_DIM / 8) {
+            float s[2];  // both rows' chains side by side (wave_sum_n: the same tree, interleaved)
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const float s = wave_sum(sumsq8(*(const u32x4*)(xs[0] + r * MG_DIM + tid * 8)));
-                if (lane == 0) red[wave * 2 + r] = s;
-            }
+            for (int r = 0; r < 2; ++r) s[r] = sumsq8(*(const u32x4*)(xs[0] + r * MG_DIM + tid * 8));
+            wave_sum_n<2>(s);
+            if (lane == 0) { red[wave * 2] = s[0]; red[wave * 2 + 1] = s[1]; }
         }
     } else {
         if (wave < 2 * NU) {
@@ -92,8 +112,7 @@ __device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x
             float s[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) s[q] = sumsq8(*(const u32x4*)(xs[u] + r * MG_DIM + (q * 64 + lane) * 8));
-#pragma unroll
-            for (int q = 0; q < 4; ++q) s[q] = wave_sum(s[q]);
+            wave_sum_n<4>(s);
             if (lane == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) red[u * 2 * MG_WAVES + q * 2 + r] = s[q];
@@ -119,7 +138,7 @@ __device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x
         rstd[u] = rms_rstd(tot, MG_DIM, eps);
     }
 #pragma unroll
-    for (int u = 0; u < NU; ++u) *(u32x4*)(xs[u] + r * MG_DIM + c) = rms_apply8(xv[u], rstd[u], nw);
+    for (int u = 0; u < NU; ++u) *(u32x4*)(xs[u] + r * MG_DIM + c) = MEGA_FAKE_REDUCE == 2 ? xv[u] : rms_apply8(xv[u], rstd[u], nw);
     __syncthreads();
 }
 
@@ -613,9 +632,11 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             __builtin_amdgcn_sched_barrier(0);
             if (u == 0) MG_STAMP(l, 13);  // wqkv dots done
             float v0 = 0.f, v1 = 0.f;
+            float sums0[6] = {acc[0][0], acc[0][1], acc[1][0], acc[1][1], acc[2][0], acc[2][1]};
+            mega_wave_sums<6>(sums0);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                float t0 = wave_sum(acc[i][0]), t1 = wave_sum(acc[i][1]);
+                float t0 = sums0[2 * i], t1 = sums0[2 * i + 1];
                 if (I8) { t0 = i8_out(t0, sc_a[i]); t1 = i8_out(t1, sc_a[i]); }
                 if (lane_p == i) { v0 = t0; v1 = t1; }
             }
@@ -916,7 +937,9 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 else mega_dots<4, 1, MG_DIM>(wv + 12, xs[u], lane_p, acc);
                 __builtin_amdgcn_sched_barrier(0);
                 if (u == 0) MG_STAMP(l, 16);  // wo dots done
-                float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
+                float sums2[2] = {acc[0][0], acc[0][1]};
+                mega_wave_sums<2>(sums2);
+                float t0 = sums2[0], t1 = sums2[1];
                 if (I8) { t0 = i8_out(t0, sc_c); t1 = i8_out(t1, sc_c); }
                 const uint32_t xr = res_s[0][u][wave_p];
                 const bf16_t y0 = epi_resid((bf16_t)xr, t0), y1 = epi_resid((bf16_t)(xr >> 16), t1);
@@ -988,9 +1011,12 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 __builtin_amdgcn_sched_barrier(0);
                 if (u == 0) MG_STAMP(l, 19);  // w1|w3 dots done
                 float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
+                float sums3[12] = {acc1[0][0], acc1[0][1], acc3[0][0], acc3[0][1], acc1[1][0], acc1[1][1], acc3[1][0], acc3[1][1],
+                                   acc1[2][0], acc1[2][1], acc3[2][0], acc3[2][1]};
+                mega_wave_sums<12>(sums3);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    float a0 = wave_sum(acc1[i][0]), a1 = wave_sum(acc1[i][1]), c0 = wave_sum(acc3[i][0]), c1 = wave_sum(acc3[i][1]);
+                    float a0 = sums3[4 * i], a1 = sums3[4 * i + 1], c0 = sums3[4 * i + 2], c1 = sums3[4 * i + 3];
                     if (I8) { a0 = i8_out(a0, sc_a[i]); a1 = i8_out(a1, sc_a[i]); c0 = i8_out(c0, sc_b[i]); c1 = i8_out(c1, sc_b[i]); }
                     if (lane_p == i) { g0 = a0; g1 = a1; u0 = c0; u1 = c1; }
                 }
@@ -1065,7 +1091,9 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 else mega_dots<11, 1, MG_INTER>(wv, xs[u], lane_p, acc);
                 __builtin_amdgcn_sched_barrier(0);
                 if (u == 0) MG_STAMP(l, 21);  // w2 dots done
-                float t0 = wave_sum(acc[0][0]), t1 = wave_sum(acc[0][1]);
+                float sums2[2] = {acc[0][0], acc[0][1]};
+                mega_wave_sums<2>(sums2);
+                float t0 = sums2[0], t1 = sums2[1];
                 if (I8) { t0 = i8_out(t0, sc_c); t1 = i8_out(t1, sc_c); }
                 const uint32_t hr = res_s[1][u][wave_p];
                 const bf16_t y0 = epi_resid((bf16_t)hr, t0), y1 = epi_resid((bf16_t)(hr >> 16), t1);
@@ -1121,9 +1149,11 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         if (I8) mega_dots_i8<2, 2, MG_DIM>(cq, xs[u], MG_DIM, lane, acc);
         else mega_dots<4, 2, MG_DIM>(wv, xs[u], lane, acc);
         float v0 = 0.f, v1 = 0.f;
+        float sumsh[4] = {acc[0][0], acc[0][1], acc[1][0], acc[1][1]};
+        mega_wave_sums<4>(sumsh);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            float t0 = wave_sum(acc[i][0]), t1 = wave_sum(acc[i][1]);
+            float t0 = sumsh[2 * i], t1 = sumsh[2 * i + 1];
             if (I8) { t0 = i8_out(t0, sc_a[i]); t1 = i8_out(t1, sc_a[i]); }
             if (lane == i) { v0 = t0; v1 = t1; }
         }
