@@ -60,6 +60,7 @@ struct AttnAcc {
 // Scores of the lane group's ATTN_U keys against q, softmax numerators against the group max, P.V; then the 4 lane
 // groups of the wave (lanes dl, dl+16, dl+32, dl+48 hold the same 8 dims) are folded.  Key index of (u, g) = s0+4u+g,
 // valid while < s1.
+template <bool PL = (MV_PERMLANE_SWAP != 0)>
 __device__ __forceinline__ AttnAcc attn_wave_partial(const u32x4 (&kv)[ATTN_U], const u32x4 (&vv)[ATTN_U], const u32x4& qv, int s0,
                                                      int s1, int g) {
     const float scale = 0.08838834764831845f;  // 1/sqrt(128)
@@ -89,43 +90,28 @@ __device__ __forceinline__ AttnAcc attn_wave_partial(const u32x4 (&kv)[ATTN_U], 
         a.o[6] = fmaf(p, bf_lo(vv[u].w), a.o[6]);
         a.o[7] = fmaf(p, bf_hi(vv[u].w), a.o[7]);
     }
-    float mo = fmaxf(a.m, __shfl_xor(a.m, 16, 64));
-    mo = fmaxf(mo, __shfl_xor(mo, 32, 64));
+    const float mo = max_groups4<PL>(a.m);
     const float w = (a.m == -INFINITY) ? 0.f : fast_exp(a.m - mo);
-    a.l *= w;
-    a.l += __shfl_xor(a.l, 16, 64);
-    a.l += __shfl_xor(a.l, 32, 64);
+    a.l = add_groups4<PL>(a.l * w);
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
-        float t = a.o[d] * w;
-        t += __shfl_xor(t, 16, 64);
-        t += __shfl_xor(t, 32, 64);
-        a.o[d] = t;
-    }
+    for (int d = 0; d < 8; ++d) a.o[d] = add_groups4<PL>(a.o[d] * w);
     a.m = mo;
     return a;
 }
 
 // `sm` = [8 waves][16 dim groups][12 floats] of per-wave (m, l, o[8]); executed by ONE whole wave: lane (g, dl) merges
 // waves g and g+4 for dims 8dl..8dl+7, then the 4 groups are folded with xor-16/32 butterflies.
+template <bool PL = (MV_PERMLANE_SWAP != 0)>
 __device__ __forceinline__ AttnAcc attn_merge_waves(const float (*sm)[16][12], int g, int dl) {
     AttnAcc b;
     const float m0 = sm[g][dl][0], m1 = sm[g + 4][dl][0];
     const float mw = fmaxf(m0, m1);
-    b.m = fmaxf(mw, __shfl_xor(mw, 16, 64));
-    b.m = fmaxf(b.m, __shfl_xor(b.m, 32, 64));
+    b.m = max_groups4<PL>(mw);
     const float f0 = (m0 == -INFINITY) ? 0.f : fast_exp(m0 - b.m);
     const float f1 = (m1 == -INFINITY) ? 0.f : fast_exp(m1 - b.m);
-    b.l = fmaf(sm[g + 4][dl][1], f1, sm[g][dl][1] * f0);
-    b.l += __shfl_xor(b.l, 16, 64);
-    b.l += __shfl_xor(b.l, 32, 64);
+    b.l = add_groups4<PL>(fmaf(sm[g + 4][dl][1], f1, sm[g][dl][1] * f0));
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
-        float t = fmaf(sm[g + 4][dl][2 + d], f1, sm[g][dl][2 + d] * f0);
-        t += __shfl_xor(t, 16, 64);
-        t += __shfl_xor(t, 32, 64);
-        b.o[d] = t;
-    }
+    for (int d = 0; d < 8; ++d) b.o[d] = add_groups4<PL>(fmaf(sm[g + 4][dl][2 + d], f1, sm[g][dl][2 + d] * f0));
     return b;
 }
 
@@ -142,10 +128,10 @@ __device__ __forceinline__ u32x4 attn_normalise(const AttnAcc& b) {
 // Combination of up to 8 split partials by one whole wave: lane group g contributes splits g and g+4 (ms[q] = -inf marks a
 // missing split), the 4 groups are folded with xor-16/32 butterflies.  Shared by the ticket form below and the tagged form of
 // the persistent kernel: identical arithmetic, identical bits.
+template <bool PL = (MV_PERMLANE_SWAP != 0)>
 __device__ __forceinline__ void attn_combine_math(AttnAcc& b, const float (&ms)[2], const float (&ls)[2], const float (&t)[2][8]) {
     float mt = fmaxf(ms[0], ms[1]);
-    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    mt = max_groups4<PL>(mt);
     float lt = 0.f, ot[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) ot[d] = 0.f;
@@ -156,14 +142,9 @@ __device__ __forceinline__ void attn_combine_math(AttnAcc& b, const float (&ms)[
 #pragma unroll
         for (int d = 0; d < 8; ++d) ot[d] = fmaf(t[q][d], f, ot[d]);
     }
-    lt += __shfl_xor(lt, 16, 64);
-    lt += __shfl_xor(lt, 32, 64);
+    lt = add_groups4<PL>(lt);
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
-        ot[d] += __shfl_xor(ot[d], 16, 64);
-        ot[d] += __shfl_xor(ot[d], 32, 64);
-        b.o[d] = ot[d];
-    }
+    for (int d = 0; d < 8; ++d) b.o[d] = add_groups4<PL>(ot[d]);
     b.m = mt;
     b.l = lt;
 }
@@ -230,6 +211,7 @@ __device__ __forceinline__ void attn_publish_tagged(const AttnAcc& b, u64* slot,
     }
 }
 // returns false on a timeout (caller raises the abort flag)
+template <bool PL = (MV_PERMLANE_SWAP != 0)>
 __device__ __forceinline__ bool attn_combine_tagged(AttnAcc& b, const u64* slots, uint32_t tag, int nact, int lane, int spin_limit) {
     const int g = lane >> 4, dl = lane & 15;
     for (int tries = 0;; ++tries) {
@@ -275,7 +257,7 @@ __device__ __forceinline__ bool attn_combine_tagged(AttnAcc& b, const u64* slots
                     t[q][2 * k + 1] = __uint_as_float(v[q][1 + k].z);
                 }
             }
-            attn_combine_math(b, ms, ls, t);
+            attn_combine_math<PL>(b, ms, ls, t);
             return true;
         }
         if (tries >= spin_limit) return false;

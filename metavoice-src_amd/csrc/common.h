@@ -129,6 +129,51 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
 #pragma unroll
     for (int j = 0; j < N; ++j) v[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[j]), 63));
 }
+// x (+ or max) the value of the lane 16 / 32 away -- `x op __shfl_xor(x, 16 | 32)` -- through gfx950's row / half swaps instead of
+// ds_bpermute_b32 (address VGPR, a trip through the LDS crossbar and an lgkmcnt wait per level: ~120 cycles, three dependent pairs of
+// them on the attention chain of every layer).  v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows
+// of its second; with both = x the results are {rows 0,0,2,2} and {rows 1,1,3,3}: every lane holds its own value in one and its
+// partner's in the other (which one depends on the row).  op is commutative, so the bits are those of the shuffle form.
+// MEASURED (profiles/r04w, persistent decode kernel, same box, identical tokens): no faster -- bf16 661.0 -> 661-666 us/step, two
+// utterances 904 -> 914, int8 634 -> 641, and the bf16 four-utterance instance spills 42 registers over the two copies each swap needs
+// (1300 -> 1443).  The shuffles' LDS round trips overlap with the other waves' work; the swaps add a copy and two wait states per level.
+// Kept as a switch, OFF.
+#ifndef MV_PERMLANE_SWAP
+#define MV_PERMLANE_SWAP 0
+#endif
+template <bool PL = (MV_PERMLANE_SWAP != 0)>
+__device__ __forceinline__ float add_xor16(float x) {
+    if constexpr (PL) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else return x + __shfl_xor(x, 16, 64);
+}
+template <bool PL = (MV_PERMLANE_SWAP != 0)>
+__device__ __forceinline__ float add_xor32(float x) {
+    if constexpr (PL) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else return x + __shfl_xor(x, 32, 64);
+}
+template <bool PL = (MV_PERMLANE_SWAP != 0)>
+__device__ __forceinline__ float max_xor16(float x) {
+    if constexpr (PL) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    } else return fmaxf(x, __shfl_xor(x, 16, 64));
+}
+template <bool PL = (MV_PERMLANE_SWAP != 0)>
+__device__ __forceinline__ float max_xor32(float x) {
+    if constexpr (PL) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    } else return fmaxf(x, __shfl_xor(x, 32, 64));
+}
+// the two levels that fold the wave's four 16-lane groups
+template <bool PL = (MV_PERMLANE_SWAP != 0)>
+__device__ __forceinline__ float add_groups4(float x) { return add_xor32<PL>(add_xor16<PL>(x)); }
+template <bool PL = (MV_PERMLANE_SWAP != 0)>
+__device__ __forceinline__ float max_groups4(float x) { return max_xor32<PL>(max_xor16<PL>(x)); }
 __device__ __forceinline__ float max_across16(float v) {
     v = fmaxf(v, dpp_f<0xB1>(v));
     v = fmaxf(v, dpp_f<0x4E>(v));

@@ -466,6 +466,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     // ATTN_V2: block = (utterance, row, head, part): SPB = NU consecutive key ranges starting at at_s, 8 / NU blocks per (utterance, row, head)
     constexpr bool ATTN_V2 = NU > 1 && MEGA_ATTN_V2;
     constexpr int BPH = ATTN_V2 ? 8 / NU : 8, SPB = ATTN_V2 ? NU : 1;
+    constexpr bool ATTN_PL = MV_PERMLANE_SWAP != 0;   // common.h: measured no faster (profiles/r04w), off
     constexpr bool ATTN_DB = ATTN_V2 && WF == MV_W_BF16;   // two register sets: the quantised instances have no idle weight registers to lend (one set, ranges back to back)
     const int at_u = ATTN_V2 ? b / (32 * BPH) : 0;
     const int at_r = (b / (16 * BPH)) & 1, at_h = (b / BPH) & 15, at_s = (b % BPH) * SPB, at_w = wave;
@@ -784,7 +785,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                                 vx[q] = *(const u32x4*)(qkv_s[0] + (2 * 2 + at_r) * 128 + dl * 8);
                             }
                         }
-                        const AttnAcc w = attn_wave_partial(kx, vx, qv, s0, s1, g);
+                        const AttnAcc w = attn_wave_partial<ATTN_PL>(kx, vx, qv, s0, s1, g);
                         if (j == 0) MG_STAMP(l, 14);  // first wave partial done
                         // this set's registers are free: the range after next is requested into them while the other set is scored
                         if constexpr (ATTN_DB) {
@@ -809,12 +810,12 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 u64* slots = (u64*)a.partial + ((size_t)(2 * u + at_r) * MG_HEADS + at_h) * ATTN_NSPLIT * ATTN_TPART_STRIDE;
                 AttnAcc bb;
                 if (at_w < n_my) {
-                    bb = attn_merge_waves(sm + at_w * ATTN_WAVES, g, dl);
+                    bb = attn_merge_waves<ATTN_PL>(sm + at_w * ATTN_WAVES, g, dl);
                     if (nactu > 1) attn_publish_tagged(bb, slots + (size_t)(at_s + at_w) * ATTN_TPART_STRIDE, tag0 + 5u, lane);
                 }
                 if (at_w == 0 && at_s == 0) {   // the workgroup of the first ranges combines (utterance, row, head) and publishes its output
                     bool last = true;
-                    if (nactu > 1 && !attn_combine_tagged(bb, slots, tag0 + 5u, nactu, lane, MG_SPIN_LIMIT)) {
+                    if (nactu > 1 && !attn_combine_tagged<ATTN_PL>(bb, slots, tag0 + 5u, nactu, lane, MG_SPIN_LIMIT)) {
                         uint32_t* af = abort_flag_of();
                         mega_report_timeout(af, tag0 + 5u);
                         __hip_atomic_store(af, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -854,7 +855,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                         vv[q] = *(const u32x4*)(qkv_s[u] + (2 * 2 + at_r) * 128 + dl * 8);
                     }
                 }
-                const AttnAcc w = attn_wave_partial(kv, vv, qv, at_s0, at_s1, g);
+                const AttnAcc w = attn_wave_partial<ATTN_PL>(kv, vv, qv, at_s0, at_s1, g);
                 if (u == 0) MG_STAMP(l, 14);  // wave partial done
                 // MEGA_NU_EARLY_KV: the K/V registers are free from here on -- the next attending utterance's slice is requested NOW, so
                 // it streams while this utterance's partial is merged and published (instead of after the publish)
@@ -870,7 +871,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 AttnAcc bb;
                 u64* slots = (u64*)a.partial + ((size_t)(2 * u + at_r) * MG_HEADS + at_h) * ATTN_NSPLIT * ATTN_TPART_STRIDE;
                 if (at_w == 0) {
-                    bb = attn_merge_waves(sm, g, dl);
+                    bb = attn_merge_waves<ATTN_PL>(sm, g, dl);
                     // split partials as tagged granules: every split publishes, one workgroup polls all of them and
                     // combines (attn_core.h) -- one hand-off instead of store + vmcnt(0) + ticket round trip + load round trip
                     if (nactu > 1) attn_publish_tagged(bb, slots + (size_t)at_s * ATTN_TPART_STRIDE, tag0 + 5u, lane);
@@ -883,7 +884,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                     bool last = true;
                     if (nactu > 1) {
                         last = at_s == (NU == 1 ? 0 : u % nactu);
-                        if (last && !attn_combine_tagged(bb, slots, tag0 + 5u, nactu, lane, MG_SPIN_LIMIT)) {
+                        if (last && !attn_combine_tagged<ATTN_PL>(bb, slots, tag0 + 5u, nactu, lane, MG_SPIN_LIMIT)) {
                             uint32_t* af = abort_flag_of();
                             mega_report_timeout(af, tag0 + 5u);
                             __hip_atomic_store(af, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
