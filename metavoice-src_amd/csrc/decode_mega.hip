@@ -65,6 +65,22 @@ bool mega_instrumented() { return MEGA_INSTR != 0; }
 #ifndef MEGA_FAKE_REDUCE
 #define MEGA_FAKE_REDUCE 0
 #endif
+// MEGA_QKV_AT_P4 = 1 | 2: that many of the two REGISTER chunks of the next layer's wqkv rows are requested at the top of P4, behind the
+// register part of the w2 row and in front of the act poll -- the act hand-off (3.3 us with nothing in front of it) has room behind the
+// w2 remainder (12.6 MB, 2.2 us), while the x hand-off has all 25 MB of wqkv between "act ready" and "x ready" (profiles/r04_final/ablate.txt).
+// The w2 register chunks move to wv[12..17] (the w3 registers, free after P3's dots) so that wv[4 i + 2 | 3] are free for them.
+#ifndef MEGA_QKV_AT_P4
+#define MEGA_QKV_AT_P4 0
+#endif
+// MEGA_V_AFTER_QKV (bit mask over 1 | 2 | 4 utterances): only the K rows are requested at "x ready"; the V rows follow behind the q/k/v publish, in front of the
+// q/k/v hand-off.  The K/V burst of all 256 workgroups (8 MB at 1024 positions) drains at HBM speed and the memory pipeline takes
+// requests only as fast as it drains them: every wave spends ~2.4 us in front of its norm issuing them (profiles/r04g, r04x).
+#ifndef MEGA_V_AFTER_QKV
+#define MEGA_V_AFTER_QKV 1
+#endif
+#ifndef MEGA_KV_UNCOND
+#define MEGA_KV_UNCOND 0   // 1: every slot always requested (see issue_kv_set; measured slower, profiles/r04x)
+#endif
 #ifndef MEGA_SUMS_INTERLEAVED
 #define MEGA_SUMS_INTERLEAVED 1   // 0: one wave_sum after the other (round 3)
 #endif
@@ -413,6 +429,8 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     constexpr bool EARLY_W2 = EARLY_ANY && MEGA_EARLY_W2, EARLY_W1 = EARLY_ANY && mega_early_w1(NU), EARLY_QKV = EARLY_ANY && MEGA_EARLY_QKV && NU == 1;
     constexpr bool W3_EARLY = EARLY_W1 && MEGA_W3_EARLY && NU == 1;
     constexpr int EW2 = mega_early_w2_chunks(NU);   // chunks of the w2 row that go to LDS early
+    constexpr int QKV_P4 = (EARLY_QKV && EARLY_W2) ? MEGA_QKV_AT_P4 : 0;
+    constexpr int W2R0 = QKV_P4 ? 12 - EW2 : 0;     // register chunk j of the w2 row lives in wv[W2R0 + j]
     u32x4* w2_lds = (u32x4*)(mg_lds + mega_lds_bytes(NU));                                                        // [MG_WAVES][EW2 chunks][64 lanes]
     u32x4* w1_lds = (u32x4*)(mg_lds + mega_lds_bytes(NU) + (MEGA_EARLY_W2 ? MG_WAVES * EW2 * 1024 : 0));  // [MG_WAVES][3 rows x 2 chunks][64 lanes]; wqkv rows of the next layer between P4 and P0
     bool w1_half_issued = false;
@@ -466,6 +484,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     // ATTN_V2: block = (utterance, row, head, part): SPB = NU consecutive key ranges starting at at_s, 8 / NU blocks per (utterance, row, head)
     constexpr bool ATTN_V2 = NU > 1 && MEGA_ATTN_V2;
     constexpr int BPH = ATTN_V2 ? 8 / NU : 8, SPB = ATTN_V2 ? NU : 1;
+    constexpr bool KV_UNCOND = MEGA_KV_UNCOND && NU == 1;   // see issue_kv_set
     constexpr bool ATTN_PL = MV_PERMLANE_SWAP != 0;   // common.h: measured no faster (profiles/r04w), off
     constexpr bool ATTN_DB = ATTN_V2 && WF == MV_W_BF16;   // two register sets: the quantised instances have no idle weight registers to lend (one set, ranges back to back)
     const int at_u = ATTN_V2 ? b / (32 * BPH) : 0;
@@ -555,14 +574,32 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         // is taken from the hand-off -- it must not even be touched here (a line fetched before its producer's store could be
         // served stale to the next launch).
         // SET 0: kv / vv.  SET 1 (ATTN_V2): wv[0..7] / wv[16..23], idle between the wqkv dots and the w1 request.  `split`: the key range.
-        auto issue_kv_set = [&](auto set_tag, int u, int kv_layer, int split) {  // u, split: runtime, block-uniform
+        auto issue_kv_set = [&](auto set_tag, int u, int kv_layer, int split, auto part_tag) {  // u, split: runtime, block-uniform
             constexpr int SET = decltype(set_tag)::value;
+            constexpr int PART = decltype(part_tag)::value;   // 0: K and V, 1: K only, 2: V only
             u32x4* const kd = SET == 0 ? kv : wv;
             u32x4* const vd = SET == 0 ? vv : wv + 16;
+            // KV_UNCOND (one utterance): all 2 x ATTN_U requests ALWAYS go out.  With "zero the slot, request it if used" every slot is a merge
+            // of a constant and a load result; hipcc gave ONE component of ONE slot (vv[0].w, which doubled as its source of zeros) a
+            // register outside the load's 4-register tuple and copied it right behind the load:
+            //     global_load_dwordx4 v[120:123], ... nt ;  s_waitcnt vmcnt(0) ;  v_mov_b32 v136, v123
+            // -- every wave sat out a full memory round trip in the middle of its K/V requests, in every layer of every one-utterance
+            // instance ("K/V requested" 2.4 us behind "x ready", profiles/r04g).  Now a slot is only ever defined by a load (no merge, no
+            // zeroing, and the 64 registers are dead between the attention and the next request as before): an unused slot
+            // (q * 4 >= kwu) re-reads the newest old row, a workgroup with nothing to read (no split of its own, or an empty cache)
+            // reads 256 bytes of the layer's norm weights.  An unused slot's key is masked by its position (score -inf, weight exactly 0)
+            // and 0 x (finite V) adds nothing: the same bits.
+            constexpr bool UNC = KV_UNCOND && SET == 0;
+            if (!UNC) {
+                if (PART != 2) {
 #pragma unroll
-            for (int q = 0; q < ATTN_U; ++q) kd[q] = u32x4{0u, 0u, 0u, 0u};
+                    for (int q = 0; q < ATTN_U; ++q) kd[q] = u32x4{0u, 0u, 0u, 0u};
+                }
+                if (PART != 1) {
 #pragma unroll
-            for (int q = 0; q < ATTN_U; ++q) vd[q] = u32x4{0u, 0u, 0u, 0u};
+                    for (int q = 0; q < ATTN_U; ++q) vd[q] = u32x4{0u, 0u, 0u, 0u};
+                }
+            }
             const int Pu = GEO(0, u), csu = GEO(1, u), nactu = GEO(2, u), kwu = GEO(3, u);
             const int go = lane_o >> 4, dlo = lane_o & 15, s0o = split * csu + wave_o * kwu;
             const size_t layer_off = (size_t)kv_layer * a.kv_layer_elems;
@@ -570,16 +607,29 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             const bf16_t* vc = a.vcache + layer_off;
             const size_t head_base = ((size_t)(2 * u + at_r) * MG_HEADS + at_h) * (size_t)a.cache_len * 128 + dlo * 8;
             const int last_old = max(Pu - 2, 0);
+            if constexpr (UNC) {
+                const bool real = Pu > 1 && split < nactu;   // block-uniform
+                const bf16_t* finite = MG_LAYER(kv_layer).attn_norm + dlo * 8;
+                const bf16_t* kb = real ? kc + head_base : finite;
+                const bf16_t* vb = real ? vc + head_base : finite;
+#pragma unroll
+                for (int q = 0; q < ATTN_U; ++q) kd[q] = load_stream16(kb + (size_t)(real ? min(s0o + q * 4 + go, last_old) : 0) * 128);
+#pragma unroll
+                for (int q = 0; q < ATTN_U; ++q) vd[q] = load_stream16(vb + (size_t)(real ? min(s0o + q * 4 + go, last_old) : 0) * 128);
+            } else
             if (Pu > 1 && split < nactu) {
+                if (PART != 2)
 #pragma unroll
                 for (int q = 0; q < ATTN_U; ++q)
                     if (q * 4 < kwu) kd[q] = load_stream16(kc + head_base + (size_t)min(s0o + q * 4 + go, last_old) * 128);
+                if (PART != 1)
 #pragma unroll
                 for (int q = 0; q < ATTN_U; ++q)
                     if (q * 4 < kwu) vd[q] = load_stream16(vc + head_base + (size_t)min(s0o + q * 4 + go, last_old) * 128);
             }
         };
-        auto issue_kv = [&](int u, int kv_layer) { issue_kv_set(std::integral_constant<int, 0>{}, u, kv_layer, at_s); };
+        auto issue_kv = [&](int u, int kv_layer) { issue_kv_set(std::integral_constant<int, 0>{}, u, kv_layer, at_s, std::integral_constant<int, 0>{}); };
+        constexpr bool V_LATE = ((MEGA_V_AFTER_QKV >> (NU >> 1)) & 1) && !KV_UNCOND && !MEGA_KV_EARLY && !MEGA_KV_AFTER_NORM;   // bit 0 | 1 | 2: 1 | 2 | 4 utterances
 
         // ================= P0: RMSNorm + wqkv (+ KV-cache write)        fast_model.py:179,209,218 ====================
         __syncthreads();
@@ -597,18 +647,20 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         // The K/V stream of the first attention slice is requested here, before the norm and the wqkv dots: it lands while they
         // run.  (Requested after the q/k/v publish instead it sits in front of the q/k/v poll: 831 vs 794 us/step.)
         const bool kv_here = !MEGA_KV_EARLY || l == 0;   // else: requested behind the previous layer's h publish
-        if (kv_here) {
+        if (kv_here && !KV_UNCOND) {
 #pragma unroll
             for (int q = 0; q < ATTN_U; ++q) kv[q] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
             for (int q = 0; q < ATTN_U; ++q) vv[q] = u32x4{0u, 0u, 0u, 0u};
         }
-        if (!MEGA_KV_AFTER_NORM && first_att >= 0 && kv_here) issue_kv(first_att, l);
+        if (V_LATE) { if (first_att >= 0) issue_kv_set(std::integral_constant<int, 0>{}, first_att, l, at_s, std::integral_constant<int, 1>{}); }
+        else
+        if (!MEGA_KV_AFTER_NORM && (first_att >= 0 || KV_UNCOND) && kv_here) issue_kv(max(first_att, 0), l);
         __builtin_amdgcn_sched_barrier(0);
         MG_STAMP(l, 11);  // K/V requested
         mega_norm<NU>(xs, nw_attn, red, a.eps, tid_p);
         MG_STAMP(l, 12);  // norm done
-        if (MEGA_KV_AFTER_NORM && first_att >= 0 && kv_here) { issue_kv(first_att, l); __builtin_amdgcn_sched_barrier(0); }
+        if (MEGA_KV_AFTER_NORM && (first_att >= 0 || KV_UNCOND) && kv_here) { issue_kv(max(first_att, 0), l); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll MEGA_NU_UNROLL_P0
         for (int u = 0; u < NU; ++u) {
             float acc[3][2];
@@ -659,6 +711,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (V_LATE && first_att >= 0) { issue_kv_set(std::integral_constant<int, 0>{}, first_att, l, at_s, std::integral_constant<int, 2>{}); __builtin_amdgcn_sched_barrier(0); }
         MG_STAMP(l, 2);
         // next: wo row 8 b + wave.  Publish-before-prefetch (profiles/r01g_handoff/NOTES.md): a wave that still has something to
         // publish does so BEFORE it queues its next weight loads -- the memory pipeline accepts loads only as fast as it
@@ -759,7 +812,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 // The second range goes out HERE, behind the q / k / v poll: every poll ends in `s_waitcnt vmcnt(0)`, and loads retire in
                 // order -- requested in front of the poll (r04g: "q/k/v ready" 4.7 us) the poll waited for the whole second range.
                 if constexpr (ATTN_DB) {
-                    if (at_s + 1 < GEO(2, at_u)) issue_kv_set(std::integral_constant<int, 1>{}, at_u, l, at_s + 1);
+                    if (at_s + 1 < GEO(2, at_u)) issue_kv_set(std::integral_constant<int, 1>{}, at_u, l, at_s + 1, std::integral_constant<int, 0>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const int u = at_u;
@@ -790,10 +843,10 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                         // this set's registers are free: the range after next is requested into them while the other set is scored
                         if constexpr (ATTN_DB) {
                             if (j + 2 < SPB && j + 2 < n_my) {
-                                if (j & 1) issue_kv_set(std::integral_constant<int, 1>{}, u, l, split + 2);
-                                else issue_kv_set(std::integral_constant<int, 0>{}, u, l, split + 2);
+                                if (j & 1) issue_kv_set(std::integral_constant<int, 1>{}, u, l, split + 2, std::integral_constant<int, 0>{});
+                                else issue_kv_set(std::integral_constant<int, 0>{}, u, l, split + 2, std::integral_constant<int, 0>{});
                             }
-                        } else if (j + 1 < SPB && j + 1 < n_my) issue_kv_set(std::integral_constant<int, 0>{}, u, l, split + 1);
+                        } else if (j + 1 < SPB && j + 1 < n_my) issue_kv_set(std::integral_constant<int, 0>{}, u, l, split + 1, std::integral_constant<int, 0>{});
                         if (g == 0) {
                             float (*smj)[16][12] = sm + j * ATTN_WAVES;
                             smj[at_w][dl][0] = w.m;
@@ -1034,7 +1087,17 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             else if (I8) { mega_issue_row_i8<6>(cq, L.q8[4], 8 * b + wave_o, MG_INTER, lane_o); sc_c = bf2f(load_global_u16(L.s8[4] + (8 * b + wave_o))); }
             else if (EARLY_W2) {
 #pragma unroll
-                for (int j = EW2; j < 11; ++j) wv[j] = load_stream16(L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8);
+                for (int j = EW2; j < 11; ++j) wv[W2R0 + j] = load_stream16(L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8);
+                if constexpr (QKV_P4 > 0) {
+                    if (l + 1 < n_layer) {
+                        const bf16_t* w = MG_LAYER(l + 1).wqkv;
+#pragma unroll
+                        for (int c = 0; c < QKV_P4; ++c)
+#pragma unroll
+                            for (int i = 0; i < 3; ++i)
+                                wv[4 * i + 2 + c] = load_stream16(w + (size_t)(24 * b + 3 * wave_o + i) * MG_DIM + (2 + c) * 512 + lane_o * 8);
+                    }
+                }
             }
             else mega_issue_row<11>(wv, L.w2, 8 * b + wave_o, MG_INTER, lane_o, MG_ABLATE);
             __builtin_amdgcn_sched_barrier(0);
@@ -1084,7 +1147,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                     acc[0][0] = acc[0][1] = 0.f;
 #pragma unroll
                     for (int j = 0; j < 11; ++j) {
-                        const u32x4 w = j < EW2 ? w2_lds[(wave_p * EW2 + j) * 64 + lane_p] : wv[j];
+                        const u32x4 w = j < EW2 ? w2_lds[(wave_p * EW2 + j) * 64 + lane_p] : wv[W2R0 + j];
 #pragma unroll
                         for (int r = 0; r < 2; ++r) acc[0][r] = dot8_bf16(w, *(const u32x4*)(xs[u] + r * MG_INTER + j * 512 + lane_p * 8), acc[0][r]);
                     }
@@ -1118,8 +1181,8 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                     else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, MG_LAYER(l + 1).q8[0], 24 * b + 3 * wave_o + i, MG_DIM, lane_o); sc_a[i] = bf2f(load_global_u16(MG_LAYER(l + 1).s8[0] + (24 * b + 3 * wave_o + i))); }
                     else if (EARLY_QKV) {
                         const bf16_t* row = w + (size_t)(24 * b + 3 * wave_o + i) * MG_DIM;
-                        wv[4 * i + 2] = load_stream16(row + 2 * 512 + lane_o * 8);
-                        wv[4 * i + 3] = load_stream16(row + 3 * 512 + lane_o * 8);
+                        if (QKV_P4 < 1) wv[4 * i + 2] = load_stream16(row + 2 * 512 + lane_o * 8);
+                        if (QKV_P4 < 2) wv[4 * i + 3] = load_stream16(row + 3 * 512 + lane_o * 8);
                     }
                     else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave_o + i, MG_DIM, lane_o, MG_ABLATE);
                 }

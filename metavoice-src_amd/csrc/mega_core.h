@@ -11,6 +11,11 @@
 // Every wait is bounded; a timeout raises a device flag that the host turns into an error (a plain launch gives no
 // residency guarantee: if another kernel occupies CUs the grid may not be co-resident).
 #pragma once
+// profiling only: every hand-off wait is satisfied by its first look (results are garbage) -- the weight stream of the persistent kernel
+// with a zero-latency dependency chain
+#ifndef MEGA_FREE_RUN
+#define MEGA_FREE_RUN 0
+#endif
 #include <type_traits>
 
 #include "attn_core.h"
@@ -74,7 +79,7 @@ __device__ __forceinline__ void wave_poll(uint32_t tag, AF abort_flag_of, int* s
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < PER; ++k) ok = ok && (!have[k] || (uint32_t)(v[k] >> 32) == tag);
-        if (__all(ok)) {
+        if (MEGA_FREE_RUN || __all(ok)) {
 #pragma unroll
             for (int k = 0; k < PER; ++k)
                 if (have[k]) sink(k, (uint32_t)v[k]);
@@ -200,7 +205,7 @@ __device__ __forceinline__ void wave_poll16(const gran_t* g, uint32_t tag, AF ab
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < PER; ++k) ok = ok && (n[k] < 0 || (v[k].y == tag && v[k].w == tag));
-        if (__all(ok)) {
+        if (MEGA_FREE_RUN || __all(ok)) {
 #pragma unroll
             for (int k = 0; k < PER; ++k)
                 if (n[k] >= 0) sink(n[k], v[k].x, v[k].z);
