@@ -76,7 +76,7 @@ bool mega_instrumented() { return MEGA_INSTR != 0; }
 // q/k/v hand-off.  The K/V burst of all 256 workgroups (8 MB at 1024 positions) drains at HBM speed and the memory pipeline takes
 // requests only as fast as it drains them: every wave spends ~2.4 us in front of its norm issuing them (profiles/r04g, r04x).
 #ifndef MEGA_V_AFTER_QKV
-#define MEGA_V_AFTER_QKV 1
+#define MEGA_V_AFTER_QKV 7
 #endif
 #ifndef MEGA_KV_UNCOND
 #define MEGA_KV_UNCOND 0   // 1: every slot always requested (see issue_kv_set; measured slower, profiles/r04x)

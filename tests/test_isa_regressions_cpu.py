@@ -1,4 +1,4 @@
-"""Compile-level guards for three compiler artefacts that cost the persistent decode kernel 4 % of a step before they were found by
+"""Compile-level guards for compiler artefacts that cost the persistent decode kernel 4 % of a step before they were found by
 reading the ISA (profiles/r03q-r03s): a select-of-loads that put an accumulator into scratch memory, `flat_load`s of weight scale
 words (their wait is `vmcnt(0) lgkmcnt(0)`), and the layer pointer table fetched with vector loads.  hipcc cross-compiles gfx950 here (no GPU needed)."""
 import os
@@ -66,6 +66,15 @@ def test_persistent_decode_kernel_has_no_scratch_and_no_flat_loads(tmp_path):
         assert not re.search(r"global_load_dword(x2)? v[\[\d:\]]+, v\[\d+:\d+\], off[^\n]*sc0 sc1", body), name
         # the layer pointer table comes through scalar loads: no vector load whose result is only read back with v_readfirstlane
         assert not re.search(r"global_load_dwordx2 v\[(\d+):\d+\], v\d+, s\[\d+:\d+\][^\n]*\n(?:[^\n]*\n){0,6}?\s*v_readfirstlane_b32 s\d+, v\1\b", body), name
+        # r04x: a streaming request is never followed directly by a full wait.  "Zero the K/V slot, request it if used" left one component of
+        # one slot outside its load's register tuple; hipcc copied it right behind the load -- `global_load_dwordx4 v[120:123] ... nt ;
+        # s_waitcnt vmcnt(0) ; v_mov_b32 v136, v123` -- and every wave sat out a memory round trip in the middle of its K/V requests
+        assert not re.search(r"global_load_dwordx4 [^\n]* nt\n\s*s_waitcnt vmcnt\(0\)", body), f"{name}: full wait directly behind a streaming request"
+        # r04u: the epilogue sums run level by level over all their values (wave_sum_n) with the two row-broadcast levels as single masked
+        # DPP adds; one chain after the other hipcc put `s_nop 1` behind every DPP add (433 in the one-utterance bf16 instance)
+        if n_utt == "1" and fmt == "0":
+            assert body.count("s_nop") < 400, f"{name}: {body.count('s_nop')} s_nop"
+            assert len(re.findall(r"v_add_f32_dpp v\d+, v\d+, v\d+ row_bcast:15 row_mask:0xa", body)) >= 20, name
     assert seen == 12   # 3 formats x (1 utterance one-step, 2, 4) + the three one-utterance instances that draw their own tokens
 
 
