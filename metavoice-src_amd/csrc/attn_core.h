@@ -7,6 +7,9 @@
 #pragma once
 // profiling only: every hand-off wait is satisfied by its first look (results are garbage) -- the weight stream of the persistent kernel
 // with a zero-latency dependency chain
+#ifndef ATTN_SKIP_SLOTS
+#define ATTN_SKIP_SLOTS 1
+#endif
 #ifndef MEGA_FREE_RUN
 #define MEGA_FREE_RUN 0
 #endif
@@ -72,18 +75,25 @@ __device__ __forceinline__ AttnAcc attn_wave_partial(const u32x4 (&kv)[ATTN_U], 
     float sc[ATTN_U];
     AttnAcc a;
     a.m = -INFINITY;
+    // slots past the wave's key range (wave-uniform) are skipped: they are all masked (score -inf, weight 0, nothing added), so the bits
+    // are the same -- at 1024 positions a wave holds 16 keys in 4 of its 8 slots
+    const int nslot = ATTN_SKIP_SLOTS ? __builtin_amdgcn_readfirstlane((s1 - s0 + 3) >> 2) : ATTN_U;
 #pragma unroll
     for (int u = 0; u < ATTN_U; ++u) {
-        float s = sum_across16(dot8_bf16(kv[u], qv, 0.f)) * scale;
-        s = (s0 + u * 4 + g < s1) ? s : -INFINITY;
-        sc[u] = s;
-        a.m = fmaxf(a.m, s);
+        sc[u] = -INFINITY;
+        if (u < nslot) {
+            float s = sum_across16(dot8_bf16(kv[u], qv, 0.f)) * scale;
+            s = (s0 + u * 4 + g < s1) ? s : -INFINITY;
+            sc[u] = s;
+            a.m = fmaxf(a.m, s);
+        }
     }
     a.l = 0.f;
 #pragma unroll
     for (int d = 0; d < 8; ++d) a.o[d] = 0.f;
 #pragma unroll
     for (int u = 0; u < ATTN_U; ++u) {
+        if (!(u < nslot)) continue;
         const float p = (sc[u] == -INFINITY) ? 0.f : fast_exp(sc[u] - a.m);
         a.l += p;
         a.o[0] = fmaf(p, bf_lo(vv[u].x), a.o[0]);
