@@ -78,6 +78,13 @@ bool mega_instrumented() { return MEGA_INSTR != 0; }
 #ifndef MEGA_V_AFTER_QKV
 #define MEGA_V_AFTER_QKV 7
 #endif
+// experiments (profiles/r04ac): the early w2 chunks requested behind P3's norm instead of in front of it; K rows late as well
+#ifndef MEGA_EW2_AFTER_NORM
+#define MEGA_EW2_AFTER_NORM 0
+#endif
+#ifndef MEGA_K_AFTER_QKV
+#define MEGA_K_AFTER_QKV 0
+#endif
 #ifndef MEGA_KV_UNCOND
 #define MEGA_KV_UNCOND 0   // 1: every slot always requested (see issue_kv_set; measured slower, profiles/r04x)
 #endif
@@ -653,7 +660,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
 #pragma unroll
             for (int q = 0; q < ATTN_U; ++q) vv[q] = u32x4{0u, 0u, 0u, 0u};
         }
-        if (V_LATE) { if (first_att >= 0) issue_kv_set(std::integral_constant<int, 0>{}, first_att, l, at_s, std::integral_constant<int, 1>{}); }
+        if (V_LATE) { if (first_att >= 0 && !(MEGA_K_AFTER_QKV && NU == 1)) issue_kv_set(std::integral_constant<int, 0>{}, first_att, l, at_s, std::integral_constant<int, 1>{}); }
         else
         if (!MEGA_KV_AFTER_NORM && (first_att >= 0 || KV_UNCOND) && kv_here) issue_kv(max(first_att, 0), l);
         __builtin_amdgcn_sched_barrier(0);
@@ -711,7 +718,11 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (V_LATE && first_att >= 0) { issue_kv_set(std::integral_constant<int, 0>{}, first_att, l, at_s, std::integral_constant<int, 2>{}); __builtin_amdgcn_sched_barrier(0); }
+        if (V_LATE && first_att >= 0) {
+            if (MEGA_K_AFTER_QKV && NU == 1) issue_kv_set(std::integral_constant<int, 0>{}, first_att, l, at_s, std::integral_constant<int, 1>{});
+            issue_kv_set(std::integral_constant<int, 0>{}, first_att, l, at_s, std::integral_constant<int, 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
         MG_STAMP(l, 2);
         // next: wo row 8 b + wave.  Publish-before-prefetch (profiles/r01g_handoff/NOTES.md): a wave that still has something to
         // publish does so BEFORE it queues its next weight loads -- the memory pipeline accepts loads only as fast as it
@@ -1025,12 +1036,14 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             __syncthreads();
             MG_ABORT_RETURN();
             MG_STAMP(l, 7);
-            if constexpr (EARLY_W2) {  // chunks 0..EW2-1 of the w2 row on their way while the norm, the w1|w3 dots and the act publish run
+            auto request_w2_early = [&]() {  // chunks 0..EW2-1 of the w2 row on their way while the norm, the w1|w3 dots and the act publish run
 #pragma unroll
                 for (int j = 0; j < EW2; ++j)
                     mega_row_to_lds(lds_addr(w2_lds + ((wave_o * EW2 + j) * 64)), L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8, MG_ABLATE);
-            }
+            };
+            if constexpr (EARLY_W2 && !MEGA_EW2_AFTER_NORM) request_w2_early();
             mega_norm<NU>(xs, nw_ffn, red, a.eps, tid_p);
+            if constexpr (EARLY_W2 && MEGA_EW2_AFTER_NORM) { request_w2_early(); __builtin_amdgcn_sched_barrier(0); }
             MG_STAMP(l, 18);  // norm done
             const int nrows = wave_p < 6 ? 3 : 2;
             const int rb = 22 * b + (wave_p < 6 ? 3 * wave_p : 18 + 2 * (wave_p - 6));
