@@ -85,6 +85,9 @@ bool mega_instrumented() { return MEGA_INSTR != 0; }
 #ifndef MEGA_K_AFTER_QKV
 #define MEGA_K_AFTER_QKV 0
 #endif
+#ifndef MEGA_POLL_NORM
+#define MEGA_POLL_NORM 0   // one utterance: poll + RMSNorm without the LDS round trip of the raw vector (mega_poll_raw8)
+#endif
 #ifndef MEGA_KV_UNCOND
 #define MEGA_KV_UNCOND 0   // 1: every slot always requested (see issue_kv_set; measured slower, profiles/r04x)
 #endif
@@ -163,6 +166,35 @@ __device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x
 #pragma unroll
     for (int u = 0; u < NU; ++u) *(u32x4*)(xs[u] + r * MG_DIM + c) = MEGA_FAKE_REDUCE == 2 ? xv[u] : rms_apply8(xv[u], rstd[u], nw);
     __syncthreads();
+}
+
+// One utterance, MEGA_POLL_NORM: the hand-off poll and the RMSNorm as one piece.  mega_poll_rowpairs + mega_norm go poll -> LDS (raw) ->
+// barrier -> statistics (LDS read) -> barrier -> apply (LDS read, LDS write) -> barrier.  Here thread t polls the four 16-byte pairs that
+// hold columns 8 (t & 255) .. + 7 of BOTH rows (threads t and t + 256 poll the same 64 bytes) and keeps row t >> 8 in registers: the
+// statistics come straight from the registers (lane l of column wave q = the same 8 columns as mega_norm / gemv.hip's prologue, the same
+// sumsq8 and the same wave_sum => the same bits), one barrier, the apply from the registers, one LDS write, one barrier.
+template <typename AF>
+__device__ __forceinline__ u32x4 mega_poll_raw8(const gran_t* g, uint32_t tag, AF abort_flag, int* s_abort, const int tid) {
+    const int r = tid >> 8, c8 = tid & 255;
+    uint32_t p0[4], p1[4];
+    wave_poll16<4>(g, tag, abort_flag, s_abort, [&](int k) { return 4 * c8 + k; },
+                   [&](auto k, int, uint32_t a0, uint32_t a1) { p0[k] = a0; p1[k] = a1; });
+    u32x4 raw;   // pair k = columns 8 c8 + 2 k, + 1: granule payloads (row 0 | row 1 << 16)
+    raw.x = r ? ((p0[0] >> 16) | (p1[0] & 0xFFFF0000u)) : ((p0[0] & 0xFFFFu) | (p1[0] << 16));
+    raw.y = r ? ((p0[1] >> 16) | (p1[1] & 0xFFFF0000u)) : ((p0[1] & 0xFFFFu) | (p1[1] << 16));
+    raw.z = r ? ((p0[2] >> 16) | (p1[2] & 0xFFFF0000u)) : ((p0[2] & 0xFFFFu) | (p1[2] << 16));
+    raw.w = r ? ((p0[3] >> 16) | (p1[3] & 0xFFFF0000u)) : ((p0[3] & 0xFFFFu) | (p1[3] << 16));
+    return raw;
+}
+__device__ __forceinline__ void mega_norm_stats_raw8(const u32x4& raw, float* red, const int tid) {
+    const float s = wave_sum(sumsq8(raw));   // wave w = column wave w & 3 of row w >> 2
+    if ((tid & 63) == 0) red[((tid >> 6) & 3) * 2 + (tid >> 8)] = s;
+}
+__device__ __forceinline__ void mega_norm_apply_raw8(const u32x4& raw, bf16_t* xs0, const u32x4& nw, const float* red, float eps, const int tid) {
+    const int r = tid >> 8, c = (tid & 255) * 8;
+    const float* rd = red + r;
+    const float tot = (rd[0] + rd[2]) + (rd[4] + rd[6]);   // == block_total over the 4 column waves (mega_norm)
+    *(u32x4*)(xs0 + r * MG_DIM + c) = rms_apply8(raw, rms_rstd(tot, MG_DIM, eps), nw);
 }
 
 // acc[i][r] += W row i (registers) . x row r (LDS), lane l covering columns 512 j + 8 l .. + 7 of chunk j
@@ -641,15 +673,21 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         // ================= P0: RMSNorm + wqkv (+ KV-cache write)        fast_model.py:179,209,218 ====================
         __syncthreads();
         MG_STAMP(l, 0);
+        constexpr bool PN = NU == 1 && MEGA_POLL_NORM;   // mega_poll_raw8: the polled vector stays in registers through its norm
+        const bool pn_here = PN && l > 0;                 // layer 0's input rows are built in LDS
+        u32x4 raw_x = {0u, 0u, 0u, 0u};
         if (l == 0) {
             if (step == 0) {
 #pragma unroll
                 for (int u = 0; u < NU; ++u)
                     *(u32x4*)(xs[u] + tid * 8) = load16(KC(step)->x_in + (size_t)u * 2 * MG_DIM + tid * 8);  // written by the sampler in the previous launch
             }  // later steps: built at the end of the previous step from the control word
-        } else mega_poll_rowpairs<NU>(g_x, tag0 - 8u + 4u, xs, abort_flag_of, &s_abort, tid_o);
-        __syncthreads();
-        MG_ABORT_RETURN();
+        } else if constexpr (PN) raw_x = mega_poll_raw8(g_x, tag0 - 8u + 4u, abort_flag_of, &s_abort, tid_o);
+        else mega_poll_rowpairs<NU>(g_x, tag0 - 8u + 4u, xs, abort_flag_of, &s_abort, tid_o);
+        if (!pn_here) {
+            __syncthreads();
+            MG_ABORT_RETURN();
+        }
         MG_STAMP(l, 1);
         // The K/V stream of the first attention slice is requested here, before the norm and the wqkv dots: it lands while they
         // run.  (Requested after the q/k/v publish instead it sits in front of the q/k/v poll: 831 vs 794 us/step.)
@@ -665,6 +703,13 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         if (!MEGA_KV_AFTER_NORM && (first_att >= 0 || KV_UNCOND) && kv_here) issue_kv(max(first_att, 0), l);
         __builtin_amdgcn_sched_barrier(0);
         MG_STAMP(l, 11);  // K/V requested
+        if (pn_here) {
+            mega_norm_stats_raw8(raw_x, red, tid_p);
+            __syncthreads();
+            MG_ABORT_RETURN();
+            mega_norm_apply_raw8(raw_x, xs[0], nw_attn, red, a.eps, tid_p);
+            __syncthreads();
+        } else
         mega_norm<NU>(xs, nw_attn, red, a.eps, tid_p);
         MG_STAMP(l, 12);  // norm done
         if (MEGA_KV_AFTER_NORM && (first_att >= 0 || KV_UNCOND) && kv_here) { issue_kv(max(first_att, 0), l); __builtin_amdgcn_sched_barrier(0); }
@@ -1032,9 +1077,13 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         __syncthreads();
         MG_STAMP(l, 6);
         {
-            mega_poll_rowpairs<NU>(g_h, tag0 + 2u, xs, abort_flag_of, &s_abort, tid_o);
-            __syncthreads();
-            MG_ABORT_RETURN();
+            u32x4 raw_h = {0u, 0u, 0u, 0u};
+            if constexpr (PN) raw_h = mega_poll_raw8(g_h, tag0 + 2u, abort_flag_of, &s_abort, tid_o);
+            else {
+                mega_poll_rowpairs<NU>(g_h, tag0 + 2u, xs, abort_flag_of, &s_abort, tid_o);
+                __syncthreads();
+                MG_ABORT_RETURN();
+            }
             MG_STAMP(l, 7);
             auto request_w2_early = [&]() {  // chunks 0..EW2-1 of the w2 row on their way while the norm, the w1|w3 dots and the act publish run
 #pragma unroll
@@ -1042,6 +1091,13 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                     mega_row_to_lds(lds_addr(w2_lds + ((wave_o * EW2 + j) * 64)), L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8, MG_ABLATE);
             };
             if constexpr (EARLY_W2 && !MEGA_EW2_AFTER_NORM) request_w2_early();
+            if constexpr (PN) {
+                mega_norm_stats_raw8(raw_h, red, tid_p);
+                __syncthreads();
+                MG_ABORT_RETURN();
+                mega_norm_apply_raw8(raw_h, xs[0], nw_ffn, red, a.eps, tid_p);
+                __syncthreads();
+            } else
             mega_norm<NU>(xs, nw_ffn, red, a.eps, tid_p);
             if constexpr (EARLY_W2 && MEGA_EW2_AFTER_NORM) { request_w2_early(); __builtin_amdgcn_sched_barrier(0); }
             MG_STAMP(l, 18);  // norm done
@@ -1216,10 +1272,19 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     // ================= LM head on the last position: logits = head(norm(x))     fast_model.py:161-162 =================
     const uint32_t tag_head = epoch + (uint32_t)n_layer * 8u + 1u;
     __syncthreads();
+    if constexpr (NU == 1 && MEGA_POLL_NORM) {
+        const u32x4 raw_f = mega_poll_raw8(g_x, epoch + (uint32_t)(n_layer - 1) * 8u + 1u + 4u, [&]() { return KC(step)->abort_flag; }, &s_abort, tid);
+        mega_norm_stats_raw8(raw_f, red, tid);
+        __syncthreads();
+        MG_ABORT_RETURN();
+        mega_norm_apply_raw8(raw_f, xs[0], nw_attn, red, a.eps, tid);
+        __syncthreads();
+    } else {
     mega_poll_rowpairs<NU>(g_x, epoch + (uint32_t)(n_layer - 1) * 8u + 1u + 4u, xs, [&]() { return KC(step)->abort_flag; }, &s_abort, tid);
     __syncthreads();
     MG_ABORT_RETURN();
     mega_norm<NU>(xs, nw_attn, red, a.eps, tid);
+    }
 #pragma unroll 1
     for (int u = 0; u < NU; ++u) {
         float acc[2][2];

@@ -611,7 +611,7 @@ static hipError_t launch_attn_mfma(hipStream_t s, const AttnRowsArgs& a) {
 }
 
 hipError_t launch_attn_rows(hipStream_t s, const AttnRowsArgs& a) {
-    static const bool force_valu = getenv("MV_ATTN_VALU") != nullptr;   // A/B switch: the one-query-per-block kernel everywhere
+    const bool force_valu = getenv("MV_ATTN_VALU") != nullptr;   // A/B switch, read per call (tests flip it inside one process): the one-query-per-block kernel everywhere
     if (a.vt_scratch != nullptr && !force_valu) {
         if (a.head_dim == 128) return launch_attn_mfma<128>(s, a);
         if (a.head_dim == 64) return launch_attn_mfma<64>(s, a);

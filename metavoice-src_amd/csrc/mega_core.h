@@ -208,7 +208,11 @@ __device__ __forceinline__ void wave_poll16(const gran_t* g, uint32_t tag, AF ab
         if (MEGA_FREE_RUN || __all(ok)) {
 #pragma unroll
             for (int k = 0; k < PER; ++k)
-                if (n[k] >= 0) sink(n[k], v[k].x, v[k].z);
+                if (n[k] >= 0) {
+                    if constexpr (std::is_invocable_v<Sink, std::integral_constant<int, 0>, int, uint32_t, uint32_t>)
+                        sink(k, n[k], v[k].x, v[k].z);   // sinks that keep the payload in registers index by the (unrolled) request number
+                    else sink(n[k], v[k].x, v[k].z);
+                }
             return;
         }
         if ((tries & 1023) == 1023) {

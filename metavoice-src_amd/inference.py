@@ -61,7 +61,7 @@ def get_cached_file(file_or_uri: str) -> str:
     name and renamed, so that an interrupted or concurrent fetch never leaves half a file under the cached name and the URI
     never reaches a command line."""
     file_or_uri = str(file_or_uri)
-    if not file_or_uri.startswith("http"):
+    if not file_or_uri.lower().startswith(("http://", "https://")):   # a local file may well be called http_take3.wav
         if os.path.exists(file_or_uri):
             return file_or_uri
         raise FileNotFoundError(f"File {file_or_uri} not found!")
@@ -102,6 +102,11 @@ def get_cached_embedding(local_file_path: str, spkemb_model) -> torch.Tensor:
     local_file_path = str(local_file_path)
     if not os.path.exists(local_file_path):
         raise FileNotFoundError(f"File {local_file_path} not found!")
+    # an upload lives under a fresh temporary name that is never seen again: caching its embedding by path would leave one file per request
+    # in ~/.cache/fam for ever (the reference does exactly that under its server)
+    tmp_root = os.path.realpath(tempfile.gettempdir()) + os.sep
+    if os.path.realpath(local_file_path).startswith(tmp_root) and os.environ.get("MV_CACHE_TMP_EMBEDDINGS") is None:
+        return spkemb_model.embed_utterance_from_file(local_file_path, numpy=False).unsqueeze(0).detach().to("cpu")
     d = cache_root("fam")
     cache_path = os.path.join(d, "embedding_" + hashlib.md5(local_file_path.encode("utf-8")).hexdigest() + ".pt")
     if os.path.exists(cache_path) and os.path.getmtime(cache_path) >= os.path.getmtime(local_file_path):

@@ -161,6 +161,7 @@ def test_get_cached_embedding_is_computed_once_per_file(tmp_path, monkeypatch):
 
     inf = load_pkg("inference")
     monkeypatch.setenv("METAVOICE_CACHE_DIR", str(tmp_path / "cache"))
+    monkeypatch.setenv("MV_CACHE_TMP_EMBEDDINGS", "1")   # pytest's tmp_path is a temporary directory: see the next test
 
     class Enc:
         calls = 0
@@ -184,6 +185,33 @@ def test_get_cached_embedding_is_computed_once_per_file(tmp_path, monkeypatch):
     entry.write_bytes(b"garbage")
     os.utime(entry, (os.path.getmtime(f) + 10, os.path.getmtime(f) + 10))
     assert float(inf.get_cached_embedding(str(f), Enc())[0, 0]) == 3.0  # unreadable entry -> recomputed, not an error
+
+
+def test_uploads_under_the_temporary_directory_leave_no_cache_entry(tmp_path, monkeypatch):
+    """A served upload is a fresh temporary file per request: keyed by path (the reference's scheme) every request would leave an
+    `embedding_*.pt` behind for ever.  Also: a local file whose name starts with "http" is a local file."""
+    inf = load_pkg("inference")
+    monkeypatch.setenv("METAVOICE_CACHE_DIR", str(tmp_path / "cache"))
+    monkeypatch.delenv("MV_CACHE_TMP_EMBEDDINGS", raising=False)
+
+    class Enc:
+        calls = 0
+
+        def embed_utterance_from_file(self, path, numpy):
+            Enc.calls += 1
+            return torch.full((256,), float(Enc.calls))
+
+    f = tmp_path / "upload.wav"
+    f.write_bytes(b"x")
+    e1 = inf.get_cached_embedding(str(f), Enc())
+    e2 = inf.get_cached_embedding(str(f), Enc())
+    assert e1.shape == (1, 256) and Enc.calls == 2 and float(e2[0, 0]) == 2.0
+    assert not (tmp_path / "cache" / "fam").exists() or not list((tmp_path / "cache" / "fam").glob("embedding_*"))
+    g = tmp_path / "http_take3.wav"
+    g.write_bytes(b"x")
+    assert inf.get_cached_file(str(g)) == str(g)
+    with pytest.raises(FileNotFoundError):
+        inf.get_cached_file("httpx://nowhere/a.wav")
 
 
 def test_mel_front_end_matches_the_independent_implementation_in_the_image():

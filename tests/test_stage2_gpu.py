@@ -143,7 +143,7 @@ def test_stage2_logits_against_oracle_and_reference_golden(name):
 
 
 @pytest.mark.parametrize("name", ["rms_swiglu", "ln_gelu_bias"])
-def test_stage2_sampling(name):
+def test_stage2_sampling(name, monkeypatch):
     g, args, sd, cfg, model = build_stage2(name)
     T = args["block_size"]
     gen = torch.Generator().manual_seed(5)
@@ -186,6 +186,14 @@ def test_stage2_sampling(name):
     print(f"[{name}] stochastic second-stage draws identical to the oracle at {match * 100:.1f}% of positions; "
           f"a differing draw is at most {worst:.4f} of cumulative probability away from the oracle's boundary")
     assert match > 0.75 and worst < 0.02
+    # the relaxed bound above is for the MFMA attention only: the one-query-per-block kernel, in the same process on the same inputs
+    # (MV_ATTN_VALU is read per call), keeps the tight one -- so the relaxation is a property of the rounding, asserted, not of a tool printout
+    monkeypatch.setenv("MV_ATTN_VALU", "1")
+    y_valu = model.generate(idx, None, temperature=1.0, top_k=200, speaker_embs=spk, batch_size=2, seed=seed)
+    monkeypatch.delenv("MV_ATTN_VALU")
+    match_valu = float((y_valu == oy).float().mean())
+    print(f"[{name}] one-query-per-block attention: {match_valu * 100:.1f}% identical draws")
+    assert match_valu > 0.9
     assert len(torch.unique(y)) > 50  # it really is sampling
     # different seed -> different draws; same seed -> same draws
     y2 = model.generate(idx, None, temperature=1.0, top_k=200, speaker_embs=spk, batch_size=2, seed=seed)
