@@ -314,7 +314,10 @@ __device__ __forceinline__ void mega_issue_row(u32x4* wv, const bf16_t* w, int n
 #ifndef MEGA_EARLY_NU
 #define MEGA_EARLY_NU 0   // measured: 4 utterances 1375 vs 1339 us/step, 2 utterances 956 vs 926 (profiles/r04m) -- off
 #endif
-__host__ __device__ constexpr int mega_early_w2_chunks(int nu) { return nu == 4 ? 4 : 5; }
+#ifndef MEGA_EW2_CHUNKS
+#define MEGA_EW2_CHUNKS 5   // of the 11 chunks of a w2 row (profiles/r04ae: 7 and 9 measured)
+#endif
+__host__ __device__ constexpr int mega_early_w2_chunks(int nu) { return nu == 4 ? 4 : MEGA_EW2_CHUNKS; }
 __host__ __device__ constexpr bool mega_early_w1(int nu) { return MEGA_EARLY_W1 && nu <= 2; }
 #define MEGA_EARLY_W1_BYTES (MG_WAVES * 6 * 1024)
 __device__ __forceinline__ void mega_row_to_lds(uint32_t lds, const bf16_t* g, int ablate = 0) {  // 64 lanes x 16 B -> 1 KB of LDS at `lds`
