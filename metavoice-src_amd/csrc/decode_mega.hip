@@ -85,6 +85,9 @@ bool mega_instrumented() { return MEGA_INSTR != 0; }
 #ifndef MEGA_K_AFTER_QKV
 #define MEGA_K_AFTER_QKV 0
 #endif
+#ifndef MEGA_COMB_W1_LATE
+#define MEGA_COMB_W1_LATE 0
+#endif
 #ifndef MEGA_POLL_NORM
 #define MEGA_POLL_NORM 0   // one utterance: poll + RMSNorm without the LDS round trip of the raw vector (mega_poll_raw8)
 #endif
@@ -857,7 +860,10 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             MG_ABORT_RETURN();
             MG_STAMP(l, 3);
             if (WO_LATE) request_wo();
-            if constexpr (EARLY_W1) {  // half of w1 on its way while the partial is computed, merged and published
+            // MEGA_COMB_W1_LATE (experiment, one utterance): the workgroups that COMBINE the split partials (split 0: 32 of 256) keep their memory
+            // queue empty until the combine is through -- a hand-off into a streaming CU costs 2.9 us, into a quiet one 1.1 (MI355X_MICROARCH.md,
+            // handoff-1to1) -- and request the LDS half of w1 with the register half, behind the attention (request_w1's fallback)
+            if constexpr (EARLY_W1) if (!(MEGA_COMB_W1_LATE && NU == 1 && at_s == 0 && GEO(2, 0) > 1)) {  // half of w1 on its way while the partial is computed, merged and published
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
