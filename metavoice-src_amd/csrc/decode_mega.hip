@@ -16,6 +16,27 @@
 #include <atomic>
 
 #include "mega_core.h"
+// MEGA_SOFT_BARRIER (profiling, profiles/r04ah): every workgroup barrier of this file as an LDS counter barrier (one ds_add per wave, then a
+// spin on the counter) instead of s_barrier -- what a barrier costs that does not need every wave of the workgroup (the question behind
+// dedicated loader waves).  The counter is monotonic: a wave that took ticket t waits for 8 (t / 8 + 1).
+#ifndef MEGA_SOFT_BARRIER
+#define MEGA_SOFT_BARRIER 0
+#endif
+#if MEGA_SOFT_BARRIER
+__shared__ unsigned mg_soft_bar_ctr;
+__device__ __forceinline__ void mega_soft_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    unsigned target = 0;
+    if ((threadIdx.x & 63) == 0) target = (__hip_atomic_fetch_add(&mg_soft_bar_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) / 8u + 1u) * 8u;
+    target = __builtin_amdgcn_readfirstlane(target);
+    while (__hip_atomic_load(&mg_soft_bar_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#define MG_FIRST_BARRIER() do { if (threadIdx.x == 0) mg_soft_bar_ctr = 0u; __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); } while (0)
+#define __syncthreads() mega_soft_barrier()
+#else
+#define MG_FIRST_BARRIER() do { } while (0)
+#endif
 #include "sample_core.h"
 #include "gemv_i4_core.h"
 #include "gemv_i8_core.h"
@@ -464,6 +485,7 @@ template <int WF, int NU, bool FOLD>  // WF: MV_W_BF16, MV_W_INT4_G128 (LM head 
                                       // FOLD: a.n_steps decode steps per launch, the token drawn inside (else one step, logits only)
 __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_kernel(const MegaArgs a) {   // hot fields by name, cold ones through KC()
     extern __shared__ __attribute__((aligned(16))) unsigned char mg_lds[];
+    MG_FIRST_BARRIER();
     // the GEMV operand of the current phase, per utterance; the residual stream is NOT kept here: a wave produces exactly the
     // columns (8 b + wave) whose residual it needs two phases later, so those ride in registers (xres / hres)
     bf16_t (*xs)[2 * MG_INTER] = (bf16_t(*)[2 * MG_INTER])mg_lds;
