@@ -106,6 +106,12 @@ bool mega_instrumented() { return MEGA_INSTR != 0; }
 #ifndef MEGA_K_AFTER_QKV
 #define MEGA_K_AFTER_QKV 0
 #endif
+// MEGA_XS_DB (one utterance): the GEMV operand vectors alternate between TWO LDS buffers -- x and h in `xa`, the attention vector and the
+// activation vector in `xs` -- so that a phase's poll never overwrites what the previous phase's dots may still be reading: the barrier at
+// the top of each phase (4 of a layer's 17) goes; the barrier behind each poll already separates a buffer's next writer from its last readers.
+#ifndef MEGA_XS_DB
+#define MEGA_XS_DB 0
+#endif
 #ifndef MEGA_COMB_W1_LATE
 #define MEGA_COMB_W1_LATE 0
 #endif
@@ -412,7 +418,8 @@ __device__ __forceinline__ void mega_poll_rowpairs(const gran_t* g, uint32_t tag
 }
 
 __host__ __device__ constexpr size_t mega_lds_bytes(int n_utt) {  // dynamic LDS of the kernel below: xs, qkv_s, sm (one per key range of the workgroup), red
-    return (size_t)n_utt * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2) + (size_t)(MEGA_ATTN_V2 ? n_utt : 1) * ATTN_WAVES * 16 * 12 * 4 + (size_t)n_utt * MG_WAVES * 2 * 4;
+    return (size_t)n_utt * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2) + (size_t)(MEGA_ATTN_V2 ? n_utt : 1) * ATTN_WAVES * 16 * 12 * 4 + (size_t)n_utt * MG_WAVES * 2 * 4 +
+           (MEGA_XS_DB && n_utt == 1 ? (size_t)2 * MG_DIM * 2 : 0);   // xa
 }
 
 // sample() + the bookkeeping of decode_n_tokens + (last step of a launch) the next launch's input rows, by the workgroup of
@@ -492,6 +499,8 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     bf16_t (*qkv_s)[3 * 2 * 128] = (bf16_t(*)[3 * 2 * 128])(mg_lds + (size_t)NU * 2 * MG_INTER * 2);  // q, k_new, v_new of this block's head
     float (*sm)[16][12] = (float(*)[16][12])(mg_lds + (size_t)NU * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2));  // [ranges of this workgroup][ATTN_WAVES][16][12]
     float* red = (float*)(sm + (MEGA_ATTN_V2 ? NU : 1) * ATTN_WAVES);  // [NU][MG_WAVES * 2]
+    constexpr bool XDB = NU == 1 && MEGA_XS_DB;   // x and h live in their own buffer (see MEGA_XS_DB)
+    bf16_t (*xa)[2 * MG_INTER] = XDB ? (bf16_t(*)[2 * MG_INTER])(mg_lds + mega_lds_bytes(NU) - (size_t)2 * MG_DIM * 2) : xs;   // only xa[0][0 .. 2 MG_DIM) exists
     constexpr bool EARLY_ANY = mega_early_rows(WF, NU);
     constexpr bool EARLY_W2 = EARLY_ANY && MEGA_EARLY_W2, EARLY_W1 = EARLY_ANY && mega_early_w1(NU), EARLY_QKV = EARLY_ANY && MEGA_EARLY_QKV && NU == 1;
     constexpr bool W3_EARLY = EARLY_W1 && MEGA_W3_EARLY && NU == 1;
@@ -610,7 +619,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             const bf16_t* xi = KC(step)->x_in + (size_t)u * 2 * MG_DIM + 8 * b + wave;
             if (lane == 0) res_s[0][u][wave] = (uint32_t)xi[0] | ((uint32_t)xi[MG_DIM] << 16);
         } else if (lane == 0) {
-            res_s[0][u][wave] = (uint32_t)xs[u][8 * b + wave] | ((uint32_t)xs[u][MG_DIM + 8 * b + wave] << 16);
+            res_s[0][u][wave] = (uint32_t)xa[u][8 * b + wave] | ((uint32_t)xa[u][MG_DIM + 8 * b + wave] << 16);
         }
     }
     __syncthreads();
@@ -699,7 +708,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         constexpr bool V_LATE = ((MEGA_V_AFTER_QKV >> (NU >> 1)) & 1) && !KV_UNCOND && !MEGA_KV_EARLY && !MEGA_KV_AFTER_NORM;   // bit 0 | 1 | 2: 1 | 2 | 4 utterances
 
         // ================= P0: RMSNorm + wqkv (+ KV-cache write)        fast_model.py:179,209,218 ====================
-        __syncthreads();
+        if (!XDB) __syncthreads();
         MG_STAMP(l, 0);
         constexpr bool PN = NU == 1 && MEGA_POLL_NORM;   // mega_poll_raw8: the polled vector stays in registers through its norm
         const bool pn_here = PN && l > 0;                 // layer 0's input rows are built in LDS
@@ -708,10 +717,10 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             if (step == 0) {
 #pragma unroll
                 for (int u = 0; u < NU; ++u)
-                    *(u32x4*)(xs[u] + tid * 8) = load16(KC(step)->x_in + (size_t)u * 2 * MG_DIM + tid * 8);  // written by the sampler in the previous launch
+                    *(u32x4*)(xa[u] + tid * 8) = load16(KC(step)->x_in + (size_t)u * 2 * MG_DIM + tid * 8);  // written by the sampler in the previous launch
             }  // later steps: built at the end of the previous step from the control word
         } else if constexpr (PN) raw_x = mega_poll_raw8(g_x, tag0 - 8u + 4u, abort_flag_of, &s_abort, tid_o);
-        else mega_poll_rowpairs<NU>(g_x, tag0 - 8u + 4u, xs, abort_flag_of, &s_abort, tid_o);
+        else mega_poll_rowpairs<NU>(g_x, tag0 - 8u + 4u, xa, abort_flag_of, &s_abort, tid_o);
         if (!pn_here) {
             __syncthreads();
             MG_ABORT_RETURN();
@@ -735,17 +744,17 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             mega_norm_stats_raw8(raw_x, red, tid_p);
             __syncthreads();
             MG_ABORT_RETURN();
-            mega_norm_apply_raw8(raw_x, xs[0], nw_attn, red, a.eps, tid_p);
+            mega_norm_apply_raw8(raw_x, xa[0], nw_attn, red, a.eps, tid_p);
             __syncthreads();
         } else
-        mega_norm<NU>(xs, nw_attn, red, a.eps, tid_p);
+        mega_norm<NU>(xa, nw_attn, red, a.eps, tid_p);
         MG_STAMP(l, 12);  // norm done
         if (MEGA_KV_AFTER_NORM && (first_att >= 0 || KV_UNCOND) && kv_here) { issue_kv(max(first_att, 0), l); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll MEGA_NU_UNROLL_P0
         for (int u = 0; u < NU; ++u) {
             float acc[3][2];
-            if (I4) mega_dots_i4<1, 3, MG_DIM>(cq, cz, xs[u], MG_DIM, lane_p, acc);
-            else if (I8) mega_dots_i8<2, 3, MG_DIM>(cq, xs[u], MG_DIM, lane_p, acc);
+            if (I4) mega_dots_i4<1, 3, MG_DIM>(cq, cz, xa[u], MG_DIM, lane_p, acc);
+            else if (I8) mega_dots_i8<2, 3, MG_DIM>(cq, xa[u], MG_DIM, lane_p, acc);
             else if (EARLY_QKV && l > 0) {  // layer 0's rows come whole, in registers (issue_layer0); same order as mega_dots
 #pragma unroll
                 for (int i = 0; i < 3; ++i) acc[i][0] = acc[i][1] = 0.f;
@@ -753,7 +762,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
-                        const u32x4 xv = *(const u32x4*)(xs[u] + r * MG_DIM + j * 512 + lane * 8);
+                        const u32x4 xv = *(const u32x4*)(xa[u] + r * MG_DIM + j * 512 + lane * 8);
 #pragma unroll
                         for (int i = 0; i < 3; ++i) {
                             const u32x4 w = j < 2 ? w1_lds[(wave * 6 + i * 2 + j) * 64 + lane] : wv[4 * i + j];
@@ -761,7 +770,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                         }
                     }
             }
-            else mega_dots<4, 3, MG_DIM>(wv, xs[u], lane_p, acc);
+            else mega_dots<4, 3, MG_DIM>(wv, xa[u], lane_p, acc);
             __builtin_amdgcn_sched_barrier(0);
             if (u == 0) MG_STAMP(l, 13);  // wqkv dots done
             float v0 = 0.f, v1 = 0.f;
@@ -1051,7 +1060,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         __builtin_amdgcn_sched_barrier(0);
 
         // ================= P2: h = x + wo(attn)                         fast_model.py:224-226,179 =====================
-        __syncthreads();
+        if (!XDB) __syncthreads();
         MG_STAMP(l, 4);
         {
             // granule i of utterance u = elements 2i, 2i+1 of its [2][2048] attention output
@@ -1105,13 +1114,13 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         }
 
         // ================= P3: act = silu(w1 n(h)) * w3 n(h)            fast_model.py:180,237 =========================
-        __syncthreads();
+        if (!XDB) __syncthreads();
         MG_STAMP(l, 6);
         {
             u32x4 raw_h = {0u, 0u, 0u, 0u};
             if constexpr (PN) raw_h = mega_poll_raw8(g_h, tag0 + 2u, abort_flag_of, &s_abort, tid_o);
             else {
-                mega_poll_rowpairs<NU>(g_h, tag0 + 2u, xs, abort_flag_of, &s_abort, tid_o);
+                mega_poll_rowpairs<NU>(g_h, tag0 + 2u, xa, abort_flag_of, &s_abort, tid_o);
                 __syncthreads();
                 MG_ABORT_RETURN();
             }
@@ -1126,10 +1135,10 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 mega_norm_stats_raw8(raw_h, red, tid_p);
                 __syncthreads();
                 MG_ABORT_RETURN();
-                mega_norm_apply_raw8(raw_h, xs[0], nw_ffn, red, a.eps, tid_p);
+                mega_norm_apply_raw8(raw_h, xa[0], nw_ffn, red, a.eps, tid_p);
                 __syncthreads();
             } else
-            mega_norm<NU>(xs, nw_ffn, red, a.eps, tid_p);
+            mega_norm<NU>(xa, nw_ffn, red, a.eps, tid_p);
             if constexpr (EARLY_W2 && MEGA_EW2_AFTER_NORM) { request_w2_early(); __builtin_amdgcn_sched_barrier(0); }
             MG_STAMP(l, 18);  // norm done
             const int nrows = wave_p < 6 ? 3 : 2;
@@ -1138,11 +1147,11 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             for (int u = 0; u < NU; ++u) {
                 float acc1[3][2], acc3[3][2];
                 if (I4) {
-                    mega_dots_i4<1, 3, MG_DIM>(cq, cz, xs[u], MG_DIM, lane_p, acc1);
-                    mega_dots_i4<1, 3, MG_DIM>(cq + 3, cz + 3, xs[u], MG_DIM, lane_p, acc3);
+                    mega_dots_i4<1, 3, MG_DIM>(cq, cz, xa[u], MG_DIM, lane_p, acc1);
+                    mega_dots_i4<1, 3, MG_DIM>(cq + 3, cz + 3, xa[u], MG_DIM, lane_p, acc3);
                 } else if (I8) {
-                    mega_dots_i8<2, 3, MG_DIM>(cq, xs[u], MG_DIM, lane_p, acc1);
-                    mega_dots_i8<2, 3, MG_DIM>(cq + 6, xs[u], MG_DIM, lane_p, acc3);
+                    mega_dots_i8<2, 3, MG_DIM>(cq, xa[u], MG_DIM, lane_p, acc1);
+                    mega_dots_i8<2, 3, MG_DIM>(cq + 6, xa[u], MG_DIM, lane_p, acc3);
                 } else {
                     if constexpr (EARLY_W1) {  // same order as mega_dots: chunk j ascending, row r, weight row i
 #pragma unroll
@@ -1151,7 +1160,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
                             for (int r = 0; r < 2; ++r) {
-                                const u32x4 xv = *(const u32x4*)(xs[u] + r * MG_DIM + j * 512 + lane_p * 8);
+                                const u32x4 xv = *(const u32x4*)(xa[u] + r * MG_DIM + j * 512 + lane_p * 8);
 #pragma unroll
                                 for (int i = 0; i < 3; ++i) {
                                     const u32x4 w = j < 2 ? w1_lds[(wave_p * 6 + i * 2 + j) * 64 + lane_p] : wv[4 * i + j];
@@ -1159,8 +1168,8 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                                 }
                             }
                     } else
-                    mega_dots<4, 3, MG_DIM>(wv, xs[u], lane_p, acc1);
-                    mega_dots<4, 3, MG_DIM>(wv + 12, xs[u], lane_p, acc3);
+                    mega_dots<4, 3, MG_DIM>(wv, xa[u], lane_p, acc1);
+                    mega_dots<4, 3, MG_DIM>(wv + 12, xa[u], lane_p, acc3);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (u == 0) MG_STAMP(l, 19);  // w1|w3 dots done
@@ -1204,7 +1213,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         }
 
         // ================= P4: x = h + w2(act)                          fast_model.py:247,180 =========================
-        __syncthreads();
+        if (!XDB) __syncthreads();
         MG_STAMP(l, 8);
         {
             // 16-byte polls carrying two granules (each half validated by its own tag): 5632 / 2 = 2816 pairs per utterance, 6 per
@@ -1308,19 +1317,19 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         mega_norm_stats_raw8(raw_f, red, tid);
         __syncthreads();
         MG_ABORT_RETURN();
-        mega_norm_apply_raw8(raw_f, xs[0], nw_attn, red, a.eps, tid);
+        mega_norm_apply_raw8(raw_f, xa[0], nw_attn, red, a.eps, tid);
         __syncthreads();
     } else {
-    mega_poll_rowpairs<NU>(g_x, epoch + (uint32_t)(n_layer - 1) * 8u + 1u + 4u, xs, [&]() { return KC(step)->abort_flag; }, &s_abort, tid);
+    mega_poll_rowpairs<NU>(g_x, epoch + (uint32_t)(n_layer - 1) * 8u + 1u + 4u, xa, [&]() { return KC(step)->abort_flag; }, &s_abort, tid);
     __syncthreads();
     MG_ABORT_RETURN();
-    mega_norm<NU>(xs, nw_attn, red, a.eps, tid);
+    mega_norm<NU>(xa, nw_attn, red, a.eps, tid);
     }
 #pragma unroll 1
     for (int u = 0; u < NU; ++u) {
         float acc[2][2];
-        if (I8) mega_dots_i8<2, 2, MG_DIM>(cq, xs[u], MG_DIM, lane, acc);
-        else mega_dots<4, 2, MG_DIM>(wv, xs[u], lane, acc);
+        if (I8) mega_dots_i8<2, 2, MG_DIM>(cq, xa[u], MG_DIM, lane, acc);
+        else mega_dots<4, 2, MG_DIM>(wv, xa[u], lane, acc);
         float v0 = 0.f, v1 = 0.f;
         float sumsh[4] = {acc[0][0], acc[0][1], acc[1][0], acc[1][1]};
         mega_wave_sums<4>(sumsh);
@@ -1409,8 +1418,8 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             r0[j] = (uint32_t)f2bf(b0 + bf2f((bf16_t)sw)) | ((uint32_t)f2bf(b1 + bf2f((bf16_t)(sw >> 16))) << 16);
             r1[j] = (uint32_t)f2bf(b0) | ((uint32_t)f2bf(b1) << 16);
         }
-        *(u32x4*)(xs[u] + c) = r0;
-        *(u32x4*)(xs[u] + MG_DIM + c) = r1;
+        *(u32x4*)(xa[u] + c) = r0;
+        *(u32x4*)(xa[u] + MG_DIM + c) = r1;
     }
     __syncthreads();
     }  // if constexpr (fold)
