@@ -109,6 +109,11 @@ bool mega_instrumented() { return MEGA_INSTR != 0; }
 // MEGA_XS_DB (one utterance): the GEMV operand vectors alternate between TWO LDS buffers -- x and h in `xa`, the attention vector and the
 // activation vector in `xs` -- so that a phase's poll never overwrites what the previous phase's dots may still be reading: the barrier at
 // the top of each phase (4 of a layer's 17) goes; the barrier behind each poll already separates a buffer's next writer from its last readers.
+// MEGA_PUB_BARRIER (experiment): the barrier at the top of P3 / P4 / the next P0 moved UP, between a phase's publish and its requests for the
+// next phase -- publish-before-prefetch for the whole workgroup there as well (r04ai: without the phase-top barriers the step is 16 % slower)
+#ifndef MEGA_PUB_BARRIER
+#define MEGA_PUB_BARRIER 0
+#endif
 #ifndef MEGA_XS_DB
 #define MEGA_XS_DB 0
 #endif
@@ -499,6 +504,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     bf16_t (*qkv_s)[3 * 2 * 128] = (bf16_t(*)[3 * 2 * 128])(mg_lds + (size_t)NU * 2 * MG_INTER * 2);  // q, k_new, v_new of this block's head
     float (*sm)[16][12] = (float(*)[16][12])(mg_lds + (size_t)NU * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2));  // [ranges of this workgroup][ATTN_WAVES][16][12]
     float* red = (float*)(sm + (MEGA_ATTN_V2 ? NU : 1) * ATTN_WAVES);  // [NU][MG_WAVES * 2]
+    constexpr bool PUB_B = NU == 1 && MEGA_PUB_BARRIER;
     constexpr bool XDB = NU == 1 && MEGA_XS_DB;   // x and h live in their own buffer (see MEGA_XS_DB)
     bf16_t (*xa)[2 * MG_INTER] = XDB ? (bf16_t(*)[2 * MG_INTER])(mg_lds + mega_lds_bytes(NU) - (size_t)2 * MG_DIM * 2) : xs;   // only xa[0][0 .. 2 MG_DIM) exists
     constexpr bool EARLY_ANY = mega_early_rows(WF, NU);
@@ -708,7 +714,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         constexpr bool V_LATE = ((MEGA_V_AFTER_QKV >> (NU >> 1)) & 1) && !KV_UNCOND && !MEGA_KV_EARLY && !MEGA_KV_AFTER_NORM;   // bit 0 | 1 | 2: 1 | 2 | 4 utterances
 
         // ================= P0: RMSNorm + wqkv (+ KV-cache write)        fast_model.py:179,209,218 ====================
-        if (!XDB) __syncthreads();
+        if (!XDB && !(PUB_B && l > 0)) __syncthreads();
         MG_STAMP(l, 0);
         constexpr bool PN = NU == 1 && MEGA_POLL_NORM;   // mega_poll_raw8: the polled vector stays in registers through its norm
         const bool pn_here = PN && l > 0;                 // layer 0's input rows are built in LDS
@@ -1107,6 +1113,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 17);  // h published
+            if (PUB_B) __syncthreads();
             // next: the w3 rows (w1 is already in flight) -- unless they went out with w1 (MEGA_W3_EARLY)
             if (!W3_EARLY) request_w3(0, 3 - W3_AT_QKV);
             if (MEGA_KV_EARLY && first_att >= 0 && l + 1 < n_layer) issue_kv(first_att, l + 1);
@@ -1114,7 +1121,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         }
 
         // ================= P3: act = silu(w1 n(h)) * w3 n(h)            fast_model.py:180,237 =========================
-        if (!XDB) __syncthreads();
+        if (!XDB && !PUB_B) __syncthreads();
         MG_STAMP(l, 6);
         {
             u32x4 raw_h = {0u, 0u, 0u, 0u};
@@ -1191,6 +1198,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 20);  // act published
+            if (PUB_B) __syncthreads();
             // next: w2 row 8 b + wave (K = 5632: 11 chunks)
             if (I4) mega_issue_row_i4<3>(cq + 6, cz + 6, L.q[4], L.sz[4], 8 * b + wave_o, MG_INTER, lane_o);
             else if (I8) { mega_issue_row_i8<6>(cq, L.q8[4], 8 * b + wave_o, MG_INTER, lane_o); sc_c = bf2f(load_global_u16(L.s8[4] + (8 * b + wave_o))); }
@@ -1213,7 +1221,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         }
 
         // ================= P4: x = h + w2(act)                          fast_model.py:247,180 =========================
-        if (!XDB) __syncthreads();
+        if (!XDB && !PUB_B) __syncthreads();
         MG_STAMP(l, 8);
         {
             // 16-byte polls carrying two granules (each half validated by its own tag): 5632 / 2 = 2816 pairs per utterance, 6 per
@@ -1280,6 +1288,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (PUB_B && l + 1 < n_layer) __syncthreads();
             // next: the following layer's wqkv rows, or the LM-head rows 11 b + wave + 8 i
             if (MEGA_KV_AFTER_NORM) nw_attn = load16((l + 1 < n_layer ? MG_LAYER(l + 1).attn_norm : KC(l)->final_norm) + (tid_o & 255) * 8);
             if (l + 1 < n_layer) {
