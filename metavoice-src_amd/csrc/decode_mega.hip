@@ -315,11 +315,13 @@ __device__ __forceinline__ void mega_issue_row(u32x4* wv, const bf16_t* w, int n
 //   MEGA_WO_AFTER_QKV:  the wo row is requested when q / k / v have arrived instead of in front of their poll.
 // how far the loops over the utterances of an engine of 2 / 4 are unrolled in the wqkv (P0) and w1|w3 (P3) phases: 1 = rolled (round 2:
 // unrolled they interleaved the utterances' temporaries and spilled 60-190 VGPRs; with the launch arguments out of the way 2 fits)
+// Round 4, with the epilogue sums interleaved (wave_sum_n): 2 gains a little (r04ak: two utterances 887 -> 881 us/step, four 1266 -> 1261) -- two
+// utterances' 6 / 12 sums run side by side; the int4 instances stay rolled (5-6 spilled registers unrolled).
 #ifndef MEGA_NU_UNROLL_P0
-#define MEGA_NU_UNROLL_P0 1
+#define MEGA_NU_UNROLL_P0 2
 #endif
 #ifndef MEGA_NU_UNROLL_P3
-#define MEGA_NU_UNROLL_P3 1
+#define MEGA_NU_UNROLL_P3 2
 #endif
 // MEGA_W3_QKV_ROWS (one utterance, bf16): that many of the wave's three w3 rows are requested together with the wo row, under the q / k / v
 // hand-off (8 MB of wo in a ~2 us hop leave room), the rest behind the h publish as before (23 MB there: the hop is stream-bound).
@@ -756,7 +758,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         mega_norm<NU>(xa, nw_attn, red, a.eps, tid_p);
         MG_STAMP(l, 12);  // norm done
         if (MEGA_KV_AFTER_NORM && (first_att >= 0 || KV_UNCOND) && kv_here) { issue_kv(max(first_att, 0), l); __builtin_amdgcn_sched_barrier(0); }
-#pragma unroll MEGA_NU_UNROLL_P0
+#pragma unroll (I4 ? 1 : MEGA_NU_UNROLL_P0)
         for (int u = 0; u < NU; ++u) {
             float acc[3][2];
             if (I4) mega_dots_i4<1, 3, MG_DIM>(cq, cz, xa[u], MG_DIM, lane_p, acc);
@@ -1150,7 +1152,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             MG_STAMP(l, 18);  // norm done
             const int nrows = wave_p < 6 ? 3 : 2;
             const int rb = 22 * b + (wave_p < 6 ? 3 * wave_p : 18 + 2 * (wave_p - 6));
-#pragma unroll MEGA_NU_UNROLL_P3
+#pragma unroll (I4 ? 1 : MEGA_NU_UNROLL_P3)
             for (int u = 0; u < NU; ++u) {
                 float acc1[3][2], acc3[3][2];
                 if (I4) {
