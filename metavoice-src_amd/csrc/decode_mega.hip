@@ -111,6 +111,11 @@ bool mega_instrumented() { return MEGA_INSTR != 0; }
 // the top of each phase (4 of a layer's 17) goes; the barrier behind each poll already separates a buffer's next writer from its last readers.
 // MEGA_PUB_BARRIER (experiment): the barrier at the top of P3 / P4 / the next P0 moved UP, between a phase's publish and its requests for the
 // next phase -- publish-before-prefetch for the whole workgroup there as well (r04ai: without the phase-top barriers the step is 16 % slower)
+// MEGA_EARLY_QKV_POS: where the LDS half of the next layer's wqkv rows is requested: 0 when the activation vector has arrived (in front of the w2
+// dots and the x publish -- round 3), 1 at the top of P4 behind the w2 remainder (in front of the act hand-off), 2 behind the x publish
+#ifndef MEGA_EARLY_QKV_POS
+#define MEGA_EARLY_QKV_POS 0
+#endif
 #ifndef MEGA_PUB_BARRIER
 #define MEGA_PUB_BARRIER 0
 #endif
@@ -861,6 +866,16 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             if (W3_EARLY && MEGA_W3_EARLY != 2) request_w3();
         };
         auto request_wo_w1 = [&]() { request_wo(); request_w1(); };
+        auto request_qkv_early = [&]() {  // EARLY_QKV: chunks 0, 1 of the next layer's three wqkv rows into the LDS slots the w1 half has left
+            if (l + 1 < n_layer) {
+                const bf16_t* w = MG_LAYER(l + 1).wqkv;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + j) * 64)), w + (size_t)(24 * b + 3 * wave_o + i) * MG_DIM + j * 512 + lane_o * 8, MG_ABLATE);
+            }
+        };
 
         // ================= P1: attention over keys [0, P)               fast_model.py:218-222 =========================
         // Publish-before-prefetch holds for the WORKGROUP here, not just per wave: wave 0 still has the block's partial (and, in
@@ -1219,6 +1234,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 }
             }
             else mega_issue_row<11>(wv, L.w2, 8 * b + wave_o, MG_INTER, lane_o, MG_ABLATE);
+            if constexpr (EARLY_QKV && MEGA_EARLY_QKV_POS == 1) request_qkv_early();   // behind the w2 remainder, in front of the act hand-off
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -1247,16 +1263,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             __syncthreads();
             MG_ABORT_RETURN();
             MG_STAMP(l, 9);
-            if constexpr (EARLY_QKV) {  // chunks 0, 1 of the next layer's three wqkv rows on their way while the w2 dots and the x publish run
-                if (l + 1 < n_layer) {
-                    const bf16_t* w = MG_LAYER(l + 1).wqkv;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + j) * 64)), w + (size_t)(24 * b + 3 * wave_o + i) * MG_DIM + j * 512 + lane_o * 8, MG_ABLATE);
-                }
-            }
+            if constexpr (EARLY_QKV && MEGA_EARLY_QKV_POS == 0) request_qkv_early();  // on their way while the w2 dots and the x publish run
 #pragma unroll 1
             for (int u = 0; u < NU; ++u) {
                 float acc[1][2];
@@ -1291,6 +1298,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }
             __builtin_amdgcn_sched_barrier(0);
             if (PUB_B && l + 1 < n_layer) __syncthreads();
+            if constexpr (EARLY_QKV && MEGA_EARLY_QKV_POS == 2) request_qkv_early();   // behind the x publish
             // next: the following layer's wqkv rows, or the LM-head rows 11 b + wave + 8 i
             if (MEGA_KV_AFTER_NORM) nw_attn = load16((l + 1 < n_layer ? MG_LAYER(l + 1).attn_norm : KC(l)->final_norm) + (tid_o & 255) * 8);
             if (l + 1 < n_layer) {
