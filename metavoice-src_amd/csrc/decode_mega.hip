@@ -148,12 +148,16 @@ __device__ __forceinline__ void mega_wave_sums(float (&v)[N]) {
 #ifndef MEGA_NORM_STATS8
 #define MEGA_NORM_STATS8 0   // 1: one utterance, statistics on all 8 waves (one row each).  A/B on one box: 678.5 / 677.6 vs 672.7 / 676.9 us/step with 0 (profiles/r04d)
 #endif
+#ifndef MEGA_NORM_EARLY_READ
+#define MEGA_NORM_EARLY_READ 1
+#endif
 #ifndef MEGA_NORM_DIRECT_TOTAL
 #define MEGA_NORM_DIRECT_TOTAL 1
 #endif
 template <int NU>
 __device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x4& nw, float* red, float eps, const int tid) {
     const int lane = tid & 63, wave = tid >> 6;   // tid: the caller's (possibly opaque) thread id -- see the layer loop
+    u32x4 xv_early = {0u, 0u, 0u, 0u};
     // statistics: lane l of "column wave" q sums the squares of columns 8 (64 q + l) .. + 7, the 64 lanes are added with wave_sum -- the
     // summation order of gemv.hip's prologue.  One utterance: waves 0..3 ARE the column waves, each does both rows.  Several utterances:
     // (utterance, row) pair p is done by wave p, which plays the four column waves one after the other with the four chains unrolled
@@ -165,13 +169,18 @@ __device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x
         const float s = wave_sum(sumsq8(*(const u32x4*)(xs[0] + r * MG_DIM + (q * 64 + lane) * 8)));
         if (lane == 0) red[q * 2 + r] = s;
     } else if constexpr (NU == 1) {
+        // MEGA_NORM_EARLY_READ: the 8 columns a thread APPLIES are fetched in front of the barrier -- waves 0..3 apply row 0 of the very columns
+        // they just summed (no second read at all), waves 4..7 read their row-1 columns while the others sum: behind the barrier hipcc had
+        // the LDS read of the operand wait for the rsqrt of the total, two dependent LDS round trips
         if (tid < MG_DIM / 8) {
             float s[2];  // both rows' chains side by side (wave_sum_n: the same tree, interleaved)
-#pragma unroll
-            for (int r = 0; r < 2; ++r) s[r] = sumsq8(*(const u32x4*)(xs[0] + r * MG_DIM + tid * 8));
+            const u32x4 x0 = *(const u32x4*)(xs[0] + tid * 8), x1 = *(const u32x4*)(xs[0] + MG_DIM + tid * 8);
+            s[0] = sumsq8(x0);
+            s[1] = sumsq8(x1);
+            if (MEGA_NORM_EARLY_READ) xv_early = x0;
             wave_sum_n<2>(s);
             if (lane == 0) { red[wave * 2] = s[0]; red[wave * 2 + 1] = s[1]; }
-        }
+        } else if (MEGA_NORM_EARLY_READ) xv_early = *(const u32x4*)(xs[0] + MG_DIM + (tid & 255) * 8);
     } else {
         if (wave < 2 * NU) {
             const int u = wave >> 1, r = wave & 1;
@@ -193,7 +202,7 @@ __device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x
     float rstd[NU];
     u32x4 xv[NU];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) xv[u] = *(const u32x4*)(xs[u] + r * MG_DIM + c);
+    for (int u = 0; u < NU; ++u) xv[u] = (NU == 1 && !MEGA_NORM_STATS8 && MEGA_NORM_EARLY_READ) ? xv_early : *(const u32x4*)(xs[u] + r * MG_DIM + c);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         // == block_total over the 4 column waves: wave_sum over lanes {v0, v1, v2, v3, 0, ...} is (v0 + v1) + (v2 + v3) plus exact zeros
