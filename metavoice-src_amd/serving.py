@@ -93,9 +93,16 @@ class BatchingDispatcher:
         return self
 
     def submit(self, text: str, spk_ref: str, top_p: float, guidance: float) -> bytes:
+        # The speaker reference is checked HERE, on the calling (HTTP handler) thread: the check may fetch a URI (60 s per read) and decodes
+        # the whole file -- on the dispatcher thread it would hold up every queued batch on every rank.  A request that fails it never
+        # reaches the queue.
+        item = dict(text=text, spk=spk_ref, top_p=top_p, guidance=guidance, checked=True)
+        err = self._validate(item)
+        if err is not None:
+            raise err
         done = threading.Event()
         slot: Dict[str, object] = {}
-        self.q.put((dict(text=text, spk=spk_ref, top_p=top_p, guidance=guidance), done, slot))
+        self.q.put((item, done, slot))
         done.wait()
         if "error" in slot:
             raise slot["error"]  # type: ignore[misc]
@@ -147,7 +154,7 @@ class BatchingDispatcher:
                 return
             live = []
             for entry in batch:
-                err = self._validate(entry[0])
+                err = None if entry[0].get("checked") else self._validate(entry[0])   # entries that did not come through submit()
                 if err is None:
                     live.append(entry)
                 else:
