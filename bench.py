@@ -103,11 +103,13 @@ def make_work(mv, args, *, long_form, long_form_chars, utterances_per_gpu, rank,
         tokenizer = tok_mod.TrainedBPETokeniser(**tok_mod.byte_level_tokenizer_info(offset=2049))
         sentence = "The quick brown fox jumps over the lazy dog near the quiet river bank, while the old mill turns slowly. "
         text = (sentence * (long_form_chars // len(sentence) + 1))[:long_form_chars]
-        work = []
+        items = []
         for c in longform.split_text(text):
             ids = torch.tensor(tokenizer.encode(c), dtype=torch.int32)
-            work.append([(ids, min(args.block_size - len(ids), int(round(7.5 * len(c)))))])
-        return work
+            items.append((ids, min(args.block_size - len(ids), int(round(7.5 * len(c))))))
+        # U chunks decode TOGETHER in one engine run (what `TTS.synthesise_long` -> `synthesise_wavs` does with max_utterances = U):
+        # the chunks of a text are independent generations with the same speaker embedding; consecutive chunks share a group
+        return [items[i:i + U] for i in range(0, len(items), U)]
     if U > 1:
         # configs[2]: ragged prompts, lengths uniform in [96, 160] (seed 0 stream, offset by the rank), 12.8 s each unless the
         # context window ends first (160 + 1920 > 2048)
@@ -117,7 +119,35 @@ def make_work(mv, args, *, long_form, long_form_chars, utterances_per_gpu, rank,
     return [[(mv.synthetic.prompt_tokens(T_PROMPT, seed=rank), N_NEW)]]
 
 
-def cpu_baseline(mv, cfgk, sample_steps=24):
+def reference_dir():
+    """The reference checkout, when this machine has one ($MV_REFERENCE or /root/reference -- the build container does, the GPU box does not)."""
+    for d in (os.environ.get("MV_REFERENCE"), "/root/reference"):
+        if d and os.path.isfile(os.path.join(d, "fam", "llm", "fast_inference_utils.py")):
+            return d
+    return None
+
+
+def pick_cpu_threads(step_fn, trial_steps=3):
+    """A decode step streams 5 GB of fp32 weights: memory-bound, and on a many-core host torch's default (one thread per logical core)
+    can be several times SLOWER than a fraction of the cores (round 4: 128 threads -> 2 tok/s on the GPU box's EPYC, 8 threads -> 13 tok/s
+    on the build container).  Time `trial_steps` steps at all / half / quarter / eighth of the cores (>= 8) and keep the fastest setting,
+    so that the baseline is the host's best, not its default.  -> (threads, {threads: s/token})."""
+    n0 = torch.get_num_threads()
+    cands = sorted({n for n in (n0, n0 // 2, n0 // 4, n0 // 8) if n >= min(8, n0)}, reverse=True)
+    seen = {}
+    for n in cands:
+        torch.set_num_threads(n)
+        step_fn()   # warm the pool at this size
+        t = time.perf_counter()
+        for _ in range(trial_steps):
+            step_fn()
+        seen[n] = (time.perf_counter() - t) / trial_steps
+    best = min(seen, key=seen.get)
+    torch.set_num_threads(best)
+    return best, {k: round(v, 4) for k, v in seen.items()}
+
+
+def cpu_baseline_port(mv, cfgk, sample_steps=24):
     """Time the oracle (oracle/stage1.py, fp32, torch CPU) on the same workload shape: bounded sample."""
     from oracle import stage1 as o_s1
 
@@ -127,22 +157,103 @@ def cpu_baseline(mv, cfgk, sample_steps=24):
     del sd
     prompt = mv.synthetic.prompt_tokens(T_PROMPT, seed=0)
     spk = mv.synthetic.speaker_embedding(0)
+    n_default = torch.get_num_threads()
     t0 = time.perf_counter()
     logits = orc.forward(prompt.view(1, -1).repeat(2, 1), spk, torch.arange(T_PROMPT))
     tok = o_s1.sample(logits, 3.0, 1.0, top_k=1)[0]
     t1 = time.perf_counter()
+    threads, scan = pick_cpu_threads(lambda: orc.forward(torch.full((2, 1), tok), spk, torch.tensor([T_PROMPT])))   # rewrites cache row T: harmless
+    t1b = time.perf_counter()
     for i in range(sample_steps):
         logits = orc.forward(torch.full((2, 1), tok), spk, torch.tensor([T_PROMPT + i]))
         tok = o_s1.sample(logits, 3.0, 1.0, top_k=1)[0]
     t2 = time.perf_counter()
-    tok_s = sample_steps / (t2 - t1)
+    torch.set_num_threads(n_default)
+    tok_s = sample_steps / (t2 - t1b)
     return {
-        "value": round(tok_s / TOKENS_PER_AUDIO_SECOND, 5), "unit": "audio-s/s", "cores": torch.get_num_threads(),
+        "value": round(tok_s / TOKENS_PER_AUDIO_SECOND, 5), "unit": "audio-s/s", "cores": threads,
         "kind": "port",
         "sample": f"oracle/stage1.py fp32 eager torch-CPU, full-size synthetic MetaVoice-1B: prefill T={T_PROMPT} "
-                  f"({t1 - t0:.2f} s) + {sample_steps} greedy decode steps ({(t2 - t1) / sample_steps:.3f} s/token, "
-                  f"{tok_s:.2f} tok/s); value = decode tok/s / 150; host has {os.cpu_count()} logical cores",
+                  f"({t1 - t0:.2f} s, {n_default} threads) + {sample_steps} greedy decode steps on {threads} threads ({(t2 - t1b) / sample_steps:.3f} s/token, "
+                  f"{tok_s:.2f} tok/s; thread scan s/token {scan}: the fastest setting is the one timed); value = decode tok/s / 150; "
+                  f"host has {os.cpu_count()} logical cores",
     }
+
+
+def cpu_baseline_reference(mv, cfgk, ref_dir, sample_steps=24):
+    """Time the REFERENCE itself -- `fam.llm.fast_inference_utils.prefill` / `decode_n_tokens` (what `generate()` runs, `:182-228`) on
+    `fam.llm.fast_model.Transformer`, eager fp32 on the CPU (BASELINE configs[0]) -- on the same full-size synthetic checkpoint,
+    prompt and speaker embedding as `cpu_baseline_port`.  Only where the reference checkout exists; `librosa` / `tiktoken` are imported at
+    module top by the reference but not used by the model code: stubbed, as in tests/golden/make_golden.py."""
+    import types
+
+    from oracle import stage1 as o_s1
+
+    for m in ("librosa", "tiktoken"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    if ref_dir not in sys.path:
+        sys.path.insert(0, ref_dir)
+    from fam.llm import fast_inference_utils as ref_fiu
+    from fam.llm.fast_model import ModelArgs as RefArgs
+    from fam.llm.fast_model import Transformer as RefTransformer
+
+    with torch.no_grad():
+        model = RefTransformer(RefArgs(n_layer=cfgk["n_layer"], n_head=cfgk["n_head"], dim=cfgk["dim"], vocab_size=cfgk["vocab_size"],
+                                       block_size=cfgk["block_size"]))
+        sd = o_s1.remap_checkpoint_keys(mv.synthetic.stage1_state_dict(seed=0, **cfgk))
+        model.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+        del sd
+        model = model.float().eval()
+        model.config.dtype = torch.float32   # ModelArgs picks fp16 when no GPU is present (fam/llm/utils.py:83-84)
+        model.setup_spk_cond_mask()
+        model.setup_caches(max_batch_size=2, max_seq_length=T_PROMPT + sample_steps + 8)
+        prompt = mv.synthetic.prompt_tokens(T_PROMPT, seed=0)
+        spk = mv.synthetic.speaker_embedding(0)
+        kw = dict(temperature=torch.tensor(1.0), top_k=1, top_p=None, guidance_scale=torch.tensor(3.0))
+        n_default = torch.get_num_threads()
+        t0 = time.perf_counter()
+        nxt = ref_fiu.prefill(model, prompt.view(1, -1).repeat(2, 1), spk, torch.arange(T_PROMPT), **kw)
+        t1 = time.perf_counter()
+        cur = nxt.view(1, -1).repeat(2, 1)
+        threads, scan = pick_cpu_threads(lambda: ref_fiu.decode_one_token(model, cur, spk, torch.tensor([T_PROMPT]), **kw))
+        t1b = time.perf_counter()
+        with contextlib.redirect_stderr(io.StringIO()):   # the reference's tqdm bar
+            toks, _ = ref_fiu.decode_n_tokens(model, cur, spk, torch.tensor([T_PROMPT]), sample_steps,
+                                              callback=lambda x: x, end_of_audio_token=9999, **kw)
+        t2 = time.perf_counter()
+        torch.set_num_threads(n_default)
+    tok_s = len(toks) / (t2 - t1b)
+    return {
+        "value": round(tok_s / TOKENS_PER_AUDIO_SECOND, 5), "unit": "audio-s/s", "cores": threads,
+        "kind": "reference",
+        "sample": f"the reference's own fam.llm.fast_inference_utils.prefill + decode_n_tokens on fam.llm.fast_model.Transformer ({ref_dir}), fp32 eager "
+                  f"torch-CPU, full-size synthetic MetaVoice-1B: prefill T={T_PROMPT} ({t1 - t0:.2f} s, {n_default} threads) + {len(toks)} greedy decode steps on "
+                  f"{threads} threads ({(t2 - t1b) / len(toks):.3f} s/token, {tok_s:.2f} tok/s; thread scan s/token {scan}: the fastest setting is the one timed); "
+                  f"value = decode tok/s / 150; host has {os.cpu_count()} logical cores",
+    }
+
+
+def cpu_baseline(mv, cfgk, sample_steps=24):
+    """`cpu_baseline` of the bench line: the reference itself where its checkout exists (kind "reference"), else its golden-pinned port
+    (kind "port": oracle/stage1.py).  profiles/cpu_baseline_pair.json holds both timed back to back on ONE box (the build container),
+    so the ratio port / reference is a known number for lines that could only time the port (the GPU box has no reference checkout)."""
+    ref = None if os.environ.get("MV_BENCH_CPU_PORT") else reference_dir()
+    if ref is not None:
+        try:
+            return cpu_baseline_reference(mv, cfgk, ref, sample_steps)
+        except Exception as e:   # e.g. a torch too new for the reference's calls: fall back to the port and say why
+            out = cpu_baseline_port(mv, cfgk, sample_steps)
+            out["sample"] += f"; the reference at {ref} could not be timed ({type(e).__name__}: {e})"[:300]
+            return out
+    out = cpu_baseline_port(mv, cfgk, sample_steps)
+    try:
+        with open(os.path.join(ROOT, "profiles", "cpu_baseline_pair.json")) as f:
+            pair = json.load(f)
+        out["port_over_reference_same_box"] = pair["port_over_reference"]
+        out["sample"] += f"; no reference checkout on this machine -- on one box ({pair['host']}) port / reference = {pair['port_over_reference']}"
+    except (OSError, KeyError, ValueError):
+        pass
+    return out
 
 
 def measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline):
@@ -376,8 +487,9 @@ def measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline):
                if diffusion is not None else "EnCodec decode (multi-band diffusion switched off)")
         if a.long_form:
             workload = (f"long-form synthesis (BASELINE configs[4]): {a.long_form_chars} characters split at sentence boundaries into "
-                        f"{len(work)} chunks of <= 220 characters, each an independent generation (MFMA prefill + 7.5 tokens per "
-                        f"character, top_p=0.95, guidance 3.0) on the same captured decode graph and speaker embedding, then token "
+                        f"{n_utt} chunks of <= 220 characters, each an independent generation (MFMA prefill + 7.5 tokens per "
+                        f"character, top_p=0.95, guidance 3.0), {U} chunk(s) decoded together per engine run ({len(work)} runs) on the same "
+                        f"resident engine and speaker embedding, then token "
                         f"adapters, second stage (placeholder sizes), {voc}; {tok_per_step / 150.0:.1f} s of audio per step; "
                         "synthetic speaker embedding (assets/bria.mp3 cannot be decoded here)")
         elif a.quantisation_mode is not None:
@@ -444,8 +556,10 @@ def measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline):
             try:
                 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "vocoder_hbm_kernels.json")) as f:
                     hk = json.load(f)
-                out["vocoder_roofline"]["hbm_kernels"] = {k: {x: v[x] for x in ("achieved_GBs", "frac_of_8TBs", "avg_us", "calls")} for k, v in hk["kernels"].items()}
-                out["vocoder_roofline"]["hbm_kernels_source"] = hk["source"]
+                # NOT measured in this run: quoted from the committed profile, labelled as such
+                out["vocoder_roofline"]["hbm_kernels_quoted_from_profile"] = {
+                    "source": hk["source"], "profile": "profiles/vocoder_hbm_kernels.json",
+                    "kernels": {k: {x: v[x] for x in ("achieved_GBs", "frac_of_8TBs", "avg_us", "calls")} for k, v in hk["kernels"].items()}}
             except (OSError, KeyError, ValueError):
                 pass
         if with_cpu_baseline:
@@ -571,8 +685,8 @@ def parse_args(argv=None):
                     help="A/B switch: auto = the engine's choice (persistent kernel drawing its own tokens where supported), step = persistent "
                          "kernel, one step per launch + sampler launch, launches = per-layer launches")
     a = ap.parse_args(argv)
-    if a.long_form and a.utterances_per_gpu != 1:
-        ap.error("--long-form runs one chunk at a time")
+    if a.long_form and a.utterances_per_gpu not in (1, 2, 4):
+        ap.error("--long-form decodes 1, 2 or 4 chunks together")
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
     return a
@@ -598,7 +712,7 @@ EXTRA_CONFIGS = [
     ("configs[3] int4 first-stage decode", dict(quantisation_mode="int4", steps=3, warmup=1)),
     ("configs[3'] int8 first-stage decode", dict(quantisation_mode="int8", steps=3, warmup=1)),
     ("configs[2] 4 utterances per GPU, full vocoder", dict(utterances_per_gpu=4, steps=2, warmup=1)),
-    ("configs[4] long-form 10000 characters, full vocoder", dict(long_form=True, long_form_chars=10000, steps=1, warmup=0)),
+    ("configs[4] long-form 10000 characters, full vocoder, 4 chunks per engine run", dict(long_form=True, long_form_chars=10000, utterances_per_gpu=4, steps=1, warmup=0)),
 ]
 
 

@@ -118,6 +118,8 @@ SYMBOLS = [
     ("mv_mbd_generate_device", C.c_int, [_P, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(C.c_float)]),
     ("mv_mbd_unet_forward", C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32,
                                       C.POINTER(C.c_float)]),
+    ("mv_mbd_unet_forward_sum", C.c_int, [_P, C.POINTER(C.c_float), C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float)]),
+    ("mv_mbd_kernel_counts", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("mv_spkenc_create", C.c_int, [C.POINTER(mv_spkenc_config), C.POINTER(_P)]),
     ("mv_spkenc_destroy", C.c_int, [_P]),
     ("mv_spkenc_load_weight", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_float), C.c_int64]),

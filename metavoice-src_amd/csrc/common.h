@@ -83,7 +83,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // builds v_mov_b32 0 / v_mov_b32_dpp / v_add_f32 (its DPP combiner folds a masked mov only into integer ops), three instructions per
 // value and level.  Lane 63 -- the only lane read -- gets the same bits (rows 1,3 then 2,3 are the enabled ones on its path).
 // Inline assembly is invisible to the compiler's hazard recogniser, so each statement opens with its own `s_nop 1`: a VALU write
-// needs two wait states before a DPP read of the register; within a statement the values are independent.
+// needs two wait states before a DPP read of the register; within a statement the values are independent.  The last level's statements
+// CLOSE with an `s_nop 0`: wave_sum_n reads the results with v_readlane right behind them, and a VALU write needs one wait state before
+// a v_readlane of the register -- the recogniser does not know these statements write VGPRs.
 #define MV_BC(k, C) "v_add_f32_dpp %" #k ", %" #k ", %" #k " " C "\n"
 #define MV_BCAST15 "row_bcast:15 row_mask:0xa bank_mask:0xf"
 #define MV_BCAST31 "row_bcast:31 row_mask:0xc bank_mask:0xf"
@@ -97,13 +99,13 @@ __device__ __forceinline__ void wave_bcast_levels(float (&v)[N]) {
                 : "+v"(v[j]), "+v"(v[j + 1]), "+v"(v[j + 2]), "+v"(v[j + 3]), "+v"(v[j + 4]), "+v"(v[j + 5]));
 #pragma unroll
         for (int j = 0; j < N; j += 6)
-            asm("s_nop 1\n" MV_BC(0, MV_BCAST31) MV_BC(1, MV_BCAST31) MV_BC(2, MV_BCAST31) MV_BC(3, MV_BCAST31) MV_BC(4, MV_BCAST31) MV_BC(5, MV_BCAST31)
+            asm("s_nop 1\n" MV_BC(0, MV_BCAST31) MV_BC(1, MV_BCAST31) MV_BC(2, MV_BCAST31) MV_BC(3, MV_BCAST31) MV_BC(4, MV_BCAST31) MV_BC(5, MV_BCAST31) "s_nop 0\n"
                 : "+v"(v[j]), "+v"(v[j + 1]), "+v"(v[j + 2]), "+v"(v[j + 3]), "+v"(v[j + 4]), "+v"(v[j + 5]));
     } else {
 #pragma unroll
         for (int j = 0; j < N; j += 2) asm("s_nop 1\n" MV_BC(0, MV_BCAST15) MV_BC(1, MV_BCAST15) : "+v"(v[j]), "+v"(v[j + 1]));
 #pragma unroll
-        for (int j = 0; j < N; j += 2) asm("s_nop 1\n" MV_BC(0, MV_BCAST31) MV_BC(1, MV_BCAST31) : "+v"(v[j]), "+v"(v[j + 1]));
+        for (int j = 0; j < N; j += 2) asm("s_nop 1\n" MV_BC(0, MV_BCAST31) MV_BC(1, MV_BCAST31) "s_nop 0\n" : "+v"(v[j]), "+v"(v[j + 1]));
     }
 }
 #ifndef MV_WAVE_SUM_ASM_BCAST

@@ -1180,8 +1180,12 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             for (int u = 0; u < NU; ++u) {
                 float acc1[3][2], acc3[3][2];
                 if (I4) {
-                    mega_dots_i4<1, 3, MG_DIM>(cq, cz, xa[u], MG_DIM, lane_p, acc1);
-                    mega_dots_i4<1, 3, MG_DIM>(cq + 3, cz + 3, xa[u], MG_DIM, lane_p, acc3);
+                    // w1 rows (slots 0..2) and w3 rows (3..5) in ONE pass: the activation blocks and their column sums are read / formed once
+                    // for all six rows; every row's own arithmetic is what two passes of three rows would do (same bits as gemv_i4.hip)
+                    float acc6[6][2];
+                    mega_dots_i4<1, 6, MG_DIM>(cq, cz, xa[u], MG_DIM, lane_p, acc6);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { acc1[i][0] = acc6[i][0]; acc1[i][1] = acc6[i][1]; acc3[i][0] = acc6[3 + i][0]; acc3[i][1] = acc6[3 + i][1]; }
                 } else if (I8) {
                     mega_dots_i8<2, 3, MG_DIM>(cq, xa[u], MG_DIM, lane_p, acc1);
                     mega_dots_i8<2, 3, MG_DIM>(cq + 6, xa[u], MG_DIM, lane_p, acc3);

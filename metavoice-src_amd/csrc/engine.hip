@@ -76,6 +76,8 @@ int mv_fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// split-K partial tiles of the prefill GEMMs: ranges x tiles < 2048 whenever launch_gemm splits the 64 x 64 grid, x gated pair (floats)
+static constexpr size_t PREFILL_SLAB_ELEMS = (size_t)2048 * GEMM_TILE * GEMM_TILE * 2;
 struct mv_engine {
     mv_config cfg{};
     int R = 0;  // CFG rows = 2 * max_utterances
@@ -303,7 +305,7 @@ int enqueue_prefill(mv_engine* e, int u, int T) {
         HIP_TRY(hipMalloc((void**)&e->pact, rows * c.intermediate * 2));
         HIP_TRY(hipMalloc((void**)&e->pvt, attn_rows_scratch_elems(2, c.n_head, 128, c.block_size) * 2));  // V transposed, for the MFMA attention
         // ranges x tiles < 2048 whenever launch_gemm splits (it doubles the ranges only while ranges x tiles < 1024), x gated pair, fp32
-        HIP_TRY(hipMalloc((void**)&e->pslab, (size_t)2048 * GEMM_TILE * GEMM_TILE * 2 * 4));
+        HIP_TRY(hipMalloc((void**)&e->pslab, PREFILL_SLAB_ELEMS * 4));
     }
     HIP_TRY(launch_embed_rows(s, e->seq + (size_t)u * c.block_size, T, c.dim, e->tok_emb, e->pos_emb,
                               e->spk_proj + (size_t)u * c.dim, e->px));
@@ -319,7 +321,7 @@ int enqueue_prefill(mv_engine* e, int u, int T) {
         g.a = e->pn; g.w = w.wqkv; g.out_bf16 = e->pq; g.M = M; g.N = 3 * c.dim; g.K = c.dim; g.lda = c.dim; g.ldc = c.dim;
         g.qkv_dim = c.dim; g.seq_len = T; g.n_head = c.n_head; g.cache_len = c.block_size; g.kcache = kc; g.vcache = vc;
         g.scale = w.s8[0];  // null unless int8
-        g.slab = e->pslab;
+        g.slab = e->pslab; g.slab_elems = PREFILL_SLAB_ELEMS;
         HIP_TRY(launch_gemm(s, g));
         AttnRowsArgs at;
         at.q = e->pq; at.k = kc; at.v = vc; at.out = e->pattn; at.k_batch_stride = (int64_t)c.n_head * c.block_size * 128;
@@ -329,19 +331,19 @@ int enqueue_prefill(mv_engine* e, int u, int T) {
         g = GemmArgs();
         g.a = e->pattn; g.w = w.wo; g.res_bf16 = e->px; g.out_bf16 = e->ph; g.M = M; g.N = c.dim; g.K = c.dim; g.lda = c.dim; g.ldc = c.dim;
         g.scale = w.s8[1];
-        g.slab = e->pslab;
+        g.slab = e->pslab; g.slab_elems = PREFILL_SLAB_ELEMS;
         HIP_TRY(launch_gemm(s, g));
         n.x_bf16 = e->ph; n.w_bf16 = w.ffn_norm;
         HIP_TRY(launch_norm_rows(s, n));
         g = GemmArgs();
         g.a = e->pn; g.w = w.w1; g.w2 = w.w3; g.out_bf16 = e->pact; g.M = M; g.N = c.intermediate; g.K = c.dim; g.lda = c.dim;
         g.ldc = c.intermediate; g.scale = w.s8[2]; g.scale2 = w.s8[3];
-        g.slab = e->pslab;
+        g.slab = e->pslab; g.slab_elems = PREFILL_SLAB_ELEMS;
         HIP_TRY(launch_gemm(s, g));
         g = GemmArgs();
         g.a = e->pact; g.w = w.w2; g.res_bf16 = e->ph; g.out_bf16 = e->px; g.M = M; g.N = c.dim; g.K = c.intermediate;
         g.lda = c.intermediate; g.ldc = c.dim; g.scale = w.s8[4];
-        g.slab = e->pslab;
+        g.slab = e->pslab; g.slab_elems = PREFILL_SLAB_ELEMS;
         HIP_TRY(launch_gemm(s, g));
     }
     for (int r = 0; r < 2; ++r)
@@ -558,6 +560,8 @@ int mv_finalize(mv_engine* e) {
                 w.q[m] = e->q_arena + off; off += align_up((size_t)shapes[m][0] * shapes[m][1] / 2, 256);
                 w.sz[m] = (uint32_t*)(e->q_arena + off); off += align_up((size_t)shapes[m][0] * (shapes[m][1] / 128) * 4, 256);
                 HIP_TRY(launch_quantize_i4(e->stream, src[m], (int)shapes[m][0], (int)shapes[m][1], w.q[m], w.sz[m], src[m]));
+                // the decode kernels read the codes pair-major inside every 32-bit word (gemv_i4_core.h); in place
+                HIP_TRY(launch_repack_i4_pairs(e->stream, w.q[m], w.q[m], (size_t)shapes[m][0] * shapes[m][1] / 2));
             }
         }
         if (c.spk_dim % 128 == 0) {  // speaker_cond_pos: only its dequantised values are ever used (the projection is hoisted)
@@ -936,7 +940,10 @@ int mv_probe_kernel(mv_engine* e, int32_t kind, int32_t iters, float* avg_ms, do
         HIP_TRY(hipMemcpy(pos.data(), e->pos_arr, pos.size() * 4, hipMemcpyDeviceToHost));
         const double weights = 3.0 * c.dim * c.dim + (double)c.dim * c.dim + 3.0 * c.intermediate * c.dim;  // elements per layer
         const double per_layer = (c.weight_format == MV_W_INT4_G128 ? weights * 0.5 + weights / 128 * 4 : c.weight_format == MV_W_INT8 ? weights : weights * 2) + 2.0 * c.dim * 2;
-        bytes = c.n_layer * (per_layer + 2.0 /*rows*/ * c.n_head * (pos[0] + 1.0) * 128 * 2 * 2) + (double)c.vocab * c.dim * 2 + c.dim * 2;
+        // weights once per launch (shared by the utterances), K/V rows [0, pos[u]] of BOTH rows of EVERY utterance of this engine run
+        double kv_rows = 0;
+        for (int u = 0; u < e->n_utt && u < (int)pos.size(); ++u) kv_rows += pos[u] + 1.0;
+        bytes = c.n_layer * (per_layer + 2.0 /*rows*/ * c.n_head * kv_rows * 128 * 2 * 2) + (double)c.vocab * c.dim * 2 + c.dim * 2;
         const MegaArgs m = mega_args(e);
         float t[2] = {0.f, 0.f};
         for (int pass = 0; pass < 2; ++pass) {  // pass 0: bump + persistent kernel, pass 1: bump only
@@ -1068,13 +1075,23 @@ int mv_op_quantize_int4(void* stream, int32_t N, int32_t K, const void* w, void*
 
 int mv_op_gemv_int4(void* stream, int32_t rows, int32_t N, int32_t K, const void* x, const void* codes, const void* scales_zeros,
                     const void* codes2, const void* scales_zeros2, const void* norm_w, float eps, const void* residual, void* out) {
+    // `codes` / `codes2` come in the ABI layout (mv_op_quantize_int4's output); the kernel reads them pair-major like the engine's own
+    // copies (mv_finalize repacks in place): this test entry repacks into scratch per call
+    if (N < 1 || K < 128 || ((size_t)N * K / 2) % 4) return fail(MV_ERR_INVALID, "gemv_int4: bad shape N=%d K=%d", N, K);
+    const size_t nbytes = (size_t)N * K / 2;
+    unsigned char* tmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&tmp, nbytes * (codes2 ? 2 : 1)));
+    hipError_t re = launch_repack_i4_pairs((hipStream_t)stream, (const unsigned char*)codes, tmp, nbytes);
+    if (re == hipSuccess && codes2) re = launch_repack_i4_pairs((hipStream_t)stream, (const unsigned char*)codes2, tmp + nbytes, nbytes);
     GemvI4Args a;
-    a.x = (const bf16_t*)x; a.codes = (const unsigned char*)codes; a.sz = (const uint32_t*)scales_zeros;
-    a.codes2 = (const unsigned char*)codes2; a.sz2 = (const uint32_t*)scales_zeros2; a.norm_w = (const bf16_t*)norm_w;
+    a.x = (const bf16_t*)x; a.codes = tmp; a.sz = (const uint32_t*)scales_zeros;
+    a.codes2 = codes2 ? tmp + nbytes : nullptr; a.sz2 = (const uint32_t*)scales_zeros2; a.norm_w = (const bf16_t*)norm_w;
     a.residual = (const bf16_t*)residual; a.out = (bf16_t*)out; a.N = N; a.K = K; a.eps = eps;
     const int epi = codes2 ? GEMV_SWIGLU : residual ? GEMV_RESID : GEMV_PLAIN;
-    if (launch_gemv_i4((hipStream_t)stream, rows, a, epi) != hipSuccess)
-        return fail(MV_ERR_INVALID, "gemv_int4: unsupported rows=%d K=%d", rows, K);
+    const hipError_t le = re == hipSuccess ? launch_gemv_i4((hipStream_t)stream, rows, a, epi) : re;
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(tmp);
+    if (le != hipSuccess) return fail(MV_ERR_INVALID, "gemv_int4: unsupported rows=%d K=%d", rows, K);
     return MV_OK;
 }
 
@@ -1086,7 +1103,8 @@ int mv_op_gemm(void* stream, int32_t M, int32_t N, int32_t K, const void* a, con
     g.act = gelu ? GEMM_ACT_GELU : GEMM_ACT_NONE;
     // the split-K path (few rows, deep K: the prefill shapes) needs scratch; this test entry allocates it per call, MV_GEMM_NO_SPLITK
     // keeps the one-range kernel -- the parity test runs both
-    HIP_TRY(hipMalloc((void**)&g.slab, gemm_slab_elems(M, N, w2 != nullptr) * 4));
+    g.slab_elems = gemm_slab_elems(M, N, w2 != nullptr);
+    HIP_TRY(hipMalloc((void**)&g.slab, g.slab_elems * 4));
     const hipError_t le = launch_gemm((hipStream_t)stream, g);
     (void)hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(g.slab);

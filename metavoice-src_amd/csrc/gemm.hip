@@ -12,6 +12,8 @@
 // current tile's MFMAs (register double buffer).  M = 2T ~ 256 only gives 4 row-tiles, so N/64 column tiles x 4 keep
 // >= 128 blocks in flight and W is re-read 4x through L2, not HBM.
 #include "common.h"
+#include <atomic>
+
 #include "kernels.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -295,14 +297,21 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& a_in) {
     // MV_GEMM_SKINNY=1 (tests, A/B runs): measured on the prefill it is NOT faster than the 64 x 64 tiles (r04j-r04l: mv_begin 3.7-3.9 ms
     // at T = 128 with either, every GEMM launch ~21.6 us = 1.2 TB/s of weights whatever the tiling -- with one K-step of prefetch distance a
     // block is a chain of dependent load round trips and the resident blocks hold too few bytes in flight; 8.4 vs 7.9 ms at T = 512).
+    const size_t per_range = (size_t)a.M * a.N * (a.w2 ? 2 : 1);   // floats of partial tiles one K range leaves in the slab
+    const size_t max_ranges = a.slab && per_range ? a.slab_elems / per_range : 0;   // what the caller's slab holds
     if (a.M >= 96 && a.K >= 512 && a.N >= 512 && a.M <= 8 * SK_BM && getenv("MV_GEMM_SKINNY") && !getenv("MV_GEMM_NO_SKINNY")) {
         const int mt256 = (a.M + SK_BM - 1) / SK_BM;
         const char* cols_env = getenv("MV_GEMM_SKINNY_COLS");   // A/B: 64 or 128 columns per block (default 128)
-        const int cols = (cols_env ? atoi(cols_env) : 128) == 64 || !a.slab ? 64 : 128;   // the 128-column instance needs the partial-tile slab
+        // the 128-column instance ALWAYS leaves partial tiles (even with one range): it needs room for at least one range in the slab
+        // (the gated w1|w3 GEMM of a long prompt -- N = 5632, M = 2 T >= ~1490 -- did not fit the prefill's fixed slab and wrote past it)
+        const int cols = (cols_env ? atoi(cols_env) : 128) == 64 || max_ranges < 1 ? 64 : 128;
         const int ntc = (a.N + cols - 1) / cols;
         if (a.slab && !getenv("MV_GEMM_NO_SPLITK"))
-            while (a.splitk < 8 && (size_t)ntc * mt256 * a.splitk * 2 <= 320 && ksteps / (a.splitk * 2) >= 4) a.splitk *= 2;
-        static bool raised = false;
+            while (a.splitk < 8 && (size_t)a.splitk * 2 <= max_ranges && (size_t)ntc * mt256 * a.splitk * 2 <= 320 && ksteps / (a.splitk * 2) >= 4) a.splitk *= 2;
+        static std::atomic<bool> raised_on[64];   // the attribute belongs to the DEVICE's copy of the function
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<bool>& raised = raised_on[dev & 63];
         if (!raised) {
             hipError_t e = hipFuncSetAttribute((const void*)gemm_skinny_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, sk_lds_bytes<4>());
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_skinny_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, sk_lds_bytes<8>());
@@ -315,7 +324,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& a_in) {
         return hipGetLastError();
     }
     if (a.slab && !getenv("MV_GEMM_NO_SPLITK"))
-        while (a.splitk < 8 && (size_t)nt * mt * a.splitk < 1024 && ksteps / (a.splitk * 2) >= 4) a.splitk *= 2;
+        while (a.splitk < 8 && (size_t)a.splitk * 2 <= max_ranges && (size_t)nt * mt * a.splitk < 1024 && ksteps / (a.splitk * 2) >= 4) a.splitk *= 2;
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3(nt, mt, a.splitk), dim3(256), 0, s, a);
     if (a.splitk > 1) hipLaunchKernelGGL(gemm_combine_kernel, dim3((unsigned)(((size_t)a.M * a.N + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();

@@ -9,12 +9,14 @@
 //                        the documented contract of aten::_weight_int4pack_mm (tinygemm dequantises to bf16 with one
 //                        bf16 fma per weight, then runs the bf16 MMA).
 // The PACKING is ours, not tinygemm's NVIDIA mma-shaped (N/8, K/128, 32, 4) int32 tiles: rows stay rows, a row is K/2
-// bytes with column 2j in the low and 2j+1 in the high nibble of byte j, so a wave reads one row's 2048 columns as one
-// contiguous 1 KiB segment (16 B = 32 columns per lane, all in one 128-column group), plus 4 bytes of (scale, zero) per lane.
+// bytes, so a wave reads one row's 2048 columns as one contiguous 1 KiB segment (16 B = 32 columns per lane, all in one
+// 128-column group), plus 4 bytes of (scale, zero) per lane.  The quantiser writes the ABI layout (column 2j in the low and
+// 2j+1 in the high nibble of byte j: what mv_op_quantize_int4 documents and the bit-exactness test reads); the GEMV kernels
+// read every 32-bit word PAIR-MAJOR (gemv_i4_core.h), `repack_i4_pairs_kernel` converts once at mv_finalize.
 //
-// Roofline: still HBM by bytes (0.53 B per weight instead of 2), but the per-weight VALU work (nibble -> float, fma, bf16
-// round, dot) is now the same order as the stream: ~5 lane-ops per weight.  The quantised decode step is launch-bound
-// (122 dependent launches x ~2.8 us), which is why the reference's "roughly 2x" (README.md:92) is also what we get.
+// Roofline: HBM by bytes (0.53 B per weight instead of 2).  Round 5: the per-weight VALU work is ~2 lane-ops (OR the nibble
+// into a bf16 128.0, dot2; the group's scale / zero applied once per lane and chunk -- gemv_i4_core.h) instead of ~5
+// (convert, subtract, fma, bf16 round, dot): until then the int4 decode step was slower than the bf16 one.
 #include "gemv_core.h"
 #include "kernels.h"
 #include "gemv_i4_core.h"
@@ -207,6 +209,18 @@ __global__ void __launch_bounds__(256) quantize_i4_kernel(const bf16_t* w, int N
         *(u32x4*)(codes + ((size_t)n * K + c) / 2) = u32x4{packed[0], packed[1], packed[2], packed[3]};
         if ((lane & 3) == 0) sz[(size_t)n * (K / 128) + c / 128] = (uint32_t)f2bf(scale) | ((uint32_t)f2bf(zero) << 16);
     }
+}
+
+__global__ void __launch_bounds__(256) repack_i4_pairs_kernel(const uint32_t* src, uint32_t* dst, size_t n_words) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_words) dst[i] = i4_word_to_pairs(src[i]);
+}
+hipError_t launch_repack_i4_pairs(hipStream_t s, const unsigned char* src, unsigned char* dst, size_t n_bytes) {
+    if (n_bytes % 4 != 0) return hipErrorInvalidValue;
+    const size_t n_words = n_bytes / 4;
+    if (n_words == 0) return hipSuccess;
+    hipLaunchKernelGGL(repack_i4_pairs_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, n_words);
+    return hipGetLastError();
 }
 
 hipError_t launch_quantize_i4(hipStream_t s, const bf16_t* w, int N, int K, unsigned char* codes, uint32_t* sz, bf16_t* deq) {

@@ -51,7 +51,7 @@ bool gemv_supported(int rows, int K);
 // ---- gemv_i4.hip: int4 group-128 weight-only projections + the quantiser ---------------------------------------
 struct GemvI4Args {
     const bf16_t* x = nullptr;            // [rows][K]
-    const unsigned char* codes = nullptr; // [N][K/2]: column 2j in the low, 2j+1 in the high nibble of byte j
+    const unsigned char* codes = nullptr; // [N][K/2], PAIR-MAJOR inside every 32-bit word (gemv_i4_core.h: i4_pair_nibble; launch_repack_i4_pairs)
     const uint32_t* sz = nullptr;         // [N][K/128]: bf16 scale | bf16 zero << 16
     const unsigned char* codes2 = nullptr;  // SWIGLU only (w3)
     const uint32_t* sz2 = nullptr;
@@ -67,8 +67,11 @@ struct GemvI4Args {
 };
 hipError_t launch_gemv_i4(hipStream_t s, int rows, const GemvI4Args& a, int epi);
 bool gemv_i4_supported(int rows, int K);
-// codes/sz as above; `deq` (may alias `w`) receives bf16((q - 8) * scale + zero) when non-null
+// the reference's quantiser: codes [N][K/2] in the ABI layout (column 2j in the low, 2j+1 in the high nibble of byte j), sz as above;
+// `deq` (may alias `w`) receives bf16((q - 8) * scale + zero) when non-null
 hipError_t launch_quantize_i4(hipStream_t s, const bf16_t* w, int N, int K, unsigned char* codes, uint32_t* sz, bf16_t* deq);
+// ABI layout -> the pair-major layout the GEMV kernels read (per 32-bit word; `dst` may alias `src`); n_bytes a multiple of 4
+hipError_t launch_repack_i4_pairs(hipStream_t s, const unsigned char* src, unsigned char* dst, size_t n_bytes);
 
 // ---- gemv_i8.hip: int8 per-channel weight-only projections + the quantiser ----------------------------------------
 struct GemvI8Args {
@@ -172,6 +175,7 @@ struct GemmArgs {
     // cuts K into up to 8 ranges (blockIdx.z), the blocks write fp32 partial tiles and gemm_combine_kernel adds them in range order
     // and applies the epilogue.  Null: one range, epilogue in the GEMM kernel.
     float* slab = nullptr;
+    size_t slab_elems = 0;          // capacity of `slab` in floats: launch_gemm never asks a kernel for more (ranges x M x N x (gated ? 2 : 1))
     int32_t splitk = 1;             // set by launch_gemm
 };
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& a);

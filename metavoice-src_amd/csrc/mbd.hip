@@ -1104,6 +1104,9 @@ struct mv_mbd {
     uint32_t* lstm_abort = nullptr;
     uint32_t lstm_serial = 0;
     Work work;   // device workspace of mv_mbd_generate, kept between calls
+    // launches per GEMM kernel since mv_mbd_create (mv_mbd_kernel_counts: the parity tests assert WHICH kernels a shape ran on):
+    // 0 t256, 1 glds3<64,192>, 2 glds3<128,128>, 3 thin, 4 glds, 5 mbd_gemm<128>, 6 mbd_gemm<64>
+    mutable int64_t gemm_launches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -1494,20 +1497,24 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
         }
         const int n_blocks = nt_m256 * nt_n256 * nb;
         if (gn_ok) { g.gn_part = gf->part; g.gn_G = gf->G; g.gn_cg = g.N / gf->G; gf->tiles = nt_m256 * nt_n256; }
+        ++m->gemm_launches[0];
         hipLaunchKernelGGL(mbd_gemm_t256_kernel, dim3(n_blocks), dim3(512), T256_LDS_BYTES, s, g, nt_m256, nt_n256, n_blocks);
     } else if (glds_mode == 2 && k64 && prec == 3 && taps == 1 && g.N % 192 == 0 && g.N % 128 != 0 && !getenv("MV_MBD_NO_N192") &&
                (size_t)(g.N / 192) * ((g.M + 63) / 64) * nb >= (getenv("MV_MBD_N192_MIN_BLOCKS") ? (size_t)atoi(getenv("MV_MBD_N192_MIN_BLOCKS")) : 400)) {
         // 192-channel layers: 64 x 192 tiles, no padding columns (MV_MBD_N192_MIN_BLOCKS: tests lower the threshold for small shapes)
         const int nt192 = g.N / 192, mt64 = (g.M + 63) / 64;
         if (gn_ok) { g.gn_part = gf->part; g.gn_G = gf->G; g.gn_cg = g.N / gf->G; gf->tiles = nt192 * mt64; }
+        ++m->gemm_launches[1];
         hipLaunchKernelGGL((mbd_gemm_glds3_kernel<64, 192>), dim3(nt192, mt64, nb), dim3(256), 0, s, g);
     } else if (glds_mode == 2 && k64 && prec == 3 && taps == 1 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400) {
         if (gn_ok) { g.gn_part = gf->part; g.gn_G = gf->G; g.gn_cg = g.N / gf->G; gf->tiles = nt * ((g.M + 127) / 128); }
+        ++m->gemm_launches[2];
         hipLaunchKernelGGL((mbd_gemm_glds3_kernel<128, 128>), dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
     }
     else if (prec == 3 && taps == 1 && g.N <= 64 && g.N % 16 == 0 && g.seg[0].K <= 160 && g.seg[0].K % 8 == 0 && !getenv("MV_MBD_NO_THIN")) {
         // thin layers: the whole W in registers, A fragments straight from global memory (MV_MBD_NO_THIN=1: the 128-column tiles; tests, A/B)
         const dim3 grid((unsigned)((g.M + 255) / 256), nb);
+        ++m->gemm_launches[3];
         switch (g.N / 16) {
             case 1: hipLaunchKernelGGL(mbd_gemm_thin_kernel<1>, grid, dim3(256), 0, s, g); break;
             case 2: hipLaunchKernelGGL(mbd_gemm_thin_kernel<2>, grid, dim3(256), 0, s, g); break;
@@ -1515,10 +1522,16 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
             default: hipLaunchKernelGGL(mbd_gemm_thin_kernel<4>, grid, dim3(256), 0, s, g); break;
         }
     }
-    else if (glds_mode >= 1 && k64 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400)
+    else if (glds_mode >= 1 && k64 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400) {
+        ++m->gemm_launches[4];
         hipLaunchKernelGGL(mbd_gemm_glds_kernel, dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
-    else if ((size_t)nt * ((g.M + 127) / 128) * nb >= 400) hipLaunchKernelGGL(mbd_gemm_kernel<128>, dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL(mbd_gemm_kernel<64>, dim3(nt, (g.M + 63) / 64, nb), dim3(256), 0, s, g);
+    } else if ((size_t)nt * ((g.M + 127) / 128) * nb >= 400) {
+        ++m->gemm_launches[5];
+        hipLaunchKernelGGL(mbd_gemm_kernel<128>, dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
+    } else {
+        ++m->gemm_launches[6];
+        hipLaunchKernelGGL(mbd_gemm_kernel<64>, dim3(nt, (g.M + 63) / 64, nb), dim3(256), 0, s, g);
+    }
     return hipGetLastError();
 }
 
@@ -1912,6 +1925,36 @@ int mv_mbd_unet_forward(mv_mbd* m, int32_t band_idx, const float* x, int32_t T, 
     m->band = all;
     if (rc != MV_OK) return rc;
     for (int i = 0; i < T; ++i) out[i] += x[i];
+    return MV_OK;
+}
+
+// One evaluation of EVERY band model in one pass -- the launch shapes of mv_mbd_generate (all bands per launch: that is what decides
+// which GEMM kernel a layer runs on), which the one-band hook above cannot reproduce.  x: host fp32 [n_models][T], band b's input;
+// out: host fp32 [T] = sum over the bands of unet_b(x_b) (the generator adds the bands up; the sum is what comes back).
+int mv_mbd_unet_forward_sum(mv_mbd* m, const float* x, int32_t T, int32_t step, const float* latent, int32_t frames, float* out) {
+    if (!m || !x || !out) return mv_fail(MV_ERR_INVALID, "mv_mbd_unet_forward_sum: null argument");
+    const mv_mbd_config saved = m->cfg;
+    const std::vector<BandW> all = m->band;
+    const int NB = saved.n_models;
+    // one evaluation, a schedule that makes the update cur' = est - x, no processor, no re_eq
+    m->cfg.n_eval = 1; m->cfg.proc_bands = 1; m->cfg.eq_bands = 1;
+    for (BandW& V : m->band) { V.steps = {step}; V.est_c = {1.0f}; V.inv_sqrt_alpha = {-1.0f}; V.sigma = {0.f}; V.clip = 0.f; V.rescale = 1.f; V.noise_scale = 1.f; }
+    std::vector<float> nz((size_t)NB * 2 * T, 0.f);   // [band][initial | evaluation 0][T]
+    for (int b = 0; b < NB; ++b) memcpy(nz.data() + (size_t)b * 2 * T, x + (size_t)b * T, (size_t)T * 4);
+    const int rc = mv_mbd_generate(m, latent, frames, nullptr, T, nz.data(), 0, out);
+    m->cfg = saved;
+    m->band = all;
+    if (rc != MV_OK) return rc;
+    for (int b = 0; b < NB; ++b)
+        for (int i = 0; i < T; ++i) out[i] += x[(size_t)b * T + i];
+    return MV_OK;
+}
+
+// Launches per GEMM kernel since mv_mbd_create: out[0] mbd_gemm_t256_kernel, [1] mbd_gemm_glds3_kernel<64, 192>, [2] <128, 128>,
+// [3] mbd_gemm_thin_kernel, [4] mbd_gemm_glds_kernel, [5] mbd_gemm_kernel<128>, [6] mbd_gemm_kernel<64>, [7] 0.
+int mv_mbd_kernel_counts(const mv_mbd* m, int64_t* out) {
+    if (!m || !out) return mv_fail(MV_ERR_INVALID, "mv_mbd_kernel_counts: null argument");
+    for (int i = 0; i < 8; ++i) out[i] = m->gemm_launches[i];
     return MV_OK;
 }
 

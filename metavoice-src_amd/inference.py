@@ -94,6 +94,9 @@ def get_cached_file(file_or_uri: str) -> str:
     return cache_path
 
 
+UPLOAD_PREFIX = "mv_upload_"   # == serving.UPLOAD_PREFIX (serving imports this module, not the other way round)
+
+
 def get_cached_embedding(local_file_path: str, spkemb_model) -> torch.Tensor:
     """`fam/llm/inference.py:419-435`: the (1, 256) speaker embedding of an audio file, computed once and kept in
     `~/.cache/fam/embedding_<md5(path)>.pt` (the reference's name, so its cache stays valid here).  One difference: a cache entry
@@ -102,10 +105,11 @@ def get_cached_embedding(local_file_path: str, spkemb_model) -> torch.Tensor:
     local_file_path = str(local_file_path)
     if not os.path.exists(local_file_path):
         raise FileNotFoundError(f"File {local_file_path} not found!")
-    # an upload lives under a fresh temporary name that is never seen again: caching its embedding by path would leave one file per request
-    # in ~/.cache/fam for ever (the reference does exactly that under its server)
+    # an UPLOAD lives under a fresh temporary name that is never seen again: caching its embedding by path would leave one file per request
+    # in ~/.cache/fam for ever (the reference does exactly that under its server).  Only the files serving.py itself stored
+    # (`serving.UPLOAD_PREFIX` under the system temp directory) are exempt -- a user's own reference kept under /tmp is cached like any other
     tmp_root = os.path.realpath(tempfile.gettempdir()) + os.sep
-    if os.path.realpath(local_file_path).startswith(tmp_root) and os.environ.get("MV_CACHE_TMP_EMBEDDINGS") is None:
+    if os.path.realpath(local_file_path).startswith(tmp_root) and os.path.basename(local_file_path).startswith(UPLOAD_PREFIX):
         return spkemb_model.embed_utterance_from_file(local_file_path, numpy=False).unsqueeze(0).detach().to("cpu")
     d = cache_root("fam")
     cache_path = os.path.join(d, "embedding_" + hashlib.md5(local_file_path.encode("utf-8")).hexdigest() + ".pt")

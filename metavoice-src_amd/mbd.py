@@ -193,3 +193,24 @@ class MultiBandDiffusionBands:
         N.check(N.lib().mv_mbd_unet_forward(self._h, band, xa.ctypes.data_as(fp), xa.size, int(step), lat.ctypes.data_as(fp) if lat is not None else None,
                                             lat.shape[1] if lat is not None else 0, out.ctypes.data_as(fp)))
         return torch.from_numpy(out)
+
+    def unet_forward_sum(self, x: torch.Tensor, step: int, latent: Optional[torch.Tensor]) -> torch.Tensor:
+        """Parity hook at the launch shapes of `tokens_to_wav`: one evaluation of EVERY band model in one pass (all bands per launch --
+        which is what decides the GEMM kernel a layer runs on); x (n_models, samples) -> (samples,) = sum over the bands of unet_b(x_b)."""
+        fp = C.POINTER(C.c_float)
+        xa = np.ascontiguousarray(x.float().numpy())
+        assert xa.ndim == 2 and xa.shape[0] == self.n_models
+        lat = np.ascontiguousarray(latent[0].float().numpy()) if latent is not None else None
+        out = np.empty(xa.shape[1], dtype=np.float32)
+        N.check(N.lib().mv_mbd_unet_forward_sum(self._h, xa.ctypes.data_as(fp), xa.shape[1], int(step), lat.ctypes.data_as(fp) if lat is not None else None,
+                                                lat.shape[1] if lat is not None else 0, out.ctypes.data_as(fp)))
+        return torch.from_numpy(out)
+
+    GEMM_KERNELS = ("mbd_gemm_t256_kernel", "mbd_gemm_glds3_kernel<64,192>", "mbd_gemm_glds3_kernel<128,128>", "mbd_gemm_thin_kernel",
+                    "mbd_gemm_glds_kernel", "mbd_gemm_kernel<128>", "mbd_gemm_kernel<64>")
+
+    def kernel_counts(self) -> dict:
+        """Launches per convolution-GEMM kernel since the engine was built (the parity tests assert which kernels a shape ran on)."""
+        out = (C.c_int64 * 8)()
+        N.check(N.lib().mv_mbd_kernel_counts(self._h, out))
+        return {k: int(out[i]) for i, k in enumerate(self.GEMM_KERNELS)}

@@ -221,7 +221,11 @@ class BatchingDispatcher:
         results: list = []
         for t in out:
             raw = bytes(t.cpu().numpy().tobytes())
-            results.append(raw[1:] if raw[:1] == self.OK else RuntimeError(raw[1:].decode("utf-8", "replace")))
+            if raw[:1] == self.OK:
+                results.append(raw[1:])
+            else:   # "<class name>: <text>" (see above): the class name decides the status, the text goes to the log
+                kind, _, msg = raw[1:].decode("utf-8", "replace").partition(": ")
+                results.append(RemoteRequestError(kind, msg))
         return results
 
     def serve_worker(self):
@@ -283,6 +287,8 @@ STREAM_WAV_HEADER = (b"RIFF" + b"\xff\xff\xff\xff" + b"WAVE" + b"fmt " + (16).to
 
 
 UPLOAD_MAX_SECONDS = 120.0   # `_convert_audiodata_to_wav_path` (serving.py:112-124): `ffmpeg -t 120`, "arbitrary 2 minute cutoff"
+UPLOAD_PREFIX = "mv_upload_"   # the temp files uploads are stored under: inference.get_cached_embedding keeps no cache entry for them
+
 
 
 def _store_upload(audiodata: bytes, wav_tmp) -> str:
@@ -316,7 +322,7 @@ def text_to_speech_stream(fields: Dict[str, str], files: Dict[str, bytes]):
     lock = _engine_lock()
 
     def pieces():
-        with tempfile.NamedTemporaryFile(suffix=".wav") as wav_tmp:
+        with tempfile.NamedTemporaryFile(prefix=UPLOAD_PREFIX, suffix=".wav") as wav_tmp:
             if fields.get("speaker_ref_path") is None:
                 spk = _store_upload(files["audiodata"], wav_tmp)
             else:
@@ -359,7 +365,7 @@ def text_to_speech(fields: Dict[str, str], files: Dict[str, bytes]) -> Tuple[int
     audiodata = files.get("audiodata")
     wav_out_path = None
     try:
-        with tempfile.NamedTemporaryFile(suffix=".wav") as wav_tmp:
+        with tempfile.NamedTemporaryFile(prefix=UPLOAD_PREFIX, suffix=".wav") as wav_tmp:
             if speaker_ref_path is None:
                 wav_path = _store_upload(audiodata, wav_tmp)
             else:
@@ -383,11 +389,37 @@ def _engine_lock():
     return GlobalState.dispatcher.engine_lock if GlobalState.dispatcher is not None else GlobalState.engine_lock
 
 
+class RemoteRequestError(RuntimeError):
+    """A request that failed on another rank: the gathered payload carries the exception's class name and text (`remote_type`, message)."""
+
+    def __init__(self, remote_type: str, message: str):
+        super().__init__(f"{remote_type}: {message}")
+        self.remote_type, self.message = remote_type, message
+
+
+UNSUPPORTED_AUDIO_DETAIL = ("the speaker reference is in an audio format this server cannot decode; send RIFF/WAVE (or install a decoder: "
+                            "soundfile / ffmpeg)")
+
+
+def _is_unsupported_audio(e: BaseException) -> bool:
+    """By TYPE, along the cause / context chain (and the class name a failure on another rank travelled under) -- never by searching the
+    message text: an unrelated internal error that merely quotes the name stays a 500."""
+    seen = 0
+    while e is not None and seen < 8:
+        if any(c.__name__ == "UnsupportedAudioFormat" for c in type(e).__mro__) or getattr(e, "remote_type", None) == "UnsupportedAudioFormat":
+            return True
+        e, seen = e.__cause__ or e.__context__, seen + 1
+    return False
+
+
 def _error_response(e: Exception) -> Tuple[int, str, bytes]:
     """Exception -> (status, content type, body), shared by `/tts` and `/tts_stream`: a speaker reference in a format nothing here can
-    decode is the client's to fix (415), everything else is the reference's fixed 500 text (`serving.py:101-105`)."""
-    if type(e).__name__ == "UnsupportedAudioFormat" or "UnsupportedAudioFormat" in str(e)[:64]:
-        return 415, "application/json", json.dumps({"detail": str(e)}).encode()
+    decode is the client's to fix (415, with the decoder's own reason when the exception IS that type: it names the file the client
+    sent, nothing internal), everything else is the reference's fixed 500 text (`serving.py:101-105`)."""
+    if _is_unsupported_audio(e):
+        own = any(c.__name__ == "UnsupportedAudioFormat" for c in type(e).__mro__)
+        detail = str(e) if own else (getattr(e, "message", None) if getattr(e, "remote_type", None) == "UnsupportedAudioFormat" else None)
+        return 415, "application/json", json.dumps({"detail": detail or UNSUPPORTED_AUDIO_DETAIL}).encode()
     return 500, "text/plain", ERROR_TEXT.encode()
 
 

@@ -38,7 +38,18 @@ def test_extra_configs_cover_the_other_baseline_configurations():
     for tag in ("configs[2]", "configs[3]", "configs[4]"):
         assert tag in names
     over = dict(bench.EXTRA_CONFIGS)
-    assert over["configs[4] long-form 10000 characters, full vocoder"]["long_form_chars"] == 10000
+    lf = over["configs[4] long-form 10000 characters, full vocoder, 4 chunks per engine run"]
+    assert lf["long_form_chars"] == 10000 and lf["utterances_per_gpu"] == 4
+    # the chunks of a long text decode in groups of --utterances-per-gpu (what TTS.synthesise_long does), consecutive chunks together
+    assert bench.parse_args(["--long-form", "--utterances-per-gpu", "4"]).long_form
+    importlib = __import__("importlib")
+    mv = importlib.import_module("metavoice-src_amd")
+    args = mv.ModelArgs.from_name("metavoice-1B")
+    one = bench.make_work(mv, args, long_form=True, long_form_chars=3000, utterances_per_gpu=1, rank=0, world=1)
+    four = bench.make_work(mv, args, long_form=True, long_form_chars=3000, utterances_per_gpu=4, rank=0, world=1)
+    assert all(len(g) == 1 for g in one) and len(four) == -(-len(one) // 4) and all(len(g) <= 4 for g in four)
+    flat1, flat4 = [x for g in one for x in g], [x for g in four for x in g]
+    assert len(flat1) == len(flat4) and all(n1 == n4 and bool((p1 == p4).all()) for (p1, n1), (p4, n4) in zip(flat1, flat4))
     a = bench.parse_args([])
     for _, o in bench.EXTRA_CONFIGS:
         for k in o:

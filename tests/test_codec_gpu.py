@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 codec = load_pkg("codec")
 
 
-@pytest.mark.parametrize("frames,n_q", [(8, 8), (75, 8), (150, 2), (33, 5)])
+@pytest.mark.parametrize("frames,n_q", [(8, 8), (75, 8), (150, 2), (33, 5), (960, 8)])   # (960, 8): the utterance bench.py times
 def test_decode_matches_oracle_and_transformers(frames, n_q):
     model = seeded_encodec(2)
     sd_raw = model.state_dict()

@@ -401,6 +401,18 @@ def test_stream_maps_errors_like_tts(server):
         pass
     Unsupported.__name__ = "UnsupportedAudioFormat"
     assert serving._error_response(Unsupported("no decoder"))[0] == 415
+    # by type along the cause chain, and under the class name a failure on another rank travelled with -- never by message text:
+    try:
+        try:
+            raise Unsupported("no decoder")
+        except Unsupported as inner:
+            raise RuntimeError("speaker embedding failed") from inner
+    except RuntimeError as wrapped:
+        code, _, body = serving._error_response(wrapped)
+        assert code == 415 and b"speaker embedding failed" not in body   # a wrapper's own text is internal: the fixed detail goes out
+    assert serving._error_response(serving.RemoteRequestError("UnsupportedAudioFormat", "x.mp3: no decoder"))[0] == 415
+    assert serving._error_response(RuntimeError("cache says: UnsupportedAudioFormat was raised earlier")) == (500, "text/plain", serving.ERROR_TEXT.encode())
+    assert serving._error_response(serving.RemoteRequestError("RuntimeError", "UnsupportedAudioFormat quoted"))[0] == 500
     assert serving._error_response(RuntimeError("x")) == (500, "text/plain", serving.ERROR_TEXT.encode())
     code, _, body = post(base + "/tts_stream", urllib.parse.urlencode({"text": "boom", "speaker_ref_path": "x"}).encode())
     assert code == 500 and body.decode() == serving.ERROR_TEXT

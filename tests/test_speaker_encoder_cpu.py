@@ -161,7 +161,6 @@ def test_get_cached_embedding_is_computed_once_per_file(tmp_path, monkeypatch):
 
     inf = load_pkg("inference")
     monkeypatch.setenv("METAVOICE_CACHE_DIR", str(tmp_path / "cache"))
-    monkeypatch.setenv("MV_CACHE_TMP_EMBEDDINGS", "1")   # pytest's tmp_path is a temporary directory: see the next test
 
     class Enc:
         calls = 0
@@ -192,7 +191,6 @@ def test_uploads_under_the_temporary_directory_leave_no_cache_entry(tmp_path, mo
     `embedding_*.pt` behind for ever.  Also: a local file whose name starts with "http" is a local file."""
     inf = load_pkg("inference")
     monkeypatch.setenv("METAVOICE_CACHE_DIR", str(tmp_path / "cache"))
-    monkeypatch.delenv("MV_CACHE_TMP_EMBEDDINGS", raising=False)
 
     class Enc:
         calls = 0
@@ -201,12 +199,18 @@ def test_uploads_under_the_temporary_directory_leave_no_cache_entry(tmp_path, mo
             Enc.calls += 1
             return torch.full((256,), float(Enc.calls))
 
-    f = tmp_path / "upload.wav"
+    f = tmp_path / (inf.UPLOAD_PREFIX + "k3j2.wav")   # the name serving.py stores an upload under (pytest's tmp_path is under the temp dir)
     f.write_bytes(b"x")
     e1 = inf.get_cached_embedding(str(f), Enc())
     e2 = inf.get_cached_embedding(str(f), Enc())
     assert e1.shape == (1, 256) and Enc.calls == 2 and float(e2[0, 0]) == 2.0
     assert not (tmp_path / "cache" / "fam").exists() or not list((tmp_path / "cache" / "fam").glob("embedding_*"))
+    # ... but a user's own reference that happens to live under the temp directory is cached like any other
+    mine = tmp_path / "my_voice.wav"
+    mine.write_bytes(b"x")
+    inf.get_cached_embedding(str(mine), Enc())
+    inf.get_cached_embedding(str(mine), Enc())
+    assert Enc.calls == 3 and len(list((tmp_path / "cache" / "fam").glob("embedding_*"))) == 1
     g = tmp_path / "http_take3.wav"
     g.write_bytes(b"x")
     assert inf.get_cached_file(str(g)) == str(g)
