@@ -1,0 +1,600 @@
+// Persistent decode-step kernel for engines of 4 utterances (8 CFG rows) on the MATRIX CORES: all 24 layers + the LM head of one token
+// in ONE launch, the same hand-off protocol, granule buffers and attention partition as decode_mega.hip -- but the five projections of a
+// layer run on v_mfma_f32_16x16x32_bf16 instead of v_dot2 + 64-lane sums.
+//
+// Why.  decode_mega.hip gives a wave whole weight rows and applies them to every activation row with v_dot2c: 4 dot2 per 8 weights per
+// activation row and one 64-lane DPP sum per (weight row, activation row).  At one utterance (2 rows) that is nothing next to the stream;
+// at four (8 rows) it is 4 x the VALU issue on two waves per SIMD plus 22 x 4 rolled epilogue sums per layer: profiles/r04h -- of a 52.6 us
+// layer, "qkv published" 1.9 us, "h published" 1.1, "act published" 3.6 behind their dots, norms 2.4 + 1.6.  A 16 x 16 x 32 MFMA multiplies 16
+// weight rows by up to 16 activation rows in 16 cycles and its accumulator IS the output tile: no lane sums at all.
+//
+// Layout (the engine owns it: mv_finalize builds a second, TILED copy of the projection weights, tile_weights_kernel).  Workgroup b owns the
+// same rows of every matrix as in decode_mega.hip (24 wqkv, 8 wo, 22 w1, 22 w3, 8 w2, 11 head rows); its slice of a matrix is stored
+// k-step major, [K / 32][rows][32 columns], so the A fragment of row tile t and k-step s -- lane (rho = lane & 15, g = lane >> 4) holds
+// columns 32 s + 8 g .. + 7 of row 16 t + rho -- is ONE 16-byte load per lane out of a contiguous rows x 64 B piece (fully coalesced; row
+// slots beyond the slice re-read its last row: no extra HBM bytes, their outputs are never read).  The K dimension is split over the 8 waves
+// of the workgroup (8 k-steps each at K = 2048, 22 at K = 5632), each wave accumulates its part of every row tile, the 8 partial tiles meet in
+// LDS (one barrier) and thread (row, utterance) adds them in wave order, applies the epilogue of gemv_core.h and publishes the granule.
+// The B fragment -- activation row lane & 15, the same 8 columns -- is a 16-byte LDS read from the operand rows xs[8][K + 8] (row stride =
+// 4 banks mod 32: conflict-free for the instruction's 16-lane groups).
+//
+// Numerics.  Same rounding points as every other path (gemv_core.h epilogues, fp32 RMSNorm, attn_core.h attention -- the attention phase
+// is decode_mega.hip's, function for function); what changes is the ORDER of the fp32 additions inside a projection (MFMA k-order per
+// wave, then 8 wave partials) -- so this kernel is NOT bit-identical to the per-layer launches or to a single-utterance run; the tests
+// hold it to the bf16 noise floor instead (tests/test_engine_gpu.py: logits within tolerance, margin-gated token agreement).
+// `mv_tune("mfma", 0)` puts engines of 4 utterances back on decode_mega.hip's bit-identical instance.
+#include <atomic>
+
+#include "mega_core.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+#define MF_KP (MG_INTER + 8)      // operand row stride in LDS (elements): 11 280 B = 2820 words = 4 banks mod 32
+#define MF_RED_TILES 4            // partial tiles per wave in the exchange buffer (w1 | w3: two row tiles each)
+
+// rows of each matrix one workgroup owns (decode_mega.hip's partition)
+#define MF_R_QKV 24
+#define MF_R_WO 8
+#define MF_R_W13 22
+#define MF_R_W2 8
+#define MF_R_HEAD 11
+
+// ---- tiled weight copy ---------------------------------------------------------------------------------------------------------------
+// dst[((b * (K / 32) + s) * rows + r) * 32 + c] = src[min(b * rows + r, N - 1)][32 s + c]   (b < 256 workgroups, r < rows per workgroup)
+__global__ void __launch_bounds__(256) tile_weights_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int K, int rows) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;   // 8 consecutive columns = one 16-byte piece of a row's k-step
+    const size_t total = (size_t)256 * rows * K;
+    if (i >= total) return;
+    const int c = (int)(i % 32);
+    const size_t t = i / 32;
+    const int r = (int)(t % rows);
+    const size_t t2 = t / rows;
+    const int s = (int)(t2 % (K / 32)), b = (int)(t2 / (K / 32));
+    const int n = min(b * rows + r, N - 1);
+    *(u32x4*)(dst + i) = *(const u32x4*)(src + (size_t)n * K + 32 * s + c);
+}
+hipError_t launch_tile_weights(hipStream_t s, const bf16_t* src, bf16_t* dst, int N, int K, int rows_per_wg) {
+    if (K % 32 != 0 || rows_per_wg < 1) return hipErrorInvalidValue;
+    const size_t pieces = (size_t)256 * rows_per_wg * K / 8;
+    hipLaunchKernelGGL(tile_weights_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, src, dst, N, K, rows_per_wg);
+    return hipGetLastError();
+}
+size_t mfma_tiled_elems(int K, int rows_per_wg) { return (size_t)256 * rows_per_wg * K; }
+
+namespace {
+
+// A fragment: row tile t, k-step s of a workgroup's slice [K / 32][NROWS][32].  The address is (wave-uniform base of the k-step: SGPRs)
+// + (the lane's 32-bit byte offset inside a k-step piece: ONE VGPR per row tile): global_load ... v_off, s[base] -- with 64-bit per-lane
+// pointers hipcc formed all addresses of a request burst first (2 VGPRs per fragment in front of 4 per fragment of data) and spilled.
+template <int NROWS>
+__device__ __forceinline__ uint32_t mf_lane_off(int t, int lane) {   // byte offset of the lane's 16 bytes inside a k-step piece of NROWS x 64 B
+    return (uint32_t)(min(16 * t + (lane & 15), NROWS - 1) * 64 + (lane >> 4) * 16);
+}
+// A PACKED half tile (a slice's last 8 or fewer rows, FIRST .. NROWS - 1): row slots 0..7 hold those rows at k-step s, row slots 8..15 hold
+// the SAME rows at k-step s + SKIP -- one fragment, two MFMAs (against the activations of k-step s: accumulator rows 0..7 are the product,
+// rows 8..15 garbage; against those of k-step s + SKIP: the other way round).  With the row slots beyond the slice merely duplicated an
+// 8-row slice (wo, w2: one row per wave in decode_mega.hip) cost twice its bytes in registers -- 88 for w2 alone.
+template <int NROWS, int FIRST, int SKIP>
+__device__ __forceinline__ uint32_t mf_lane_off_half(int lane) {
+    const int rho = lane & 15;
+    return (uint32_t)(min(FIRST + (rho & 7), NROWS - 1) * 64 + (lane >> 4) * 16 + (rho >> 3) * SKIP * NROWS * 64);
+}
+// the two accumulators of a packed half tile as ONE tile: rows 0..7 from the MFMAs against k-step s (lane groups 0, 1 hold accumulator rows
+// 0..7), rows 8..15 from those against k-step s + SKIP; the reducer adds row i and row i + 8
+__device__ __forceinline__ f32x4_t mf_half_tile(const f32x4_t& lo, const f32x4_t& hi, int lane) { return (lane & 32) ? hi : lo; }
+template <int NROWS>
+__device__ __forceinline__ u32x4 mf_frag(const bf16_t* slice, int s, uint32_t lane_off) {   // slice, s: wave-uniform
+    const char* piece = (const char*)slice + (size_t)s * NROWS * 64;
+    return load_stream16(piece + lane_off);
+}
+// B fragment: activation row (lane & 15) mod R, columns 32 s + 8 (lane >> 4) .. + 7
+template <int R>
+__device__ __forceinline__ bf16x8_t mf_bfrag(const bf16_t* xs, int s, int lane) {
+    return *(const bf16x8_t*)(xs + (size_t)(lane & (R - 1)) * MF_KP + 32 * s + (lane >> 4) * 8);
+}
+__device__ __forceinline__ f32x4_t mf_mma(const u32x4& a, const bf16x8_t& b, const f32x4_t& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), b, c, 0, 0, 0);
+}
+// the wave's partial of row tile `tile` into the exchange buffer red[wave][tile][lane][4]
+__device__ __forceinline__ void mf_put(float* red, int wave, int tile, int lane, const f32x4_t& acc) {
+    *(f32x4_t*)(red + (((size_t)wave * MF_RED_TILES + tile) * 64 + lane) * 4) = acc;
+}
+// D[row slot i of tile][activation row j], summed over the 8 waves in wave order (accumulator layout: column = lane & 15 = activation row,
+// row = 4 (lane >> 4) + register)
+__device__ __forceinline__ float mf_get(const float* red, int tile, int i, int j) {
+    const float* p = red + ((size_t)tile * 64 + (i >> 2) * 16 + j) * 4 + (i & 3);
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < MG_WAVES; ++w) s += p[(size_t)w * MF_RED_TILES * 256];
+    return s;
+}
+
+// RMSNorm of the R operand rows in place (fp32 inside, bf16 rounding points of fast_model.py:256-261 through rms_apply8): wave w does rows
+// w, w + 8, ...; lane l holds columns 512 q + 8 l .. + 7.  The norm weights come from LDS (`nws`, written by the whole workgroup a phase
+// ahead) and the row is read twice (statistics, then apply), one 16-byte piece at a time: held in registers through the norm -- 16 for the
+// weights, 16 for the row, ~60 of unrolled apply temporaries -- next to the 128 registers of w1 | w3 fragments in flight, the norm was what
+// tipped this kernel over the 256-register budget.
+template <int R>
+__device__ __forceinline__ void mf_norm(bf16_t* xs, const bf16_t* nws, float eps, int lane, int wave) {
+#pragma unroll
+    for (int rho = wave; rho < R; rho += MG_WAVES) {
+        bf16_t* row = xs + (size_t)rho * MF_KP + lane * 8;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s += sumsq8(*(const u32x4*)(row + q * 512));
+        const float rstd = rms_rstd(wave_sum(s), MG_DIM, eps);
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) *(u32x4*)(row + q * 512) = rms_apply8(*(const u32x4*)(row + q * 512), rstd, *(const u32x4*)(nws + q * 512 + lane * 8));
+    }
+}
+
+// 16-byte polls of a row-paired vector of NCOL columns of every utterance ([NU][NCOL] granules) into the operand rows: pair n = granules
+// 2n, 2n + 1 = columns 2n, 2n + 1 of both rows of its utterance.  UPP utterances per poll loop (poll16_loads has instances up to 12 requests).
+template <int NU, int NCOL, typename AF>
+__device__ __forceinline__ void mf_poll_rows(const gran_t* g, uint32_t tag, bf16_t* xs, AF abort_flag, int* s_abort, int tid) {
+    constexpr int PPT = (NCOL / 2 + MG_THREADS - 1) / MG_THREADS;   // pairs per thread and utterance: 2 (2048 columns) or 6 (5632)
+    constexpr int UPP = PPT <= 2 ? 4 : 2;
+    static_assert(NU % UPP == 0, "utterances per poll loop");
+#pragma unroll
+    for (int u0 = 0; u0 < NU; u0 += UPP) {
+        wave_poll16<PPT * UPP>(g + (size_t)u0 * NCOL, tag, abort_flag, s_abort,
+                               [&](int k) {
+                                   const int n = tid + (k % PPT) * MG_THREADS;
+                                   return n < NCOL / 2 ? (k / PPT) * (NCOL / 2) + n : -1;
+                               },
+                               [&](int n, uint32_t p0, uint32_t p1) {
+                                   bf16_t* row = xs + (size_t)(2 * (u0 + n / (NCOL / 2))) * MF_KP;
+                                   const int c = n % (NCOL / 2);
+                                   *(uint32_t*)(row + 2 * c) = (p0 & 0xFFFFu) | (p1 << 16);
+                                   *(uint32_t*)(row + MF_KP + 2 * c) = (p0 >> 16) | (p1 & 0xFFFF0000u);
+                               });
+    }
+}
+
+}  // namespace
+
+__host__ __device__ constexpr size_t mfma_lds_bytes(int nu) {
+    return (size_t)2 * nu * MF_KP * 2 + (size_t)MG_WAVES * MF_RED_TILES * 256 * 4 + (size_t)3 * 2 * 128 * 2 + (size_t)nu * ATTN_WAVES * 16 * 12 * 4 +
+           (size_t)2 * MG_DIM * 2;   // + the two norm weight vectors of a layer
+}
+
+template <int NU>
+__global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaArgs a) {
+    constexpr int R = 2 * NU;
+    static_assert(NU == 4, "the 8-utterance instance needs the activation vector of the w2 phase outside LDS (180 KB)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char mf_lds[];
+    bf16_t* xs = (bf16_t*)mf_lds;                                                        // [R][MF_KP] operand rows of the current phase
+    float* red = (float*)(mf_lds + (size_t)R * MF_KP * 2);                               // [8 waves][4 tiles][64 lanes][4]
+    bf16_t* qkv_s = (bf16_t*)(red + (size_t)MG_WAVES * MF_RED_TILES * 256);              // q | k_new | v_new of this workgroup's head, both rows
+    float (*sm)[16][12] = (float(*)[16][12])(qkv_s + 3 * 2 * 128);                       // [NU ranges][8 waves][16][12]
+    bf16_t* nws = (bf16_t*)(sm + NU * ATTN_WAVES);                                       // [2][2048]: attention norm | ffn norm weights of the layer (final norm: [0])
+    __shared__ int s_abort;
+    __shared__ int geo[4][NU];   // P, cs, nact, kw per utterance
+    __shared__ int pos_s[NU];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    if (tid == 0) s_abort = 0;
+    if (tid < NU) pos_s[tid] = a.pos[tid];
+    __syncthreads();
+#define MF_LAYER(i) (*((const __attribute__((address_space(4))) MegaLayer*)(a.layers) + (i)))
+#define MF_ABORTED() (*(volatile int*)&s_abort != 0)
+#define MF_ABORT_RETURN() do { if (MF_ABORTED()) return; } while (0)
+#define MF_GEO(k, u) __builtin_amdgcn_readfirstlane(geo[k][u])
+    auto abort_flag_of = [&]() { return a.abort_flag; };
+    const uint32_t epoch = a.step_counter[0] * 256u;
+    const int n_layer = a.n_layer;
+
+    // attention: this workgroup = (utterance, row, head, part): SPB = NU consecutive key ranges starting at at_s, 8 / NU workgroups per
+    // (utterance, row, head) -- decode_mega.hip's MEGA_ATTN_V2 partition
+    constexpr int BPH = 8 / NU, SPB = NU;
+    const int at_u = b / (32 * BPH), at_r = (b / (16 * BPH)) & 1, at_h = (b / BPH) & 15, at_s = (b % BPH) * SPB;
+    bool any_att = false;
+#pragma unroll
+    for (int u = NU - 1; u >= 0; --u) {
+        const int Pu = pos_s[u] + 1;  // keys [0, P): the cache holds [0, P-1), key P-1 is produced by this step's QKV phase
+        const int csu = attn_keys_per_split(Pu), nactu = (Pu + csu - 1) / csu;
+        if (tid == 0) { geo[0][u] = Pu; geo[1][u] = csu; geo[2][u] = nactu; geo[3][u] = attn_keys_per_wave(csu); }
+        if (u == at_u && at_s < nactu) any_att = true;
+    }
+    __syncthreads();
+
+    // the six exchanged vectors of every utterance sit in ONE slab at compile-time offsets (engine.hip: mega_args)
+    gran_t* const g_x = a.g_x;
+    gran_t* const g_qkv = g_x + (size_t)NU * MG_DIM;
+    gran_t* const g_attn = g_qkv + (size_t)NU * 3 * MG_DIM;
+    gran_t* const g_h = g_attn + (size_t)NU * MG_DIM;
+    gran_t* const g_act = g_h + (size_t)NU * MG_DIM;
+
+    // reduce / publish thread t = (row slot i, utterance u): consecutive threads = the utterances of one weight row
+    uint32_t xres = 0u, hres = 0u;   // residual pair (row 0 | row 1 << 16) of column 8 b + pi of utterance pu: threads < 8 NU
+    if (tid < MF_R_WO * NU) {
+        const int pu = tid % NU, pi = tid / NU;
+        const bf16_t* xi = a.x_in + (size_t)pu * 2 * MG_DIM + 8 * b + pi;
+        xres = (uint32_t)xi[0] | ((uint32_t)xi[MG_DIM] << 16);
+    }
+
+    u32x4 wq[12];      // wqkv fragments: rows 0..15 x 8 k-steps, rows 16..23 packed x 4 (head: 8 k-steps of one tile) -- requested at the end of a layer for the next
+    u32x4 nwp;         // this thread's 16 bytes of the next layer's norm weights (threads < 256: attention norm, the others: ffn norm), on their
+                       // way to `nws` -- requested with the layer's wqkv fragments, stored to LDS once the x poll has seen them land
+
+    // (lane, wave) below are the CALLER's ids, made opaque once per layer: every fragment address is a function of them and of the layer's
+    // base pointer -- left alone hipcc hoists the ~90 loop-invariant offsets out of the layer loop, keeps them live and spills
+    // (first build: 1418 spilled VGPRs); opaque, each address is one or two VALU ops next to its load (decode_mega.hip does the same)
+    auto request_wqkv = [&](int l, int lane, int wave) {
+        const bf16_t* slice = MF_LAYER(l).t[0] + (size_t)b * MF_R_QKV * MG_DIM;
+        const int ws = __builtin_amdgcn_readfirstlane(wave);
+        const uint32_t o0 = mf_lane_off<MF_R_QKV>(0, lane), o1 = mf_lane_off_half<MF_R_QKV, 16, 4>(lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wq[i] = mf_frag<MF_R_QKV>(slice, 8 * ws + i, o0);          // rows 0..15, k-step 8 w + i
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wq[8 + i] = mf_frag<MF_R_QKV>(slice, 8 * ws + i, o1);      // rows 16..23, k-steps 8 w + i | 8 w + 4 + i
+        const int t = wave * 64 + lane;
+        nwp = load16((t < 256 ? MF_LAYER(l).attn_norm : MF_LAYER(l).ffn_norm) + (t & 255) * 8);
+    };
+    request_wqkv(0, lane, wave);
+
+    // this workgroup's K/V rows of key range `split` of utterance u (rows of EARLIER steps); part 0: K and V, 1: K only, 2: V only
+    auto issue_kv = [&](u32x4 (&kd)[ATTN_U], u32x4 (&vd)[ATTN_U], int u, int layer, int split, int part, int lane, int wave) {
+        if (part != 2) {
+#pragma unroll
+            for (int q = 0; q < ATTN_U; ++q) kd[q] = u32x4{0u, 0u, 0u, 0u};
+        }
+        if (part != 1) {
+#pragma unroll
+            for (int q = 0; q < ATTN_U; ++q) vd[q] = u32x4{0u, 0u, 0u, 0u};
+        }
+        const int Pu = MF_GEO(0, u), csu = MF_GEO(1, u), nactu = MF_GEO(2, u), kwu = MF_GEO(3, u);
+        const int go = lane >> 4, dlo = lane & 15, s0o = split * csu + wave * kwu;
+        const size_t layer_off = (size_t)layer * a.kv_layer_elems;
+        const bf16_t* kc = a.kcache + layer_off;
+        const bf16_t* vc = a.vcache + layer_off;
+        const size_t head_base = ((size_t)(2 * u + at_r) * MG_HEADS + at_h) * (size_t)a.cache_len * 128 + dlo * 8;
+        const int last_old = max(Pu - 2, 0);   // row P-1 is being written by this launch: never touched here (taken from the hand-off)
+        if (Pu > 1 && split < nactu) {
+            if (part != 2) {
+#pragma unroll
+                for (int q = 0; q < ATTN_U; ++q)
+                    if (q * 4 < kwu) kd[q] = load_stream16(kc + head_base + (size_t)min(s0o + q * 4 + go, last_old) * 128);
+            }
+            if (part != 1) {
+#pragma unroll
+                for (int q = 0; q < ATTN_U; ++q)
+                    if (q * 4 < kwu) vd[q] = load_stream16(vc + head_base + (size_t)min(s0o + q * 4 + go, last_old) * 128);
+            }
+        }
+    };
+
+    for (int l = 0; l < n_layer; ++l) {
+        int lane_o = lane, wave_o = wave;
+        asm volatile("" : "+v"(lane_o), "+v"(wave_o));
+        const int tid_o = wave_o * 64 + lane_o;
+        const int wave_s = __builtin_amdgcn_readfirstlane(wave_o);   // wave-uniform: the k-step part of a fragment address stays in SGPRs
+        const int pu = tid_o % NU, pi = tid_o / NU;   // reduce / publish thread = (row slot pi, utterance pu): from the opaque id, see above
+        // declared per layer: a register array that is assigned under a condition (the K/V rows of a workgroup that attends) and declared
+        // outside the loop is live around the whole loop for the compiler
+        u32x4 wo_r[4];     // wo: 8 rows packed, 4 fragments = 8 k-steps
+        u32x4 w13[24];     // w1: rows 0..15 x 8 k-steps + rows 16..21 packed x 4; w3 the same behind it
+        u32x4 w2_r[11];    // w2: 8 rows packed, 11 fragments = 22 k-steps
+        u32x4 kv[ATTN_U], vv[ATTN_U];
+        const __attribute__((address_space(4))) MegaLayer& L = MF_LAYER(l);
+        const uint32_t tag0 = epoch + (uint32_t)l * 8u + 1u;  // + phase index
+
+        // ================= P0: RMSNorm + wqkv (+ KV-cache write)        fast_model.py:179,209,218 ====================
+        __syncthreads();
+        if (l == 0) {
+            for (int it = tid_o; it < R * (MG_DIM / 8); it += MG_THREADS) {
+                const int rho = it / (MG_DIM / 8), c = (it % (MG_DIM / 8)) * 8;
+                *(u32x4*)(xs + (size_t)rho * MF_KP + c) = load16(a.x_in + (size_t)rho * MG_DIM + c);
+            }
+        } else mf_poll_rows<NU, MG_DIM>(g_x, tag0 - 8u + 4u, xs, abort_flag_of, &s_abort, tid_o);
+        *(u32x4*)(nws + tid_o * 8) = nwp;   // this layer's norm weights (requested with its wqkv fragments; landed: the poll ended in vmcnt(0))
+        __syncthreads();
+        MF_ABORT_RETURN();
+        if (any_att) issue_kv(kv, vv, at_u, l, at_s, 1, lane_o, wave_o);   // K rows of the first range: they land under the norm and the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        mf_norm<R>(xs, nws, a.eps, lane_o, wave_o);
+        __syncthreads();
+        {
+            f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, lo = acc0, hi = acc0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8_t b0 = mf_bfrag<R>(xs, 8 * wave_o + i, lane_o), b1 = mf_bfrag<R>(xs, 8 * wave_o + 4 + i, lane_o);
+                acc0 = mf_mma(wq[i], b0, acc0);
+                acc0 = mf_mma(wq[4 + i], b1, acc0);
+                lo = mf_mma(wq[8 + i], b0, lo);
+                hi = mf_mma(wq[8 + i], b1, hi);
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            mf_put(red, wave_o, 0, lane_o, acc0);
+            mf_put(red, wave_o, 1, lane_o, mf_half_tile(lo, hi, lane_o));
+        }
+        __syncthreads();
+        if (tid_o < MF_R_QKV * NU) {
+            const int i = pi, u = pu, n = MF_R_QKV * b + i;
+            // rows 0..15: tile 0; rows 16..23: the packed half tile, k-range halves in row slots i - 16 and i - 8
+            const bf16_t y0 = f2bf(i < 16 ? mf_get(red, 0, i, 2 * u) : mf_get(red, 1, i - 16, 2 * u) + mf_get(red, 1, i - 8, 2 * u));
+            const bf16_t y1 = f2bf(i < 16 ? mf_get(red, 0, i, 2 * u + 1) : mf_get(red, 1, i - 16, 2 * u + 1) + mf_get(red, 1, i - 8, 2 * u + 1));
+            gran_store(g_qkv + (size_t)u * 3 * MG_DIM + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 0u);
+            if (n >= MG_DIM) {  // K / V rows also go to the cache for the FUTURE steps (this step reads them from the granules)
+                const int which = (n - MG_DIM) / MG_DIM, hd = (n - MG_DIM) % MG_DIM;
+                const size_t cache_len = (size_t)a.cache_len;
+                bf16_t* cache = (which ? a.vcache : a.kcache) + (size_t)l * a.kv_layer_elems + (size_t)2 * u * MG_HEADS * cache_len * 128;
+                const size_t off = ((size_t)(hd / 128) * cache_len + (MF_GEO(0, u) - 1)) * 128 + hd % 128;
+                cache[off] = y0;
+                cache[(size_t)MG_HEADS * cache_len * 128 + off] = y1;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (any_att) issue_kv(kv, vv, at_u, l, at_s, 2, lane_o, wave_o);   // V rows behind the publish, in front of the q/k/v hand-off
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();   // every publish of the workgroup has left: bulk requests may enter the CU's memory pipeline
+        {   // wo rows 8 b .. 8 b + 7 (one half tile), under the q/k/v hand-off
+            const bf16_t* slice = L.t[1] + (size_t)b * MF_R_WO * MG_DIM;
+            const uint32_t o0 = mf_lane_off_half<MF_R_WO, 0, 4>(lane_o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wo_r[i] = mf_frag<MF_R_WO>(slice, 8 * wave_s + i, o0);   // k-steps 8 w + i | 8 w + 4 + i
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // w1 behind the attention, w3 behind the h publish: all 32 fragments (128 registers) at once, next to the wo fragments and a poll's
+        // 56, left no room for the norm (first builds: 250-1400 spilled registers -- a scratch reload waits behind every row in flight)
+        auto request_w1 = [&]() {
+            const bf16_t* s1 = L.t[2] + (size_t)b * MF_R_W13 * MG_DIM;
+            const uint32_t o0 = mf_lane_off<MF_R_W13>(0, lane_o), o1 = mf_lane_off_half<MF_R_W13, 16, 4>(lane_o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w13[i] = mf_frag<MF_R_W13>(s1, 8 * wave_s + i, o0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w13[8 + i] = mf_frag<MF_R_W13>(s1, 8 * wave_s + i, o1);
+        };
+
+        // ================= P1: attention over keys [0, P)               fast_model.py:218-222 =========================
+        if (!any_att) request_w1();
+        if (any_att) {
+            {   // q, k_new, v_new of head at_h of this workgroup's utterance: 3 x 128 row-paired granules
+                const int sec = tid_o >> 7, c = tid_o & 127;
+                wave_poll<1>(tag0 + 0u, abort_flag_of, &s_abort,
+                             [&](int, u64& v) {
+                                 if (tid_o >= 384) return false;
+                                 v = gran_load(g_qkv + (size_t)at_u * 3 * MG_DIM + sec * MG_DIM + at_h * 128 + c);
+                                 return true;
+                             },
+                             [&](int, uint32_t p) { qkv_s[(sec * 2 + 0) * 128 + c] = (bf16_t)p; qkv_s[(sec * 2 + 1) * 128 + c] = (bf16_t)(p >> 16); });
+            }
+            __syncthreads();
+            MF_ABORT_RETURN();
+            const int u = at_u;
+            const int g = lane_o >> 4, dl = lane_o & 15, at_w = wave_o, lane = lane_o;
+            const int Pu = MF_GEO(0, u), csu = MF_GEO(1, u), nactu = MF_GEO(2, u), kwu = MF_GEO(3, u);
+            const int n_my = min(SPB, nactu - at_s);   // >= 1: this workgroup attends
+            const u32x4 qv = *(const u32x4*)(qkv_s + (0 * 2 + at_r) * 128 + dl * 8);
+            // ONE K/V register set, the workgroup's ranges back to back (rolled): decode_mega.hip's second set would live in registers this
+            // kernel does not have (its quantised instances do the same)
+#pragma unroll 1
+            for (int j = 0; j < n_my; ++j) {
+                const int split = at_s + j;
+                const int s0 = split * csu + at_w * kwu, s1 = min(min(Pu, split * csu + csu), s0 + kwu);
+#pragma unroll
+                for (int q = 0; q < ATTN_U; ++q) {
+                    if (s0 + q * 4 + g == Pu - 1) {  // the key produced by this step: not in the cache yet for this launch
+                        kv[q] = *(const u32x4*)(qkv_s + (1 * 2 + at_r) * 128 + dl * 8);
+                        vv[q] = *(const u32x4*)(qkv_s + (2 * 2 + at_r) * 128 + dl * 8);
+                    }
+                }
+                const AttnAcc w = attn_wave_partial<false>(kv, vv, qv, s0, s1, g);
+                if (j + 1 < n_my) issue_kv(kv, vv, u, l, split + 1, 0, lane_o, wave_o);   // the next range streams while this one is stored / merged
+                if (g == 0) {
+                    float (*smj)[16][12] = sm + j * ATTN_WAVES;
+                    smj[at_w][dl][0] = w.m;
+                    smj[at_w][dl][1] = w.l;
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) smj[at_w][dl][2 + d] = w.o[d];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            // wave j merges range j and publishes its partial; with a single range (<= 256 keys) the merged result is the output
+            u64* slots = (u64*)a.partial + ((size_t)(2 * u + at_r) * MG_HEADS + at_h) * ATTN_NSPLIT * ATTN_TPART_STRIDE;
+            AttnAcc bb;
+            if (at_w < n_my) {
+                bb = attn_merge_waves<false>(sm + at_w * ATTN_WAVES, g, dl);
+                if (nactu > 1) attn_publish_tagged(bb, slots + (size_t)(at_s + at_w) * ATTN_TPART_STRIDE, tag0 + 5u, lane);
+            }
+            if (at_w == 0 && at_s == 0) {   // the workgroup of the first ranges combines (utterance, row, head) and publishes its output
+                bool last = true;
+                if (nactu > 1 && !attn_combine_tagged<false>(bb, slots, tag0 + 5u, nactu, lane, MG_SPIN_LIMIT)) {
+                    uint32_t* af = a.abort_flag;
+                    mega_report_timeout(af, tag0 + 5u);
+                    __hip_atomic_store(af, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *(volatile int*)&s_abort = 1;
+                    last = false;
+                }
+                if (last && g == 0) {  // 8 dims per lane = 4 column-paired granules
+                    const u32x4 y = attn_normalise(bb);
+                    gran_t* gp = g_attn + (size_t)u * MG_DIM + at_r * (MG_DIM / 2) + (at_h * 128 + dl * 8) / 2;
+                    gran_store(gp + 0, y.x, tag0 + 1u);
+                    gran_store(gp + 1, y.y, tag0 + 1u);
+                    gran_store(gp + 2, y.z, tag0 + 1u);
+                    gran_store(gp + 3, y.w, tag0 + 1u);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            request_w1();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ================= P2: h = x + wo(attn)                         fast_model.py:224-226,179 =====================
+        __syncthreads();
+        {   // granule i of utterance u = elements 2i, 2i+1 of its [2][2048] attention output (both rows back to back)
+            wave_poll16<2 * NU>(g_attn, tag0 + 1u, abort_flag_of, &s_abort, [&](int k) { return (k >> 1) * (MG_DIM / 2) + tid_o + (k & 1) * MG_THREADS; },
+                                [&](int n, uint32_t p0, uint32_t p1) {
+                                    const int u = n / (MG_DIM / 2), e = (n % (MG_DIM / 2)) * 4;   // element index inside the utterance's [2][2048]
+                                    bf16_t* dst = xs + (size_t)(2 * u + e / MG_DIM) * MF_KP + e % MG_DIM;
+                                    *(uint2*)dst = make_uint2(p0, p1);
+                                });
+        }
+        __syncthreads();
+        MF_ABORT_RETURN();
+        {
+            f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lo = mf_mma(wo_r[i], mf_bfrag<R>(xs, 8 * wave_o + i, lane_o), lo);
+                hi = mf_mma(wo_r[i], mf_bfrag<R>(xs, 8 * wave_o + 4 + i, lane_o), hi);
+            }
+            mf_put(red, wave_o, 0, lane_o, mf_half_tile(lo, hi, lane_o));
+        }
+        __syncthreads();
+        if (tid_o < MF_R_WO * NU) {
+            const int i = pi, u = pu, n = MF_R_WO * b + i;
+            const bf16_t y0 = epi_resid((bf16_t)xres, mf_get(red, 0, i, 2 * u) + mf_get(red, 0, i + 8, 2 * u));
+            const bf16_t y1 = epi_resid((bf16_t)(xres >> 16), mf_get(red, 0, i, 2 * u + 1) + mf_get(red, 0, i + 8, 2 * u + 1));
+            hres = (uint32_t)y0 | ((uint32_t)y1 << 16);
+            bool withhold = false;   // test hook (mv_tune "mega_fault"): see decode_mega.hip
+            if (l == 1) { const int fault = a.fault; withhold = fault != 0 && b == ((fault - 1) & 255); }
+            if (!withhold) gran_store(g_h + (size_t)u * MG_DIM + n, hres, tag0 + 2u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();   // published: the w3 fragments may go out (w1 is already in flight)
+        {
+            const bf16_t* s3 = L.t[3] + (size_t)b * MF_R_W13 * MG_DIM;
+            const uint32_t o0 = mf_lane_off<MF_R_W13>(0, lane_o), o1 = mf_lane_off_half<MF_R_W13, 16, 4>(lane_o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w13[12 + i] = mf_frag<MF_R_W13>(s3, 8 * wave_s + i, o0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w13[20 + i] = mf_frag<MF_R_W13>(s3, 8 * wave_s + i, o1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ================= P3: act = silu(w1 n(h)) * w3 n(h)            fast_model.py:180,237 =========================
+        mf_poll_rows<NU, MG_DIM>(g_h, tag0 + 2u, xs, abort_flag_of, &s_abort, tid_o);
+        __syncthreads();
+        MF_ABORT_RETURN();
+        mf_norm<R>(xs, nws + MG_DIM, a.eps, lane_o, wave_o);
+        __syncthreads();
+        {
+            f32x4_t c0 = {0.f, 0.f, 0.f, 0.f}, l1 = c0, h1 = c0, c2 = c0, l3 = c0, h3 = c0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8_t b0 = mf_bfrag<R>(xs, 8 * wave_o + i, lane_o), b1 = mf_bfrag<R>(xs, 8 * wave_o + 4 + i, lane_o);
+                c0 = mf_mma(w13[i], b0, c0);
+                c0 = mf_mma(w13[4 + i], b1, c0);
+                l1 = mf_mma(w13[8 + i], b0, l1);
+                h1 = mf_mma(w13[8 + i], b1, h1);
+                c2 = mf_mma(w13[12 + i], b0, c2);
+                c2 = mf_mma(w13[16 + i], b1, c2);
+                l3 = mf_mma(w13[20 + i], b0, l3);
+                h3 = mf_mma(w13[20 + i], b1, h3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mf_put(red, wave_o, 0, lane_o, c0);
+            mf_put(red, wave_o, 1, lane_o, mf_half_tile(l1, h1, lane_o));
+            mf_put(red, wave_o, 2, lane_o, c2);
+            mf_put(red, wave_o, 3, lane_o, mf_half_tile(l3, h3, lane_o));
+        }
+        __syncthreads();
+        if (tid_o < MF_R_W13 * NU) {
+            const int i = pi, u = pu, n = MF_R_W13 * b + i;
+            auto out = [&](int base, int j) { return i < 16 ? mf_get(red, base, i, j) : mf_get(red, base + 1, i - 16, j) + mf_get(red, base + 1, i - 8, j); };
+            const bf16_t y0 = epi_swiglu(out(0, 2 * u), out(2, 2 * u));
+            const bf16_t y1 = epi_swiglu(out(0, 2 * u + 1), out(2, 2 * u + 1));
+            gran_store(g_act + (size_t)u * MG_INTER + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 3u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();   // published: the w2 rows may go out
+        {   // w2 rows 8 b .. 8 b + 7, K = 5632 = 176 k-steps: 22 per wave
+            const bf16_t* slice = L.t[4] + (size_t)b * MF_R_W2 * MG_INTER;
+            const uint32_t o0 = mf_lane_off_half<MF_R_W2, 0, 11>(lane_o);
+#pragma unroll
+            for (int i = 0; i < 11; ++i) w2_r[i] = mf_frag<MF_R_W2>(slice, 22 * wave_s + i, o0);   // k-steps 22 w + i | 22 w + 11 + i
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ================= P4: x = h + w2(act)                          fast_model.py:247,180 =========================
+        mf_poll_rows<NU, MG_INTER>(g_act, tag0 + 3u, xs, abort_flag_of, &s_abort, tid_o);
+        __syncthreads();
+        MF_ABORT_RETURN();
+        {
+            f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+#pragma unroll
+            for (int i = 0; i < 11; ++i) {
+                lo = mf_mma(w2_r[i], mf_bfrag<R>(xs, 22 * wave_o + i, lane_o), lo);
+                hi = mf_mma(w2_r[i], mf_bfrag<R>(xs, 22 * wave_o + 11 + i, lane_o), hi);
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            mf_put(red, wave_o, 0, lane_o, mf_half_tile(lo, hi, lane_o));
+        }
+        __syncthreads();
+        if (tid_o < MF_R_W2 * NU) {
+            const int i = pi, u = pu, n = MF_R_W2 * b + i;
+            const bf16_t y0 = epi_resid((bf16_t)hres, mf_get(red, 0, i, 2 * u) + mf_get(red, 0, i + 8, 2 * u));
+            const bf16_t y1 = epi_resid((bf16_t)(hres >> 16), mf_get(red, 0, i, 2 * u + 1) + mf_get(red, 0, i + 8, 2 * u + 1));
+            xres = (uint32_t)y0 | ((uint32_t)y1 << 16);
+            gran_store(g_x + (size_t)u * MG_DIM + n, xres, tag0 + 4u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();   // published
+        if (l + 1 < n_layer) request_wqkv(l + 1, lane_o, wave_o);
+        else {   // LM-head rows 11 b .. 11 b + 10 (one row tile, 11 rows), and the final norm's weights
+            const bf16_t* slice = a.head_t + (size_t)b * MF_R_HEAD * MG_DIM;
+            const uint32_t o0 = mf_lane_off<MF_R_HEAD>(0, lane_o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wq[i] = mf_frag<MF_R_HEAD>(slice, 8 * wave_s + i, o0);
+#pragma unroll
+            for (int i = 8; i < 12; ++i) wq[i] = u32x4{0u, 0u, 0u, 0u};   // defined on every path: else the wqkv fragments of P0 stay live through the layer
+            nwp = load16(a.final_norm + (tid_o & 255) * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ================= LM head on the last position: logits = head(norm(x))     fast_model.py:161-162 =================
+    __syncthreads();
+    mf_poll_rows<NU, MG_DIM>(g_x, epoch + (uint32_t)(n_layer - 1) * 8u + 1u + 4u, xs, abort_flag_of, &s_abort, tid);
+    *(u32x4*)(nws + tid * 8) = nwp;   // the final norm's weights (both halves hold them)
+    __syncthreads();
+    MF_ABORT_RETURN();
+    mf_norm<R>(xs, nws, a.eps, lane, wave);
+    __syncthreads();
+    {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = mf_mma(wq[i], mf_bfrag<R>(xs, 8 * wave + i, lane), acc);
+        mf_put(red, wave, 0, lane, acc);
+    }
+    __syncthreads();
+    if (tid < MF_R_HEAD * NU) {
+        const int i = tid / NU, u = tid % NU, n = MF_R_HEAD * b + i, vocab = a.vocab;
+        if (n < vocab) {
+            a.logits[(size_t)(2 * u) * vocab + n] = f2bf(mf_get(red, 0, i, 2 * u));
+            a.logits[(size_t)(2 * u + 1) * vocab + n] = f2bf(mf_get(red, 0, i, 2 * u + 1));
+        }
+    }
+}
+
+bool mfma_decode_supported(int weight_format, int n_utt) { return weight_format == MV_W_BF16 && n_utt == 4; }
+
+bool mfma_decode_fits(int n_utt, int n_cus) {
+    if (n_utt != 4) return false;
+    const size_t lds = mfma_lds_bytes(4);
+    if (hipFuncSetAttribute((const void*)decode_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)decode_mfma_kernel<4>, MG_THREADS, lds) != hipSuccess) return false;
+    return per_cu >= 1 && (long)per_cu * n_cus >= 256;
+}
+
+hipError_t launch_decode_mfma(hipStream_t s, const MegaArgs& a) {
+    if (a.n_utt != 4 || a.head_t == nullptr) return hipErrorInvalidValue;
+    static std::atomic<bool> raised_on[64];   // the attribute belongs to the device's copy of the function
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<bool>& raised = raised_on[dev & 63];
+    const size_t lds = mfma_lds_bytes(4);
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)decode_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL((decode_mfma_kernel<4>), dim3(256), dim3(MG_THREADS), lds, s, a);
+    return hipGetLastError();
+}

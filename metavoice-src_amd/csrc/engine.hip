@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <string>
 #include <vector>
 
@@ -114,6 +115,9 @@ struct mv_engine {
 
     // persistent decode-step kernel (decode_mega.hip)
     bool mega_ok = false;
+    bool mfma_ok = false;                // 4 utterances, bf16: the tiled weight copy exists and decode_mfma.hip's instance fits (mv_tune "mfma" selects it)
+    bf16_t* tiled = nullptr;             // tiled copy of the projection weights + LM head for decode_mfma.hip
+    bf16_t* head_t = nullptr;
     bool mega_failed = false;            // a hand-off timed out: this engine keeps to the per-layer launches ...
     int mega_retry_in = 0;               // ... for this many more utterances (mv_begin calls), then tries the persistent kernel again;
     int mega_backoff = 0;                // the wait doubles with every failed attempt (4, 8, ... 256) and resets after a clean utterance
@@ -166,7 +170,7 @@ static MegaArgs mega_args(mv_engine* e) {
     const mv_config& c = e->cfg;
     MegaArgs m;
     m.x_in = e->x; m.layers = e->mega_layers; m.n_layer = c.n_layer; m.vocab = c.vocab; m.cache_len = c.block_size;
-    m.final_norm = e->final_norm; m.head = e->head; m.head_q8 = e->head_q8; m.head_s8 = e->head_s8; m.logits = e->logits; m.kcache = e->kcache; m.vcache = e->vcache;
+    m.final_norm = e->final_norm; m.head = e->head; m.head_t = e->head_t; m.head_q8 = e->head_q8; m.head_s8 = e->head_s8; m.logits = e->logits; m.kcache = e->kcache; m.vcache = e->vcache;
     m.kv_layer_elems = e->kv_layer_elems; m.pos = e->pos_arr; m.step_counter = e->step_counter;
     const size_t U = (size_t)c.max_utterances;
     m.n_utt = c.max_utterances;
@@ -188,7 +192,8 @@ int enqueue_step(mv_engine* e) {
     const int R = e->R;
     hipStream_t s = e->stream;
     if (e->mega_ok && g_tune.mega && !e->mega_failed) {  // one persistent launch for the 24 layers + LM head, then the sampler
-        HIP_TRY(launch_decode_mega(s, mega_args(e), c.weight_format));
+        if (e->mfma_ok && g_tune.mfma) HIP_TRY(launch_decode_mfma(s, mega_args(e)));
+        else HIP_TRY(launch_decode_mega(s, mega_args(e), c.weight_format));
         return enqueue_sampler(e);
     }
     for (int l = 0; l < c.n_layer; ++l) {
@@ -411,6 +416,7 @@ int mv_tune(mv_engine* e, const char* key, int32_t value) {
     else if (k == "mega_fold") g_tune.mega_fold = value;
     else if (k == "mega_steps") g_tune.mega_steps = value < 1 ? 1 : value;
     else if (k == "mega_fault") g_tune.mega_fault = value;
+    else if (k == "mfma") g_tune.mfma = value;
     else return fail(MV_ERR_INVALID, "unknown tuning key '%s'", key);
     if (e && e->finalized) e->graph_dirty = true;  // launch geometry is frozen in the captured graph: re-capture at mv_begin
     return MV_OK;
@@ -493,7 +499,7 @@ int mv_engine_destroy(mv_engine* e) {
     void* bufs[] = {e->q_arena, e->arena, e->x, e->h, e->q, e->attn, e->act, e->logits, e->kcache, e->vcache, e->partial, e->counters,
                     e->utt, e->pos_arr, e->seq, e->spk_emb, e->spk_proj, e->n_active, e->capture, e->px, e->ph, e->pn, e->pq,
                     e->pattn, e->pact, e->pvt, e->pslab, e->mega_layers, e->granules, e->step_counter, e->abort_flag, e->dbg, e->stamps, e->utt_shadow,
-                    e->pos_shadow};
+                    e->pos_shadow, e->tiled};
     for (void* b : bufs)
         if (b) hipFree(b);
     if (e->host_flag) hipHostFree(e->host_flag);
@@ -667,12 +673,39 @@ int mv_finalize(mv_engine* e) {
         // here (occupancy query), not discovered by a time-out in the first mv_run
         e->mega_ok = mega_supported(c, R, n_cus) && mega_fits(c.weight_format, c.max_utterances, n_cus);
         if (e->mega_ok) {
+            // engines of 4 utterances (bf16): a second, TILED copy of the projection weights for the matrix-core instance of the persistent
+            // step (decode_mfma.hip: per workgroup [K / 32][rows][32], 2.5 GB more of the 288 GB).  The row-major arena stays: the prefill
+            // GEMMs, the per-layer launches and decode_mega.hip's bit-identical instance (mv_tune "mfma" 0) read it.
+            const int tile_rows[5] = {24, 8, 22, 22, 8};
+            const int64_t tshape[5][2] = {{3 * (int64_t)c.dim, c.dim}, {c.dim, c.dim}, {c.intermediate, c.dim}, {c.intermediate, c.dim}, {c.dim, c.intermediate}};
+            std::vector<std::array<const bf16_t*, 5>> tptr(c.n_layer, std::array<const bf16_t*, 5>{nullptr, nullptr, nullptr, nullptr, nullptr});
+            if (mfma_decode_supported(c.weight_format, c.max_utterances) && mfma_decode_fits(c.max_utterances, n_cus)) {
+                size_t per_layer = 0;
+                for (int m = 0; m < 5; ++m) per_layer += mfma_tiled_elems((int)tshape[m][1], tile_rows[m]);
+                const size_t head_elems = mfma_tiled_elems(c.dim, 11);
+                HIP_TRY(hipMalloc((void**)&e->tiled, (per_layer * c.n_layer + head_elems) * 2));
+                size_t toff = 0;
+                for (int l = 0; l < c.n_layer; ++l) {
+                    const LayerW& w = e->layers[l];
+                    const bf16_t* src[5] = {w.wqkv, w.wo, w.w1, w.w3, w.w2};
+                    for (int m = 0; m < 5; ++m) {
+                        HIP_TRY(launch_tile_weights(e->stream, src[m], e->tiled + toff, (int)tshape[m][0], (int)tshape[m][1], tile_rows[m]));
+                        tptr[l][m] = e->tiled + toff;
+                        toff += mfma_tiled_elems((int)tshape[m][1], tile_rows[m]);
+                    }
+                }
+                e->head_t = e->tiled + toff;
+                HIP_TRY(launch_tile_weights(e->stream, e->head, e->head_t, c.vocab, c.dim, 11));
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                e->mfma_ok = true;
+            }
             std::vector<MegaLayer> ml(c.n_layer);
             for (int l = 0; l < c.n_layer; ++l) {
                 const LayerW& w = e->layers[l];
                 ml[l] = MegaLayer{w.attn_norm, w.wqkv, w.wo, w.ffn_norm, w.w1, w.w3, w.w2,
                                   {w.q[0], w.q[1], w.q[2], w.q[3], w.q[4]}, {w.sz[0], w.sz[1], w.sz[2], w.sz[3], w.sz[4]},
-                                  {w.q8[0], w.q8[1], w.q8[2], w.q8[3], w.q8[4]}, {w.s8[0], w.s8[1], w.s8[2], w.s8[3], w.s8[4]}};
+                                  {w.q8[0], w.q8[1], w.q8[2], w.q8[3], w.q8[4]}, {w.s8[0], w.s8[1], w.s8[2], w.s8[3], w.s8[4]},
+                                  {tptr[l][0], tptr[l][1], tptr[l][2], tptr[l][3], tptr[l][4]}};
             }
             HIP_TRY(hipMalloc((void**)&e->mega_layers, ml.size() * sizeof(MegaLayer)));
             HIP_TRY(hipMemcpy(e->mega_layers, ml.data(), ml.size() * sizeof(MegaLayer), hipMemcpyHostToDevice));
@@ -903,6 +936,7 @@ int32_t mv_decode_path(const mv_engine* e, int32_t* timeouts) {
     if (!e) return -1;
     if (timeouts) *timeouts = e->mega_timeouts;
     if (!(e->mega_ok && g_tune.mega && !e->mega_failed)) return 0;
+    if (e->mfma_ok && g_tune.mfma) return 3;   // the matrix-core instance of the persistent step (decode_mfma.hip), one step per launch
     return g_tune.mega_fold && mega_folds(e->cfg) ? 2 : 1;
 }
 
@@ -950,8 +984,10 @@ int mv_probe_kernel(mv_engine* e, int32_t kind, int32_t iters, float* avg_ms, do
             for (int i = -2; i < iters; ++i) {
                 if (i == 0) HIP_TRY(hipEventRecord(e->ev0, s));
                 HIP_TRY(launch_bump_counter(s, e->step_counter));
-                if (pass == 0)
-                    HIP_TRY(launch_decode_mega(s, m, c.weight_format));
+                if (pass == 0) {
+                    if (e->mfma_ok && g_tune.mfma) HIP_TRY(launch_decode_mfma(s, m));
+                    else HIP_TRY(launch_decode_mega(s, m, c.weight_format));
+                }
             }
             HIP_TRY(hipEventRecord(e->ev1, s));
             HIP_TRY(hipStreamSynchronize(s));

@@ -25,6 +25,8 @@ struct MvTune {
     int mega_steps = 512;                // decode steps per launch of the folding persistent kernel
     int mega_fold = 1;                   // 1: the persistent kernel also draws the token and runs several steps per launch (engines
                                          // of up to MEGA_FOLD_MAX_UTT utterances); 0: one step per launch + sample_kernel
+    int mfma = 1;                        // 1: engines of 4 utterances (bf16) run the persistent step on the matrix cores (decode_mfma.hip: tiled
+                                         // weight copy, not bit-identical to the launches); 0: decode_mega.hip's bit-identical instance
 };
 extern MvTune g_tune;
 
@@ -258,6 +260,8 @@ struct MegaLayer {
     // int8 (per output channel) engines: codes [N][K] and bf16 row scales, same order (gemv_i8.hip layout), else null
     const signed char* q8[5];
     const bf16_t* s8[5];
+    // engines of 4 utterances (bf16): the same five matrices TILED for the matrix cores (decode_mfma.hip: per workgroup [K / 32][rows][32]), else null
+    const bf16_t* t[5];
 };
 struct MegaArgs {
     const bf16_t* x_in = nullptr;          // [2 n_utt][2048]: input rows of layer 0 (written by the sampler / prefill)
@@ -266,6 +270,7 @@ struct MegaArgs {
     int32_t n_utt = 1;                     // utterances decoded together (1, 2 or 4): rows 2u, 2u+1 belong to utterance u
     const bf16_t* final_norm = nullptr;
     const bf16_t* head = nullptr;
+    const bf16_t* head_t = nullptr;        // decode_mfma.hip: the LM head tiled like MegaLayer::t (11 rows per workgroup, rows clamped to the vocabulary)
     const signed char* head_q8 = nullptr;  // int8 engines: the LM head is quantised too
     const bf16_t* head_s8 = nullptr;
     bf16_t* logits = nullptr;              // [2 n_utt][vocab]
@@ -299,6 +304,12 @@ struct MegaArgs {
     float* capture = nullptr;
     uint32_t* step_counter_out = nullptr;  // = step_counter: advanced once per step by block 0
 };
+// ---- decode_mfma.hip: the persistent step of 4-utterance bf16 engines on v_mfma_f32_16x16x32_bf16 --------------------------------------
+bool mfma_decode_supported(int weight_format, int n_utt);
+bool mfma_decode_fits(int n_utt, int n_cus);                       // occupancy query, like mega_fits
+size_t mfma_tiled_elems(int K, int rows_per_wg);                   // elements of a tiled matrix copy (256 workgroups x rows x K)
+hipError_t launch_tile_weights(hipStream_t s, const bf16_t* src, bf16_t* dst, int N, int K, int rows_per_wg);
+hipError_t launch_decode_mfma(hipStream_t s, const MegaArgs& a);   // one decode step (logits only; sample_kernel follows)
 bool mega_supported(const mv_config& c, int rows, int n_cus);
 bool mega_fits(int weight_format, int n_utt, int n_cus);  // occupancy query: one workgroup of the instance per CU, 256 resident (asked once, at mv_finalize)
 bool mega_instrumented();  // decode_mega.hip was built with -DMEGA_INSTR=1 (phase stamps, debug vectors, the no-weights ablation)

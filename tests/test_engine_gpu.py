@@ -332,6 +332,7 @@ def test_persistent_kernel_with_several_utterances_is_bit_identical_to_launches(
     sps = [mv.SamplingParams(guidance_scale=3.0, seed=50 + u, **combo) for u in range(n_utt)]
     engine.capture_logits(True)
     out = {}
+    engine.tune(mfma=0)   # engines of 4 utterances default to the matrix-core instance (decode_mfma.hip: another summation order, its own test below)
     for mega in (1, 0):
         engine.tune(mega=mega)
         engine.begin(prompts, spks, sps, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
@@ -341,6 +342,7 @@ def test_persistent_kernel_with_several_utterances_is_bit_identical_to_launches(
         out[mega] = (toks, engine.captured_logits(max(lens) - 1, n_new - 1))  # steps every utterance is decoding in
     engine.tune(mega=1)
     assert engine.decode_path() == (1, 0), "the persistent kernel was abandoned (hand-off timed out) during the test"
+    engine.tune(mfma=1)   # process-wide: back to the default
     for u in range(n_utt):
         assert len(out[1][0][u]) == lens[u] + n_new
         assert out[1][0][u] == out[0][0][u], f"utterance {u}: token streams differ between the persistent kernel and the launches"
@@ -353,6 +355,67 @@ def test_persistent_kernel_with_several_utterances_is_bit_identical_to_launches(
         single.run()
         assert single.tokens(0) == out[1][0][u], f"utterance {u} decodes differently alone and in a batch of {n_utt}"
     single.close()
+
+
+@pytest.mark.parametrize("n_layer,lens,n_new,combo", [
+    (3, [96, 160, 131, 17], 40, dict(top_k=1)),
+    (2, [300, 12, 2000, 255], 24, dict(top_k=1)),    # every attention regime at once: one key range, 8 ranges + combine, the last cache rows
+    (4, [600, 1100, 40, 258], 32, dict(top_p=0.95)),
+])
+def test_matrix_core_persistent_kernel_for_four_utterances(n_layer, lens, n_new, combo):
+    """decode_mfma.hip: the persistent step of 4-utterance engines on v_mfma_f32_16x16x32_bf16 (tiled weight copy, K split over the 8 waves
+    of a workgroup, packed half tiles).  Same rounding points as the launches, another ORDER of the fp32 additions inside every projection:
+    not bit-identical, so (i) every position of every utterance TEACHER-FORCED through both paths (`prefill_mode=0`: the prompt goes through
+    the decode kernels token by token) must give logits within the engine-vs-oracle tolerance of this file (0.06 sigma), (ii) the
+    free-running streams agree with the launches' wherever the launches' own top-2 gap of the CFG mix exceeds that noise, and (iii) the
+    kernel is the one that ran (`decode_path() == (3, 0)`) and is run-to-run reproducible."""
+    cfgk = dict(WIDE2, n_layer=n_layer)
+    engine, sd, cfg = build(cfgk, 17, max_utterances=4)
+    prompts = [synthetic.prompt_tokens(t, seed=90 + u) for u, t in enumerate(lens)]
+    spks = torch.cat([synthetic.speaker_embedding(95 + u) for u in range(4)])
+    sps = [mv.SamplingParams(guidance_scale=3.0, seed=70 + u, **combo) for u in range(4)]
+    engine.capture_logits(True)
+    L = max(lens)
+    forced = {}
+    for mfma, mega in ((1, 1), (0, 0), (1, 1)):
+        engine.tune(mfma=mfma, mega=mega)
+        engine.begin(prompts, spks, sps, max_new_tokens=2, end_of_audio_token=9999, prefill_mode=0)
+        engine.run()
+        lg = engine.captured_logits(0, L)   # (L, 8 rows, vocab): entry p = logits computed at input position p
+        if (mfma, mega) in forced:
+            assert torch.equal(lg, forced[(mfma, mega)]), "the matrix-core kernel is not reproducible run to run"
+        forced[(mfma, mega)] = lg
+        if mfma:
+            assert engine.decode_path() == (3, 0), "decode_mfma.hip did not run (or a hand-off timed out)"
+    worst = 0.0
+    for u, t in enumerate(lens):
+        a, b = forced[(1, 1)][:t, 2 * u:2 * u + 2], forced[(0, 0)][:t, 2 * u:2 * u + 2]   # the positions utterance u really decoded
+        scale = float(b.std())
+        d = float((a - b).abs().max())
+        worst = max(worst, d / scale)
+        assert d <= 0.06 * scale, f"utterance {u}: teacher-forced logits differ by {d:.4f} (logit std {scale:.3f})"
+    # free running
+    free = {}
+    for mfma, mega in ((1, 1), (0, 0)):
+        engine.tune(mfma=mfma, mega=mega)
+        engine.begin(prompts, spks, sps, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
+        engine.run()
+        free[mfma] = ([engine.tokens(u) for u in range(4)], engine.captured_logits(L - 1, n_new - 1))
+    engine.tune(mfma=1, mega=1)
+    agree = []
+    for u, t in enumerate(lens):
+        ta, tb = free[1][0][u], free[0][0][u]
+        assert len(ta) == len(tb) == t + n_new and ta[:t] == tb[:t]
+        fork = first_fork(ta, tb)
+        agree.append(n_new if fork is None else fork - t)
+        if fork is not None and "top_k" in combo and fork - 1 >= L - 1:   # greedy, and the deciding logits were captured: the launches' gap there must be inside the noise
+            lg = free[0][1][fork - 1 - (L - 1), 2 * u:2 * u + 2]
+            mixed = o_s1.cfg_mix(lg[:, None, :], 3.0, o_s1._round_bf16)[0]
+            top2 = torch.topk(mixed, 2).values
+            assert float(top2[0] - top2[1]) <= 0.25, f"utterance {u} forks at {fork} although the launches' top-2 gap is {float(top2[0] - top2[1]):.3f}"
+    print(f"[mfma x 4, {n_layer} layers, prompts {lens}] teacher-forced max |dlogit| / sigma {worst:.4f}; free-running agreement with the launches {agree} of {n_new}")
+    assert min(agree) >= 2
+    engine.close()
 
 
 def test_persistent_kernel_times_out_cleanly_and_the_run_falls_back_to_launches():

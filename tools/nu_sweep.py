@@ -25,7 +25,7 @@ for case in os.environ.get("NU_CASES", "bf16:2,bf16:4,int8:1,int4:1").split(",")
     sps = [mv.SamplingParams(top_p=0.95, guidance_scale=3.0, seed=1 + 7 * u) for u in range(nu)]
     ref = None
     for fold in (1, 0, 1):
-        e.tune(mega=1, mega_fold=fold)
+        e.tune(mega=1, mega_fold=fold, mfma=int(os.environ.get("NU_MFMA", "1")))   # NU_MFMA=0: engines of 4 utterances on decode_mega.hip's instance
         e.begin(prompts, spk, sps, max_new_tokens=min(n_new, args.block_size - max(lens)), end_of_audio_token=9999, prefill_mode=1)
         steps = e.run(poll_every=1 << 20)
         toks = [e.tokens(u) for u in range(nu)]
