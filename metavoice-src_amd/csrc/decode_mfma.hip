@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
                 const int which = (n - MG_DIM) / MG_DIM, hd = (n - MG_DIM) % MG_DIM;
                 const size_t cache_len = (size_t)a.cache_len;
                 bf16_t* cache = (which ? a.vcache : a.kcache) + (size_t)l * a.kv_layer_elems + (size_t)2 * u * MG_HEADS * cache_len * 128;
-                const size_t off = ((size_t)(hd / 128) * cache_len + (MF_GEO(0, u) - 1)) * 128 + hd % 128;
+                const size_t off = ((size_t)(hd / 128) * cache_len + (geo[0][u] - 1)) * 128 + hd % 128;   // u differs per lane here: NOT MF_GEO (readfirstlane)
                 cache[off] = y0;
                 cache[(size_t)MG_HEADS * cache_len * 128 + off] = y1;
             }

@@ -366,7 +366,7 @@ def test_matrix_core_persistent_kernel_for_four_utterances(n_layer, lens, n_new,
     """decode_mfma.hip: the persistent step of 4-utterance engines on v_mfma_f32_16x16x32_bf16 (tiled weight copy, K split over the 8 waves
     of a workgroup, packed half tiles).  Same rounding points as the launches, another ORDER of the fp32 additions inside every projection:
     not bit-identical, so (i) every position of every utterance TEACHER-FORCED through both paths (`prefill_mode=0`: the prompt goes through
-    the decode kernels token by token) must give logits within the engine-vs-oracle tolerance of this file (0.06 sigma), (ii) the
+    the decode kernels token by token) must give logits within 0.1 sigma of each other (engine vs oracle in this file: 0.06 sigma at 2 layers), (ii) the
     free-running streams agree with the launches' wherever the launches' own top-2 gap of the CFG mix exceeds that noise, and (iii) the
     kernel is the one that ran (`decode_path() == (3, 0)`) and is run-to-run reproducible."""
     cfgk = dict(WIDE2, n_layer=n_layer)
@@ -382,8 +382,9 @@ def test_matrix_core_persistent_kernel_for_four_utterances(n_layer, lens, n_new,
         engine.begin(prompts, spks, sps, max_new_tokens=2, end_of_audio_token=9999, prefill_mode=0)
         engine.run()
         lg = engine.captured_logits(0, L)   # (L, 8 rows, vocab): entry p = logits computed at input position p
-        if (mfma, mega) in forced:
-            assert torch.equal(lg, forced[(mfma, mega)]), "the matrix-core kernel is not reproducible run to run"
+        for u, t in enumerate(lens):        # only the positions an utterance really decoded: the rest of the capture buffer is never written
+            if (mfma, mega) in forced:
+                assert torch.equal(lg[:t, 2 * u:2 * u + 2], forced[(mfma, mega)][:t, 2 * u:2 * u + 2]), "the matrix-core kernel is not reproducible run to run"
         forced[(mfma, mega)] = lg
         if mfma:
             assert engine.decode_path() == (3, 0), "decode_mfma.hip did not run (or a hand-off timed out)"
@@ -393,14 +394,20 @@ def test_matrix_core_persistent_kernel_for_four_utterances(n_layer, lens, n_new,
         scale = float(b.std())
         d = float((a - b).abs().max())
         worst = max(worst, d / scale)
-        assert d <= 0.06 * scale, f"utterance {u}: teacher-forced logits differ by {d:.4f} (logit std {scale:.3f})"
+        # two bf16 evaluations that differ in the order of fp32 additions: 1-2 bf16 ulps of a logit (0.016-0.031 at |x| ~ 2-4, sigma 0.9) per
+        # layer pair; measured 0.039-0.059 sigma at 2-4 layers (profiles/r05e), bound 0.1 sigma
+        assert d <= 0.1 * scale, f"utterance {u}: teacher-forced logits differ by {d:.4f} (logit std {scale:.3f})"
     # free running
     free = {}
-    for mfma, mega in ((1, 1), (0, 0)):
+    for mfma, mega in ((1, 1), (0, 0), (1, 1)):   # ragged prompts behind the MFMA prefill: every utterance at its own position
         engine.tune(mfma=mfma, mega=mega)
         engine.begin(prompts, spks, sps, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
         engine.run()
-        free[mfma] = ([engine.tokens(u) for u in range(4)], engine.captured_logits(L - 1, n_new - 1))
+        # logits per utterance at the positions IT decoded (the capture is indexed by each utterance's own input position)
+        res = ([engine.tokens(u) for u in range(4)], [engine.captured_logits(t, n_new - 1)[:, 2 * u:2 * u + 2].clone() for u, t in enumerate(lens)])
+        if mfma in free:
+            assert res[0] == free[mfma][0] and all(torch.equal(x, y) for x, y in zip(res[1], free[mfma][1])), "free-running: the matrix-core kernel is not reproducible run to run"
+        free[mfma] = res
     engine.tune(mfma=1, mega=1)
     agree = []
     for u, t in enumerate(lens):
@@ -408,13 +415,14 @@ def test_matrix_core_persistent_kernel_for_four_utterances(n_layer, lens, n_new,
         assert len(ta) == len(tb) == t + n_new and ta[:t] == tb[:t]
         fork = first_fork(ta, tb)
         agree.append(n_new if fork is None else fork - t)
-        if fork is not None and "top_k" in combo and fork - 1 >= L - 1:   # greedy, and the deciding logits were captured: the launches' gap there must be inside the noise
-            lg = free[0][1][fork - 1 - (L - 1), 2 * u:2 * u + 2]
+        if fork is not None and "top_k" in combo and fork - 1 >= t:   # greedy, and the deciding logits were captured: the launches' gap there must be inside the noise
+            lg = free[0][1][u][fork - 1 - t]
             mixed = o_s1.cfg_mix(lg[:, None, :], 3.0, o_s1._round_bf16)[0]
             top2 = torch.topk(mixed, 2).values
             assert float(top2[0] - top2[1]) <= 0.25, f"utterance {u} forks at {fork} although the launches' top-2 gap is {float(top2[0] - top2[1]):.3f}"
     print(f"[mfma x 4, {n_layer} layers, prompts {lens}] teacher-forced max |dlogit| / sigma {worst:.4f}; free-running agreement with the launches {agree} of {n_new}")
-    assert min(agree) >= 2
+    if "top_k" in combo:
+        assert min(agree) >= 2   # greedy: a fork is margin-gated above; sampled streams (top-p) may fork at the first near-tie of the race
     engine.close()
 
 
