@@ -1460,7 +1460,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
 
 
 bool mega_supported(const mv_config& c, int rows, int n_cus) {
-    return (rows == 2 || rows == 4 || rows == 8) && c.dim == MG_DIM && c.intermediate == MG_INTER && c.n_head == MG_HEADS && c.vocab <= 256 * 11 && n_cus >= 256 &&
+    return (rows == 2 || rows == 4 || rows == 8 || rows == 16) && c.dim == MG_DIM && c.intermediate == MG_INTER && c.n_head == MG_HEADS && c.vocab <= 256 * 11 && n_cus >= 256 &&
            c.block_size <= ATTN_NSPLIT * 256 &&
            c.n_layer <= 31;  // hand-off tag = step * 256 + layer * 8 + phase + 1: layer * 8 + 6 must stay below 256
 }

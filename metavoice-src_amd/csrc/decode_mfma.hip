@@ -30,7 +30,28 @@
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-#define MF_KP (MG_INTER + 8)      // operand row stride in LDS (elements): 11 280 B = 2820 words = 4 banks mod 32
+// MF_KV_DB: two K/V register sets in the attention phase (the next key range streams while the current one is scored, decode_mega.hip's
+// MEGA_ATTN_V2 form) instead of one set with the workgroup's ranges back to back
+#ifndef MF_KV_DB
+#define MF_KV_DB 0   // 388-587 spilled registers with the second set (44 without): off
+#endif
+// MF_W1_EARLY: the w1 fragments go out with the wo fragments (under the q/k/v hand-off and the attention) instead of behind the attention
+#ifndef MF_W1_EARLY
+#define MF_W1_EARLY 0
+#endif
+// MF_KV_LDS: while a key range is scored from the K/V registers, the NEXT range's rows stream into LDS (global_load_lds: no registers)
+// -- into the operand rows `xs`, idle between the wqkv MFMAs and the attention-vector poll: 11 KB per wave, i.e. ranges of up to 20 keys per
+// wave (K and V, 1 KB per 4 keys each); wider ranges are requested into the registers as before.
+#ifndef MF_KV_LDS
+#define MF_KV_LDS 0   // measured SLOWER (profiles/r05g: 1220 vs 1160 us/step): the loop still reloads spilled registers from scratch, and a scratch reload waits -- in order -- for the whole range in flight
+#endif
+// MF_NSPLIT4: four key ranges per (utterance, row, head) between 257 and 1024 keys instead of attn_core.h's eight
+#ifndef MF_NSPLIT4
+#define MF_NSPLIT4 1
+#endif
+// operand row stride in LDS (elements).  4 utterances: 8 rows of a whole 5632-column activation vector (11 280 B = 2820 words = 4 banks
+// mod 32); 8 utterances: 16 rows of HALF of it (the w2 phase runs in two passes over the column halves: 16 whole rows would be 180 KB)
+__host__ __device__ constexpr int mf_kp(int nu) { return (nu <= 4 ? MG_INTER : MG_INTER / 2) + 8; }
 #define MF_RED_TILES 4            // partial tiles per wave in the exchange buffer (w1 | w3: two row tiles each)
 
 // rows of each matrix one workgroup owns (decode_mega.hip's partition)
@@ -91,7 +112,7 @@ __device__ __forceinline__ u32x4 mf_frag(const bf16_t* slice, int s, uint32_t la
 // B fragment: activation row (lane & 15) mod R, columns 32 s + 8 (lane >> 4) .. + 7
 template <int R>
 __device__ __forceinline__ bf16x8_t mf_bfrag(const bf16_t* xs, int s, int lane) {
-    return *(const bf16x8_t*)(xs + (size_t)(lane & (R - 1)) * MF_KP + 32 * s + (lane >> 4) * 8);
+    return *(const bf16x8_t*)(xs + (size_t)(lane & (R - 1)) * mf_kp(R / 2) + 32 * s + (lane >> 4) * 8);
 }
 __device__ __forceinline__ f32x4_t mf_mma(const u32x4& a, const bf16x8_t& b, const f32x4_t& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), b, c, 0, 0, 0);
@@ -119,7 +140,7 @@ template <int R>
 __device__ __forceinline__ void mf_norm(bf16_t* xs, const bf16_t* nws, float eps, int lane, int wave) {
 #pragma unroll
     for (int rho = wave; rho < R; rho += MG_WAVES) {
-        bf16_t* row = xs + (size_t)rho * MF_KP + lane * 8;
+        bf16_t* row = xs + (size_t)rho * mf_kp(R / 2) + lane * 8;
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) s += sumsq8(*(const u32x4*)(row + q * 512));
@@ -129,48 +150,64 @@ __device__ __forceinline__ void mf_norm(bf16_t* xs, const bf16_t* nws, float eps
     }
 }
 
-// 16-byte polls of a row-paired vector of NCOL columns of every utterance ([NU][NCOL] granules) into the operand rows: pair n = granules
-// 2n, 2n + 1 = columns 2n, 2n + 1 of both rows of its utterance.  UPP utterances per poll loop (poll16_loads has instances up to 12 requests).
-template <int NU, int NCOL, typename AF>
+// 64 lanes x 16 B of global memory -> 1 KB of LDS at `lds` (wave-uniform byte address), no registers: global_load_lds_dwordx4 (LDS
+// address = M0 + 16 x lane).  Completion is the wave's vmcnt like any load; the wave reads only slots it requested itself.
+__device__ __forceinline__ void mf_row_to_lds(uint32_t lds, const void* g) {
+    uint32_t m0_save;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_save) : "s"(lds), "v"(g) : "memory");
+}
+
+// 16-byte polls of NCOL columns of a row-paired vector of every utterance into the operand rows: `g` = the first polled column of
+// utterance 0, GSTRIDE granules from one utterance to the next; pair n = granules 2n, 2n + 1 = columns 2n, 2n + 1 of both rows of its
+// utterance.  UPP utterances per poll loop (poll16_loads has instances up to 12 requests).
+template <int NU, int NCOL, int GSTRIDE, typename AF>
 __device__ __forceinline__ void mf_poll_rows(const gran_t* g, uint32_t tag, bf16_t* xs, AF abort_flag, int* s_abort, int tid) {
-    constexpr int PPT = (NCOL / 2 + MG_THREADS - 1) / MG_THREADS;   // pairs per thread and utterance: 2 (2048 columns) or 6 (5632)
-    constexpr int UPP = PPT <= 2 ? 4 : 2;
-    static_assert(NU % UPP == 0, "utterances per poll loop");
+    constexpr int KP = mf_kp(NU);
+    constexpr int PPT = (NCOL / 2 + MG_THREADS - 1) / MG_THREADS;   // pairs per thread and utterance: 2 (2048 columns), 3 (2816) or 6 (5632)
+    constexpr int UPP = PPT <= 3 ? 4 : 2;
+    static_assert(NU % UPP == 0 && PPT * UPP <= 12, "utterances per poll loop");
 #pragma unroll
     for (int u0 = 0; u0 < NU; u0 += UPP) {
-        wave_poll16<PPT * UPP>(g + (size_t)u0 * NCOL, tag, abort_flag, s_abort,
-                               [&](int k) {
+        wave_poll16<PPT * UPP>(g, tag, abort_flag, s_abort,
+                               [&](int k) {   // pair index relative to g, in granule PAIRS
                                    const int n = tid + (k % PPT) * MG_THREADS;
-                                   return n < NCOL / 2 ? (k / PPT) * (NCOL / 2) + n : -1;
+                                   return n < NCOL / 2 ? (u0 + k / PPT) * (GSTRIDE / 2) + n : -1;
                                },
                                [&](int n, uint32_t p0, uint32_t p1) {
-                                   bf16_t* row = xs + (size_t)(2 * (u0 + n / (NCOL / 2))) * MF_KP;
-                                   const int c = n % (NCOL / 2);
+                                   bf16_t* row = xs + (size_t)(2 * (n / (GSTRIDE / 2))) * KP;
+                                   const int c = n % (GSTRIDE / 2);
                                    *(uint32_t*)(row + 2 * c) = (p0 & 0xFFFFu) | (p1 << 16);
-                                   *(uint32_t*)(row + MF_KP + 2 * c) = (p0 >> 16) | (p1 & 0xFFFF0000u);
+                                   *(uint32_t*)(row + KP + 2 * c) = (p0 >> 16) | (p1 & 0xFFFF0000u);
                                });
     }
 }
 
 }  // namespace
 
+// the exchange buffer of the MFMA phases (`red`) and the wave partials of the attention phase (`sm`: one slot per key range of the
+// workgroup, up to 8) are never live together (barriers between the phases): ONE region
+__host__ __device__ constexpr size_t mfma_red_bytes(int nu) {
+    return (size_t)MG_WAVES * MF_RED_TILES * 256 * 4 > (size_t)(nu > 4 ? 8 : nu) * ATTN_WAVES * 16 * 12 * 4 ? (size_t)MG_WAVES * MF_RED_TILES * 256 * 4
+                                                                                                                : (size_t)(nu > 4 ? 8 : nu) * ATTN_WAVES * 16 * 12 * 4;
+}
 __host__ __device__ constexpr size_t mfma_lds_bytes(int nu) {
-    return (size_t)2 * nu * MF_KP * 2 + (size_t)MG_WAVES * MF_RED_TILES * 256 * 4 + (size_t)3 * 2 * 128 * 2 + (size_t)nu * ATTN_WAVES * 16 * 12 * 4 +
-           (size_t)2 * MG_DIM * 2;   // + the two norm weight vectors of a layer
+    return (size_t)2 * nu * mf_kp(nu) * 2 + mfma_red_bytes(nu) + (size_t)3 * 2 * 128 * 2 + (size_t)2 * MG_DIM * 2;   // operand rows, red | sm, q/k/v, norm weights
 }
 
 template <int NU>
 __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaArgs a) {
     constexpr int R = 2 * NU;
-    static_assert(NU == 4, "the 8-utterance instance needs the activation vector of the w2 phase outside LDS (180 KB)");
+    static_assert(NU == 4 || NU == 8, "instances: 4 or 8 utterances");
+    constexpr int MF_KP = mf_kp(NU);
     extern __shared__ __attribute__((aligned(16))) unsigned char mf_lds[];
     bf16_t* xs = (bf16_t*)mf_lds;                                                        // [R][MF_KP] operand rows of the current phase
     float* red = (float*)(mf_lds + (size_t)R * MF_KP * 2);                               // [8 waves][4 tiles][64 lanes][4]
-    bf16_t* qkv_s = (bf16_t*)(red + (size_t)MG_WAVES * MF_RED_TILES * 256);              // q | k_new | v_new of this workgroup's head, both rows
-    float (*sm)[16][12] = (float(*)[16][12])(qkv_s + 3 * 2 * 128);                       // [NU ranges][8 waves][16][12]
-    bf16_t* nws = (bf16_t*)(sm + NU * ATTN_WAVES);                                       // [2][2048]: attention norm | ffn norm weights of the layer (final norm: [0])
+    float (*sm)[16][12] = (float(*)[16][12])red;                                         // [ranges of the workgroup][8 waves][16][12]: the same region
+    bf16_t* qkv_s = (bf16_t*)(mf_lds + (size_t)R * MF_KP * 2 + mfma_red_bytes(NU));      // q | k_new | v_new of this workgroup's head, both rows
+    bf16_t* nws = qkv_s + 3 * 2 * 128;                                                   // [2][2048]: attention norm | ffn norm weights of the layer (final norm: [0])
     __shared__ int s_abort;
-    __shared__ int geo[4][NU];   // P, cs, nact, kw per utterance
+    __shared__ int geo[5][NU];   // P, cs, nact, kw, ranges per workgroup -- per utterance
     __shared__ int pos_s[NU];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
@@ -185,19 +222,23 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
     const uint32_t epoch = a.step_counter[0] * 256u;
     const int n_layer = a.n_layer;
 
-    // attention: this workgroup = (utterance, row, head, part): SPB = NU consecutive key ranges starting at at_s, 8 / NU workgroups per
-    // (utterance, row, head) -- decode_mega.hip's MEGA_ATTN_V2 partition
+    // attention: this workgroup = (utterance, row, head, part): 8 / NU workgroups per (utterance, row, head) -- decode_mega.hip's MEGA_ATTN_V2
+    // partition -- but the number of key ranges follows the context: 1 up to 256 keys, FOUR up to 1024, 8 beyond (attn_core.h always cuts
+    // 8 above 256).  A workgroup walks its ranges one after the other through one K/V register set, every range a request -> land -> score
+    // round; at 1024 keys four ranges of 4 x 8 x 32 key slots hold what eight did at half-empty slots, in half the rounds.
     constexpr int BPH = 8 / NU, SPB = NU;
-    const int at_u = b / (32 * BPH), at_r = (b / (16 * BPH)) & 1, at_h = (b / BPH) & 15, at_s = (b % BPH) * SPB;
-    bool any_att = false;
+    const int at_u = b / (32 * BPH), at_r = (b / (16 * BPH)) & 1, at_h = (b / BPH) & 15;
 #pragma unroll
     for (int u = NU - 1; u >= 0; --u) {
         const int Pu = pos_s[u] + 1;  // keys [0, P): the cache holds [0, P-1), key P-1 is produced by this step's QKV phase
-        const int csu = attn_keys_per_split(Pu), nactu = (Pu + csu - 1) / csu;
-        if (tid == 0) { geo[0][u] = Pu; geo[1][u] = csu; geo[2][u] = nactu; geo[3][u] = attn_keys_per_wave(csu); }
-        if (u == at_u && at_s < nactu) any_att = true;
+        const int ns = Pu <= ATTN_KEYS_PER_BLOCK ? 1 : (MF_NSPLIT4 && Pu <= 4 * ATTN_KEYS_PER_BLOCK ? 4 : ATTN_NSPLIT);
+        const int csu = (((Pu + ns - 1) / ns) + 3) & ~3, nactu = (Pu + csu - 1) / csu;
+        if (tid == 0) { geo[0][u] = Pu; geo[1][u] = csu; geo[2][u] = nactu; geo[3][u] = attn_keys_per_wave(csu); geo[4][u] = ns > BPH ? ns / BPH : 1; }
     }
     __syncthreads();
+    const int rpw = geo[4][at_u];                     // key ranges per workgroup of this (utterance, row, head)
+    const int at_s = (b % BPH) * rpw;                 // this workgroup's first range
+    const bool any_att = at_s < geo[2][at_u];
 
     // the six exchanged vectors of every utterance sit in ONE slab at compile-time offsets (engine.hip: mega_args)
     gran_t* const g_x = a.g_x;
@@ -277,6 +318,9 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
         u32x4 w13[24];     // w1: rows 0..15 x 8 k-steps + rows 16..21 packed x 4; w3 the same behind it
         u32x4 w2_r[11];    // w2: 8 rows packed, 11 fragments = 22 k-steps
         u32x4 kv[ATTN_U], vv[ATTN_U];
+#if MF_KV_DB
+        u32x4 kvB[ATTN_U], vvB[ATTN_U];
+#endif
         const __attribute__((address_space(4))) MegaLayer& L = MF_LAYER(l);
         const uint32_t tag0 = epoch + (uint32_t)l * 8u + 1u;  // + phase index
 
@@ -287,7 +331,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
                 const int rho = it / (MG_DIM / 8), c = (it % (MG_DIM / 8)) * 8;
                 *(u32x4*)(xs + (size_t)rho * MF_KP + c) = load16(a.x_in + (size_t)rho * MG_DIM + c);
             }
-        } else mf_poll_rows<NU, MG_DIM>(g_x, tag0 - 8u + 4u, xs, abort_flag_of, &s_abort, tid_o);
+        } else mf_poll_rows<NU, MG_DIM, MG_DIM>(g_x, tag0 - 8u + 4u, xs, abort_flag_of, &s_abort, tid_o);
         *(u32x4*)(nws + tid_o * 8) = nwp;   // this layer's norm weights (requested with its wqkv fragments; landed: the poll ended in vmcnt(0))
         __syncthreads();
         MF_ABORT_RETURN();
@@ -348,7 +392,8 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
         };
 
         // ================= P1: attention over keys [0, P)               fast_model.py:218-222 =========================
-        if (!any_att) request_w1();
+        if (MF_W1_EARLY) { request_w1(); __builtin_amdgcn_sched_barrier(0); }
+        if (!MF_W1_EARLY && !any_att) request_w1();
         if (any_att) {
             {   // q, k_new, v_new of head at_h of this workgroup's utterance: 3 x 128 row-paired granules
                 const int sec = tid_o >> 7, c = tid_o & 127;
@@ -365,10 +410,61 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
             const int u = at_u;
             const int g = lane_o >> 4, dl = lane_o & 15, at_w = wave_o, lane = lane_o;
             const int Pu = MF_GEO(0, u), csu = MF_GEO(1, u), nactu = MF_GEO(2, u), kwu = MF_GEO(3, u);
-            const int n_my = min(SPB, nactu - at_s);   // >= 1: this workgroup attends
+            const int n_my = min(rpw, nactu - at_s);   // >= 1: this workgroup attends
             const u32x4 qv = *(const u32x4*)(qkv_s + (0 * 2 + at_r) * 128 + dl * 8);
+#if MF_KV_DB
+            // the second range goes out behind the q/k/v poll (in front of it the poll's wait would cover the whole range)
+            if (n_my > 1) issue_kv(kvB, vvB, u, l, at_s + 1, 0, lane_o, wave_o);
+            __builtin_amdgcn_sched_barrier(0);
+            // ranges in PAIRS, the pair loop rolled: set A scores range jj while set B's rows stream, then the other way round; each set is
+            // re-requested for the pair after next as soon as it has been scored.  (All four ranges unrolled -- decode_mega.hip's form -- took
+            // this kernel from 44 to 587 spilled registers.)
+            auto score = [&](u32x4 (&kx)[ATTN_U], u32x4 (&vx)[ATTN_U], int j) {
+                const int split = at_s + j;
+                const int s0 = split * csu + at_w * kwu, s1 = min(min(Pu, split * csu + csu), s0 + kwu);
+#pragma unroll
+                for (int q = 0; q < ATTN_U; ++q) {
+                    if (s0 + q * 4 + g == Pu - 1) {  // the key produced by this step: not in the cache yet for this launch
+                        kx[q] = *(const u32x4*)(qkv_s + (1 * 2 + at_r) * 128 + dl * 8);
+                        vx[q] = *(const u32x4*)(qkv_s + (2 * 2 + at_r) * 128 + dl * 8);
+                    }
+                }
+                const AttnAcc w = attn_wave_partial<false>(kx, vx, qv, s0, s1, g);
+                if (j + 2 < n_my) issue_kv(kx, vx, u, l, split + 2, 0, lane_o, wave_o);
+                if (g == 0) {
+                    float (*smj)[16][12] = sm + j * ATTN_WAVES;
+                    smj[at_w][dl][0] = w.m;
+                    smj[at_w][dl][1] = w.l;
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) smj[at_w][dl][2 + d] = w.o[d];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+#pragma unroll 1
+            for (int jj = 0; jj < n_my; jj += 2) {
+                score(kv, vv, jj);
+                if (jj + 1 < n_my) score(kvB, vvB, jj + 1);
+            }
+#else
             // ONE K/V register set, the workgroup's ranges back to back (rolled): decode_mega.hip's second set would live in registers this
-            // kernel does not have (its quantised instances do the same)
+            // kernel does not have.  MF_KV_LDS: the next range waits in LDS instead (see the switch).
+            constexpr int PF_SLOTS = (int)(((size_t)R * MF_KP * 2) / MG_WAVES / 1024);   // 1 KB slots per wave in the operand rows: 11 (`red` is `sm` here)
+            const bool pf_fits = MF_KV_LDS && 2 * ((kwu + 3) >> 2) <= PF_SLOTS;   // K and V of one range of this wave
+            const uint32_t pf_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)mf_lds) +
+                                     (uint32_t)wave_s * (uint32_t)(PF_SLOTS * 1024);
+            auto prefetch_range = [&](int split) {   // K slots 0 .. kw/4 - 1, then the V slots behind them
+                const int s0o = split * csu + wave_o * kwu, last_old = max(Pu - 2, 0), nsl = (kwu + 3) >> 2;
+                const size_t layer_off = (size_t)l * a.kv_layer_elems;
+                const size_t head_base = ((size_t)(2 * u + at_r) * MG_HEADS + at_h) * (size_t)a.cache_len * 128 + dl * 8;
+#pragma unroll
+                for (int q = 0; q < ATTN_U; ++q)
+                    if (q < nsl) mf_row_to_lds(pf_base + q * 1024, a.kcache + layer_off + head_base + (size_t)min(s0o + q * 4 + g, last_old) * 128);
+#pragma unroll
+                for (int q = 0; q < ATTN_U; ++q)
+                    if (q < nsl) mf_row_to_lds(pf_base + (nsl + q) * 1024, a.vcache + layer_off + head_base + (size_t)min(s0o + q * 4 + g, last_old) * 128);
+            };
+            if (pf_fits && n_my > 1) prefetch_range(at_s + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
             for (int j = 0; j < n_my; ++j) {
                 const int split = at_s + j;
@@ -381,7 +477,24 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
                     }
                 }
                 const AttnAcc w = attn_wave_partial<false>(kv, vv, qv, s0, s1, g);
-                if (j + 1 < n_my) issue_kv(kv, vv, u, l, split + 1, 0, lane_o, wave_o);   // the next range streams while this one is stored / merged
+                if (j + 1 < n_my) {
+                    if (pf_fits) {
+                        // the next range has been streaming into LDS while this one was scored: LDS -> registers, then the range after it
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        mega_loads_have_landed();
+                        const int nsl = (kwu + 3) >> 2;
+                        const u32x4* pf = (const u32x4*)(mf_lds + (size_t)wave_s * (PF_SLOTS * 1024)) + lane_o;
+#pragma unroll
+                        for (int q = 0; q < ATTN_U; ++q) {
+                            kv[q] = q < nsl ? pf[q * 64] : u32x4{0u, 0u, 0u, 0u};
+                            vv[q] = q < nsl ? pf[(nsl + q) * 64] : u32x4{0u, 0u, 0u, 0u};
+                        }
+                        if (j + 2 < n_my) {
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slots have been read: they may be overwritten
+                            prefetch_range(split + 2);
+                        }
+                    } else issue_kv(kv, vv, u, l, split + 1, 0, lane_o, wave_o);   // the next range streams while this one is stored / merged
+                }
                 if (g == 0) {
                     float (*smj)[16][12] = sm + j * ATTN_WAVES;
                     smj[at_w][dl][0] = w.m;
@@ -391,6 +504,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#endif
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
             // wave j merges range j and publishes its partial; with a single range (<= 256 keys) the merged result is the output
@@ -420,19 +534,21 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
             }
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
-            request_w1();
+            if (!MF_W1_EARLY) request_w1();
         }
         __builtin_amdgcn_sched_barrier(0);
 
         // ================= P2: h = x + wo(attn)                         fast_model.py:224-226,179 =====================
         __syncthreads();
-        {   // granule i of utterance u = elements 2i, 2i+1 of its [2][2048] attention output (both rows back to back)
-            wave_poll16<2 * NU>(g_attn, tag0 + 1u, abort_flag_of, &s_abort, [&](int k) { return (k >> 1) * (MG_DIM / 2) + tid_o + (k & 1) * MG_THREADS; },
-                                [&](int n, uint32_t p0, uint32_t p1) {
-                                    const int u = n / (MG_DIM / 2), e = (n % (MG_DIM / 2)) * 4;   // element index inside the utterance's [2][2048]
-                                    bf16_t* dst = xs + (size_t)(2 * u + e / MG_DIM) * MF_KP + e % MG_DIM;
-                                    *(uint2*)dst = make_uint2(p0, p1);
-                                });
+        // granule i of utterance u = elements 2i, 2i+1 of its [2][2048] attention output (both rows back to back); 4 utterances per poll loop
+#pragma unroll
+        for (int u0 = 0; u0 < NU; u0 += 4) {
+            wave_poll16<8>(g_attn + (size_t)u0 * MG_DIM, tag0 + 1u, abort_flag_of, &s_abort, [&](int k) { return (k >> 1) * (MG_DIM / 2) + tid_o + (k & 1) * MG_THREADS; },
+                           [&](int n, uint32_t p0, uint32_t p1) {
+                               const int u = u0 + n / (MG_DIM / 2), e = (n % (MG_DIM / 2)) * 4;   // element index inside the utterance's [2][2048]
+                               bf16_t* dst = xs + (size_t)(2 * u + e / MG_DIM) * MF_KP + e % MG_DIM;
+                               *(uint2*)dst = make_uint2(p0, p1);
+                           });
         }
         __syncthreads();
         MF_ABORT_RETURN();
@@ -468,7 +584,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
         __builtin_amdgcn_sched_barrier(0);
 
         // ================= P3: act = silu(w1 n(h)) * w3 n(h)            fast_model.py:180,237 =========================
-        mf_poll_rows<NU, MG_DIM>(g_h, tag0 + 2u, xs, abort_flag_of, &s_abort, tid_o);
+        mf_poll_rows<NU, MG_DIM, MG_DIM>(g_h, tag0 + 2u, xs, abort_flag_of, &s_abort, tid_o);
         __syncthreads();
         MF_ABORT_RETURN();
         mf_norm<R>(xs, nws + MG_DIM, a.eps, lane_o, wave_o);
@@ -503,25 +619,40 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();   // published: the w2 rows may go out
-        {   // w2 rows 8 b .. 8 b + 7, K = 5632 = 176 k-steps: 22 per wave
+        {   // w2 rows 8 b .. 8 b + 7, K = 5632 = 176 k-steps: 11 of each column half per wave, packed
             const bf16_t* slice = L.t[4] + (size_t)b * MF_R_W2 * MG_INTER;
-            const uint32_t o0 = mf_lane_off_half<MF_R_W2, 0, 11>(lane_o);
+            const uint32_t o0 = mf_lane_off_half<MF_R_W2, 0, 88>(lane_o);
 #pragma unroll
-            for (int i = 0; i < 11; ++i) w2_r[i] = mf_frag<MF_R_W2>(slice, 22 * wave_s + i, o0);   // k-steps 22 w + i | 22 w + 11 + i
+            for (int i = 0; i < 11; ++i) w2_r[i] = mf_frag<MF_R_W2>(slice, 11 * wave_s + i, o0);   // k-steps 11 w + i (columns 0..2815) | 88 + 11 w + i (2816..5631)
         }
         __builtin_amdgcn_sched_barrier(0);
 
         // ================= P4: x = h + w2(act)                          fast_model.py:247,180 =========================
-        mf_poll_rows<NU, MG_INTER>(g_act, tag0 + 3u, xs, abort_flag_of, &s_abort, tid_o);
-        __syncthreads();
-        MF_ABORT_RETURN();
         {
             f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+            if constexpr (NU <= 4) {   // the whole activation vector in the operand rows: one pass
+                mf_poll_rows<NU, MG_INTER, MG_INTER>(g_act, tag0 + 3u, xs, abort_flag_of, &s_abort, tid_o);
+                __syncthreads();
+                MF_ABORT_RETURN();
 #pragma unroll
-            for (int i = 0; i < 11; ++i) {
-                lo = mf_mma(w2_r[i], mf_bfrag<R>(xs, 22 * wave_o + i, lane_o), lo);
-                hi = mf_mma(w2_r[i], mf_bfrag<R>(xs, 22 * wave_o + 11 + i, lane_o), hi);
-                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < 11; ++i) {
+                    lo = mf_mma(w2_r[i], mf_bfrag<R>(xs, 11 * wave_o + i, lane_o), lo);
+                    hi = mf_mma(w2_r[i], mf_bfrag<R>(xs, 88 + 11 * wave_o + i, lane_o), hi);
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {                   // 16 rows: the operand rows hold one column half at a time
+                mf_poll_rows<NU, MG_INTER / 2, MG_INTER>(g_act, tag0 + 3u, xs, abort_flag_of, &s_abort, tid_o);
+                __syncthreads();
+                MF_ABORT_RETURN();
+#pragma unroll
+                for (int i = 0; i < 11; ++i) lo = mf_mma(w2_r[i], mf_bfrag<R>(xs, 11 * wave_o + i, lane_o), lo);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();       // every wave has read the first half
+                mf_poll_rows<NU, MG_INTER / 2, MG_INTER>(g_act + MG_INTER / 2, tag0 + 3u, xs, abort_flag_of, &s_abort, tid_o);
+                __syncthreads();
+                MF_ABORT_RETURN();
+#pragma unroll
+                for (int i = 0; i < 11; ++i) hi = mf_mma(w2_r[i], mf_bfrag<R>(xs, 11 * wave_o + i, lane_o), hi);
             }
             mf_put(red, wave_o, 0, lane_o, mf_half_tile(lo, hi, lane_o));
         }
@@ -550,7 +681,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
 
     // ================= LM head on the last position: logits = head(norm(x))     fast_model.py:161-162 =================
     __syncthreads();
-    mf_poll_rows<NU, MG_DIM>(g_x, epoch + (uint32_t)(n_layer - 1) * 8u + 1u + 4u, xs, abort_flag_of, &s_abort, tid);
+    mf_poll_rows<NU, MG_DIM, MG_DIM>(g_x, epoch + (uint32_t)(n_layer - 1) * 8u + 1u + 4u, xs, abort_flag_of, &s_abort, tid);
     *(u32x4*)(nws + tid * 8) = nwp;   // the final norm's weights (both halves hold them)
     __syncthreads();
     MF_ABORT_RETURN();
@@ -572,29 +703,34 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
     }
 }
 
-bool mfma_decode_supported(int weight_format, int n_utt) { return weight_format == MV_W_BF16 && n_utt == 4; }
+bool mfma_decode_supported(int weight_format, int n_utt) { return weight_format == MV_W_BF16 && (n_utt == 4 || n_utt == 8); }
 
-bool mfma_decode_fits(int n_utt, int n_cus) {
-    if (n_utt != 4) return false;
-    const size_t lds = mfma_lds_bytes(4);
-    if (hipFuncSetAttribute((const void*)decode_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+template <int NU>
+static bool mfma_instance_fits(int n_cus) {
+    const size_t lds = mfma_lds_bytes(NU);
+    if (hipFuncSetAttribute((const void*)decode_mfma_kernel<NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)decode_mfma_kernel<4>, MG_THREADS, lds) != hipSuccess) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)decode_mfma_kernel<NU>, MG_THREADS, lds) != hipSuccess) return false;
     return per_cu >= 1 && (long)per_cu * n_cus >= 256;
 }
+bool mfma_decode_fits(int n_utt, int n_cus) { return n_utt == 4 ? mfma_instance_fits<4>(n_cus) : n_utt == 8 ? mfma_instance_fits<8>(n_cus) : false; }
 
-hipError_t launch_decode_mfma(hipStream_t s, const MegaArgs& a) {
-    if (a.n_utt != 4 || a.head_t == nullptr) return hipErrorInvalidValue;
+template <int NU>
+static hipError_t launch_mfma_instance(hipStream_t s, const MegaArgs& a) {
     static std::atomic<bool> raised_on[64];   // the attribute belongs to the device's copy of the function
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::atomic<bool>& raised = raised_on[dev & 63];
-    const size_t lds = mfma_lds_bytes(4);
+    const size_t lds = mfma_lds_bytes(NU);
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)decode_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)decode_mfma_kernel<NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL((decode_mfma_kernel<4>), dim3(256), dim3(MG_THREADS), lds, s, a);
+    hipLaunchKernelGGL((decode_mfma_kernel<NU>), dim3(256), dim3(MG_THREADS), lds, s, a);
     return hipGetLastError();
+}
+hipError_t launch_decode_mfma(hipStream_t s, const MegaArgs& a) {
+    if (a.head_t == nullptr) return hipErrorInvalidValue;
+    return a.n_utt == 4 ? launch_mfma_instance<4>(s, a) : a.n_utt == 8 ? launch_mfma_instance<8>(s, a) : hipErrorInvalidValue;
 }

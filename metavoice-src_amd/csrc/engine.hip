@@ -192,10 +192,11 @@ int enqueue_step(mv_engine* e) {
     const int R = e->R;
     hipStream_t s = e->stream;
     if (e->mega_ok && g_tune.mega && !e->mega_failed) {  // one persistent launch for the 24 layers + LM head, then the sampler
-        if (e->mfma_ok && g_tune.mfma) HIP_TRY(launch_decode_mfma(s, mega_args(e)));
+        if (e->mfma_ok && (g_tune.mfma || c.max_utterances == 8)) HIP_TRY(launch_decode_mfma(s, mega_args(e)));
         else HIP_TRY(launch_decode_mega(s, mega_args(e), c.weight_format));
         return enqueue_sampler(e);
     }
+    if (c.max_utterances == 8) return fail(MV_ERR_STATE, "an engine of 8 utterances decodes on the persistent matrix-core kernel only (mv_tune \"mega\" 0 / a timed-out launch leave it without a path)");
     for (int l = 0; l < c.n_layer; ++l) {
         const LayerW& w = e->layers[l];
         bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
@@ -272,6 +273,13 @@ int enqueue_tail(mv_engine* e) {
         a.x = e->x; a.w = e->head; a.norm_w = e->final_norm; a.out = e->logits; a.N = c.vocab; a.K = c.dim;
         a.eps = c.norm_eps;
         if (c.weight_format == MV_W_INT8) HIP_TRY(launch_gemv_i8(s, R, to_i8(a, e->head_q8, e->head_s8), GEMV_PLAIN));
+        else if (R == 16) {   // engines of 8 utterances (the end of a prefill; their decode steps never come here): the GEMV takes up to 8 rows
+            for (int half = 0; half < 2; ++half) {
+                GemvArgs h = a;
+                h.x = e->x + (size_t)half * 8 * c.dim; h.out = e->logits + (size_t)half * 8 * c.vocab;
+                HIP_TRY(launch_gemv(s, 8, h, GEMV_PLAIN));
+            }
+        }
         else HIP_TRY(launch_gemv(s, R, a, GEMV_PLAIN));
     }
     return enqueue_sampler(e);
@@ -429,8 +437,11 @@ int mv_engine_create(const mv_config* cfg, mv_engine** out) {
     if (c.n_layer < 1 || c.n_head < 1 || c.dim < 128 || c.dim % c.n_head != 0 || c.dim / c.n_head != 128)
         return fail(MV_ERR_INVALID, "head_dim must be 128 (dim=%d n_head=%d)", c.dim, c.n_head);
     if (c.vocab < 2 || c.vocab > 4096) return fail(MV_ERR_INVALID, "vocab %d out of range [2,4096]", c.vocab);
-    if (c.max_utterances < 1 || c.max_utterances > 4) return fail(MV_ERR_INVALID, "max_utterances must be 1..4");
-    if (!gemv_supported(2 * c.max_utterances, c.dim) || !gemv_supported(2 * c.max_utterances, c.intermediate))
+    // 8 utterances: only the matrix-core persistent kernel (decode_mfma.hip) decodes 16 rows -- bf16, MetaVoice-1B shape, checked at
+    // mv_finalize; there are no per-layer launches behind it (they stop at 8 rows), so a hand-off time-out is an error for such an engine
+    const bool eight = c.max_utterances == 8 && c.weight_format == MV_W_BF16;
+    if ((c.max_utterances < 1 || c.max_utterances > 4) && !eight) return fail(MV_ERR_INVALID, "max_utterances must be 1..4, or 8 with bf16 weights");
+    if (!eight && (!gemv_supported(2 * c.max_utterances, c.dim) || !gemv_supported(2 * c.max_utterances, c.intermediate)))
         return fail(MV_ERR_INVALID, "unsupported dim/intermediate %d/%d (K must be a multiple of 8 with ceil(K/512) in {1,2,4,11})",
                     c.dim, c.intermediate);
     if (c.weight_format != MV_W_BF16 && c.weight_format != MV_W_INT4_G128 && c.weight_format != MV_W_INT8)
@@ -671,7 +682,10 @@ int mv_finalize(mv_engine* e) {
         HIP_TRY(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev));
         // every weight format has an instance of the persistent kernel; whether its 256 workgroups can be resident together is asked
         // here (occupancy query), not discovered by a time-out in the first mv_run
-        e->mega_ok = mega_supported(c, R, n_cus) && mega_fits(c.weight_format, c.max_utterances, n_cus);
+        e->mega_ok = mega_supported(c, R, n_cus) && (c.max_utterances == 8 ? mfma_decode_fits(8, n_cus) : mega_fits(c.weight_format, c.max_utterances, n_cus));
+        if (c.max_utterances == 8 && !e->mega_ok)
+            return fail(MV_ERR_INVALID, "max_utterances = 8 needs the matrix-core persistent decode kernel: MetaVoice-1B shape, bf16 weights, >= 256 CUs with "
+                                        "one workgroup of decode_mfma_kernel<8> resident per CU");
         if (e->mega_ok) {
             // engines of 4 utterances (bf16): a second, TILED copy of the projection weights for the matrix-core instance of the persistent
             // step (decode_mfma.hip: per workgroup [K / 32][rows][32], 2.5 GB more of the 288 GB).  The row-major arena stays: the prefill
@@ -884,6 +898,13 @@ int mv_run(mv_engine* e, int32_t max_steps, int32_t poll_every, int32_t* steps_r
         HIP_TRY(hipMemcpyAsync(e->host_flag, e->n_active, 4, hipMemcpyDeviceToHost, e->stream));
         if (mega_live) HIP_TRY(hipMemcpyAsync(e->host_flag + 1, e->abort_flag, 16, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
+        if (mega_live && e->host_flag[1] != 0 && U == 8) {
+            HIP_TRY(hipMemsetAsync(e->abort_flag, 0, 16, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            ++e->mega_timeouts;
+            return fail(MV_ERR_HIP, "persistent decode kernel timed out waiting for a peer workgroup (grid not co-resident: is another kernel occupying the GPU?) "
+                                    "and an engine of 8 utterances has no per-layer launches to fall back to: run the batch again");
+        }
         if (mega_live && e->host_flag[1] != 0) {
             // A hand-off of the persistent kernel timed out (the 256 workgroups were not co-resident: another kernel held CUs).
             // A plain launch gives no residency guarantee, so this is a condition to survive, not an error: roll every utterance
@@ -936,7 +957,7 @@ int32_t mv_decode_path(const mv_engine* e, int32_t* timeouts) {
     if (!e) return -1;
     if (timeouts) *timeouts = e->mega_timeouts;
     if (!(e->mega_ok && g_tune.mega && !e->mega_failed)) return 0;
-    if (e->mfma_ok && g_tune.mfma) return 3;   // the matrix-core instance of the persistent step (decode_mfma.hip), one step per launch
+    if (e->mfma_ok && (g_tune.mfma || e->cfg.max_utterances == 8)) return 3;   // the matrix-core instance of the persistent step (decode_mfma.hip), one step per launch
     return g_tune.mega_fold && mega_folds(e->cfg) ? 2 : 1;
 }
 
@@ -985,7 +1006,7 @@ int mv_probe_kernel(mv_engine* e, int32_t kind, int32_t iters, float* avg_ms, do
                 if (i == 0) HIP_TRY(hipEventRecord(e->ev0, s));
                 HIP_TRY(launch_bump_counter(s, e->step_counter));
                 if (pass == 0) {
-                    if (e->mfma_ok && g_tune.mfma) HIP_TRY(launch_decode_mfma(s, m));
+                    if (e->mfma_ok && (g_tune.mfma || c.max_utterances == 8)) HIP_TRY(launch_decode_mfma(s, m));
                     else HIP_TRY(launch_decode_mega(s, m, c.weight_format));
                 }
             }

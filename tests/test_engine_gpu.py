@@ -426,6 +426,55 @@ def test_matrix_core_persistent_kernel_for_four_utterances(n_layer, lens, n_new,
     engine.close()
 
 
+def test_matrix_core_persistent_kernel_for_eight_utterances():
+    """decode_mfma_kernel<8>: 16 CFG rows = one full 16 x 16 MFMA tile of activations; the w2 phase in two passes over the column halves (16
+    whole activation rows would be 180 KB of LDS), one workgroup per (utterance, row, head) walking all of its key ranges.  There are no
+    per-layer launches for 16 rows, so the reference is the SAME eight utterances decoded four at a time by an engine of 4 on the per-layer
+    launches (the bit-identical family), teacher-forced; bound as for the 4-utterance instance (0.1 sigma)."""
+    cfgk = dict(WIDE2, n_layer=2)
+    lens = [300, 12, 1030, 255, 40, 700, 17, 1500]
+    sd = o_s1.remap_checkpoint_keys(synthetic.stage1_state_dict(seed=19, **cfgk))
+    prompts = [synthetic.prompt_tokens(t, seed=110 + u) for u, t in enumerate(lens)]
+    spks = torch.cat([synthetic.speaker_embedding(120 + u) for u in range(8)])
+    sps = [mv.SamplingParams(guidance_scale=3.0, seed=130 + u, top_k=1) for u in range(8)]
+    ref = []
+    e4 = mv.Stage1Engine(mv.ModelArgs(**cfgk), max_utterances=4)
+    e4.load_state_dict(sd); e4.finalize()
+    e4.capture_logits(True)
+    e4.tune(mega=0)
+    for g0 in (0, 4):
+        e4.begin(prompts[g0:g0 + 4], spks[g0:g0 + 4], sps[g0:g0 + 4], max_new_tokens=2, end_of_audio_token=9999, prefill_mode=0)
+        e4.run()
+        lg = e4.captured_logits(0, max(lens[g0:g0 + 4]))
+        ref += [lg[:lens[g0 + k], 2 * k:2 * k + 2].clone() for k in range(4)]
+    e4.tune(mega=1)
+    e4.close()
+    e8 = mv.Stage1Engine(mv.ModelArgs(**cfgk), max_utterances=8)
+    e8.load_state_dict(sd); e8.finalize()
+    e8.capture_logits(True)
+    got = None
+    for rep in range(2):
+        e8.begin(prompts, spks, sps, max_new_tokens=2, end_of_audio_token=9999, prefill_mode=0)
+        e8.run()
+        assert e8.decode_path() == (3, 0), "decode_mfma_kernel<8> did not run (or a hand-off timed out)"
+        lg = e8.captured_logits(0, max(lens))
+        cur = [lg[:t, 2 * u:2 * u + 2].clone() for u, t in enumerate(lens)]
+        if got is not None:
+            assert all(torch.equal(x, y) for x, y in zip(cur, got)), "not reproducible run to run"
+        got = cur
+    worst = 0.0
+    for u in range(8):
+        scale, d = float(ref[u].std()), float((got[u] - ref[u]).abs().max())
+        worst = max(worst, d / scale)
+        assert d <= 0.1 * scale, f"utterance {u} (prompt {lens[u]}): teacher-forced logits differ by {d:.4f} (logit std {scale:.3f})"
+    # free running behind the MFMA prefill: ragged positions, every attention regime, length caps honoured
+    e8.begin(prompts, spks, sps, max_new_tokens=20, end_of_audio_token=9999, prefill_mode=1)
+    e8.run()
+    assert [len(e8.tokens(u)) for u in range(8)] == [t + 20 for t in lens] and e8.decode_path() == (3, 0)
+    print(f"[mfma x 8, prompts {lens}] teacher-forced max |dlogit| / sigma vs the launches (engines of 4) {worst:.4f}")
+    e8.close()
+
+
 def test_persistent_kernel_times_out_cleanly_and_the_run_falls_back_to_launches():
     """A persistent kernel whose grid is not co-resident (or whose peer dies) must not hang and must not fail the run: every
     wait is bounded, the first workgroup to give up raises a device flag, the rest leave within a polling interval, and mv_run

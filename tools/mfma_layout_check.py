@@ -47,7 +47,11 @@ def half_tile(lo, hi):                    # mf_half_tile: lane groups 0, 1 (rows
     out = lo.copy(); out[8:] = hi[8:]; return out
 
 
-def run(N, K, rows, ksteps_per_wave, packed_first, skip):
+def skip_base(w, skip):                  # w2: wave w owns k-steps 11 w + i of the first column half and 88 + 11 w + i of the second
+    return 11 * w
+
+
+def run(N, K, rows, ksteps_per_wave, packed_first, skip, half_split=False):
     W = rng.standard_normal((N, K)); xs = rng.standard_normal((R, K))
     T = tile_weights(W, rows)
     for b in (0, 3, 255):
@@ -55,7 +59,7 @@ def run(N, K, rows, ksteps_per_wave, packed_first, skip):
         red = []                          # per wave: list of tiles
         for w in range(WAVES):
             tiles = []
-            base = ksteps_per_wave * w
+            base = ksteps_per_wave * w if not half_split else skip_base(w, skip)
             if packed_first > 0:          # a full tile of rows 0..15 over all the wave's k-steps
                 acc = np.zeros((16, 16))
                 for i in range(ksteps_per_wave):
@@ -63,7 +67,7 @@ def run(N, K, rows, ksteps_per_wave, packed_first, skip):
                     acc = mfma(a, [bfrag(xs, base + i, l) for l in range(64)], acc)
                 tiles.append(acc)
             lo = np.zeros((16, 16)); hi = np.zeros((16, 16))
-            for i in range(skip):         # packed half tile: fragment i = k-steps base + i | base + skip + i
+            for i in range(skip if not half_split else ksteps_per_wave // 2):   # packed half tile: fragment i = k-steps base + i | base + skip + i
                 a = [frag(sl, base + i, lane_off_half(rows, packed_first, skip, l)) for l in range(64)]
                 lo = mfma(a, [bfrag(xs, base + i, l) for l in range(64)], lo)
                 hi = mfma(a, [bfrag(xs, base + skip + i, l) for l in range(64)], hi)
@@ -86,4 +90,4 @@ def run(N, K, rows, ksteps_per_wave, packed_first, skip):
 run(6144, 2048, 24, 8, 16, 4)     # wqkv: rows 0..15 full, 16..23 packed (k-steps 8 w + i | 8 w + 4 + i)
 run(2048, 2048, 8, 8, 0, 4)       # wo: 8 rows packed
 run(5632, 2048, 22, 8, 16, 4)     # w1 / w3: rows 0..15 full, 16..21 packed (slots 6, 7 re-read row 21, never read back)
-run(2048, 5632, 8, 22, 0, 11)     # w2: 8 rows packed, 22 k-steps per wave in pairs (i, 11 + i)
+run(2048, 5632, 8, 22, 0, 88, half_split=True)   # w2: 8 rows packed, wave w: k-steps 11 w + i (first column half) | 88 + 11 w + i (second)
