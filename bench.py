@@ -334,6 +334,8 @@ def measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline):
             stage_ms["stage1_prefill+decode"] += (t1 - t0) * 1e3
             stage_ms["stage1_decode_gpu"] += engine.last_run_ms
             run_ms += engine.last_run_ms
+            pending = []   # (latent, wav_encodec) of the group's utterances when their diffusion bands run on concurrent lanes
+            many = diffusion is not None and len(group) > 1 and a.vocoder_lanes > 1
             for u, toks in enumerate(streams):
                 n_gen += len(toks) - len(prompts[u])
                 if stage1_only:
@@ -349,7 +351,12 @@ def measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline):
                     _, audio_ids = second_adapter.decode(torch.cat([in_x, y], dim=1)[0].tolist())
                 t2 = time.perf_counter()
                 grid8 = torch.tensor(audio_ids, dtype=torch.long).unsqueeze(0)
-                if diffusion is not None:
+                if many:
+                    # a batch: EnCodec decodes one after the other, the diffusion bands of up to --vocoder-lanes utterances concurrently below
+                    wav_encodec, latent = vocoder.decode(grid8, return_latent=True)
+                    pending.append((latent, wav_encodec))
+                    t3 = time.perf_counter()
+                elif diffusion is not None:
                     # the codec's waveform and latent stay in device memory for the diffusion bands (vocoder.MultiBandDiffusion.tokens_to_wav)
                     d_wav, d_lat, samples, frames = vocoder.decode_device(grid8)
                     t3 = time.perf_counter()
@@ -360,7 +367,12 @@ def measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline):
                     t3 = time.perf_counter()
                 stage_ms["encodec_decode"] += (t3 - t2) * 1e3
                 stage_ms["adapters+stage2"] += (t2 - t1) * 1e3
-                wavs.append(wav.reshape(-1))
+                if not many:
+                    wavs.append(wav.reshape(-1))
+            if pending:
+                t3 = time.perf_counter()
+                wavs += [w.reshape(-1) for w in diffusion.tokens_to_wav_many(pending, lanes=a.vocoder_lanes)]
+                stage_ms["multiband_diffusion"] += (time.perf_counter() - t3) * 1e3
         if world > 1 and wavs:
             # batched-serving path: every rank ends up with every utterance's fp32 waveform, in input order
             dev = torch.device("cuda", local_rank)
@@ -413,8 +425,10 @@ def measure(a, rank, local_rank, world, dist, shared, with_cpu_baseline):
                      max_new_tokens=2, end_of_audio_token=9999, prefill_mode=1)
         engine.run(max_steps=1)
         if N.lib().mv_probe_kernel(engine._h, 6, 200, C.byref(ms), C.byref(nbytes)) == 0:
-            kname = ("decode_mega_kernel<.., false> (persistent: 24 layers + LM head of one token for %d utterance(s); probed at context %s = the "
-                     "mean of the timed utterances)" % (len(g0), [c + 1 for c in ctxs]))
+            kernel = (f"decode_mfma_kernel<{U}> (matrix-core instance of the persistent step: v_mfma_f32_16x16x32_bf16 on a tiled weight copy)" if path == 3
+                      else "decode_mega_kernel<.., false>")
+            kname = ("%s (persistent: 24 layers + LM head of one token for %d utterance(s); probed at context %s = the "
+                     "mean of the timed utterances)" % (kernel, len(g0), [c + 1 for c in ctxs]))
         else:
             N.check(N.lib().mv_probe_kernel(engine._h, 3, 24 * 20, C.byref(ms), C.byref(nbytes)))
             kname = "gemv_kernel<SWIGLU> (RMSNorm + w1|w3 + SiLU gate; per-layer launches)"
@@ -681,12 +695,16 @@ def parse_args(argv=None):
     ap.add_argument("--long-form-chars", type=int, default=10000)
     ap.add_argument("--mbd-precision", type=int, default=3, choices=[0, 1, 3],
                     help="multi-band diffusion vocoder: MFMA terms per product (3 = bf16 hi/lo split, ~fp32; 1 = bf16 operands; 0 = EnCodec decode only)")
+    ap.add_argument("--vocoder-lanes", type=int, default=4,
+                    help="utterances of a batch whose diffusion bands run concurrently (mv_mbd_clone: shared weights, one stream and workspace per lane); 1 = one after the other")
     ap.add_argument("--decode-path", choices=["auto", "step", "launches"], default="auto",
                     help="A/B switch: auto = the engine's choice (persistent kernel drawing its own tokens where supported), step = persistent "
                          "kernel, one step per launch + sampler launch, launches = per-layer launches")
     a = ap.parse_args(argv)
-    if a.long_form and a.utterances_per_gpu not in (1, 2, 4):
-        ap.error("--long-form decodes 1, 2 or 4 chunks together")
+    if a.utterances_per_gpu not in (1, 2, 3, 4, 8):
+        ap.error("--utterances-per-gpu: 1..4 or 8 (engines of 8 utterances run on the matrix-core persistent kernel, bf16 only)")
+    if a.utterances_per_gpu == 8 and a.quantisation_mode is not None:
+        ap.error("--utterances-per-gpu 8 is bf16 only")
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
     return a
@@ -712,7 +730,8 @@ EXTRA_CONFIGS = [
     ("configs[3] int4 first-stage decode", dict(quantisation_mode="int4", steps=3, warmup=1)),
     ("configs[3'] int8 first-stage decode", dict(quantisation_mode="int8", steps=3, warmup=1)),
     ("configs[2] 4 utterances per GPU, full vocoder", dict(utterances_per_gpu=4, steps=2, warmup=1)),
-    ("configs[4] long-form 10000 characters, full vocoder, 4 chunks per engine run", dict(long_form=True, long_form_chars=10000, utterances_per_gpu=4, steps=1, warmup=0)),
+    ("configs[2'] 8 utterances per GPU (batch 64 over 8 GPUs), full vocoder", dict(utterances_per_gpu=8, steps=1, warmup=1)),
+    ("configs[4] long-form 10000 characters, full vocoder, 8 chunks per engine run", dict(long_form=True, long_form_chars=10000, utterances_per_gpu=8, steps=1, warmup=0)),
 ]
 
 

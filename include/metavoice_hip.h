@@ -235,6 +235,9 @@ int mv_mbd_set_processor(mv_mbd* m, int32_t band, int32_t n_bands, const float* 
 /* julius.LowPassFilters bank of SplitBands: which 0 = processor (proc_bands - 1 filters), 1 = re_eq (eq_bands - 1); taps odd */
 int mv_mbd_set_filterbank(mv_mbd* m, int32_t which, int32_t n_filters, int32_t taps, const float* coeffs);
 int mv_mbd_finalize(mv_mbd* m);
+/* a second handle on the same (finalized) weights with its own stream and device workspace: the utterances of a batch are vocoded on several
+ * lanes concurrently (they differ in length and GroupNorm spans a whole utterance, so there is no batch dimension).  Destroy clones first. */
+int mv_mbd_clone(mv_mbd* src, mv_mbd** out);
 /* latent: host fp32 [codec_dim][frames] (mv_codec_decode's latent_out); wav_ref: host fp32 [samples], the EnCodec decode (NULL: no
  * re_eq); noise: host fp32 [n_models][n_eval + 1][samples] injected Gaussian draws (parity tests) or NULL = Philox stream of `seed` */
 int mv_mbd_generate(mv_mbd* m, const float* latent, int32_t frames, const float* wav_ref, int32_t samples, const float* noise, uint64_t seed,

@@ -113,6 +113,7 @@ SYMBOLS = [
     ("mv_mbd_set_processor", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("mv_mbd_set_filterbank", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
     ("mv_mbd_finalize", C.c_int, [_P]),
+    ("mv_mbd_clone", C.c_int, [_P, C.POINTER(_P)]),
     ("mv_mbd_generate", C.c_int, [_P, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.c_uint64,
                                   C.POINTER(C.c_float)]),
     ("mv_mbd_generate_device", C.c_int, [_P, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(C.c_float)]),

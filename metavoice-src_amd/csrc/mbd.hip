@@ -1104,6 +1104,7 @@ struct mv_mbd {
     uint32_t* lstm_abort = nullptr;
     uint32_t lstm_serial = 0;
     Work work;   // device workspace of mv_mbd_generate, kept between calls
+    int device = 0;   // the device the handle was created on: mv_mbd_generate may be called from a worker thread (whose current device is 0)
     // launches per GEMM kernel since mv_mbd_create (mv_mbd_kernel_counts: the parity tests assert WHICH kernels a shape ran on):
     // 0 t256, 1 glds3<64,192>, 2 glds3<128,128>, 3 thin, 4 glds, 5 mbd_gemm<128>, 6 mbd_gemm<64>
     mutable int64_t gemm_launches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1165,6 +1166,7 @@ int mv_mbd_create(const mv_mbd_config* cfg, mv_mbd** out) {
         return mv_fail(MV_ERR_INVALID, "mv_mbd_create: BiLSTM width %d not supported", g.channels[g.depth - 1]);
     mv_mbd* m = new mv_mbd();
     m->cfg = g;
+    (void)hipGetDevice(&m->device);
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return mv_fail(MV_ERR_HIP, "stream creation failed"); }
     m->ch.assign(g.channels, g.channels + g.depth);
     m->band.resize(g.n_models);
@@ -1179,6 +1181,36 @@ int mv_mbd_create(const mv_mbd_config* cfg, mv_mbd** out) {
             b.lstm.loaded.assign(4, 0);
         }
     }
+    *out = m;
+    return MV_OK;
+}
+
+// A second handle on the SAME weights (device pointers shared, nothing copied) with its own stream, device workspace and LSTM scratch: the
+// utterances of a batch are independent and differ in length (GroupNorm statistics span a whole utterance: no batch dimension), so a
+// batching server runs them on several lanes at once -- the small-layer launches of one utterance fill the CUs another one's leave idle.
+// The clone must be destroyed before its parent.
+int mv_mbd_clone(mv_mbd* src, mv_mbd** out) {
+    if (!src || !out) return mv_fail(MV_ERR_INVALID, "mv_mbd_clone: null argument");
+    if (!src->finalized) return mv_fail(MV_ERR_STATE, "mv_mbd_clone before mv_mbd_finalize");
+    mv_mbd* m = new mv_mbd();
+    m->cfg = src->cfg;
+    m->device = src->device;
+    (void)hipSetDevice(m->device);
+    m->band = src->band;   // device pointers: shared, owned by the parent (m->allocs stays empty)
+    m->ch = src->ch;
+    m->proc_bank = src->proc_bank; m->eq_bank = src->eq_bank; m->proc_bank_t = src->proc_bank_t; m->eq_bank_t = src->eq_bank_t;
+    m->proc_taps = src->proc_taps; m->eq_taps = src->eq_taps;
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return mv_fail(MV_ERR_HIP, "stream creation failed"); }
+    if (m->cfg.bilstm) {   // the recurrence's hand-off granules and abort word are per handle
+        const int H = m->ch[m->cfg.depth - 1];
+        int rc = dev_alloc(m, &m->lstm_hx, (size_t)2 * H);
+        if (rc == MV_OK) rc = dev_alloc(m, &m->lstm_abort, 1);
+        if (rc != MV_OK || hipMemset(m->lstm_hx, 0, (size_t)2 * H * 8) != hipSuccess || hipMemset(m->lstm_abort, 0, 4) != hipSuccess) {
+            mv_mbd_destroy(m);
+            return mv_fail(MV_ERR_HIP, "mv_mbd_clone: LSTM scratch allocation failed");
+        }
+    }
+    m->finalized = true;
     *out = m;
     return MV_OK;
 }
@@ -1625,6 +1657,7 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
                              float* wav_out, bool inputs_on_device) {
     if (!m || !wav_out) return mv_fail(MV_ERR_INVALID, "mv_mbd_generate: null argument");
     if (!m->finalized) return mv_fail(MV_ERR_STATE, "mv_mbd_generate before mv_mbd_finalize");
+    (void)hipSetDevice(m->device);   // lanes of a batch are driven from worker threads: a new thread's current device is 0
     const mv_mbd_config& g = m->cfg;
     if (T < g.kernel * 4 || (g.codec_dim > 0 && (!latent || frames < 1))) return mv_fail(MV_ERR_INVALID, "mv_mbd_generate: bad sizes (T = %d, frames = %d)", T, frames);
     hipStream_t s = m->stream;

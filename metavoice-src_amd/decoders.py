@@ -81,6 +81,24 @@ class EncodecDecoder(Decoder):
             raise Exception("wav predicted is shorter than 400ms!")  # decoders.py:88-91
         return wav
 
+    def decode_wavs(self, token_lists: List[List[List[int]]], return_exceptions: bool = False) -> list:
+        """`decode_wav` for the utterances of a batch: the vocoder runs their diffusion bands on concurrent lanes where it can
+        (`vocoder.MultiBandDiffusion.tokens_to_wav_many`; the same samples as one call per utterance).  With `return_exceptions` an
+        utterance that fails ('wav predicted is shorter than 400ms!') leaves its exception in its slot."""
+        grids = [self._grid(t)[1] for t in token_lists]
+        many = getattr(self.vocoder, "tokens_to_wav_many", None)
+        wavs = many(grids) if many is not None and len(grids) > 1 else [self.vocoder(g) for g in grids]
+        out: list = []
+        for wav in wavs:
+            if wav.shape[-1] < 9600:
+                e = Exception("wav predicted is shorter than 400ms!")  # decoders.py:88-91
+                if not return_exceptions:
+                    raise e
+                out.append(e)
+            else:
+                out.append(wav)
+        return out
+
     def wav_bytes(self, wav: torch.Tensor) -> bytes:
         """Loudness-normalised 16-bit PCM RIFF bytes of `wav`: what `_save_audio` writes, kept in memory."""
         import io

@@ -203,13 +203,24 @@ class TTS:
                 for i in good:
                     out[i] = e
                 return out
+            # adapter + second stage per utterance (a failure is that utterance's), then ONE vocoder call for the group: the diffusion bands
+            # of up to four utterances run concurrently (`decoders.decode_wavs`); samples and seeds as with one call per utterance
+            expanded = []
             for i, tokens in zip(good, streams):
                 try:
-                    out[i] = self._expand_tokens(norm[i], tokens, embs[i])
+                    _, ids = self.first_stage_adapter.decode([tokens])
+                    (tl,) = list(self.llm_second_stage._second_stage_token_lists(
+                        texts=[norm[i]], encodec_tokens=[torch.tensor(ids, dtype=torch.int32).unsqueeze(0)], speaker_embs=embs[i].unsqueeze(0),
+                        batch_size=1, top_k=200, temperature=1.0))
+                    expanded.append((i, tl))
                 except Exception as e:
                     if not return_exceptions:
                         raise
                     out[i] = e
+            if expanded:
+                wavs = self.llm_second_stage.decoder.decode_wavs([tl for _, tl in expanded], return_exceptions=return_exceptions)
+                for (i, _), w in zip(expanded, wavs):
+                    out[i] = w
         return out
 
     def synthesise_batch(self, texts: Sequence[str], spk_refs, top_p=0.95, guidance_scale=3.0, temperature=1.0,

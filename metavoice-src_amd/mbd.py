@@ -146,9 +146,61 @@ class MultiBandDiffusionBands:
         return self
 
     def close(self):
+        for lane in getattr(self, "_lanes", []):   # clones share this handle's weights: they go first
+            lane.close()
+        self._lanes = []
         if getattr(self, "_h", None):
             N.lib().mv_mbd_destroy(self._h)
             self._h = None
+
+    def clone(self) -> "MultiBandDiffusionBands":
+        """A second handle on the same device weights with its own stream and workspace (`mv_mbd_clone`)."""
+        h = C.c_void_p()
+        N.check(N.lib().mv_mbd_clone(self._h, C.byref(h)))
+        other = MultiBandDiffusionBands(h, self.n_models, self.n_eval, self.sample_rate, self._seed)
+        other.codec_dim = self.codec_dim
+        return other
+
+    def tokens_to_wav_many(self, items: Sequence, lanes: int = 4) -> List[torch.Tensor]:
+        """`tokens_to_wav` for the utterances of a batch -- items = [(latent (1, codec_dim, frames), wav_encodec (1, 1, samples)), ...] -- on
+        up to `lanes` handles at once (this one + clones, one host thread each: the C call releases the GIL).  Every utterance gets the
+        seed the one-at-a-time path would have given it (call order), so the waveforms are the same samples."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        n = len(items)
+        if n == 0:
+            return []
+        if not hasattr(self, "_lanes"):
+            self._lanes = []
+        while len(self._lanes) + 1 < min(lanes, n):
+            self._lanes.append(self.clone())
+        handles = [self] + self._lanes[:max(0, min(lanes, n) - 1)]
+        seeds = [(self._seed + 7919 * (self._calls + 1 + i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)]
+        self._calls += n
+        fp = C.POINTER(C.c_float)
+
+        def one(i: int, h) -> torch.Tensor:
+            latent, wav_encodec = items[i]
+            T = int(wav_encodec.shape[-1])
+            lat = np.ascontiguousarray(latent[0].detach().float().cpu().numpy()) if self.codec_dim else None
+            ref = np.ascontiguousarray(wav_encodec.reshape(-1).detach().float().cpu().numpy())
+            out = np.empty(T, dtype=np.float32)
+            N.check(N.lib().mv_mbd_generate(h._h, lat.ctypes.data_as(fp) if lat is not None else None, lat.shape[1] if lat is not None else 0,
+                                            ref.ctypes.data_as(fp), T, None, seeds[i], out.ctypes.data_as(fp)))
+            return torch.from_numpy(out).view(1, 1, -1)
+
+        if len(handles) == 1:
+            return [one(i, self) for i in range(n)]
+
+        def lane_work(k: int):   # lane k takes utterances k, k + L, ...: a handle serves one call at a time
+            return [(i, one(i, handles[k])) for i in range(k, n, len(handles))]
+
+        out: List[Optional[torch.Tensor]] = [None] * n
+        with ThreadPoolExecutor(max_workers=len(handles)) as pool:
+            for part in pool.map(lane_work, range(len(handles))):
+                for i, w in part:
+                    out[i] = w
+        return out
 
     def __del__(self):
         try:

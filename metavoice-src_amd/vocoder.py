@@ -91,6 +91,17 @@ class MultiBandDiffusion:
 
     __call__ = tokens_to_wav
 
+    def tokens_to_wav_many(self, tokens_list, lanes: int = 4):
+        """`tokens_to_wav` for the utterances of a batch: the EnCodec decodes one after the other (4-5 ms each), the diffusion bands of up to
+        `lanes` utterances concurrently (`mbd.MultiBandDiffusionBands.tokens_to_wav_many`); the same samples as one call per utterance."""
+        if self.diffusion is None or not hasattr(self.diffusion, "tokens_to_wav_many"):
+            return [self.tokens_to_wav(t) for t in tokens_list]
+        items = []
+        for t in tokens_list:
+            wav_encodec, latent = self.codec_model.decode(t, return_latent=True)
+            items.append((latent, wav_encodec))
+        return self.diffusion.tokens_to_wav_many(items, lanes=lanes)
+
     def close(self):
         self.codec_model.close()
         if self.diffusion is not None:

@@ -38,8 +38,9 @@ def test_extra_configs_cover_the_other_baseline_configurations():
     for tag in ("configs[2]", "configs[3]", "configs[4]"):
         assert tag in names
     over = dict(bench.EXTRA_CONFIGS)
-    lf = over["configs[4] long-form 10000 characters, full vocoder, 4 chunks per engine run"]
-    assert lf["long_form_chars"] == 10000 and lf["utterances_per_gpu"] == 4
+    lf = over["configs[4] long-form 10000 characters, full vocoder, 8 chunks per engine run"]
+    assert lf["long_form_chars"] == 10000 and lf["utterances_per_gpu"] == 8
+    assert over["configs[2'] 8 utterances per GPU (batch 64 over 8 GPUs), full vocoder"]["utterances_per_gpu"] == 8
     # the chunks of a long text decode in groups of --utterances-per-gpu (what TTS.synthesise_long does), consecutive chunks together
     assert bench.parse_args(["--long-form", "--utterances-per-gpu", "4"]).long_form
     importlib = __import__("importlib")

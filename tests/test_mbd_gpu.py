@@ -265,3 +265,30 @@ def test_device_hand_off_from_the_codec_equals_the_host_path():
     assert torch.equal(a2, host.tokens_to_wav(l2, w2))
     host.close()
     dev.close()
+
+
+def test_concurrent_lanes_give_the_samples_of_one_call_per_utterance():
+    """`tokens_to_wav_many`: the utterances of a batch on several handles at once (`mv_mbd_clone`: shared weights, own stream and workspace,
+    one host thread each).  Every utterance gets the seed of its place in the call order, so the waveforms are the SAME samples as with
+    one `tokens_to_wav` per utterance -- utterances of different lengths, more utterances than lanes."""
+    kw = dict(hidden=16, depth=3, growth=2.0, codec_dim=32)
+    pkg = synthetic.mbd_package(seed=31, n_bands=2, proc_bands=4, **kw)
+    g = torch.Generator().manual_seed(4)
+    items = []
+    for frames in (20, 33, 25, 40, 20):
+        T = frames * 320
+        items.append((torch.randn(1, 32, frames, generator=g), 0.3 * torch.randn(1, 1, T, generator=g).cumsum(-1) / 20.0))
+    one = mbd.MultiBandDiffusionBands.from_package(pkg, precision=3, seed=99, step_list=[999, 666, 333, 0], eq_bands=8)
+    seq = [one.tokens_to_wav(lat, wav) for lat, wav in items]
+    many = mbd.MultiBandDiffusionBands.from_package(pkg, precision=3, seed=99, step_list=[999, 666, 333, 0], eq_bands=8)
+    par = many.tokens_to_wav_many(items, lanes=3)
+    assert len(par) == len(seq) and len(many._lanes) == 2
+    for a, b in zip(seq, par):
+        assert a.shape == b.shape and torch.isfinite(b).all()
+        assert torch.equal(a, b), f"max |d| {float((a - b).abs().max()):.3e}"
+    # and again on the same lanes (workspaces kept, call counter advanced): still the one-at-a-time samples
+    seq2 = [one.tokens_to_wav(lat, wav) for lat, wav in items[:3]]
+    par2 = many.tokens_to_wav_many(items[:3], lanes=3)
+    assert all(torch.equal(a, b) for a, b in zip(seq2, par2)) and not torch.equal(seq2[0], seq[0])
+    one.close()
+    many.close()
