@@ -45,9 +45,11 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #ifndef MF_KV_LDS
 #define MF_KV_LDS 0   // measured SLOWER (profiles/r05g: 1220 vs 1160 us/step): the loop still reloads spilled registers from scratch, and a scratch reload waits -- in order -- for the whole range in flight
 #endif
-// MF_NSPLIT4: four key ranges per (utterance, row, head) between 257 and 1024 keys instead of attn_core.h's eight
-#ifndef MF_NSPLIT4
-#define MF_NSPLIT4 1
+// MF_NSPLIT: how many key ranges a (utterance, row, head) is cut into (see the geometry below): -1 = per instance -- 4 utterances: 1 | 4 | 8
+// (two workgroups share a (utterance, row, head): ceil(P / 256) ranges split 3 + 2 between them and measured no gain, r05j: 1164-1167 vs
+// 1169-1171 us/step), 8 utterances: ceil(P / 256) (one workgroup walks them all: 1859-1868 vs 1898 us/step)
+#ifndef MF_NSPLIT
+#define MF_NSPLIT -1
 #endif
 // operand row stride in LDS (elements).  4 utterances: 8 rows of a whole 5632-column activation vector (11 280 B = 2820 words = 4 banks
 // mod 32); 8 utterances: 16 rows of HALF of it (the w2 phase runs in two passes over the column halves: 16 whole rows would be 180 KB)
@@ -223,17 +225,21 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
     const int n_layer = a.n_layer;
 
     // attention: this workgroup = (utterance, row, head, part): 8 / NU workgroups per (utterance, row, head) -- decode_mega.hip's MEGA_ATTN_V2
-    // partition -- but the number of key ranges follows the context: 1 up to 256 keys, FOUR up to 1024, 8 beyond (attn_core.h always cuts
-    // 8 above 256).  A workgroup walks its ranges one after the other through one K/V register set, every range a request -> land -> score
-    // round; at 1024 keys four ranges of 4 x 8 x 32 key slots hold what eight did at half-empty slots, in half the rounds.
+    // partition -- but with FEWER key ranges than attn_core.h's 8 above 256 keys.  A workgroup walks its ranges one after the other through
+    // one K/V register set, every range a request -> land -> score round whose latency nothing hides; a range of 256 keys fills the set (8
+    // waves x 8 slots x 4 keys), so fewer, fuller ranges mean fewer rounds (4 utterances: 4 ranges up to 1024 keys, r05f: 1147-1158 vs
+    // 1174-1180 us/step; 8 utterances: ceil(P / 256) ranges, r05j).
     constexpr int BPH = 8 / NU, SPB = NU;
     const int at_u = b / (32 * BPH), at_r = (b / (16 * BPH)) & 1, at_h = (b / BPH) & 15;
 #pragma unroll
     for (int u = NU - 1; u >= 0; --u) {
         const int Pu = pos_s[u] + 1;  // keys [0, P): the cache holds [0, P-1), key P-1 is produced by this step's QKV phase
-        const int ns = Pu <= ATTN_KEYS_PER_BLOCK ? 1 : (MF_NSPLIT4 && Pu <= 4 * ATTN_KEYS_PER_BLOCK ? 4 : ATTN_NSPLIT);
+        // MF_NSPLIT: 2 = as FEW ranges as the K/V register set allows (256 keys each: 8 waves x 8 slots x 4 keys), 1 = 1 | 4 | 8, 0 = attn_core.h's 1 | 8
+        constexpr int NSM = MF_NSPLIT >= 0 ? MF_NSPLIT : (NU >= 8 ? 2 : 1);
+        const int ns = Pu <= ATTN_KEYS_PER_BLOCK ? 1 : NSM == 2 ? (Pu + ATTN_KEYS_PER_BLOCK - 1) / ATTN_KEYS_PER_BLOCK
+                                                     : (NSM == 1 && Pu <= 4 * ATTN_KEYS_PER_BLOCK ? 4 : ATTN_NSPLIT);
         const int csu = (((Pu + ns - 1) / ns) + 3) & ~3, nactu = (Pu + csu - 1) / csu;
-        if (tid == 0) { geo[0][u] = Pu; geo[1][u] = csu; geo[2][u] = nactu; geo[3][u] = attn_keys_per_wave(csu); geo[4][u] = ns > BPH ? ns / BPH : 1; }
+        if (tid == 0) { geo[0][u] = Pu; geo[1][u] = csu; geo[2][u] = nactu; geo[3][u] = attn_keys_per_wave(csu); geo[4][u] = (ns + BPH - 1) / BPH; }
     }
     __syncthreads();
     const int rpw = geo[4][at_u];                     // key ranges per workgroup of this (utterance, row, head)
