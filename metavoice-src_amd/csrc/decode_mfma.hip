@@ -45,6 +45,10 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #ifndef MF_KV_LDS
 #define MF_KV_LDS 0   // measured SLOWER (profiles/r05g: 1220 vs 1160 us/step): the loop still reloads spilled registers from scratch, and a scratch reload waits -- in order -- for the whole range in flight
 #endif
+// MF_ACT8_UPP: utterances per poll loop of the activation halves in the 8-utterance instance (4: 12 requests per lane and loop, 2: 6)
+#ifndef MF_ACT8_UPP
+#define MF_ACT8_UPP 2
+#endif
 // MF_NSPLIT: how many key ranges a (utterance, row, head) is cut into (see the geometry below): -1 = per instance -- 4 utterances: 1 | 4 | 8
 // (two workgroups share a (utterance, row, head): ceil(P / 256) ranges split 3 + 2 between them and measured no gain, r05j: 1164-1167 vs
 // 1169-1171 us/step), 8 utterances: ceil(P / 256) (one workgroup walks them all: 1859-1868 vs 1898 us/step)
@@ -163,11 +167,11 @@ __device__ __forceinline__ void mf_row_to_lds(uint32_t lds, const void* g) {
 // 16-byte polls of NCOL columns of a row-paired vector of every utterance into the operand rows: `g` = the first polled column of
 // utterance 0, GSTRIDE granules from one utterance to the next; pair n = granules 2n, 2n + 1 = columns 2n, 2n + 1 of both rows of its
 // utterance.  UPP utterances per poll loop (poll16_loads has instances up to 12 requests).
-template <int NU, int NCOL, int GSTRIDE, typename AF>
+template <int NU, int NCOL, int GSTRIDE, int UPP_MAX = 4, typename AF>
 __device__ __forceinline__ void mf_poll_rows(const gran_t* g, uint32_t tag, bf16_t* xs, AF abort_flag, int* s_abort, int tid) {
     constexpr int KP = mf_kp(NU);
     constexpr int PPT = (NCOL / 2 + MG_THREADS - 1) / MG_THREADS;   // pairs per thread and utterance: 2 (2048 columns), 3 (2816) or 6 (5632)
-    constexpr int UPP = PPT <= 3 ? 4 : 2;
+    constexpr int UPP = PPT <= 3 ? (UPP_MAX < 4 ? UPP_MAX : 4) : 2;
     static_assert(NU % UPP == 0 && PPT * UPP <= 12, "utterances per poll loop");
 #pragma unroll
     for (int u0 = 0; u0 < NU; u0 += UPP) {
@@ -647,14 +651,14 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
                     if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             } else {                   // 16 rows: the operand rows hold one column half at a time
-                mf_poll_rows<NU, MG_INTER / 2, MG_INTER>(g_act, tag0 + 3u, xs, abort_flag_of, &s_abort, tid_o);
+                mf_poll_rows<NU, MG_INTER / 2, MG_INTER, MF_ACT8_UPP>(g_act, tag0 + 3u, xs, abort_flag_of, &s_abort, tid_o);
                 __syncthreads();
                 MF_ABORT_RETURN();
 #pragma unroll
                 for (int i = 0; i < 11; ++i) lo = mf_mma(w2_r[i], mf_bfrag<R>(xs, 11 * wave_o + i, lane_o), lo);
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();       // every wave has read the first half
-                mf_poll_rows<NU, MG_INTER / 2, MG_INTER>(g_act + MG_INTER / 2, tag0 + 3u, xs, abort_flag_of, &s_abort, tid_o);
+                mf_poll_rows<NU, MG_INTER / 2, MG_INTER, MF_ACT8_UPP>(g_act + MG_INTER / 2, tag0 + 3u, xs, abort_flag_of, &s_abort, tid_o);
                 __syncthreads();
                 MF_ABORT_RETURN();
 #pragma unroll

@@ -78,6 +78,24 @@ def test_persistent_decode_kernel_has_no_scratch_and_no_flat_loads(tmp_path):
     assert seen == 12   # 3 formats x (1 utterance one-step, 2, 4) + the three one-utterance instances that draw their own tokens
 
 
+def test_matrix_core_decode_kernel_keeps_its_fragments_in_registers(tmp_path):
+    """decode_mfma.hip (round 5): the first builds of this kernel spilled 250-1400 registers -- every fragment stored to scratch right behind its
+    load, behind a full `s_waitcnt vmcnt(0)` -- until the register arrays were scoped per layer, the half tiles packed and the norm weights moved
+    to LDS.  Guard: both instances exist, run on v_mfma_f32_16x16x32_bf16, stay under a spill bound, and no streaming load is followed
+    directly by a full wait (the signature of a fragment spilled on arrival)."""
+    asm, usage = compile_to_asm("decode_mfma", tmp_path)
+    seen = {}
+    for name, body in kernel_bodies(asm, "decode_mfma_kernel"):
+        nu = re.search(r"ILi(\d)E", name).group(1)
+        seen[nu] = usage[name]
+        assert body.count("v_mfma_f32_16x16x32_bf16") >= 60, name
+        assert usage[name]["spill"] <= (64 if nu == "4" else 128), f"{name}: {usage[name]}"
+        assert not re.search(r"global_load_dwordx4 [^\n]* nt\n(?:\s*[sv]_[^\n]*\n){0,3}?\s*s_waitcnt vmcnt\(0\)\n\s*scratch_store", body), \
+            f"{name}: a fragment is spilled right behind its load (r05: the 8-utterance instance did that to 6 of its 11 w2 fragments with 12-request act polls)"
+        assert "flat_load_dwordx4" not in body, name
+    assert set(seen) == {"4", "8"}, seen
+
+
 def test_fused_lstm_keeps_its_rows_in_registers(tmp_path):
     asm, usage = compile_to_asm("lstm", tmp_path)
     names = [n for n in usage if "lstm_seq2_kernelILi8E" in n]
