@@ -273,6 +273,20 @@ int mv_spkenc_finalize(mv_spkenc* e);
 /* mels: host fp32 [n_partials][frames][n_mels]; out: host fp32 [n_partials][emb]. */
 int mv_spkenc_embed(mv_spkenc* e, const float* mels, int32_t n_partials, int32_t frames, float* out);
 
+/* ---- speaker-reference front end on the GPU: what SpeakerEncoder.embed_utterance_from_file does to the audio through librosa before the
+ * LSTM (fam/quantiser/audio/speaker_encoder/model.py:112-117, audio.py:10-22).  Host buffers in and out; filters are designed on the host
+ * (metavoice-src_amd/speaker_encoder/audio.py).
+ * mv_audio_resample : librosa.load(sr=16000)'s resampling as a polyphase FIR (scipy.signal.upfirdn's definition):
+ *                     y[m] = sum_k h[(m + n_pre_remove) * down - k * up] * x[k], m < n_out
+ * mv_audio_frame_rms: librosa.effects.trim's frame RMS: centred frames (zero padding frame_length / 2), rms_out[n_frames] in double,
+ *                     n_frames = 1 + (n + 2 (frame_length / 2) - frame_length) / hop_length
+ * mv_audio_mel      : librosa.feature.melspectrogram(power=2): centred frames of n_fft samples (zero padded), times `window`, |DFT|^2,
+ *                     times filterbank [n_mels][n_fft / 2 + 1] -> mel_out [n_frames][n_mels], n_frames = 1 + n / hop_length */
+int mv_audio_resample(const float* x, int64_t n, const float* h, int32_t taps, int32_t up, int32_t down, int64_t n_pre_remove, int64_t n_out, float* y);
+int mv_audio_frame_rms(const float* x, int64_t n, int32_t frame_length, int32_t hop_length, double* rms_out, int64_t n_frames);
+int mv_audio_mel(const float* wav, int64_t n, const float* window, const float* filterbank, int32_t n_fft, int32_t hop_length, int32_t n_mels,
+                 float* mel_out, int64_t n_frames);
+
 /* Debug hook (MV_DEBUG_VECTORS=1 in the environment at mv_finalize, MetaVoice-1B widths only): bf16 bits of every layer's
  * q | attention output | h | SwiGLU activation | x of the LAST decode step, [n_layer][5][2 rows][5632]. */
 int mv_debug_vectors(mv_engine* e, uint16_t* out, int64_t cap_elems);

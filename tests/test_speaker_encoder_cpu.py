@@ -13,6 +13,7 @@ from oracle import speaker_encoder as o_spk
 
 synthetic = load_pkg("synthetic")
 audio = load_pkg("speaker_encoder.audio")
+from oracle import audio_frontend as o_audio  # noqa: E402  (round 5: the numpy front end is the checker; the product runs it on the GPU)
 
 
 def test_oracle_forward_matches_the_reference_class():
@@ -40,6 +41,7 @@ def test_partial_slices_match_the_reference():
 def test_mel_front_end_closed_forms():
     sr, n_fft = 16000, 400
     fb = audio.mel_filterbank(sr, n_fft, 40)
+    assert np.array_equal(fb, o_audio.mel_filterbank(sr, n_fft, 40))   # the product builds the bank on the host (configuration), the oracle restates it
     assert fb.shape == (40, 201) and float(fb.min()) >= 0
     # Slaney area normalisation: every triangle integrates to ~1 over Hz (bin spacing sr / n_fft)
     area = fb.sum(axis=1) * (sr / n_fft)
@@ -50,7 +52,7 @@ def test_mel_front_end_closed_forms():
     assert abs(float(audio._hz_to_mel(1000.0)) - 15.0) < 1e-9 and abs(float(audio._mel_to_hz(15.0)) - 1000.0) < 1e-6
     # a pure tone lands in the band whose triangle covers it, frames = 1 + len // hop (centred STFT)
     t = np.arange(sr, dtype=np.float32) / sr
-    mel = audio.wav_to_mel_spectrogram(np.sin(2 * np.pi * 1000.0 * t).astype(np.float32))
+    mel = o_audio.wav_to_mel_spectrogram(np.sin(2 * np.pi * 1000.0 * t).astype(np.float32))
     assert mel.shape == (101, 40) and mel.dtype == np.float32
     band = int(mel[50].argmax())
     assert fb[band, int(round(1000.0 / (sr / n_fft)))] > 0
@@ -68,14 +70,22 @@ def test_trim_and_wav_reader(tmp_path):
     t = np.arange(sr) / sr
     tone = (0.5 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
     y = np.concatenate([np.zeros(sr, np.float32), tone, np.zeros(sr // 2, np.float32)])
-    trimmed = audio.trim_silence(y, top_db=20)
+    trimmed = o_audio.trim_silence(y, top_db=20)
     assert abs(len(trimmed) - sr) <= 2 * 2048  # the tone survives, the silence goes (frame granularity)
     path = str(tmp_path / "a.wav")
     wavfile.write(path, sr, (y * 32767).astype(np.int16))
-    x = audio.load_audio(path, sr=16000)
-    assert abs(len(x) - int(len(y) * 16000 / sr)) <= 2 and x.dtype == np.float32
+    x = audio.load_audio(path, sr=sr)   # the reader (no rate change here: the resampler runs on the GPU, tests/test_audio_front_gpu.py)
+    assert len(x) == len(y) and x.dtype == np.float32
     assert abs(float(np.abs(x).max()) - 0.5) < 0.02
-    assert audio.trim_silence(np.zeros(5000, np.float32)).size == 0
+    assert o_audio.trim_silence(np.zeros(5000, np.float32)).size == 0
+    # the resampling filter the product designs on the host is scipy.signal.resample_poly's own (firwin, Kaiser 5.0), with its alignment
+    from scipy.signal import firwin
+    for up, down in ((160, 441), (1, 3), (2, 1)):
+        h, pre = audio.resample_filter(up, down)
+        half = 10 * max(up, down)
+        n_pre_pad = down - half % down
+        assert pre == (half + n_pre_pad) // down and not h[:n_pre_pad].any()
+        assert float(np.abs(h[n_pre_pad:] - (firwin(2 * half + 1, 1.0 / max(up, down), window=("kaiser", 5.0)) * up).astype(np.float32)).max()) < 1e-7
 
 
 def test_load_audio_falls_back_to_an_installed_decoder_or_says_so(tmp_path, monkeypatch):
@@ -90,8 +100,8 @@ def test_load_audio_falls_back_to_an_installed_decoder_or_says_so(tmp_path, monk
     audio = load_pkg("speaker_encoder.audio")
     wav = tmp_path / "upload.mp3"   # a WAVE file under another name still loads
     wavfile.write(wav, 8000, (np.sin(np.arange(4000) / 7.0) * 12000).astype(np.int16))
-    x = audio.load_audio(str(wav))
-    assert x.dtype == np.float32 and x.shape == (8000,) and 0.3 < float(np.abs(x).max()) < 0.4
+    x = audio.load_audio(str(wav), sr=8000)
+    assert x.dtype == np.float32 and x.shape == (4000,) and 0.3 < float(np.abs(x).max()) < 0.4
     mp3 = tmp_path / "voice.wav"    # ...and something that is not WAVE does not, whatever it is called
     mp3.write_bytes(b"ID3\x03\x00" + bytes(range(256)) * 8)
     for m in ("soundfile", "audioread"):
@@ -103,8 +113,8 @@ def test_load_audio_falls_back_to_an_installed_decoder_or_says_so(tmp_path, monk
     fake = types.ModuleType("soundfile")
     fake.read = lambda path, dtype="float32", always_2d=False: (np.stack([np.full(32000, 0.25, np.float32), np.full(32000, 0.75, np.float32)], axis=1), 32000)
     monkeypatch.setitem(sys.modules, "soundfile", fake)
-    y = audio.load_audio(str(mp3))
-    assert y.shape == (16000,) and abs(float(y[8000]) - 0.5) < 1e-3   # stereo -> mono, 32 kHz -> 16 kHz
+    y = audio.load_audio(str(mp3), sr=32000)
+    assert y.shape == (32000,) and abs(float(y[8000]) - 0.5) < 1e-6   # stereo -> mono (32 kHz -> 16 kHz is the GPU resampler's: tests/test_audio_front_gpu.py)
 
 
 def test_get_cached_file_local_and_uri(tmp_path, monkeypatch):
@@ -222,7 +232,8 @@ def test_mel_front_end_matches_the_independent_implementation_in_the_image():
     """`fam/quantiser/audio/speaker_encoder/audio.py:15-21` is one librosa call.  librosa is not in the image; `transformers.audio_utils`
     (its numpy equivalent: `mel_filter_bank(norm="slaney", mel_scale="slaney")`, `spectrogram(center=True, pad_mode="constant",
     power=2.0)`, periodic Hann 400 / hop 160) is, and minted `tests/golden/mel_frontend.npz` (`make_frontend_golden.py`, committed).
-    The product's restated front end reproduces the filter bank exactly and the mel power spectrogram to float32 rounding."""
+    The restated front end (oracle/audio_frontend.py; the product's host-built filter bank is the same array) reproduces the filter bank
+    exactly and the mel power spectrogram to float32 rounding."""
     import importlib.util
 
     g = np.load(os.path.join(GOLDEN, "mel_frontend.npz"))
@@ -235,7 +246,7 @@ def test_mel_front_end_matches_the_independent_implementation_in_the_image():
     fb = audio.mel_filterbank(16000, 400, 40)
     assert fb.shape == g["filter_bank"].shape == (40, 201)
     assert float(np.abs(fb - g["filter_bank"]).max()) <= 1e-9
-    mel = audio.wav_to_mel_spectrogram(wav)
+    mel = o_audio.wav_to_mel_spectrogram(wav)   # the oracle is what the golden pins; the GPU kernel is held to the oracle (tests/test_audio_front_gpu.py)
     assert mel.shape == g["mel"].shape == (151, 40)
     assert float(np.abs(mel - g["mel"]).max()) <= 2e-6 * float(np.abs(g["mel"]).max())
     rel = np.abs(mel - g["mel"]) / (np.abs(g["mel"]) + 1e-6)
