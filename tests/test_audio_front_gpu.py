@@ -46,8 +46,9 @@ def test_trim_is_the_oracles():
         got, ref = audio.trim_silence(y, top_db=20), o_audio.trim_silence(y, top_db=20)
         assert got.shape == ref.shape and np.array_equal(got, ref), (lead, tail, got.shape, ref.shape)
     assert audio.trim_silence(np.zeros(5000, np.float32)).size == 0
-    assert audio.trim_silence(np.zeros(100, np.float32)).size == 100   # shorter than a frame even with the padding: returned as is, like the oracle
-    assert o_audio.trim_silence(np.zeros(100, np.float32)).size == 100
+    assert audio.trim_silence(np.zeros(100, np.float32)).size == o_audio.trim_silence(np.zeros(100, np.float32)).size == 0   # one padded frame, silent
+    short = speechlike(100, 8)
+    assert np.array_equal(audio.trim_silence(short), o_audio.trim_silence(short))
 
 
 @pytest.mark.parametrize("rate,n", [(44100, 88200), (48000, 30001), (8000, 12345), (22050, 40000), (24000, 7), (32000, 64000)])
