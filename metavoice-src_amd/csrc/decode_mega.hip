@@ -16,27 +16,6 @@
 #include <atomic>
 
 #include "mega_core.h"
-// MEGA_SOFT_BARRIER (profiling, profiles/r04ah): every workgroup barrier of this file as an LDS counter barrier (one ds_add per wave, then a
-// spin on the counter) instead of s_barrier -- what a barrier costs that does not need every wave of the workgroup (the question behind
-// dedicated loader waves).  The counter is monotonic: a wave that took ticket t waits for 8 (t / 8 + 1).
-#ifndef MEGA_SOFT_BARRIER
-#define MEGA_SOFT_BARRIER 0
-#endif
-#if MEGA_SOFT_BARRIER
-__shared__ unsigned mg_soft_bar_ctr;
-__device__ __forceinline__ void mega_soft_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    unsigned target = 0;
-    if ((threadIdx.x & 63) == 0) target = (__hip_atomic_fetch_add(&mg_soft_bar_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) / 8u + 1u) * 8u;
-    target = __builtin_amdgcn_readfirstlane(target);
-    while (__hip_atomic_load(&mg_soft_bar_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(0);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-#define MG_FIRST_BARRIER() do { if (threadIdx.x == 0) mg_soft_bar_ctr = 0u; __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); } while (0)
-#define __syncthreads() mega_soft_barrier()
-#else
-#define MG_FIRST_BARRIER() do { } while (0)
-#endif
 #include "sample_core.h"
 #include "gemv_i4_core.h"
 #include "gemv_i8_core.h"
@@ -106,27 +85,13 @@ bool mega_instrumented() { return MEGA_INSTR != 0; }
 #ifndef MEGA_K_AFTER_QKV
 #define MEGA_K_AFTER_QKV 0
 #endif
-// MEGA_XS_DB (one utterance): the GEMV operand vectors alternate between TWO LDS buffers -- x and h in `xa`, the attention vector and the
-// activation vector in `xs` -- so that a phase's poll never overwrites what the previous phase's dots may still be reading: the barrier at
-// the top of each phase (4 of a layer's 17) goes; the barrier behind each poll already separates a buffer's next writer from its last readers.
-// MEGA_PUB_BARRIER (experiment): the barrier at the top of P3 / P4 / the next P0 moved UP, between a phase's publish and its requests for the
-// next phase -- publish-before-prefetch for the whole workgroup there as well (r04ai: without the phase-top barriers the step is 16 % slower)
 // MEGA_EARLY_QKV_POS: where the LDS half of the next layer's wqkv rows is requested: 0 when the activation vector has arrived (in front of the w2
 // dots and the x publish -- round 3), 1 at the top of P4 behind the w2 remainder (in front of the act hand-off), 2 behind the x publish
 #ifndef MEGA_EARLY_QKV_POS
 #define MEGA_EARLY_QKV_POS 0
 #endif
-#ifndef MEGA_PUB_BARRIER
-#define MEGA_PUB_BARRIER 0
-#endif
-#ifndef MEGA_XS_DB
-#define MEGA_XS_DB 0
-#endif
 #ifndef MEGA_COMB_W1_LATE
 #define MEGA_COMB_W1_LATE 0
-#endif
-#ifndef MEGA_POLL_NORM
-#define MEGA_POLL_NORM 0   // one utterance: poll + RMSNorm without the LDS round trip of the raw vector (mega_poll_raw8)
 #endif
 #ifndef MEGA_KV_UNCOND
 #define MEGA_KV_UNCOND 0   // 1: every slot always requested (see issue_kv_set; measured slower, profiles/r04x)
@@ -145,9 +110,6 @@ __device__ __forceinline__ void mega_wave_sums(float (&v)[N]) {
         for (int j = 0; j < N; ++j) v[j] = wave_sum(v[j]);
     }
 }
-#ifndef MEGA_NORM_STATS8
-#define MEGA_NORM_STATS8 0   // 1: one utterance, statistics on all 8 waves (one row each).  A/B on one box: 678.5 / 677.6 vs 672.7 / 676.9 us/step with 0 (profiles/r04d)
-#endif
 #ifndef MEGA_NORM_EARLY_READ
 #define MEGA_NORM_EARLY_READ 1
 #endif
@@ -163,12 +125,7 @@ __device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x
     // (utterance, row) pair p is done by wave p, which plays the four column waves one after the other with the four chains unrolled
     // -- all 8 waves busy and no serial walk over the utterances (rolled, each row waited for its own ds_read and wave_sum:
     // 2.5 us per norm at four utterances against 0.7 at one, profiles/r03u).
-    if constexpr (NU == 1 && MEGA_NORM_STATS8) {
-        // all 8 waves: wave w plays column wave w & 3 for row w >> 2 (round 3: waves 0..3 did both rows one after the other)
-        const int r = wave >> 2, q = wave & 3;
-        const float s = wave_sum(sumsq8(*(const u32x4*)(xs[0] + r * MG_DIM + (q * 64 + lane) * 8)));
-        if (lane == 0) red[q * 2 + r] = s;
-    } else if constexpr (NU == 1) {
+    if constexpr (NU == 1) {
         // MEGA_NORM_EARLY_READ: the 8 columns a thread APPLIES are fetched in front of the barrier -- waves 0..3 apply row 0 of the very columns
         // they just summed (no second read at all), waves 4..7 read their row-1 columns while the others sum: behind the barrier hipcc had
         // the LDS read of the operand wait for the rsqrt of the total, two dependent LDS round trips
@@ -202,7 +159,7 @@ __device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x
     float rstd[NU];
     u32x4 xv[NU];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) xv[u] = (NU == 1 && !MEGA_NORM_STATS8 && MEGA_NORM_EARLY_READ) ? xv_early : *(const u32x4*)(xs[u] + r * MG_DIM + c);
+    for (int u = 0; u < NU; ++u) xv[u] = (NU == 1 && MEGA_NORM_EARLY_READ) ? xv_early : *(const u32x4*)(xs[u] + r * MG_DIM + c);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         // == block_total over the 4 column waves: wave_sum over lanes {v0, v1, v2, v3, 0, ...} is (v0 + v1) + (v2 + v3) plus exact zeros
@@ -215,35 +172,6 @@ __device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x
 #pragma unroll
     for (int u = 0; u < NU; ++u) *(u32x4*)(xs[u] + r * MG_DIM + c) = MEGA_FAKE_REDUCE == 2 ? xv[u] : rms_apply8(xv[u], rstd[u], nw);
     __syncthreads();
-}
-
-// One utterance, MEGA_POLL_NORM: the hand-off poll and the RMSNorm as one piece.  mega_poll_rowpairs + mega_norm go poll -> LDS (raw) ->
-// barrier -> statistics (LDS read) -> barrier -> apply (LDS read, LDS write) -> barrier.  Here thread t polls the four 16-byte pairs that
-// hold columns 8 (t & 255) .. + 7 of BOTH rows (threads t and t + 256 poll the same 64 bytes) and keeps row t >> 8 in registers: the
-// statistics come straight from the registers (lane l of column wave q = the same 8 columns as mega_norm / gemv.hip's prologue, the same
-// sumsq8 and the same wave_sum => the same bits), one barrier, the apply from the registers, one LDS write, one barrier.
-template <typename AF>
-__device__ __forceinline__ u32x4 mega_poll_raw8(const gran_t* g, uint32_t tag, AF abort_flag, int* s_abort, const int tid) {
-    const int r = tid >> 8, c8 = tid & 255;
-    uint32_t p0[4], p1[4];
-    wave_poll16<4>(g, tag, abort_flag, s_abort, [&](int k) { return 4 * c8 + k; },
-                   [&](auto k, int, uint32_t a0, uint32_t a1) { p0[k] = a0; p1[k] = a1; });
-    u32x4 raw;   // pair k = columns 8 c8 + 2 k, + 1: granule payloads (row 0 | row 1 << 16)
-    raw.x = r ? ((p0[0] >> 16) | (p1[0] & 0xFFFF0000u)) : ((p0[0] & 0xFFFFu) | (p1[0] << 16));
-    raw.y = r ? ((p0[1] >> 16) | (p1[1] & 0xFFFF0000u)) : ((p0[1] & 0xFFFFu) | (p1[1] << 16));
-    raw.z = r ? ((p0[2] >> 16) | (p1[2] & 0xFFFF0000u)) : ((p0[2] & 0xFFFFu) | (p1[2] << 16));
-    raw.w = r ? ((p0[3] >> 16) | (p1[3] & 0xFFFF0000u)) : ((p0[3] & 0xFFFFu) | (p1[3] << 16));
-    return raw;
-}
-__device__ __forceinline__ void mega_norm_stats_raw8(const u32x4& raw, float* red, const int tid) {
-    const float s = wave_sum(sumsq8(raw));   // wave w = column wave w & 3 of row w >> 2
-    if ((tid & 63) == 0) red[((tid >> 6) & 3) * 2 + (tid >> 8)] = s;
-}
-__device__ __forceinline__ void mega_norm_apply_raw8(const u32x4& raw, bf16_t* xs0, const u32x4& nw, const float* red, float eps, const int tid) {
-    const int r = tid >> 8, c = (tid & 255) * 8;
-    const float* rd = red + r;
-    const float tot = (rd[0] + rd[2]) + (rd[4] + rd[6]);   // == block_total over the 4 column waves (mega_norm)
-    *(u32x4*)(xs0 + r * MG_DIM + c) = rms_apply8(raw, rms_rstd(tot, MG_DIM, eps), nw);
 }
 
 // acc[i][r] += W row i (registers) . x row r (LDS), lane l covering columns 512 j + 8 l .. + 7 of chunk j
@@ -439,8 +367,7 @@ __device__ __forceinline__ void mega_poll_rowpairs(const gran_t* g, uint32_t tag
 }
 
 __host__ __device__ constexpr size_t mega_lds_bytes(int n_utt) {  // dynamic LDS of the kernel below: xs, qkv_s, sm (one per key range of the workgroup), red
-    return (size_t)n_utt * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2) + (size_t)(MEGA_ATTN_V2 ? n_utt : 1) * ATTN_WAVES * 16 * 12 * 4 + (size_t)n_utt * MG_WAVES * 2 * 4 +
-           (MEGA_XS_DB && n_utt == 1 ? (size_t)2 * MG_DIM * 2 : 0);   // xa
+    return (size_t)n_utt * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2) + (size_t)(MEGA_ATTN_V2 ? n_utt : 1) * ATTN_WAVES * 16 * 12 * 4 + (size_t)n_utt * MG_WAVES * 2 * 4;
 }
 
 // sample() + the bookkeeping of decode_n_tokens + (last step of a launch) the next launch's input rows, by the workgroup of
@@ -513,16 +440,13 @@ template <int WF, int NU, bool FOLD>  // WF: MV_W_BF16, MV_W_INT4_G128 (LM head 
                                       // FOLD: a.n_steps decode steps per launch, the token drawn inside (else one step, logits only)
 __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_kernel(const MegaArgs a) {   // hot fields by name, cold ones through KC()
     extern __shared__ __attribute__((aligned(16))) unsigned char mg_lds[];
-    MG_FIRST_BARRIER();
     // the GEMV operand of the current phase, per utterance; the residual stream is NOT kept here: a wave produces exactly the
     // columns (8 b + wave) whose residual it needs two phases later, so those ride in registers (xres / hres)
     bf16_t (*xs)[2 * MG_INTER] = (bf16_t(*)[2 * MG_INTER])mg_lds;
     bf16_t (*qkv_s)[3 * 2 * 128] = (bf16_t(*)[3 * 2 * 128])(mg_lds + (size_t)NU * 2 * MG_INTER * 2);  // q, k_new, v_new of this block's head
     float (*sm)[16][12] = (float(*)[16][12])(mg_lds + (size_t)NU * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2));  // [ranges of this workgroup][ATTN_WAVES][16][12]
     float* red = (float*)(sm + (MEGA_ATTN_V2 ? NU : 1) * ATTN_WAVES);  // [NU][MG_WAVES * 2]
-    constexpr bool PUB_B = NU == 1 && MEGA_PUB_BARRIER;
-    constexpr bool XDB = NU == 1 && MEGA_XS_DB;   // x and h live in their own buffer (see MEGA_XS_DB)
-    bf16_t (*xa)[2 * MG_INTER] = XDB ? (bf16_t(*)[2 * MG_INTER])(mg_lds + mega_lds_bytes(NU) - (size_t)2 * MG_DIM * 2) : xs;   // only xa[0][0 .. 2 MG_DIM) exists
+    bf16_t (*const xa)[2 * MG_INTER] = xs;   // x and h (the operand of P0 / P3 and of the head): the same buffer as the attention / activation vectors
     constexpr bool EARLY_ANY = mega_early_rows(WF, NU);
     constexpr bool EARLY_W2 = EARLY_ANY && MEGA_EARLY_W2, EARLY_W1 = EARLY_ANY && mega_early_w1(NU), EARLY_QKV = EARLY_ANY && MEGA_EARLY_QKV && NU == 1;
     constexpr bool W3_EARLY = EARLY_W1 && MEGA_W3_EARLY && NU == 1;
@@ -730,23 +654,17 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         constexpr bool V_LATE = ((MEGA_V_AFTER_QKV >> (NU >> 1)) & 1) && !KV_UNCOND && !MEGA_KV_EARLY && !MEGA_KV_AFTER_NORM;   // bit 0 | 1 | 2: 1 | 2 | 4 utterances
 
         // ================= P0: RMSNorm + wqkv (+ KV-cache write)        fast_model.py:179,209,218 ====================
-        if (!XDB && !(PUB_B && l > 0)) __syncthreads();
+        __syncthreads();
         MG_STAMP(l, 0);
-        constexpr bool PN = NU == 1 && MEGA_POLL_NORM;   // mega_poll_raw8: the polled vector stays in registers through its norm
-        const bool pn_here = PN && l > 0;                 // layer 0's input rows are built in LDS
-        u32x4 raw_x = {0u, 0u, 0u, 0u};
         if (l == 0) {
             if (step == 0) {
 #pragma unroll
                 for (int u = 0; u < NU; ++u)
                     *(u32x4*)(xa[u] + tid * 8) = load16(KC(step)->x_in + (size_t)u * 2 * MG_DIM + tid * 8);  // written by the sampler in the previous launch
             }  // later steps: built at the end of the previous step from the control word
-        } else if constexpr (PN) raw_x = mega_poll_raw8(g_x, tag0 - 8u + 4u, abort_flag_of, &s_abort, tid_o);
-        else mega_poll_rowpairs<NU>(g_x, tag0 - 8u + 4u, xa, abort_flag_of, &s_abort, tid_o);
-        if (!pn_here) {
-            __syncthreads();
-            MG_ABORT_RETURN();
-        }
+        } else mega_poll_rowpairs<NU>(g_x, tag0 - 8u + 4u, xa, abort_flag_of, &s_abort, tid_o);
+        __syncthreads();
+        MG_ABORT_RETURN();
         MG_STAMP(l, 1);
         // The K/V stream of the first attention slice is requested here, before the norm and the wqkv dots: it lands while they
         // run.  (Requested after the q/k/v publish instead it sits in front of the q/k/v poll: 831 vs 794 us/step.)
@@ -762,13 +680,6 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         if (!MEGA_KV_AFTER_NORM && (first_att >= 0 || KV_UNCOND) && kv_here) issue_kv(max(first_att, 0), l);
         __builtin_amdgcn_sched_barrier(0);
         MG_STAMP(l, 11);  // K/V requested
-        if (pn_here) {
-            mega_norm_stats_raw8(raw_x, red, tid_p);
-            __syncthreads();
-            MG_ABORT_RETURN();
-            mega_norm_apply_raw8(raw_x, xa[0], nw_attn, red, a.eps, tid_p);
-            __syncthreads();
-        } else
         mega_norm<NU>(xa, nw_attn, red, a.eps, tid_p);
         MG_STAMP(l, 12);  // norm done
         if (MEGA_KV_AFTER_NORM && (first_att >= 0 || KV_UNCOND) && kv_here) { issue_kv(max(first_att, 0), l); __builtin_amdgcn_sched_barrier(0); }
@@ -1092,7 +1003,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         __builtin_amdgcn_sched_barrier(0);
 
         // ================= P2: h = x + wo(attn)                         fast_model.py:224-226,179 =====================
-        if (!XDB) __syncthreads();
+        __syncthreads();
         MG_STAMP(l, 4);
         {
             // granule i of utterance u = elements 2i, 2i+1 of its [2][2048] attention output
@@ -1139,7 +1050,6 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 17);  // h published
-            if (PUB_B) __syncthreads();
             // next: the w3 rows (w1 is already in flight) -- unless they went out with w1 (MEGA_W3_EARLY)
             if (!W3_EARLY) request_w3(0, 3 - W3_AT_QKV);
             if (MEGA_KV_EARLY && first_att >= 0 && l + 1 < n_layer) issue_kv(first_att, l + 1);
@@ -1147,16 +1057,17 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         }
 
         // ================= P3: act = silu(w1 n(h)) * w3 n(h)            fast_model.py:180,237 =========================
-        if (!XDB && !PUB_B) __syncthreads();
+        __syncthreads();
         MG_STAMP(l, 6);
         {
+            // An unused 16-byte local: the register allocation of the one-utterance bf16 instance depends on its presence (206 vs 209 VGPRs,
+            // 62 vs 70 SGPR spills without it; the ISA comparison of tests/test_isa_regressions_cpu.py's recipe).  Left from round 4's
+            // MEGA_POLL_NORM experiment (tools/experiments/decode_mega_r04_switches.patch); remove only together with a measurement.
             u32x4 raw_h = {0u, 0u, 0u, 0u};
-            if constexpr (PN) raw_h = mega_poll_raw8(g_h, tag0 + 2u, abort_flag_of, &s_abort, tid_o);
-            else {
-                mega_poll_rowpairs<NU>(g_h, tag0 + 2u, xa, abort_flag_of, &s_abort, tid_o);
-                __syncthreads();
-                MG_ABORT_RETURN();
-            }
+            (void)raw_h;
+            mega_poll_rowpairs<NU>(g_h, tag0 + 2u, xa, abort_flag_of, &s_abort, tid_o);
+            __syncthreads();
+            MG_ABORT_RETURN();
             MG_STAMP(l, 7);
             auto request_w2_early = [&]() {  // chunks 0..EW2-1 of the w2 row on their way while the norm, the w1|w3 dots and the act publish run
 #pragma unroll
@@ -1164,13 +1075,6 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                     mega_row_to_lds(lds_addr(w2_lds + ((wave_o * EW2 + j) * 64)), L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8, MG_ABLATE);
             };
             if constexpr (EARLY_W2 && !MEGA_EW2_AFTER_NORM) request_w2_early();
-            if constexpr (PN) {
-                mega_norm_stats_raw8(raw_h, red, tid_p);
-                __syncthreads();
-                MG_ABORT_RETURN();
-                mega_norm_apply_raw8(raw_h, xa[0], nw_ffn, red, a.eps, tid_p);
-                __syncthreads();
-            } else
             mega_norm<NU>(xa, nw_ffn, red, a.eps, tid_p);
             if constexpr (EARLY_W2 && MEGA_EW2_AFTER_NORM) { request_w2_early(); __builtin_amdgcn_sched_barrier(0); }
             MG_STAMP(l, 18);  // norm done
@@ -1228,7 +1132,6 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 20);  // act published
-            if (PUB_B) __syncthreads();
             // next: w2 row 8 b + wave (K = 5632: 11 chunks)
             if (I4) mega_issue_row_i4<3>(cq + 6, cz + 6, L.q[4], L.sz[4], 8 * b + wave_o, MG_INTER, lane_o);
             else if (I8) { mega_issue_row_i8<6>(cq, L.q8[4], 8 * b + wave_o, MG_INTER, lane_o); sc_c = bf2f(load_global_u16(L.s8[4] + (8 * b + wave_o))); }
@@ -1252,7 +1155,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         }
 
         // ================= P4: x = h + w2(act)                          fast_model.py:247,180 =========================
-        if (!XDB && !PUB_B) __syncthreads();
+        __syncthreads();
         MG_STAMP(l, 8);
         {
             // 16-byte polls carrying two granules (each half validated by its own tag): 5632 / 2 = 2816 pairs per utterance, 6 per
@@ -1310,7 +1213,6 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (PUB_B && l + 1 < n_layer) __syncthreads();
             if constexpr (EARLY_QKV && MEGA_EARLY_QKV_POS == 2) request_qkv_early();   // behind the x publish
             // next: the following layer's wqkv rows, or the LM-head rows 11 b + wave + 8 i
             if (MEGA_KV_AFTER_NORM) nw_attn = load16((l + 1 < n_layer ? MG_LAYER(l + 1).attn_norm : KC(l)->final_norm) + (tid_o & 255) * 8);
@@ -1344,19 +1246,10 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     // ================= LM head on the last position: logits = head(norm(x))     fast_model.py:161-162 =================
     const uint32_t tag_head = epoch + (uint32_t)n_layer * 8u + 1u;
     __syncthreads();
-    if constexpr (NU == 1 && MEGA_POLL_NORM) {
-        const u32x4 raw_f = mega_poll_raw8(g_x, epoch + (uint32_t)(n_layer - 1) * 8u + 1u + 4u, [&]() { return KC(step)->abort_flag; }, &s_abort, tid);
-        mega_norm_stats_raw8(raw_f, red, tid);
-        __syncthreads();
-        MG_ABORT_RETURN();
-        mega_norm_apply_raw8(raw_f, xa[0], nw_attn, red, a.eps, tid);
-        __syncthreads();
-    } else {
     mega_poll_rowpairs<NU>(g_x, epoch + (uint32_t)(n_layer - 1) * 8u + 1u + 4u, xa, [&]() { return KC(step)->abort_flag; }, &s_abort, tid);
     __syncthreads();
     MG_ABORT_RETURN();
     mega_norm<NU>(xa, nw_attn, red, a.eps, tid);
-    }
 #pragma unroll 1
     for (int u = 0; u < NU; ++u) {
         float acc[2][2];
