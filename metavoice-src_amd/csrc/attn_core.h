@@ -5,14 +5,6 @@
 // outputs).
 //
 #pragma once
-// profiling only: every hand-off wait is satisfied by its first look (results are garbage) -- the weight stream of the persistent kernel
-// with a zero-latency dependency chain
-#ifndef ATTN_SKIP_SLOTS
-#define ATTN_SKIP_SLOTS 1
-#endif
-#ifndef MEGA_FREE_RUN
-#define MEGA_FREE_RUN 0
-#endif
 #include "common.h"
 #include "kernels.h"
 
@@ -77,7 +69,7 @@ __device__ __forceinline__ AttnAcc attn_wave_partial(const u32x4 (&kv)[ATTN_U], 
     a.m = -INFINITY;
     // slots past the wave's key range (wave-uniform) are skipped: they are all masked (score -inf, weight 0, nothing added), so the bits
     // are the same -- at 1024 positions a wave holds 16 keys in 4 of its 8 slots
-    const int nslot = ATTN_SKIP_SLOTS ? __builtin_amdgcn_readfirstlane((s1 - s0 + 3) >> 2) : ATTN_U;
+    const int nslot = __builtin_amdgcn_readfirstlane((s1 - s0 + 3) >> 2);
 #pragma unroll
     for (int u = 0; u < ATTN_U; ++u) {
         sc[u] = -INFINITY;
@@ -253,14 +245,12 @@ __device__ __forceinline__ bool attn_combine_tagged(AttnAcc& b, const u64* slots
               "=&v"(v[1][3]), "=&v"(v[1][4])
             : "v"(p0), "v"(p0d), "v"(p1), "v"(p1d)
             : "memory");
-#if !defined(MEGA_POLL_SCOREBOARD) || MEGA_POLL_SCOREBOARD
         __builtin_amdgcn_s_waitcnt(0x0F70);   // compiler-visible vmcnt(0) behind the asm's own: see mega_core.h, mega_loads_have_landed
-#endif
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int k = 0; k < 5; ++k) ok = ok && v[q][k].y == tag && v[q][k].w == tag;
-        if (MEGA_FREE_RUN || __all(ok)) {
+        if (__all(ok)) {
             float ms[2], ls[2], t[2][8];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {

@@ -316,7 +316,7 @@ int upload_conv_weight(Conv& cv, const float* w) {
 
 hipError_t run_conv(hipStream_t s, const Conv& cv, const float* in, float* out, int T, bool accumulate) {
     ConvArgs a{in, cv.w, cv.b, out, cv.cin, cv.cout, cv.coutp, cv.k, cv.dil, T, accumulate ? 1 : 0};
-    if (!getenv("MV_CODEC_VALU") && (cv.cin * cv.k) % 2 == 0) {   // fp32 matrix cores
+    if ((cv.cin * cv.k) % 2 == 0) {   // fp32 matrix cores (an odd reduction length -- no such layer in EnCodec 24 kHz -- takes the VALU kernels below)
         if (!cv.transposed) {
             if (cv.coutp >= 64) hipLaunchKernelGGL((conv1d_mfma_kernel<2, 2>), dim3((T + 255) / 256, (cv.coutp + 63) / 64), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((conv1d_mfma_kernel<1, 4>), dim3((T + 511) / 512, cv.coutp / 32), dim3(256), 0, s, a);

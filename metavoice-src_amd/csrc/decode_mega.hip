@@ -59,63 +59,8 @@ bool mega_instrumented() { return MEGA_INSTR != 0; }
 // each, of both rows of every utterance; every thread holds its columns in registers across the two barriers).
 // The norm weights `nw` (columns 8 tid .. 8 tid + 7) are requested by the caller a phase ahead: loaded here, their load would
 // return in order behind the K/V and weight requests already in flight and the norm would wait ~2 us for data it does not need.
-// profiling only (results are garbage): MEGA_FAKE_REDUCE = 1: the 64-lane sums of the GEMV epilogues (wqkv, wo, w1|w3, w2, head) cost one
-// v_readlane instead of six DPP adds + one; 2: additionally the RMSNorm apply is skipped.  Upper bounds for what a cheaper reduction / norm
-// could give (profiles/r04t).
-#ifndef MEGA_FAKE_REDUCE
-#define MEGA_FAKE_REDUCE 0
-#endif
-// MEGA_QKV_AT_P4 = 1 | 2: that many of the two REGISTER chunks of the next layer's wqkv rows are requested at the top of P4, behind the
-// register part of the w2 row and in front of the act poll -- the act hand-off (3.3 us with nothing in front of it) has room behind the
-// w2 remainder (12.6 MB, 2.2 us), while the x hand-off has all 25 MB of wqkv between "act ready" and "x ready" (profiles/r04_final/ablate.txt).
-// The w2 register chunks move to wv[12..17] (the w3 registers, free after P3's dots) so that wv[4 i + 2 | 3] are free for them.
-#ifndef MEGA_QKV_AT_P4
-#define MEGA_QKV_AT_P4 0
-#endif
-// MEGA_V_AFTER_QKV (bit mask over 1 | 2 | 4 utterances): only the K rows are requested at "x ready"; the V rows follow behind the q/k/v publish, in front of the
-// q/k/v hand-off.  The K/V burst of all 256 workgroups (8 MB at 1024 positions) drains at HBM speed and the memory pipeline takes
-// requests only as fast as it drains them: every wave spends ~2.4 us in front of its norm issuing them (profiles/r04g, r04x).
-#ifndef MEGA_V_AFTER_QKV
-#define MEGA_V_AFTER_QKV 7
-#endif
-// experiments (profiles/r04ac): the early w2 chunks requested behind P3's norm instead of in front of it; K rows late as well
-#ifndef MEGA_EW2_AFTER_NORM
-#define MEGA_EW2_AFTER_NORM 0
-#endif
-#ifndef MEGA_K_AFTER_QKV
-#define MEGA_K_AFTER_QKV 0
-#endif
-// MEGA_EARLY_QKV_POS: where the LDS half of the next layer's wqkv rows is requested: 0 when the activation vector has arrived (in front of the w2
-// dots and the x publish -- round 3), 1 at the top of P4 behind the w2 remainder (in front of the act hand-off), 2 behind the x publish
-#ifndef MEGA_EARLY_QKV_POS
-#define MEGA_EARLY_QKV_POS 0
-#endif
-#ifndef MEGA_COMB_W1_LATE
-#define MEGA_COMB_W1_LATE 0
-#endif
-#ifndef MEGA_KV_UNCOND
-#define MEGA_KV_UNCOND 0   // 1: every slot always requested (see issue_kv_set; measured slower, profiles/r04x)
-#endif
-#ifndef MEGA_SUMS_INTERLEAVED
-#define MEGA_SUMS_INTERLEAVED 1   // 0: one wave_sum after the other (round 3)
-#endif
 template <int N>
-__device__ __forceinline__ void mega_wave_sums(float (&v)[N]) {
-    if (MEGA_FAKE_REDUCE) {
-#pragma unroll
-        for (int j = 0; j < N; ++j) v[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[j]), 63));
-    } else if (MEGA_SUMS_INTERLEAVED) wave_sum_n<N>(v);
-    else {
-#pragma unroll
-        for (int j = 0; j < N; ++j) v[j] = wave_sum(v[j]);
-    }
-}
-#ifndef MEGA_NORM_EARLY_READ
-#define MEGA_NORM_EARLY_READ 1
-#endif
-#ifndef MEGA_NORM_DIRECT_TOTAL
-#define MEGA_NORM_DIRECT_TOTAL 1
-#endif
+__device__ __forceinline__ void mega_wave_sums(float (&v)[N]) { wave_sum_n<N>(v); }   // the N 64-lane sums of an epilogue, their DPP chains interleaved
 template <int NU>
 __device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x4& nw, float* red, float eps, const int tid) {
     const int lane = tid & 63, wave = tid >> 6;   // tid: the caller's (possibly opaque) thread id -- see the layer loop
@@ -126,7 +71,7 @@ __device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x
     // -- all 8 waves busy and no serial walk over the utterances (rolled, each row waited for its own ds_read and wave_sum:
     // 2.5 us per norm at four utterances against 0.7 at one, profiles/r03u).
     if constexpr (NU == 1) {
-        // MEGA_NORM_EARLY_READ: the 8 columns a thread APPLIES are fetched in front of the barrier -- waves 0..3 apply row 0 of the very columns
+        // the 8 columns a thread APPLIES are fetched in front of the barrier -- waves 0..3 apply row 0 of the very columns
         // they just summed (no second read at all), waves 4..7 read their row-1 columns while the others sum: behind the barrier hipcc had
         // the LDS read of the operand wait for the rsqrt of the total, two dependent LDS round trips
         if (tid < MG_DIM / 8) {
@@ -134,10 +79,10 @@ __device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x
             const u32x4 x0 = *(const u32x4*)(xs[0] + tid * 8), x1 = *(const u32x4*)(xs[0] + MG_DIM + tid * 8);
             s[0] = sumsq8(x0);
             s[1] = sumsq8(x1);
-            if (MEGA_NORM_EARLY_READ) xv_early = x0;
+            xv_early = x0;
             wave_sum_n<2>(s);
             if (lane == 0) { red[wave * 2] = s[0]; red[wave * 2 + 1] = s[1]; }
-        } else if (MEGA_NORM_EARLY_READ) xv_early = *(const u32x4*)(xs[0] + MG_DIM + (tid & 255) * 8);
+        } else xv_early = *(const u32x4*)(xs[0] + MG_DIM + (tid & 255) * 8);
     } else {
         if (wave < 2 * NU) {
             const int u = wave >> 1, r = wave & 1;
@@ -159,18 +104,17 @@ __device__ __forceinline__ void mega_norm(bf16_t (*xs)[2 * MG_INTER], const u32x
     float rstd[NU];
     u32x4 xv[NU];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) xv[u] = (NU == 1 && MEGA_NORM_EARLY_READ) ? xv_early : *(const u32x4*)(xs[u] + r * MG_DIM + c);
+    for (int u = 0; u < NU; ++u) xv[u] = NU == 1 ? xv_early : *(const u32x4*)(xs[u] + r * MG_DIM + c);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         // == block_total over the 4 column waves: wave_sum over lanes {v0, v1, v2, v3, 0, ...} is (v0 + v1) + (v2 + v3) plus exact zeros
         // (common.h: xor-1, xor-2, then mirrors and row broadcasts that only add zeros) -- the same bits without the 7-deep DPP chain
         const float* rd = red + u * 2 * MG_WAVES + r;
-        const float tot = MEGA_NORM_DIRECT_TOTAL ? (rd[0] + rd[2]) + (rd[4] + rd[6])
-                                                 : wave_sum(lane < MG_DIM / 8 / 64 ? red[u * 2 * MG_WAVES + lane * 2 + r] : 0.f);
+        const float tot = (rd[0] + rd[2]) + (rd[4] + rd[6]);
         rstd[u] = rms_rstd(tot, MG_DIM, eps);
     }
 #pragma unroll
-    for (int u = 0; u < NU; ++u) *(u32x4*)(xs[u] + r * MG_DIM + c) = MEGA_FAKE_REDUCE == 2 ? xv[u] : rms_apply8(xv[u], rstd[u], nw);
+    for (int u = 0; u < NU; ++u) *(u32x4*)(xs[u] + r * MG_DIM + c) = rms_apply8(xv[u], rstd[u], nw);
     __syncthreads();
 }
 
@@ -209,8 +153,7 @@ __device__ __forceinline__ void mega_issue_row(u32x4* wv, const bf16_t* w, int n
 // half is requested where all of it used to be.  Round 2 measured W1 + W2 together: 704.9 vs 717-721 us/step, identical bits.
 //   MEGA_EARLY_W2 : chunks 0..4 of the wave's w2 row, after "h ready", consumed from LDS in P4
 //   MEGA_EARLY_W1 : chunks 0, 1 of each of the wave's 3 w1 rows, after "q/k/v ready", consumed from LDS in P3
-//   MEGA_EARLY_QKV: chunks 0, 1 of each of the wave's 3 wqkv rows of the NEXT layer, after "act ready", consumed from LDS in P0
-//                   (shares the W1 slots: those are dead between P3's dots and the next layer's "q/k/v ready")
+// (The same for the next layer's wqkv rows, after "act ready", measured slower: tools/experiments/decode_mega_r04_switches.patch.)
 // Visibility: a wave reads only LDS slots it requested itself, and between every request and its first read sits one of the
 // wave's hand-off polls, whose asm statement ends in `s_waitcnt vmcnt(0)` (mega_core.h: poll16_loads) -- loads retire in order,
 // so the rows have landed.  Every early `return` of the kernel drains the wave's requests first (MG_ABORT_RETURN): a row landing
@@ -221,40 +164,6 @@ __device__ __forceinline__ void mega_issue_row(u32x4* wv, const bf16_t* w, int n
 #ifndef MEGA_EARLY_W2
 #define MEGA_EARLY_W2 1
 #endif
-#ifndef MEGA_EARLY_QKV
-#define MEGA_EARLY_QKV 0
-#endif
-#ifndef MEGA_NU_EARLY_KV
-#define MEGA_NU_EARLY_KV 0
-#endif
-// MEGA_KV_AFTER_NORM: the first attention slice's K/V rows are requested AFTER the RMSNorm of P0 instead of before it.  Before the
-// norm the requests sit behind the 96 KB of wqkv rows still draining from the end of the previous layer, so the wave is stalled in
-// the issue (2.3 us, profiles/r02b_fold/stamps_final.txt) with the norm still to do; the norm needs only LDS and the norm weights
-// (requested AHEAD of the wqkv rows in this mode), so it can run while the backlog drains.
-#ifndef MEGA_KV_AFTER_NORM
-#define MEGA_KV_AFTER_NORM 0
-#endif
-// MEGA_W3_EARLY (bf16, one utterance, with MEGA_EARLY_W1): the w3 rows are requested together with the register half of w1 -- after the
-// workgroup's attention partial / output has been published -- instead of after the h publish.  From there to "h published" a layer
-// spends ~5 us (split-partial exchange, combine, attention-vector exchange, wo dots) in which only w1's 12 MB per chip were in
-// flight, and the w3 requests then stalled for 2.25 us in front of the h poll (profiles/r04a/stamps_1utt.txt).  Registers: with the
-// first two chunks of every w1 row in LDS, wv[0], [1], [4], [5], [8], [9] are unused; the wo row moves there (wv[0], [1], [4], [5]) and
-// wv[12..23] are free for w3 a whole phase earlier.
-#ifndef MEGA_W3_EARLY
-#define MEGA_W3_EARLY 0
-#endif
-// MEGA_KV_EARLY: the first attention slice's K/V rows of layer l + 1 (rows of EARLIER steps: independent of this step) are requested
-// right behind the h publish of layer l -- the kv / vv registers are free from the end of layer l's attention on -- instead of at the top
-// of layer l + 1, where they queued behind the 25 MB of wqkv rows and stalled the wave for 2.4 us in front of the norm.  With
-// MEGA_W3_EARLY the hand-off of h has nothing else in flight.  Layer 0's slice is requested where it always was.
-#ifndef MEGA_KV_EARLY
-#define MEGA_KV_EARLY 0
-#endif
-// Two more placements, both about keeping the memory system quiet while a hand-off is in the air (one utterance, experiments):
-//   MEGA_W1_AFTER_ATTN: the register half of w1 (+ the ffn norm weights) is requested when the attention vector HAS ARRIVED (in front of the
-//                       wo dots) instead of behind the workgroup's attention partial -- nothing streams during the split-partial and the
-//                       attention-vector hops;
-//   MEGA_WO_AFTER_QKV:  the wo row is requested when q / k / v have arrived instead of in front of their poll.
 // how far the loops over the utterances of an engine of 2 / 4 are unrolled in the wqkv (P0) and w1|w3 (P3) phases: 1 = rolled (round 2:
 // unrolled they interleaved the utterances' temporaries and spilled 60-190 VGPRs; with the launch arguments out of the way 2 fits)
 // Round 4, with the epilogue sums interleaved (wave_sum_n): 2 gains a little (r04ak: two utterances 887 -> 881 us/step, four 1266 -> 1261) -- two
@@ -265,18 +174,7 @@ __device__ __forceinline__ void mega_issue_row(u32x4* wv, const bf16_t* w, int n
 #ifndef MEGA_NU_UNROLL_P3
 #define MEGA_NU_UNROLL_P3 2
 #endif
-// MEGA_W3_QKV_ROWS (one utterance, bf16): that many of the wave's three w3 rows are requested together with the wo row, under the q / k / v
-// hand-off (8 MB of wo in a ~2 us hop leave room), the rest behind the h publish as before (23 MB there: the hop is stream-bound).
-#ifndef MEGA_W3_QKV_ROWS
-#define MEGA_W3_QKV_ROWS 0
-#endif
-#ifndef MEGA_W1_AFTER_ATTN
-#define MEGA_W1_AFTER_ATTN 0
-#endif
-#ifndef MEGA_WO_AFTER_QKV
-#define MEGA_WO_AFTER_QKV 0
-#endif
-// MEGA_ATTN_V2 (engines of 2 / 4 utterances).  Round 3 gave every workgroup one key range of (row, head) of EVERY utterance and walked
+// Attention of the engines of 2 / 4 utterances (ATTN_V2 below).  Round 3 gave every workgroup one key range of (row, head) of EVERY utterance and walked
 // the utterances one after the other: K/V slice requested, landed, scored, merged, published, the next slice requested -- 16.6 us of a
 // 60 us layer at four utterances, with the memory system idle for most of it (profiles/r04a/stamps_4utt.txt).  Now a workgroup belongs
 // to ONE (utterance, row, head) and owns NU consecutive key ranges of it (8 / NU workgroups per (utterance, row, head)): the ranges are
@@ -285,19 +183,12 @@ __device__ __forceinline__ void mega_issue_row(u32x4* wv, const bf16_t* w, int n
 // sets (kv / vv, and the weight registers wv[0..7] / wv[16..23], idle between the wqkv dots and the w1 request): the next range's rows
 // are in flight while the current one is scored, the wave partials of all ranges wait in LDS for ONE merge (wave j merges range j) and
 // ONE publish, and each (utterance, row, head) is combined once, by the workgroup of its first ranges.
-#ifndef MEGA_ATTN_V2
-#define MEGA_ATTN_V2 1
-#endif
-// Engines of 2 / 4 utterances (round 4, MEGA_EARLY_NU): two utterances have the LDS for both (62 + 88 KB); four only for FOUR chunks of
-// the w2 row (121 + 32 KB of 160) -- "P4 top (w2 requested)" was a 3.1 us issue stall per layer there (profiles/r04h).
-#ifndef MEGA_EARLY_NU
-#define MEGA_EARLY_NU 0   // measured: 4 utterances 1375 vs 1339 us/step, 2 utterances 956 vs 926 (profiles/r04m) -- off
-#endif
+// One utterance only: for engines of 2 / 4 utterances the same early rows measured slower (1375 vs 1339, 956 vs 926 us/step, profiles/r04m).
 #ifndef MEGA_EW2_CHUNKS
 #define MEGA_EW2_CHUNKS 5   // of the 11 chunks of a w2 row (profiles/r04ae: 7 and 9 measured)
 #endif
-__host__ __device__ constexpr int mega_early_w2_chunks(int nu) { return nu == 4 ? 4 : MEGA_EW2_CHUNKS; }
-__host__ __device__ constexpr bool mega_early_w1(int nu) { return MEGA_EARLY_W1 && nu <= 2; }
+__host__ __device__ constexpr int mega_early_w2_chunks(int) { return MEGA_EW2_CHUNKS; }
+__host__ __device__ constexpr bool mega_early_w1(int) { return MEGA_EARLY_W1 != 0; }
 #define MEGA_EARLY_W1_BYTES (MG_WAVES * 6 * 1024)
 __device__ __forceinline__ void mega_row_to_lds(uint32_t lds, const bf16_t* g, int ablate = 0) {  // 64 lanes x 16 B -> 1 KB of LDS at `lds`
     if (ablate & 1) return;  // profiling only (mv_tune gemv_ablate bit 0): no weight requests at all, results are garbage
@@ -306,10 +197,10 @@ __device__ __forceinline__ void mega_row_to_lds(uint32_t lds, const bf16_t* g, i
                  : "=&s"(m0_save) : "s"(lds), "v"(g) : "memory");
 }
 __host__ __device__ constexpr bool mega_early_rows(int wf, int nu) {
-    return wf == MV_W_BF16 && (nu == 1 || (MEGA_EARLY_NU && (nu == 2 || nu == 4))) && (MEGA_EARLY_W1 || MEGA_EARLY_W2 || MEGA_EARLY_QKV);
+    return wf == MV_W_BF16 && nu == 1 && (MEGA_EARLY_W1 || MEGA_EARLY_W2);
 }
 __host__ __device__ constexpr size_t mega_early_lds_bytes(int wf, int nu) {   // the LDS slots of the early rows, behind mega_lds_bytes(nu)
-    return !mega_early_rows(wf, nu) ? 0 : (size_t)(MEGA_EARLY_W2 ? MG_WAVES * mega_early_w2_chunks(nu) * 1024 : 0) + (mega_early_w1(nu) || MEGA_EARLY_QKV ? MEGA_EARLY_W1_BYTES : 0);
+    return !mega_early_rows(wf, nu) ? 0 : (size_t)(MEGA_EARLY_W2 ? MG_WAVES * mega_early_w2_chunks(nu) * 1024 : 0) + (mega_early_w1(nu) ? MEGA_EARLY_W1_BYTES : 0);
 }
 
 // int4 (group-128) weight rows: per 2048-column chunk a lane requests 16 B of codes (32 columns) and the (scale, zero) word of
@@ -367,7 +258,7 @@ __device__ __forceinline__ void mega_poll_rowpairs(const gran_t* g, uint32_t tag
 }
 
 __host__ __device__ constexpr size_t mega_lds_bytes(int n_utt) {  // dynamic LDS of the kernel below: xs, qkv_s, sm (one per key range of the workgroup), red
-    return (size_t)n_utt * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2) + (size_t)(MEGA_ATTN_V2 ? n_utt : 1) * ATTN_WAVES * 16 * 12 * 4 + (size_t)n_utt * MG_WAVES * 2 * 4;
+    return (size_t)n_utt * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2) + (size_t)n_utt * ATTN_WAVES * 16 * 12 * 4 + (size_t)n_utt * MG_WAVES * 2 * 4;
 }
 
 // sample() + the bookkeeping of decode_n_tokens + (last step of a launch) the next launch's input rows, by the workgroup of
@@ -445,16 +336,13 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     bf16_t (*xs)[2 * MG_INTER] = (bf16_t(*)[2 * MG_INTER])mg_lds;
     bf16_t (*qkv_s)[3 * 2 * 128] = (bf16_t(*)[3 * 2 * 128])(mg_lds + (size_t)NU * 2 * MG_INTER * 2);  // q, k_new, v_new of this block's head
     float (*sm)[16][12] = (float(*)[16][12])(mg_lds + (size_t)NU * (2 * MG_INTER * 2 + 3 * 2 * 128 * 2));  // [ranges of this workgroup][ATTN_WAVES][16][12]
-    float* red = (float*)(sm + (MEGA_ATTN_V2 ? NU : 1) * ATTN_WAVES);  // [NU][MG_WAVES * 2]
+    float* red = (float*)(sm + NU * ATTN_WAVES);  // [NU][MG_WAVES * 2]
     bf16_t (*const xa)[2 * MG_INTER] = xs;   // x and h (the operand of P0 / P3 and of the head): the same buffer as the attention / activation vectors
     constexpr bool EARLY_ANY = mega_early_rows(WF, NU);
-    constexpr bool EARLY_W2 = EARLY_ANY && MEGA_EARLY_W2, EARLY_W1 = EARLY_ANY && mega_early_w1(NU), EARLY_QKV = EARLY_ANY && MEGA_EARLY_QKV && NU == 1;
-    constexpr bool W3_EARLY = EARLY_W1 && MEGA_W3_EARLY && NU == 1;
+    constexpr bool EARLY_W2 = EARLY_ANY && MEGA_EARLY_W2, EARLY_W1 = EARLY_ANY && mega_early_w1(NU);
     constexpr int EW2 = mega_early_w2_chunks(NU);   // chunks of the w2 row that go to LDS early
-    constexpr int QKV_P4 = (EARLY_QKV && EARLY_W2) ? MEGA_QKV_AT_P4 : 0;
-    constexpr int W2R0 = QKV_P4 ? 12 - EW2 : 0;     // register chunk j of the w2 row lives in wv[W2R0 + j]
     u32x4* w2_lds = (u32x4*)(mg_lds + mega_lds_bytes(NU));                                                        // [MG_WAVES][EW2 chunks][64 lanes]
-    u32x4* w1_lds = (u32x4*)(mg_lds + mega_lds_bytes(NU) + (MEGA_EARLY_W2 ? MG_WAVES * EW2 * 1024 : 0));  // [MG_WAVES][3 rows x 2 chunks][64 lanes]; wqkv rows of the next layer between P4 and P0
+    u32x4* w1_lds = (u32x4*)(mg_lds + mega_lds_bytes(NU) + (MEGA_EARLY_W2 ? MG_WAVES * EW2 * 1024 : 0));  // [MG_WAVES][3 rows x 2 chunks][64 lanes]
     bool w1_half_issued = false;
     auto lds_addr = [&](const u32x4* p) { return __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p); };
     __shared__ int s_abort;
@@ -484,14 +372,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     // pointer hipcc fetched the pointers with vector loads next to their uses (global_load_dwordx2 + v_readfirstlane) and waited for them
     // with `s_waitcnt vmcnt(0)` -- i.e. for every weight row in flight -- in front of the address arithmetic of the next requests.
 #define MG_LAYER(i) (*((const __attribute__((address_space(4))) MegaLayer*)(a.layers) + (i)))
-#ifndef MEGA_ABORT_LDS
-#define MEGA_ABORT_LDS 0
-#endif
-#if MEGA_ABORT_LDS
-#define MG_ABORTED() (*(volatile __attribute__((address_space(3))) int*)(__attribute__((address_space(3))) int*)&s_abort != 0)
-#else
 #define MG_ABORTED() (*(volatile int*)&s_abort != 0)
-#endif
 #define MG_ABORT_RETURN() do { if (MG_ABORTED()) { if (EARLY_ANY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; } } while (0)
     if (fold) {  // a launch queued behind the one in which the last utterance ended: nothing to do
         bool all_done = true;
@@ -504,9 +385,8 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
 
     // attention geometry: block (r, h, s) = one of the (up to) 8 even key ranges of (row r, head h) of EVERY utterance; 8 waves x 32 keys
     // ATTN_V2: block = (utterance, row, head, part): SPB = NU consecutive key ranges starting at at_s, 8 / NU blocks per (utterance, row, head)
-    constexpr bool ATTN_V2 = NU > 1 && MEGA_ATTN_V2;
+    constexpr bool ATTN_V2 = NU > 1;
     constexpr int BPH = ATTN_V2 ? 8 / NU : 8, SPB = ATTN_V2 ? NU : 1;
-    constexpr bool KV_UNCOND = MEGA_KV_UNCOND && NU == 1;   // see issue_kv_set
     constexpr bool ATTN_PL = MV_PERMLANE_SWAP != 0;   // common.h: measured no faster (profiles/r04w), off
     constexpr bool ATTN_DB = ATTN_V2 && WF == MV_W_BF16;   // two register sets: the quantised instances have no idle weight registers to lend (one set, ranges back to back)
     const int at_u = ATTN_V2 ? b / (32 * BPH) : 0;
@@ -531,14 +411,13 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
     u32x4 nw_attn, nw_ffn = u32x4{0u, 0u, 0u, 0u};
     auto issue_layer0 = [&](int lane, int wave) {  // (lane, wave): the caller's ids, opaque to the optimiser inside the step loop
         const bf16_t* w = MG_LAYER(0).wqkv;
-        if (MEGA_KV_AFTER_NORM) nw_attn = load16(MG_LAYER(0).attn_norm + ((wave * 64 + lane) & 255) * 8);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             if (I4) mega_issue_row_i4<1>(cq + i, cz + i, MG_LAYER(0).q[0], MG_LAYER(0).sz[0], 24 * b + 3 * wave + i, MG_DIM, lane);
             else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, MG_LAYER(0).q8[0], 24 * b + 3 * wave + i, MG_DIM, lane); sc_a[i] = bf2f(load_global_u16(MG_LAYER(0).s8[0] + (24 * b + 3 * wave + i))); }
             else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave + i, MG_DIM, lane, MG_ABLATE);
         }
-        if (!MEGA_KV_AFTER_NORM) nw_attn = load16(MG_LAYER(0).attn_norm + ((wave * 64 + lane) & 255) * 8);
+        nw_attn = load16(MG_LAYER(0).attn_norm + ((wave * 64 + lane) & 255) * 8);
     };
     issue_layer0(lane, wave);
 
@@ -601,26 +480,15 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             constexpr int PART = decltype(part_tag)::value;   // 0: K and V, 1: K only, 2: V only
             u32x4* const kd = SET == 0 ? kv : wv;
             u32x4* const vd = SET == 0 ? vv : wv + 16;
-            // KV_UNCOND (one utterance): all 2 x ATTN_U requests ALWAYS go out.  With "zero the slot, request it if used" every slot is a merge
-            // of a constant and a load result; hipcc gave ONE component of ONE slot (vv[0].w, which doubled as its source of zeros) a
-            // register outside the load's 4-register tuple and copied it right behind the load:
-            //     global_load_dwordx4 v[120:123], ... nt ;  s_waitcnt vmcnt(0) ;  v_mov_b32 v136, v123
-            // -- every wave sat out a full memory round trip in the middle of its K/V requests, in every layer of every one-utterance
-            // instance ("K/V requested" 2.4 us behind "x ready", profiles/r04g).  Now a slot is only ever defined by a load (no merge, no
-            // zeroing, and the 64 registers are dead between the attention and the next request as before): an unused slot
-            // (q * 4 >= kwu) re-reads the newest old row, a workgroup with nothing to read (no split of its own, or an empty cache)
-            // reads 256 bytes of the layer's norm weights.  An unused slot's key is masked by its position (score -inf, weight exactly 0)
-            // and 0 x (finite V) adds nothing: the same bits.
-            constexpr bool UNC = KV_UNCOND && SET == 0;
-            if (!UNC) {
-                if (PART != 2) {
+            // unused slots are zero (a variant that always requested every slot -- no merge of a constant and a load result -- measured slower,
+            // profiles/r04x)
+            if (PART != 2) {
 #pragma unroll
-                    for (int q = 0; q < ATTN_U; ++q) kd[q] = u32x4{0u, 0u, 0u, 0u};
-                }
-                if (PART != 1) {
+                for (int q = 0; q < ATTN_U; ++q) kd[q] = u32x4{0u, 0u, 0u, 0u};
+            }
+            if (PART != 1) {
 #pragma unroll
-                    for (int q = 0; q < ATTN_U; ++q) vd[q] = u32x4{0u, 0u, 0u, 0u};
-                }
+                for (int q = 0; q < ATTN_U; ++q) vd[q] = u32x4{0u, 0u, 0u, 0u};
             }
             const int Pu = GEO(0, u), csu = GEO(1, u), nactu = GEO(2, u), kwu = GEO(3, u);
             const int go = lane_o >> 4, dlo = lane_o & 15, s0o = split * csu + wave_o * kwu;
@@ -629,16 +497,6 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             const bf16_t* vc = a.vcache + layer_off;
             const size_t head_base = ((size_t)(2 * u + at_r) * MG_HEADS + at_h) * (size_t)a.cache_len * 128 + dlo * 8;
             const int last_old = max(Pu - 2, 0);
-            if constexpr (UNC) {
-                const bool real = Pu > 1 && split < nactu;   // block-uniform
-                const bf16_t* finite = MG_LAYER(kv_layer).attn_norm + dlo * 8;
-                const bf16_t* kb = real ? kc + head_base : finite;
-                const bf16_t* vb = real ? vc + head_base : finite;
-#pragma unroll
-                for (int q = 0; q < ATTN_U; ++q) kd[q] = load_stream16(kb + (size_t)(real ? min(s0o + q * 4 + go, last_old) : 0) * 128);
-#pragma unroll
-                for (int q = 0; q < ATTN_U; ++q) vd[q] = load_stream16(vb + (size_t)(real ? min(s0o + q * 4 + go, last_old) : 0) * 128);
-            } else
             if (Pu > 1 && split < nactu) {
                 if (PART != 2)
 #pragma unroll
@@ -651,7 +509,6 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }
         };
         auto issue_kv = [&](int u, int kv_layer) { issue_kv_set(std::integral_constant<int, 0>{}, u, kv_layer, at_s, std::integral_constant<int, 0>{}); };
-        constexpr bool V_LATE = ((MEGA_V_AFTER_QKV >> (NU >> 1)) & 1) && !KV_UNCOND && !MEGA_KV_EARLY && !MEGA_KV_AFTER_NORM;   // bit 0 | 1 | 2: 1 | 2 | 4 utterances
 
         // ================= P0: RMSNorm + wqkv (+ KV-cache write)        fast_model.py:179,209,218 ====================
         __syncthreads();
@@ -666,43 +523,25 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         __syncthreads();
         MG_ABORT_RETURN();
         MG_STAMP(l, 1);
-        // The K/V stream of the first attention slice is requested here, before the norm and the wqkv dots: it lands while they
-        // run.  (Requested after the q/k/v publish instead it sits in front of the q/k/v poll: 831 vs 794 us/step.)
-        const bool kv_here = !MEGA_KV_EARLY || l == 0;   // else: requested behind the previous layer's h publish
-        if (kv_here && !KV_UNCOND) {
+        // The K rows of the first attention slice are requested here, before the norm and the wqkv dots: they land while those run.  (All of
+        // the slice requested after the q/k/v publish sits in front of the q/k/v poll: 831 vs 794 us/step.)  The V rows follow behind the
+        // q/k/v publish, in front of the q/k/v hand-off: the K/V burst of all 256 workgroups (8 MB at 1024 positions) drains at HBM speed and
+        // the memory pipeline takes requests only as fast as it drains them -- with both halves here every wave spent ~2.4 us in front of its
+        // norm issuing them (profiles/r04g, r04x).
 #pragma unroll
-            for (int q = 0; q < ATTN_U; ++q) kv[q] = u32x4{0u, 0u, 0u, 0u};
+        for (int q = 0; q < ATTN_U; ++q) kv[q] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int q = 0; q < ATTN_U; ++q) vv[q] = u32x4{0u, 0u, 0u, 0u};
-        }
-        if (V_LATE) { if (first_att >= 0 && !(MEGA_K_AFTER_QKV && NU == 1)) issue_kv_set(std::integral_constant<int, 0>{}, first_att, l, at_s, std::integral_constant<int, 1>{}); }
-        else
-        if (!MEGA_KV_AFTER_NORM && (first_att >= 0 || KV_UNCOND) && kv_here) issue_kv(max(first_att, 0), l);
+        for (int q = 0; q < ATTN_U; ++q) vv[q] = u32x4{0u, 0u, 0u, 0u};
+        if (first_att >= 0) issue_kv_set(std::integral_constant<int, 0>{}, first_att, l, at_s, std::integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
         MG_STAMP(l, 11);  // K/V requested
         mega_norm<NU>(xa, nw_attn, red, a.eps, tid_p);
         MG_STAMP(l, 12);  // norm done
-        if (MEGA_KV_AFTER_NORM && (first_att >= 0 || KV_UNCOND) && kv_here) { issue_kv(max(first_att, 0), l); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll (I4 ? 1 : MEGA_NU_UNROLL_P0)
         for (int u = 0; u < NU; ++u) {
             float acc[3][2];
             if (I4) mega_dots_i4<1, 3, MG_DIM>(cq, cz, xa[u], MG_DIM, lane_p, acc);
             else if (I8) mega_dots_i8<2, 3, MG_DIM>(cq, xa[u], MG_DIM, lane_p, acc);
-            else if (EARLY_QKV && l > 0) {  // layer 0's rows come whole, in registers (issue_layer0); same order as mega_dots
-#pragma unroll
-                for (int i = 0; i < 3; ++i) acc[i][0] = acc[i][1] = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        const u32x4 xv = *(const u32x4*)(xa[u] + r * MG_DIM + j * 512 + lane * 8);
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) {
-                            const u32x4 w = j < 2 ? w1_lds[(wave * 6 + i * 2 + j) * 64 + lane] : wv[4 * i + j];
-                            acc[i][r] = dot8_bf16(w, xv, acc[i][r]);
-                        }
-                    }
-            }
             else mega_dots<4, 3, MG_DIM>(wv, xa[u], lane_p, acc);
             __builtin_amdgcn_sched_barrier(0);
             if (u == 0) MG_STAMP(l, 13);  // wqkv dots done
@@ -733,8 +572,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (V_LATE && first_att >= 0) {
-            if (MEGA_K_AFTER_QKV && NU == 1) issue_kv_set(std::integral_constant<int, 0>{}, first_att, l, at_s, std::integral_constant<int, 1>{});
+        if (first_att >= 0) {
             issue_kv_set(std::integral_constant<int, 0>{}, first_att, l, at_s, std::integral_constant<int, 2>{});
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -748,18 +586,11 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         auto request_wo = [&]() {
             if (I4) mega_issue_row_i4<1>(cq + 6, cz + 6, L.q[1], L.sz[1], 8 * b + wave_o, MG_DIM, lane_o);
             else if (I8) { mega_issue_row_i8<2>(cq + 12, L.q8[1], 8 * b + wave_o, MG_DIM, lane_o); sc_c = bf2f(load_global_u16(L.s8[1] + (8 * b + wave_o))); }
-            else if (W3_EARLY) {  // chunks 0..3 -> wv[0], [1], [4], [5]: the slots the LDS half of w1 leaves unused
-                const bf16_t* row = L.wo + (size_t)(8 * b + wave_o) * MG_DIM + lane_o * 8;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wv[(j >> 1) * 4 + (j & 1)] = load_stream16(row + j * 512);
-            }
             else mega_issue_row<4>(wv + 12, L.wo, 8 * b + wave_o, MG_DIM, lane_o, MG_ABLATE);
         };
-        constexpr int W3_AT_QKV = (NU == 1 && WF == MV_W_BF16 && !(EARLY_ANY && MEGA_EARLY_W1 && MEGA_W3_EARLY)) ? MEGA_W3_QKV_ROWS : 0;
-        auto request_w3 = [&](int i0 = 0, int i1 = 3) {  // 22 rows per block: waves 0..5 take 3, waves 6, 7 take 2 (third slot clamped, masked)
+        auto request_w3 = [&]() {  // 22 rows per block: waves 0..5 take 3, waves 6, 7 take 2 (third slot clamped, masked)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                if (i < i0 || i >= i1) continue;
                 if (I4) mega_issue_row_i4<1>(cq + 3 + i, cz + 3 + i, L.q[3], L.sz[3], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o);
                 else if (I8) { mega_issue_row_i8<2>(cq + 6 + 2 * i, L.q8[3], min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o); sc_b[i] = bf2f(load_global_u16(L.s8[3] + (min(rb13 + i, MG_INTER - 1)))); }
                 else mega_issue_row<4>(wv + 12 + 4 * i, L.w3, min(rb13 + i, MG_INTER - 1), MG_DIM, lane_o, MG_ABLATE);
@@ -783,18 +614,6 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }
             w1_half_issued = false;  // next layer
             nw_ffn = load16(L.ffn_norm + (tid_o & 255) * 8);
-            if (W3_EARLY && MEGA_W3_EARLY != 2) request_w3();
-        };
-        auto request_wo_w1 = [&]() { request_wo(); request_w1(); };
-        auto request_qkv_early = [&]() {  // EARLY_QKV: chunks 0, 1 of the next layer's three wqkv rows into the LDS slots the w1 half has left
-            if (l + 1 < n_layer) {
-                const bf16_t* w = MG_LAYER(l + 1).wqkv;
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        mega_row_to_lds(lds_addr(w1_lds + ((wave_o * 6 + i * 2 + j) * 64)), w + (size_t)(24 * b + 3 * wave_o + i) * MG_DIM + j * 512 + lane_o * 8, MG_ABLATE);
-            }
         };
 
         // ================= P1: attention over keys [0, P)               fast_model.py:218-222 =========================
@@ -802,14 +621,12 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         // the workgroup of split 0, the combined output) to publish, and a store queued behind 112 KB of the other waves' bulk
         // requests in this CU's memory pipeline reaches the combiner -- on everybody's critical path -- microseconds late.  So the
         // other waves of an attending workgroup hold their requests (the next utterance's K/V, then wo | w1) until wave 0 is through.
-        constexpr bool W1_LATE = NU == 1 && MEGA_W1_AFTER_ATTN, WO_LATE = NU == 1 && MEGA_WO_AFTER_QKV;
-        if (!any_att) { request_wo(); if (W3_AT_QKV > 0) request_w3(3 - W3_AT_QKV, 3); if (!W1_LATE) request_w1(); }
+        if (!any_att) { request_wo(); request_w1(); }
         if (any_att) {
             __syncthreads();
             // every wave of the block has published its q/k/v rows: the wo row (8 MB chip-wide, ~1 us of stream) is requested HERE, under
             // the q/k/v hand-off, which costs its ~1.7 us of latency whatever is queued behind it; w1 follows after the attention
-            if (!WO_LATE) request_wo();
-            if (W3_AT_QKV > 0) request_w3(3 - W3_AT_QKV, 3);   // the LAST rows: wv[16..23] / wv[20..23], idle until the h publish
+            request_wo();
             {   // q, k_new, v_new of head at_h of every utterance this block attends for: 3 x 128 row-paired granules each
                 const int sec = tid_o >> 7, c = tid_o & 127;
                 const gran_t* gq = g_qkv;
@@ -833,11 +650,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             __syncthreads();
             MG_ABORT_RETURN();
             MG_STAMP(l, 3);
-            if (WO_LATE) request_wo();
-            // MEGA_COMB_W1_LATE (experiment, one utterance): the workgroups that COMBINE the split partials (split 0: 32 of 256) keep their memory
-            // queue empty until the combine is through -- a hand-off into a streaming CU costs 2.9 us, into a quiet one 1.1 (MI355X_MICROARCH.md,
-            // handoff-1to1) -- and request the LDS half of w1 with the register half, behind the attention (request_w1's fallback)
-            if constexpr (EARLY_W1) if (!(MEGA_COMB_W1_LATE && NU == 1 && at_s == 0 && GEO(2, 0) > 1)) {  // half of w1 on its way while the partial is computed, merged and published
+            if constexpr (EARLY_W1) {  // half of w1 on its way while the partial is computed, merged and published
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -949,9 +762,6 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 }
                 const AttnAcc w = attn_wave_partial<ATTN_PL>(kv, vv, qv, at_s0, at_s1, g);
                 if (u == 0) MG_STAMP(l, 14);  // wave partial done
-                // MEGA_NU_EARLY_KV: the K/V registers are free from here on -- the next attending utterance's slice is requested NOW, so
-                // it streams while this utterance's partial is merged and published (instead of after the publish)
-                if (MEGA_NU_EARLY_KV && NU > 1 && next_att >= 0) issue_kv(next_att, l);
                 if (g == 0) {
                     sm[at_w][dl][0] = w.m;
                     sm[at_w][dl][1] = w.l;
@@ -970,7 +780,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 }
                 if (next_att >= 0) {
                     __syncthreads();  // the partial has left, `sm` has been consumed
-                    if (!(MEGA_NU_EARLY_KV && NU > 1)) issue_kv(next_att, l);
+                    issue_kv(next_att, l);
                 }
                 if (at_w == 0) {
                     bool last = true;
@@ -998,7 +808,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }
             MG_STAMP(l, 15);  // wave 0: attention output (or partial) published
             __syncthreads();
-            if (!W1_LATE) request_w1();
+            request_w1();
         }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -1012,21 +822,11 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             __syncthreads();
             MG_ABORT_RETURN();
             MG_STAMP(l, 5);
-            if (W1_LATE) { request_w1(); __builtin_amdgcn_sched_barrier(0); }
-            if (W3_EARLY && MEGA_W3_EARLY == 2) { request_w3(); __builtin_amdgcn_sched_barrier(0); }  // experiment: behind the attention vector, in front of the h publish
 #pragma unroll 1
             for (int u = 0; u < NU; ++u) {
                 float acc[1][2];
                 if (I4) mega_dots_i4<1, 1, MG_DIM>(cq + 6, cz + 6, xs[u], MG_DIM, lane_p, acc);
                 else if (I8) mega_dots_i8<2, 1, MG_DIM>(cq + 12, xs[u], MG_DIM, lane_p, acc);
-                else if (W3_EARLY) {  // same order as mega_dots: chunk j ascending, row r
-                    acc[0][0] = acc[0][1] = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int r = 0; r < 2; ++r)
-                            acc[0][r] = dot8_bf16(wv[(j >> 1) * 4 + (j & 1)], *(const u32x4*)(xs[u] + r * MG_DIM + j * 512 + lane * 8), acc[0][r]);
-                }
                 else mega_dots<4, 1, MG_DIM>(wv + 12, xs[u], lane_p, acc);
                 __builtin_amdgcn_sched_barrier(0);
                 if (u == 0) MG_STAMP(l, 16);  // wo dots done
@@ -1050,9 +850,8 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             }
             __builtin_amdgcn_sched_barrier(0);
             MG_STAMP(l, 17);  // h published
-            // next: the w3 rows (w1 is already in flight) -- unless they went out with w1 (MEGA_W3_EARLY)
-            if (!W3_EARLY) request_w3(0, 3 - W3_AT_QKV);
-            if (MEGA_KV_EARLY && first_att >= 0 && l + 1 < n_layer) issue_kv(first_att, l + 1);
+            // next: the w3 rows (w1 is already in flight)
+            request_w3();
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -1074,9 +873,8 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 for (int j = 0; j < EW2; ++j)
                     mega_row_to_lds(lds_addr(w2_lds + ((wave_o * EW2 + j) * 64)), L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8, MG_ABLATE);
             };
-            if constexpr (EARLY_W2 && !MEGA_EW2_AFTER_NORM) request_w2_early();
+            if constexpr (EARLY_W2) request_w2_early();
             mega_norm<NU>(xa, nw_ffn, red, a.eps, tid_p);
-            if constexpr (EARLY_W2 && MEGA_EW2_AFTER_NORM) { request_w2_early(); __builtin_amdgcn_sched_barrier(0); }
             MG_STAMP(l, 18);  // norm done
             const int nrows = wave_p < 6 ? 3 : 2;
             const int rb = 22 * b + (wave_p < 6 ? 3 * wave_p : 18 + 2 * (wave_p - 6));
@@ -1137,20 +935,9 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             else if (I8) { mega_issue_row_i8<6>(cq, L.q8[4], 8 * b + wave_o, MG_INTER, lane_o); sc_c = bf2f(load_global_u16(L.s8[4] + (8 * b + wave_o))); }
             else if (EARLY_W2) {
 #pragma unroll
-                for (int j = EW2; j < 11; ++j) wv[W2R0 + j] = load_stream16(L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8);
-                if constexpr (QKV_P4 > 0) {
-                    if (l + 1 < n_layer) {
-                        const bf16_t* w = MG_LAYER(l + 1).wqkv;
-#pragma unroll
-                        for (int c = 0; c < QKV_P4; ++c)
-#pragma unroll
-                            for (int i = 0; i < 3; ++i)
-                                wv[4 * i + 2 + c] = load_stream16(w + (size_t)(24 * b + 3 * wave_o + i) * MG_DIM + (2 + c) * 512 + lane_o * 8);
-                    }
-                }
+                for (int j = EW2; j < 11; ++j) wv[j] = load_stream16(L.w2 + (size_t)(8 * b + wave_o) * MG_INTER + j * 512 + lane_o * 8);
             }
             else mega_issue_row<11>(wv, L.w2, 8 * b + wave_o, MG_INTER, lane_o, MG_ABLATE);
-            if constexpr (EARLY_QKV && MEGA_EARLY_QKV_POS == 1) request_qkv_early();   // behind the w2 remainder, in front of the act hand-off
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -1179,7 +966,6 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             __syncthreads();
             MG_ABORT_RETURN();
             MG_STAMP(l, 9);
-            if constexpr (EARLY_QKV && MEGA_EARLY_QKV_POS == 0) request_qkv_early();  // on their way while the w2 dots and the x publish run
 #pragma unroll 1
             for (int u = 0; u < NU; ++u) {
                 float acc[1][2];
@@ -1189,7 +975,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                     acc[0][0] = acc[0][1] = 0.f;
 #pragma unroll
                     for (int j = 0; j < 11; ++j) {
-                        const u32x4 w = j < EW2 ? w2_lds[(wave_p * EW2 + j) * 64 + lane_p] : wv[W2R0 + j];
+                        const u32x4 w = j < EW2 ? w2_lds[(wave_p * EW2 + j) * 64 + lane_p] : wv[j];
 #pragma unroll
                         for (int r = 0; r < 2; ++r) acc[0][r] = dot8_bf16(w, *(const u32x4*)(xs[u] + r * MG_INTER + j * 512 + lane_p * 8), acc[0][r]);
                     }
@@ -1213,20 +999,13 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (EARLY_QKV && MEGA_EARLY_QKV_POS == 2) request_qkv_early();   // behind the x publish
             // next: the following layer's wqkv rows, or the LM-head rows 11 b + wave + 8 i
-            if (MEGA_KV_AFTER_NORM) nw_attn = load16((l + 1 < n_layer ? MG_LAYER(l + 1).attn_norm : KC(l)->final_norm) + (tid_o & 255) * 8);
             if (l + 1 < n_layer) {
                 const bf16_t* w = MG_LAYER(l + 1).wqkv;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     if (I4) mega_issue_row_i4<1>(cq + i, cz + i, MG_LAYER(l + 1).q[0], MG_LAYER(l + 1).sz[0], 24 * b + 3 * wave_o + i, MG_DIM, lane_o);
                     else if (I8) { mega_issue_row_i8<2>(cq + 2 * i, MG_LAYER(l + 1).q8[0], 24 * b + 3 * wave_o + i, MG_DIM, lane_o); sc_a[i] = bf2f(load_global_u16(MG_LAYER(l + 1).s8[0] + (24 * b + 3 * wave_o + i))); }
-                    else if (EARLY_QKV) {
-                        const bf16_t* row = w + (size_t)(24 * b + 3 * wave_o + i) * MG_DIM;
-                        if (QKV_P4 < 1) wv[4 * i + 2] = load_stream16(row + 2 * 512 + lane_o * 8);
-                        if (QKV_P4 < 2) wv[4 * i + 3] = load_stream16(row + 3 * 512 + lane_o * 8);
-                    }
                     else mega_issue_row<4>(wv + 4 * i, w, 24 * b + 3 * wave_o + i, MG_DIM, lane_o, MG_ABLATE);
                 }
             } else {
@@ -1238,7 +1017,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                     else mega_issue_row<4>(wv + 4 * i, A->head, hn, MG_DIM, lane_o, MG_ABLATE);
                 }
             }
-            if (!MEGA_KV_AFTER_NORM) nw_attn = load16((l + 1 < n_layer ? MG_LAYER(l + 1).attn_norm : KC(l)->final_norm) + (tid_o & 255) * 8);
+            nw_attn = load16((l + 1 < n_layer ? MG_LAYER(l + 1).attn_norm : KC(l)->final_norm) + (tid_o & 255) * 8);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1362,11 +1141,7 @@ bool mega_supported(const mv_config& c, int rows, int n_cus) {
 // tail is compiled in).
 // int8 engines draw their tokens inside the launch like bf16 / int4 ones: 647 vs 655 us/step (profiles/r03w; in round 2, with the
 // accumulator of the split-partial publish in scratch, the instance was the slower one and int8 kept sample_kernel).
-// -DMEGA_FOLD_INT8=0 restores that.
-#ifndef MEGA_FOLD_INT8
-#define MEGA_FOLD_INT8 1
-#endif
-bool mega_folds(const mv_config& c) { return c.max_utterances <= MEGA_FOLD_MAX_UTT && (MEGA_FOLD_INT8 || c.weight_format != MV_W_INT8); }
+bool mega_folds(const mv_config& c) { return c.max_utterances == 1; }
 
 __global__ void bump_counter_kernel(uint32_t* c) { c[0] += 1u; }
 hipError_t launch_bump_counter(hipStream_t s, uint32_t* c) {
@@ -1394,11 +1169,8 @@ static hipError_t launch_mega_instance(hipStream_t s, const MegaArgs& a) {
 template <int WF>
 static hipError_t launch_mega_format(hipStream_t s, const MegaArgs& a) {
     switch (a.n_utt) {
-        case 1: return a.n_steps > 0 ? (WF == MV_W_INT8 && !MEGA_FOLD_INT8 ? hipErrorInvalidValue : launch_mega_instance<WF, 1, MEGA_FOLD_INT8 || WF != MV_W_INT8>(s, a))
-                                     : launch_mega_instance<WF, 1, false>(s, a);
-        case 2:
-            if constexpr (MEGA_FOLD_MAX_UTT >= 2) { if (a.n_steps > 0) return launch_mega_instance<WF, 2, true>(s, a); }
-            return a.n_steps > 0 ? hipErrorInvalidValue : launch_mega_instance<WF, 2, false>(s, a);
+        case 1: return a.n_steps > 0 ? launch_mega_instance<WF, 1, true>(s, a) : launch_mega_instance<WF, 1, false>(s, a);
+        case 2: return a.n_steps > 0 ? hipErrorInvalidValue : launch_mega_instance<WF, 2, false>(s, a);
         case 4: return a.n_steps > 0 ? hipErrorInvalidValue : launch_mega_instance<WF, 4, false>(s, a);
         default: return hipErrorInvalidValue;
     }
@@ -1417,7 +1189,7 @@ static bool mega_instance_fits(int n_cus) {
 template <int WF>
 static bool mega_format_fits(int n_utt, int n_cus) {
     switch (n_utt) {
-        case 1: return mega_instance_fits<WF, 1, false>(n_cus) && (WF == MV_W_INT8 && !MEGA_FOLD_INT8 ? true : mega_instance_fits<WF, 1, MEGA_FOLD_INT8 || WF != MV_W_INT8>(n_cus));
+        case 1: return mega_instance_fits<WF, 1, false>(n_cus) && mega_instance_fits<WF, 1, true>(n_cus);   // the instances launch_mega_format launches
         case 2: return mega_instance_fits<WF, 2, false>(n_cus);
         case 4: return mega_instance_fits<WF, 4, false>(n_cus);
         default: return false;

@@ -137,7 +137,6 @@ struct mv_engine {
 
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
-    bool use_graph = true;
     bool graph_dirty = false;   // a tuning knob changed after capture
 
 
@@ -366,15 +365,15 @@ int enqueue_prefill(mv_engine* e, int u, int T) {
 }
 
 int build_graph(mv_engine* e) {
-    if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
-    if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
+    if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+    if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
     e->graph_dirty = false;
-    if (!e->use_graph || !g_tune.use_graph) return MV_OK;
+    if (!g_tune.use_graph) return MV_OK;
     HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeRelaxed));
     const int rc = enqueue_step(e);
     hipGraph_t g = nullptr;
     hipError_t ce = hipStreamEndCapture(e->stream, &g);
-    if (rc != MV_OK) { if (g) hipGraphDestroy(g); return rc; }
+    if (rc != MV_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
     if (ce != hipSuccess) return fail(MV_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
     e->graph = g;
     HIP_TRY(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
@@ -458,7 +457,6 @@ int mv_engine_create(const mv_config* cfg, mv_engine** out) {
     mv_engine* e = new mv_engine();
     e->cfg = c;
     e->R = 2 * c.max_utterances;
-    e->use_graph = getenv("MV_NO_GRAPH") == nullptr;
     e->layers.resize(c.n_layer);
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
         hipEventCreate(&e->ev1) != hipSuccess) {
@@ -504,19 +502,19 @@ int mv_engine_create(const mv_config* cfg, mv_engine** out) {
 
 int mv_engine_destroy(mv_engine* e) {
     if (!e) return MV_OK;
-    if (e->stream) hipStreamSynchronize(e->stream);
-    if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
-    if (e->graph) hipGraphDestroy(e->graph);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+    if (e->graph) (void)hipGraphDestroy(e->graph);
     void* bufs[] = {e->q_arena, e->arena, e->x, e->h, e->q, e->attn, e->act, e->logits, e->kcache, e->vcache, e->partial, e->counters,
                     e->utt, e->pos_arr, e->seq, e->spk_emb, e->spk_proj, e->n_active, e->capture, e->px, e->ph, e->pn, e->pq,
                     e->pattn, e->pact, e->pvt, e->pslab, e->mega_layers, e->granules, e->step_counter, e->abort_flag, e->dbg, e->stamps, e->utt_shadow,
                     e->pos_shadow, e->tiled};
     for (void* b : bufs)
-        if (b) hipFree(b);
-    if (e->host_flag) hipHostFree(e->host_flag);
-    if (e->ev0) hipEventDestroy(e->ev0);
-    if (e->ev1) hipEventDestroy(e->ev1);
-    if (e->stream) hipStreamDestroy(e->stream);
+        if (b) (void)hipFree(b);
+    if (e->host_flag) (void)hipHostFree(e->host_flag);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return MV_OK;
 }
@@ -540,7 +538,7 @@ int mv_load_weight(mv_engine* e, const char* name, const void* data, int32_t dty
                 hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, tmp, *s.ptr, n);
                 ce = hipStreamSynchronize(e->stream);
             }
-            hipFree(tmp);
+            (void)hipFree(tmp);
             if (ce != hipSuccess) return fail(MV_ERR_HIP, "%s: upload failed: %s", name, hipGetErrorString(ce));
         } else {
             return fail(MV_ERR_INVALID, "%s: dtype %d not accepted (bf16 or f32)", name, dtype);
@@ -752,7 +750,7 @@ int mv_set_logits_capture(mv_engine* e, int32_t enable, int32_t max_steps) {
     if (want) {
         if (max_steps < 1 || max_steps > e->cfg.block_size) max_steps = e->cfg.block_size;
         if (!e->capture || e->capture_max < max_steps) {
-            if (e->capture) hipFree(e->capture);
+            if (e->capture) (void)hipFree(e->capture);
             e->capture = nullptr;
             HIP_TRY(hipMalloc((void**)&e->capture, (size_t)max_steps * e->R * e->cfg.vocab * 4));
             e->capture_max = max_steps;
@@ -1206,7 +1204,7 @@ int mv_op_sample(void* stream, int32_t vocab, const void* logits_pair, const mv_
         ce = launch_sample(st, a, true);
     }
     if (ce == hipSuccess) ce = hipStreamSynchronize(st);
-    hipFree(d);
+    (void)hipFree(d);
     if (ce != hipSuccess) return fail(MV_ERR_HIP, "mv_op_sample: %s", hipGetErrorString(ce));
     return MV_OK;
 }

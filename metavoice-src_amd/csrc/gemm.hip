@@ -299,7 +299,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& a_in) {
     // block is a chain of dependent load round trips and the resident blocks hold too few bytes in flight; 8.4 vs 7.9 ms at T = 512).
     const size_t per_range = (size_t)a.M * a.N * (a.w2 ? 2 : 1);   // floats of partial tiles one K range leaves in the slab
     const size_t max_ranges = a.slab && per_range ? a.slab_elems / per_range : 0;   // what the caller's slab holds
-    if (a.M >= 96 && a.K >= 512 && a.N >= 512 && a.M <= 8 * SK_BM && getenv("MV_GEMM_SKINNY") && !getenv("MV_GEMM_NO_SKINNY")) {
+    if (a.M >= 96 && a.K >= 512 && a.N >= 512 && a.M <= 8 * SK_BM && getenv("MV_GEMM_SKINNY")) {
         const int mt256 = (a.M + SK_BM - 1) / SK_BM;
         const char* cols_env = getenv("MV_GEMM_SKINNY_COLS");   // A/B: 64 or 128 columns per block (default 128)
         // the 128-column instance ALWAYS leaves partial tiles (even with one range): it needs room for at least one range in the slab

@@ -7,10 +7,7 @@
 typedef uint16_t bf16_t;
 
 // Engines of more utterances keep sample_kernel behind every step: with the token draw compiled in (inlined or out of line) those
-// instances measured slower (r03a: see decode_mega.hip).  One-utterance engines of every format draw inside the launch.
-#ifndef MEGA_FOLD_MAX_UTT
-#define MEGA_FOLD_MAX_UTT 1   // -DMEGA_FOLD_MAX_UTT=2 (decode_mega.hip only): A/B build with the two-utterance instances drawing inside the launch
-#endif
+// instances measured slower (r03a, r03x: tools/experiments/README.md).  One-utterance engines of every format draw inside the launch.
 
 // ---- tuning knobs (mv_tune): defaults are the measured best for MetaVoice-1B on MI355X (DESIGN.md "Tuning") ------
 struct MvTune {
@@ -24,7 +21,7 @@ struct MvTune {
                                          // (MetaVoice-1B shape, >= 256 CUs); 0: per-layer launches
     int mega_steps = 512;                // decode steps per launch of the folding persistent kernel
     int mega_fold = 1;                   // 1: the persistent kernel also draws the token and runs several steps per launch (engines
-                                         // of up to MEGA_FOLD_MAX_UTT utterances); 0: one step per launch + sample_kernel
+                                         // of one utterance); 0: one step per launch + sample_kernel
     int mfma = 1;                        // 1: engines of 4 utterances (bf16) run the persistent step on the matrix cores (decode_mfma.hip: tiled
                                          // weight copy, not bit-identical to the launches); 0: decode_mega.hip's bit-identical instance
 };

@@ -1511,8 +1511,6 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
     const int nt = (g.N + BN - 1) / BN;
     bool k64 = true;
     for (int i = 0; i < g.n_seg; ++i) k64 = k64 && g.seg[i].K % 64 == 0;
-    static const int glds_mode = getenv("MV_MBD_NO_GLDS") ? 0 : getenv("MV_MBD_NO_FUSED3") ? 1 : 2;
-    static const bool t256 = !getenv("MV_MBD_NO_T256");
     static std::atomic<bool> t256_raised_on[64];   // per device
     int t256_dev = 0;
     (void)hipGetDevice(&t256_dev);
@@ -1521,7 +1519,7 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
     const int nt_m256 = (g.M + 255) / 256, nt_n256 = (g.N + 255) / 256;
     const char* t256_min_env = getenv("MV_MBD_T256_MIN_BLOCKS");   // tests lower it so that small shapes (ragged tiles) take this kernel
     const size_t t256_min = t256_min_env ? (size_t)atoi(t256_min_env) : 192;
-    if (t256 && glds_mode == 2 && k64 && prec == 3 && taps == 1 && g.N >= 256 && (size_t)nt_m256 * nt_n256 * nb >= t256_min) {
+    if (k64 && prec == 3 && taps == 1 && g.N >= 256 && (size_t)nt_m256 * nt_n256 * nb >= t256_min) {
         if (!t256_raised) {
             hipError_t e = hipFuncSetAttribute((const void*)mbd_gemm_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T256_LDS_BYTES);
             if (e != hipSuccess) return e;
@@ -1531,14 +1529,14 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
         if (gn_ok) { g.gn_part = gf->part; g.gn_G = gf->G; g.gn_cg = g.N / gf->G; gf->tiles = nt_m256 * nt_n256; }
         ++m->gemm_launches[0];
         hipLaunchKernelGGL(mbd_gemm_t256_kernel, dim3(n_blocks), dim3(512), T256_LDS_BYTES, s, g, nt_m256, nt_n256, n_blocks);
-    } else if (glds_mode == 2 && k64 && prec == 3 && taps == 1 && g.N % 192 == 0 && g.N % 128 != 0 && !getenv("MV_MBD_NO_N192") &&
+    } else if (k64 && prec == 3 && taps == 1 && g.N % 192 == 0 && g.N % 128 != 0 && !getenv("MV_MBD_NO_N192") &&
                (size_t)(g.N / 192) * ((g.M + 63) / 64) * nb >= (getenv("MV_MBD_N192_MIN_BLOCKS") ? (size_t)atoi(getenv("MV_MBD_N192_MIN_BLOCKS")) : 400)) {
         // 192-channel layers: 64 x 192 tiles, no padding columns (MV_MBD_N192_MIN_BLOCKS: tests lower the threshold for small shapes)
         const int nt192 = g.N / 192, mt64 = (g.M + 63) / 64;
         if (gn_ok) { g.gn_part = gf->part; g.gn_G = gf->G; g.gn_cg = g.N / gf->G; gf->tiles = nt192 * mt64; }
         ++m->gemm_launches[1];
         hipLaunchKernelGGL((mbd_gemm_glds3_kernel<64, 192>), dim3(nt192, mt64, nb), dim3(256), 0, s, g);
-    } else if (glds_mode == 2 && k64 && prec == 3 && taps == 1 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400) {
+    } else if (k64 && prec == 3 && taps == 1 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400) {
         if (gn_ok) { g.gn_part = gf->part; g.gn_G = gf->G; g.gn_cg = g.N / gf->G; gf->tiles = nt * ((g.M + 127) / 128); }
         ++m->gemm_launches[2];
         hipLaunchKernelGGL((mbd_gemm_glds3_kernel<128, 128>), dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
@@ -1554,7 +1552,7 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
             default: hipLaunchKernelGGL(mbd_gemm_thin_kernel<4>, grid, dim3(256), 0, s, g); break;
         }
     }
-    else if (glds_mode >= 1 && k64 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400) {
+    else if (k64 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400) {
         ++m->gemm_launches[4];
         hipLaunchKernelGGL(mbd_gemm_glds_kernel, dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
     } else if ((size_t)nt * ((g.M + 127) / 128) * nb >= 400) {

@@ -11,11 +11,6 @@
 // Every wait is bounded; a timeout raises a device flag that the host turns into an error (a plain launch gives no
 // residency guarantee: if another kernel occupies CUs the grid may not be co-resident).
 #pragma once
-// profiling only: every hand-off wait is satisfied by its first look (results are garbage) -- the weight stream of the persistent kernel
-// with a zero-latency dependency chain
-#ifndef MEGA_FREE_RUN
-#define MEGA_FREE_RUN 0
-#endif
 #include <type_traits>
 
 #include "attn_core.h"
@@ -53,11 +48,8 @@ __device__ __forceinline__ void mega_report_timeout(uint32_t* abort_flag, uint32
 // scoreboard and puts a counted `s_waitcnt vmcnt(N)` in front of their first use, where N no longer means what it assumed (LDS-direct
 // requests and the next poll's loads were issued in between): a wait for traffic the use does not depend on.  This compiler-visible
 // wait right behind the poll costs nothing (nothing is outstanding) and clears the scoreboard.
-#ifndef MEGA_POLL_SCOREBOARD
-#define MEGA_POLL_SCOREBOARD 1
-#endif
 __device__ __forceinline__ void mega_loads_have_landed() {
-    if (MEGA_POLL_SCOREBOARD) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
 }
 
 // The abort flag as the polls take it: a pointer, or a callable returning it that is evaluated only when a wait runs out (the persistent
@@ -79,7 +71,7 @@ __device__ __forceinline__ void wave_poll(uint32_t tag, AF abort_flag_of, int* s
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < PER; ++k) ok = ok && (!have[k] || (uint32_t)(v[k] >> 32) == tag);
-        if (MEGA_FREE_RUN || __all(ok)) {
+        if (__all(ok)) {
 #pragma unroll
             for (int k = 0; k < PER; ++k)
                 if (have[k]) sink(k, (uint32_t)v[k]);
@@ -205,7 +197,7 @@ __device__ __forceinline__ void wave_poll16(const gran_t* g, uint32_t tag, AF ab
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < PER; ++k) ok = ok && (n[k] < 0 || (v[k].y == tag && v[k].w == tag));
-        if (MEGA_FREE_RUN || __all(ok)) {
+        if (__all(ok)) {
 #pragma unroll
             for (int k = 0; k < PER; ++k)
                 if (n[k] >= 0) {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """VGPRs / scratch / spills of every kernel of one source, from hipcc's -Rpass-analysis=kernel-resource-usage remarks:
-    python tools/kernel_resources.py decode_mega ["-DMEGA_EARLY_QKV=1"]"""
+    python tools/kernel_resources.py decode_mega ["-DMEGA_EW2_CHUNKS=7"]"""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]

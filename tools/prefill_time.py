@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """mv_begin (state upload + MFMA prefill + first token) of the full-size engine at several prompt lengths, with the 64-column x all-rows
-GEMM (`gemm_skinny_kernel`, round 4) and with the 64 x 64 tiles (MV_GEMM_NO_SKINNY=1); the first sampled tokens must agree.
+GEMM (`gemm_skinny_kernel`, round 4) and with the 64 x 64 tiles (the default: MV_GEMM_SKINNY unset); the first sampled tokens must agree.
 usage: prefill_time.py [reps]   env PREFILL_T="50,128,256,512,1100,2016" """
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
