@@ -701,10 +701,10 @@ def parse_args(argv=None):
                     help="A/B switch: auto = the engine's choice (persistent kernel drawing its own tokens where supported), step = persistent "
                          "kernel, one step per launch + sampler launch, launches = per-layer launches")
     a = ap.parse_args(argv)
-    if a.utterances_per_gpu not in (1, 2, 3, 4, 8):
-        ap.error("--utterances-per-gpu: 1..4 or 8 (engines of 8 utterances run on the matrix-core persistent kernel, bf16 only)")
-    if a.utterances_per_gpu == 8 and a.quantisation_mode is not None:
-        ap.error("--utterances-per-gpu 8 is bf16 only")
+    if not 1 <= a.utterances_per_gpu <= 8:
+        ap.error("--utterances-per-gpu: 1..8 (3 and 5..7 run on engines of 4 / 8 slots with the spare slots idle; more than 4 is bf16 only)")
+    if a.utterances_per_gpu > 4 and a.quantisation_mode is not None:
+        ap.error("--utterances-per-gpu above 4 is bf16 only (engines of 8 utterances run on the matrix-core persistent kernel)")
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
     return a

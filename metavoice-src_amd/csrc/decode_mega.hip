@@ -36,6 +36,7 @@
 //  * COLD fields -- everything the step prologue, the token draw, the time-out path and the test hooks need -- are read through
 //    `KC(i)`: the kernarg pointer plus `(i >> 30)` elements, i being the step or layer counter: the optimiser cannot prove the offset
 //    zero, so it can neither hoist those s_loads out of the loop nor keep their results live across it.
+//    `i` must stay below 2^30 (then `i >> 30` IS zero): today's indices are the workgroup id (< 256), the layer (< 32) and the step (<= 512).
 // (Tried first: a VOLATILE view of the whole struct, every access an s_load at its use.  The publishes then waited for a scalar load
 // each -- 683-690 vs 678 us/step -- and in the one-step instances hipcc moved the kernarg pointer into a VGPR pair and fetched every
 // field with `global_load ... sc0 sc1`: 790 vs 691 us/step, profiles/r04a.  An empty asm with a "+s" operand on the pointer does not

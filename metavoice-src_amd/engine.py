@@ -53,10 +53,19 @@ class Stage1Engine:
             raise Exception(f"Invalid quantisation mode {quantisation_mode}! Must be either 'int4' or 'int8'!")
         self.args = args
         self.max_utterances = max_utterances
-        self.rows = 2 * max_utterances
+        # The persistent decode kernels exist for engines of 1, 2, 4 and (bf16) 8 utterances.  A request for 3 / 5..7 gets the next size
+        # up: the spare slots stay idle (mv_begin marks them done, their rows cost a few cache lines), where a native engine of 3 would
+        # decode on the per-layer launches and one of 5..7 does not exist.
+        slots = max_utterances
+        if max_utterances == 3:
+            slots = 4
+        elif 5 <= max_utterances <= 7 and fmt == N.MV_W_BF16:
+            slots = 8
+        self.slots = slots
+        self.rows = 2 * slots
         cfg = N.mv_config(n_layer=args.n_layer, n_head=args.n_head, dim=args.dim, intermediate=args.intermediate_size,
                           vocab=args.vocab_size, block_size=args.block_size, spk_dim=args.speaker_emb_dim,
-                          norm_eps=args.norm_eps, max_utterances=max_utterances, weight_format=fmt)
+                          norm_eps=args.norm_eps, max_utterances=slots, weight_format=fmt)
         self._h = C.c_void_p()
         N.check(N.lib().mv_engine_create(C.byref(cfg), C.byref(self._h)))
         self._finalized = False

@@ -320,6 +320,7 @@ def test_persistent_decode_kernel_is_bit_identical_to_per_layer_launches(n_layer
     (2, 2, [250, 700], 20, dict(top_k=1)),                    # one utterance crosses 256 keys (1 -> 8 key ranges), the other is beyond
     (4, 3, [96, 160, 131, 17], 40, dict(top_p=0.95)),
     (4, 2, [300, 12, 2000, 255], 24, dict(top_p=0.9, temperature=0.8)),  # every attention regime at once
+    (3, 2, [70, 300, 19], 20, dict(top_k=1)),                 # an engine "of 3": four slots, one idle (Stage1Engine rounds up to a persistent-kernel size)
 ])
 def test_persistent_kernel_with_several_utterances_is_bit_identical_to_launches(n_utt, n_layer, lens, n_new, combo):
     """The persistent kernel decoding 2 or 4 utterances together (the weight rows a wave holds are applied to every utterance;
@@ -327,6 +328,7 @@ def test_persistent_kernel_with_several_utterances_is_bit_identical_to_launches(
     each utterance decoded ALONE: identical tokens and logits."""
     cfgk = dict(WIDE2, n_layer=n_layer)
     engine, sd, cfg = build(cfgk, 13, max_utterances=n_utt)
+    assert engine.slots == (4 if n_utt == 3 else n_utt)
     prompts = [synthetic.prompt_tokens(t, seed=30 + u) for u, t in enumerate(lens)]
     spks = torch.cat([synthetic.speaker_embedding(40 + u) for u in range(n_utt)])
     sps = [mv.SamplingParams(guidance_scale=3.0, seed=50 + u, **combo) for u in range(n_utt)]
@@ -339,7 +341,7 @@ def test_persistent_kernel_with_several_utterances_is_bit_identical_to_launches(
         engine.run()
         toks = [engine.tokens(u) for u in range(n_utt)]
         first = min(lens) - 1
-        out[mega] = (toks, engine.captured_logits(max(lens) - 1, n_new - 1))  # steps every utterance is decoding in
+        out[mega] = (toks, engine.captured_logits(max(lens) - 1, n_new - 1)[:, :2 * n_utt])  # steps every utterance is decoding in; an idle slot's rows are never written
     engine.tune(mega=1)
     assert engine.decode_path() == (1, 0), "the persistent kernel was abandoned (hand-off timed out) during the test"
     engine.tune(mfma=1)   # process-wide: back to the default
