@@ -1,4 +1,4 @@
-// Persistent decode-step kernel for engines of 4 utterances (8 CFG rows) on the MATRIX CORES: all 24 layers + the LM head of one token
+// Persistent decode-step kernel for engines of 4 and 8 utterances (8 / 16 CFG rows) on the MATRIX CORES: all 24 layers + the LM head of one token
 // in ONE launch, the same hand-off protocol, granule buffers and attention partition as decode_mega.hip -- but the five projections of a
 // layer run on v_mfma_f32_16x16x32_bf16 instead of v_dot2 + 64-lane sums.
 //
@@ -22,7 +22,8 @@
 // is decode_mega.hip's, function for function); what changes is the ORDER of the fp32 additions inside a projection (MFMA k-order per
 // wave, then 8 wave partials) -- so this kernel is NOT bit-identical to the per-layer launches or to a single-utterance run; the tests
 // hold it to the bf16 noise floor instead (tests/test_engine_gpu.py: logits within tolerance, margin-gated token agreement).
-// `mv_tune("mfma", 0)` puts engines of 4 utterances back on decode_mega.hip's bit-identical instance.
+// `mv_tune("mfma", 0)` puts engines of 4 utterances back on decode_mega.hip's bit-identical instance.  Engines of 8 utterances (16 rows = one full
+// B tile; the w2 phase in two passes over the column halves of the activation vector) exist only here.
 #include <atomic>
 
 #include "mega_core.h"
