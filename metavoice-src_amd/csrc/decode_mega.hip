@@ -860,11 +860,6 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         __syncthreads();
         MG_STAMP(l, 6);
         {
-            // An unused 16-byte local: the register allocation of the one-utterance bf16 instance depends on its presence (206 vs 209 VGPRs,
-            // 62 vs 70 SGPR spills without it; the ISA comparison of tests/test_isa_regressions_cpu.py's recipe).  Left from round 4's
-            // MEGA_POLL_NORM experiment (tools/experiments/decode_mega_r04_switches.patch); remove only together with a measurement.
-            u32x4 raw_h = {0u, 0u, 0u, 0u};
-            (void)raw_h;
             mega_poll_rowpairs<NU>(g_h, tag0 + 2u, xa, abort_flag_of, &s_abort, tid_o);
             __syncthreads();
             MG_ABORT_RETURN();

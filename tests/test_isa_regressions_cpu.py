@@ -73,7 +73,11 @@ def test_persistent_decode_kernel_has_no_scratch_and_no_flat_loads(tmp_path):
         # r04u: the epilogue sums run level by level over all their values (wave_sum_n) with the two row-broadcast levels as single masked
         # DPP adds; one chain after the other hipcc put `s_nop 1` behind every DPP add (433 in the one-utterance bf16 instance)
         if n_utt == "1" and fmt == "0":
-            assert body.count("s_nop") < 400, f"{name}: {body.count('s_nop')} s_nop"
+            lines = body.split("\n")
+            after_dpp = sum(1 for i in range(1, len(lines)) if "s_nop" in lines[i] and "dpp" in lines[i - 1])
+            # 83 today in both one-utterance bf16 instances; the total count (397-408 with the token draw inside) also moves with the
+            # number of spilled SGPRs (v_readlane + s_nop), which is not what this guards
+            assert after_dpp < 120, f"{name}: {after_dpp} s_nop directly behind a DPP add"
             assert len(re.findall(r"v_add_f32_dpp v\d+, v\d+, v\d+ row_bcast:15 row_mask:0xa", body)) >= 20, name
     assert seen == 12   # 3 formats x (1 utterance one-step, 2, 4) + the three one-utterance instances that draw their own tokens
 
