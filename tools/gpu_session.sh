@@ -8,6 +8,7 @@
 #                                  e.g. ab:r03,product:bf16x1,bf16x4
 #   fold:<libs>                    tools/fold_sweep.py (launches / one step per launch / token drawn in the launch) per library
 #   tests[:<pytest -k expression>] the GPU suite (or a subset)
+#   lines[:<pytest -k expression>] the figures the parity tests print (pytest -s), collected into pytest_lines.txt
 #   smoke                          __graft_entry__.smoke()
 #   bench[:<bench.py arguments>]   the default bench line (+ a one-line summary)
 #   stamps[:<utterances>[:<pos>]]  phase stamps of the persistent kernel (instrumented library)
@@ -40,6 +41,10 @@ for step in "$@"; do
     tests)
       if [ -n "${a1:-}" ]; then timeout 1500 python -m pytest tests -m gpu -x -q -k "$a1" > $OUT/pytest.log 2>&1 < /dev/null; else timeout 1700 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1 < /dev/null; fi
       echo "pytest rc=$?" | tee $OUT/pytest.rc; tail -5 $OUT/pytest.log ;;
+    lines)
+      # the figures the parity tests print (-s): SNR / distance lines of the benched-size, matrix-core, int4 and front-end tests, for profiles/
+      timeout 900 python -m pytest tests -m gpu -q -s -k "${a1:-benched or matrix_core or audio_front or int4 or fullsize_golden}" > $OUT/pytest_s.log 2>&1 < /dev/null
+      grep -aE "\[[^]]+\]|passed|failed" $OUT/pytest_s.log | sed 's/^\.*//' | sort -u > $OUT/pytest_lines.txt; tail -3 $OUT/pytest_lines.txt ;;
     smoke)
       timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('__SMOKE_OK__')" > $OUT/smoke.log 2>&1 < /dev/null; tail -4 $OUT/smoke.log ;;
     bench)
