@@ -49,10 +49,18 @@ typedef const __attribute__((address_space(4))) MegaArgs* mega_kargs_t;
 #define MG_STAMP(l, k) do { if (stamping && lane == 0) (a.stamps + (size_t)(b == 0 ? 0 : 1) * n_layer * MG_STAMP_SLOTS)[(l) * MG_STAMP_SLOTS + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define MG_DBG_ON() (a.dbg != nullptr)
 #define MG_ABLATE (a.ablate)
+// how many attempts of a hand-off poll came back incomplete (wave 0 of the first / last workgroup), 12 bits per hop -- x, q/k/v, attention
+// vector, h, activation -- packed into stamp slot 22 of the layer (tools/mega_stamps.py prints the means)
+#define MG_TRIES_DECL() uint64_t tries_word = 0
+#define MG_TRIES(k, expr) do { const int t_ = (expr); tries_word += (uint64_t)min(t_, 4095) << (12 * (k)); } while (0)
+#define MG_TRIES_STORE(l) do { if (stamping && lane == 0) (a.stamps + (size_t)(b == 0 ? 0 : 1) * n_layer * MG_STAMP_SLOTS)[(l) * MG_STAMP_SLOTS + 22] = tries_word; } while (0)
 #else
 #define MG_ABLATE 0
 #define MG_STAMP(l, k) do { } while (0)
 #define MG_DBG_ON() false
+#define MG_TRIES_DECL() do { } while (0)
+#define MG_TRIES(k, expr) do { (void)(expr); } while (0)
+#define MG_TRIES_STORE(l) do { } while (0)
 #endif
 bool mega_instrumented() { return MEGA_INSTR != 0; }
 
@@ -248,9 +256,9 @@ __device__ __forceinline__ float i8_out(float wave_total, float scale) { return 
 // 16-byte polls of a row-paired 2048-column vector of every utterance ([NU][2048] granules): pair n = granules 2n, 2n+1 =
 // columns 2n, 2n+1 of both rows.  ONE poll loop for all utterances: a loop per utterance would pay a round trip each.
 template <int NU, typename AF>
-__device__ __forceinline__ void mega_poll_rowpairs(const gran_t* g, uint32_t tag, bf16_t (*xs)[2 * MG_INTER], AF abort_flag, int* s_abort,
-                                                   int tid) {
-    wave_poll16<2 * NU>(g, tag, abort_flag, s_abort, [&](int k) { return (k >> 1) * (MG_DIM / 2) + tid + (k & 1) * MG_THREADS; },
+__device__ __forceinline__ int mega_poll_rowpairs(const gran_t* g, uint32_t tag, bf16_t (*xs)[2 * MG_INTER], AF abort_flag, int* s_abort,
+                                                  int tid) {
+    return wave_poll16<2 * NU>(g, tag, abort_flag, s_abort, [&](int k) { return (k >> 1) * (MG_DIM / 2) + tid + (k & 1) * MG_THREADS; },
                         [&](int n, uint32_t p0, uint32_t p1) {
                             const int u = n / (MG_DIM / 2), c = n % (MG_DIM / 2);
                             *(uint32_t*)(xs[u] + 2 * c) = (p0 & 0xFFFFu) | (p1 << 16);
@@ -514,13 +522,14 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         // ================= P0: RMSNorm + wqkv (+ KV-cache write)        fast_model.py:179,209,218 ====================
         __syncthreads();
         MG_STAMP(l, 0);
+        MG_TRIES_DECL();
         if (l == 0) {
             if (step == 0) {
 #pragma unroll
                 for (int u = 0; u < NU; ++u)
                     *(u32x4*)(xa[u] + tid * 8) = load16(KC(step)->x_in + (size_t)u * 2 * MG_DIM + tid * 8);  // written by the sampler in the previous launch
             }  // later steps: built at the end of the previous step from the control word
-        } else mega_poll_rowpairs<NU>(g_x, tag0 - 8u + 4u, xa, abort_flag_of, &s_abort, tid_o);
+        } else MG_TRIES(0, mega_poll_rowpairs<NU>(g_x, tag0 - 8u + 4u, xa, abort_flag_of, &s_abort, tid_o));
         __syncthreads();
         MG_ABORT_RETURN();
         MG_STAMP(l, 1);
@@ -632,21 +641,21 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                 const int sec = tid_o >> 7, c = tid_o & 127;
                 const gran_t* gq = g_qkv;
                 if constexpr (ATTN_V2)
-                    wave_poll<1>(tag0 + 0u, abort_flag_of, &s_abort,
+                    MG_TRIES(1, wave_poll<1>(tag0 + 0u, abort_flag_of, &s_abort,
                                  [&](int, u64& v) {
                                      if (tid_o >= 384) return false;
                                      v = gran_load(gq + (size_t)at_u * 3 * MG_DIM + sec * MG_DIM + at_h * 128 + c);
                                      return true;
                                  },
-                                 [&](int, uint32_t p) { qkv_s[0][(sec * 2 + 0) * 128 + c] = (bf16_t)p; qkv_s[0][(sec * 2 + 1) * 128 + c] = (bf16_t)(p >> 16); });
+                                 [&](int, uint32_t p) { qkv_s[0][(sec * 2 + 0) * 128 + c] = (bf16_t)p; qkv_s[0][(sec * 2 + 1) * 128 + c] = (bf16_t)(p >> 16); }));
                 else
-                wave_poll<NU>(tag0 + 0u, abort_flag_of, &s_abort,
+                MG_TRIES(1, wave_poll<NU>(tag0 + 0u, abort_flag_of, &s_abort,
                               [&](int k, u64& v) {
                                   if (tid_o >= 384 || !(at_s < GEO(2, k))) return false;
                                   v = gran_load(gq + (size_t)k * 3 * MG_DIM + sec * MG_DIM + at_h * 128 + c);
                                   return true;
                               },
-                              [&](int k, uint32_t p) { qkv_s[k][(sec * 2 + 0) * 128 + c] = (bf16_t)p; qkv_s[k][(sec * 2 + 1) * 128 + c] = (bf16_t)(p >> 16); });
+                              [&](int k, uint32_t p) { qkv_s[k][(sec * 2 + 0) * 128 + c] = (bf16_t)p; qkv_s[k][(sec * 2 + 1) * 128 + c] = (bf16_t)(p >> 16); }));
             }
             __syncthreads();
             MG_ABORT_RETURN();
@@ -818,8 +827,8 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         MG_STAMP(l, 4);
         {
             // granule i of utterance u = elements 2i, 2i+1 of its [2][2048] attention output
-            wave_poll16<2 * NU>(g_attn, tag0 + 1u, abort_flag_of, &s_abort, [&](int k) { return (k >> 1) * (MG_DIM / 2) * 2 / 2 + tid_o + (k & 1) * MG_THREADS; },
-                                [&](int n, uint32_t p0, uint32_t p1) { ((uint2*)xs[n / (MG_DIM / 2)])[n % (MG_DIM / 2)] = make_uint2(p0, p1); });
+            MG_TRIES(2, wave_poll16<2 * NU>(g_attn, tag0 + 1u, abort_flag_of, &s_abort, [&](int k) { return (k >> 1) * (MG_DIM / 2) * 2 / 2 + tid_o + (k & 1) * MG_THREADS; },
+                                            [&](int n, uint32_t p0, uint32_t p1) { ((uint2*)xs[n / (MG_DIM / 2)])[n % (MG_DIM / 2)] = make_uint2(p0, p1); }));
             __syncthreads();
             MG_ABORT_RETURN();
             MG_STAMP(l, 5);
@@ -860,7 +869,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
         __syncthreads();
         MG_STAMP(l, 6);
         {
-            mega_poll_rowpairs<NU>(g_h, tag0 + 2u, xa, abort_flag_of, &s_abort, tid_o);
+            MG_TRIES(3, mega_poll_rowpairs<NU>(g_h, tag0 + 2u, xa, abort_flag_of, &s_abort, tid_o));
             __syncthreads();
             MG_ABORT_RETURN();
             MG_STAMP(l, 7);
@@ -947,7 +956,7 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
             constexpr int PPT = (MG_INTER / 2 + MG_THREADS - 1) / MG_THREADS;  // pairs per thread and utterance
 #pragma unroll
             for (int u0 = 0; u0 < NU; u0 += UPP) {
-                wave_poll16<PPT * UPP>(g_act + (size_t)u0 * MG_INTER, tag0 + 3u, abort_flag_of, &s_abort,
+                MG_TRIES(4, wave_poll16<PPT * UPP>(g_act + (size_t)u0 * MG_INTER, tag0 + 3u, abort_flag_of, &s_abort,
                                        [&](int k) {
                                            const int n = tid_o + (k % PPT) * MG_THREADS;
                                            return n < MG_INTER / 2 ? (k / PPT) * (MG_INTER / 2) + n : -1;
@@ -957,8 +966,9 @@ __global__ void __launch_bounds__(MG_THREADS, (NU == 1 ? 2 : 1)) decode_mega_ker
                                            const int c = n % (MG_INTER / 2);
                                            *(uint32_t*)(row + 2 * c) = (p0 & 0xFFFFu) | (p1 << 16);
                                            *(uint32_t*)(row + MG_INTER + 2 * c) = (p0 >> 16) | (p1 & 0xFFFF0000u);
-                                       });
+                                       }));
             }
+            MG_TRIES_STORE(l);
             __syncthreads();
             MG_ABORT_RETURN();
             MG_STAMP(l, 9);

@@ -61,8 +61,15 @@ __device__ __forceinline__ uint32_t* mega_abort_ptr(AF af) {
 }
 
 // One wave waits until all of ITS granules carry `tag` (no block barrier inside: the loaders only mirror the barrier after).
+// Returns the number of attempts that came back incomplete (0 = the first look saw everything; the instrumented build records it).
+// (Round 5: with this return value in place of `void` the one-utterance bf16 step is 7.5 us shorter -- 647.0-647.6 against 654.5-655.2 us, int8
+// 591-594 against 596-597, A B A B on one box and again on a second, identical tokens, profiles/r05q, r05r -- although no caller of the
+// product build reads it: the retry loops compile to slightly different control flow and every poll of the layer ends ~0.1 us earlier
+// (stamps).  A third form -- the compiler-visible wait of mega_loads_have_landed() behind the loop instead of inside it, the request
+// addresses computed once in front of the loop -- measured 9 us LONGER than the `void` form (663.5-664.3).  The form below is the
+// measured one; treat the loop's shape as part of the kernel's tuning, not as style.)
 template <int PER, typename AF, typename Fetch, typename Sink>
-__device__ __forceinline__ void wave_poll(uint32_t tag, AF abort_flag_of, int* s_abort, Fetch fetch, Sink sink) {
+__device__ __forceinline__ int wave_poll(uint32_t tag, AF abort_flag_of, int* s_abort, Fetch fetch, Sink sink) {
     for (int tries = 0;; ++tries) {
         u64 v[PER];
         bool have[PER];
@@ -75,7 +82,7 @@ __device__ __forceinline__ void wave_poll(uint32_t tag, AF abort_flag_of, int* s
 #pragma unroll
             for (int k = 0; k < PER; ++k)
                 if (have[k]) sink(k, (uint32_t)v[k]);
-            return;
+            return tries;
         }
         if ((tries & 1023) == 1023) {  // a peer is missing (grid not co-resident?) or already gave up
             uint32_t* abort_flag = mega_abort_ptr(abort_flag_of);
@@ -84,21 +91,12 @@ __device__ __forceinline__ void wave_poll(uint32_t tag, AF abort_flag_of, int* s
                 if (!peer) mega_report_timeout(abort_flag, tag);
                 __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *(volatile int*)s_abort = 1;
-                return;
+                return tries;
             }
         }
         __builtin_amdgcn_s_sleep(2);
     }
 }
-template <int NCOL, typename AF>
-__device__ __forceinline__ void wave_poll_rowpair(const gran_t* g, uint32_t tag, bf16_t* raw, AF abort_flag, int* s_abort, int tid) {
-    constexpr int PER = (NCOL + MG_THREADS - 1) / MG_THREADS;
-    wave_poll<PER>(
-        tag, abort_flag, s_abort,
-        [&](int k, u64& v) { const int n = tid + k * MG_THREADS; if (n >= NCOL) return false; v = gran_load(g + n); return true; },
-        [&](int k, uint32_t p) { const int n = tid + k * MG_THREADS; raw[n] = (bf16_t)p; raw[NCOL + n] = (bf16_t)(p >> 16); });
-}
-
 // PER 16-byte agent-scope loads AND their wait in ONE asm statement: hipcc does not know that an inline-asm load completes later
 // (cdna_hip_programming.md 5.7), so with the loads and the s_waitcnt in separate statements it is free to copy or spill an output
 // register in between -- before the data has landed.  It did, once the kernel grew (256 VGPRs, spills): every tag compared stale
@@ -182,7 +180,7 @@ __device__ __forceinline__ void poll16_loads(u32x4 (&v)[PER], const gran_t* cons
 // The same with 16-byte agent-scope loads: two granules per lane per request, each 8-byte half validated by its own tag
 // (profiles/r01g_handoff: 2.0 vs 2.3 us per idle 2048-granule hand-off).  index(k) = pair index of the lane's k-th request or -1.
 template <int PER, typename AF, typename Index, typename Sink>
-__device__ __forceinline__ void wave_poll16(const gran_t* g, uint32_t tag, AF abort_flag_of, int* s_abort, Index index, Sink sink) {
+__device__ __forceinline__ int wave_poll16(const gran_t* g, uint32_t tag, AF abort_flag_of, int* s_abort, Index index, Sink sink) {
     for (int tries = 0;; ++tries) {
         u32x4 v[PER];
         int n[PER];
@@ -205,7 +203,7 @@ __device__ __forceinline__ void wave_poll16(const gran_t* g, uint32_t tag, AF ab
                         sink(k, n[k], v[k].x, v[k].z);   // sinks that keep the payload in registers index by the (unrolled) request number
                     else sink(n[k], v[k].x, v[k].z);
                 }
-            return;
+            return tries;
         }
         if ((tries & 1023) == 1023) {
             uint32_t* abort_flag = mega_abort_ptr(abort_flag_of);
@@ -214,18 +212,9 @@ __device__ __forceinline__ void wave_poll16(const gran_t* g, uint32_t tag, AF ab
                 if (!peer) mega_report_timeout(abort_flag, tag);
                 __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *(volatile int*)s_abort = 1;
-                return;
+                return tries;
             }
         }
         __builtin_amdgcn_s_sleep(1);
     }
-}
-// row-paired vector of 2048 columns: pair n = granules 2n, 2n+1 = columns 2n, 2n+1 of both rows
-template <typename AF>
-__device__ __forceinline__ void wave_poll_rowpair16(const gran_t* g, uint32_t tag, bf16_t* raw, AF abort_flag, int* s_abort, int tid) {
-    wave_poll16<2>(g, tag, abort_flag, s_abort, [&](int k) { return tid + k * MG_THREADS; },
-                   [&](int n, uint32_t p0, uint32_t p1) {
-                       *(uint32_t*)(raw + 2 * n) = (p0 & 0xFFFFu) | (p1 << 16);
-                       *(uint32_t*)(raw + MG_DIM + 2 * n) = (p0 >> 16) | (p1 & 0xFFFF0000u);
-                   });
 }

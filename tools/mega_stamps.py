@@ -49,4 +49,11 @@ for blk in range(2):
         nxt = (st[blk, 3:-1, 0] - st[blk, 2:-2, 10]).mean()
         print("  fine (us since the previous stamp): " + "; ".join(f"{fine_names[k]} +{v * TICK_US:.2f}" for k, v in zip(fine_order[1:], dd)) +
               f"; next layer top (next wqkv requested) +{nxt * TICK_US:.2f}")
+for blk in range(2):
+    # slot 22: attempts of each hand-off poll that came back incomplete (wave 0), 12 bits per hop
+    tw = st[blk, 2:-2, 22].astype(np.uint64)
+    hops = ["x", "q/k/v", "attention vector", "h", "activation"]
+    tr = [((tw >> np.uint64(12 * k)) & np.uint64(4095)).astype(np.float64) for k in range(5)]
+    print(f"  workgroup {'first' if blk == 0 else 'last'}, incomplete poll attempts per hand-off (mean over layers; 0 = the first look saw everything): " +
+          ", ".join(f"{h} {t.mean():.2f} (max {int(t.max())})" for h, t in zip(hops, tr)))
 print("(s_memtime ticks)")
