@@ -474,7 +474,18 @@ def test_matrix_core_persistent_kernel_for_eight_utterances():
     e8.run()
     assert [len(e8.tokens(u)) for u in range(8)] == [t + 20 for t in lens] and e8.decode_path() == (3, 0)
     print(f"[mfma x 8, prompts {lens}] teacher-forced max |dlogit| / sigma vs the launches (engines of 4) {worst:.4f}")
+    full = [e8.tokens(u) for u in range(8)]
     e8.close()
+    # an engine "of 6": Stage1Engine rounds up to 8 slots, two stay idle (done from the start: no K/V reads, their rows never written) -- the six
+    # utterances must decode exactly as they did in the full batch (every utterance's arithmetic is its own: same kernel, same order)
+    e6 = mv.Stage1Engine(mv.ModelArgs(**cfgk), max_utterances=6)
+    assert e6.slots == 8
+    e6.load_state_dict(sd); e6.finalize()
+    e6.begin(prompts[:6], spks[:6], sps[:6], max_new_tokens=20, end_of_audio_token=9999, prefill_mode=1)
+    e6.run()
+    assert e6.decode_path() == (3, 0)
+    assert [e6.tokens(u) for u in range(6)] == full[:6], "six utterances on an engine of 8 slots decode differently from the full batch"
+    e6.close()
 
 
 def test_persistent_kernel_times_out_cleanly_and_the_run_falls_back_to_launches():
