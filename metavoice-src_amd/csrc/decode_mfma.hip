@@ -225,6 +225,16 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
 #define MF_ABORTED() (*(volatile int*)&s_abort != 0)
 #define MF_ABORT_RETURN() do { if (MF_ABORTED()) return; } while (0)
 #define MF_GEO(k, u) __builtin_amdgcn_readfirstlane(geo[k][u])
+    // optional phase stamps (instrumented library only: `make instr` compiles this file under -DMEGA_INSTR=1 too; workgroups 0 and 255, wave 0):
+    // 0 layer top, 1 x ready, 2 norm done, 3 wqkv partial tiles stored, 4 q/k/v published, 5 q/k/v ready, 6 key ranges scored, 7 attention
+    // partial / output published, 8 attention vector ready, 9 h published, 10 h ready, 11 norm done, 12 w1|w3 tiles stored, 13 act published,
+    // 14 act ready (8 utterances: second half), 15 w2 tiles stored, 16 x published (tools/mega_stamps.py with MV_UTT=4 | 8)
+#if defined(MEGA_INSTR) && MEGA_INSTR
+    const bool stamping = a.stamps != nullptr && (b == 0 || b == 255) && wave == 0;
+#define MF_STAMP(l, k) do { if (stamping && lane == 0) (a.stamps + (size_t)(b == 0 ? 0 : 1) * n_layer * MG_STAMP_SLOTS)[(l) * MG_STAMP_SLOTS + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MF_STAMP(l, k) do { } while (0)
+#endif
     auto abort_flag_of = [&]() { return a.abort_flag; };
     const uint32_t epoch = a.step_counter[0] * 256u;
     const int n_layer = a.n_layer;
@@ -337,6 +347,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
 
         // ================= P0: RMSNorm + wqkv (+ KV-cache write)        fast_model.py:179,209,218 ====================
         __syncthreads();
+        MF_STAMP(l, 0);
         if (l == 0) {
             for (int it = tid_o; it < R * (MG_DIM / 8); it += MG_THREADS) {
                 const int rho = it / (MG_DIM / 8), c = (it % (MG_DIM / 8)) * 8;
@@ -346,10 +357,12 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
         *(u32x4*)(nws + tid_o * 8) = nwp;   // this layer's norm weights (requested with its wqkv fragments; landed: the poll ended in vmcnt(0))
         __syncthreads();
         MF_ABORT_RETURN();
+        MF_STAMP(l, 1);
         if (any_att) issue_kv(kv, vv, at_u, l, at_s, 1, lane_o, wave_o);   // K rows of the first range: they land under the norm and the MFMAs
         __builtin_amdgcn_sched_barrier(0);
         mf_norm<R>(xs, nws, a.eps, lane_o, wave_o);
         __syncthreads();
+        MF_STAMP(l, 2);
         {
             f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, lo = acc0, hi = acc0;
 #pragma unroll
@@ -365,6 +378,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
             mf_put(red, wave_o, 1, lane_o, mf_half_tile(lo, hi, lane_o));
         }
         __syncthreads();
+        MF_STAMP(l, 3);
         if (tid_o < MF_R_QKV * NU) {
             const int i = pi, u = pu, n = MF_R_QKV * b + i;
             // rows 0..15: tile 0; rows 16..23: the packed half tile, k-range halves in row slots i - 16 and i - 8
@@ -381,6 +395,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        MF_STAMP(l, 4);
         if (any_att) issue_kv(kv, vv, at_u, l, at_s, 2, lane_o, wave_o);   // V rows behind the publish, in front of the q/k/v hand-off
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();   // every publish of the workgroup has left: bulk requests may enter the CU's memory pipeline
@@ -418,6 +433,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
             }
             __syncthreads();
             MF_ABORT_RETURN();
+            MF_STAMP(l, 5);
             const int u = at_u;
             const int g = lane_o >> 4, dl = lane_o & 15, at_w = wave_o, lane = lane_o;
             const int Pu = MF_GEO(0, u), csu = MF_GEO(1, u), nactu = MF_GEO(2, u), kwu = MF_GEO(3, u);
@@ -517,6 +533,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
             }
 #endif
             __syncthreads();
+            MF_STAMP(l, 6);
             __builtin_amdgcn_sched_barrier(0);
             // wave j merges range j and publishes its partial; with a single range (<= 256 keys) the merged result is the output
             u64* slots = (u64*)a.partial + ((size_t)(2 * u + at_r) * MG_HEADS + at_h) * ATTN_NSPLIT * ATTN_TPART_STRIDE;
@@ -544,6 +561,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            MF_STAMP(l, 7);
             __syncthreads();
             if (!MF_W1_EARLY) request_w1();
         }
@@ -563,6 +581,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
         }
         __syncthreads();
         MF_ABORT_RETURN();
+        MF_STAMP(l, 8);
         {
             f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
 #pragma unroll
@@ -583,6 +602,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
             if (!withhold) gran_store(g_h + (size_t)u * MG_DIM + n, hres, tag0 + 2u);
         }
         __builtin_amdgcn_sched_barrier(0);
+        MF_STAMP(l, 9);
         __syncthreads();   // published: the w3 fragments may go out (w1 is already in flight)
         {
             const bf16_t* s3 = L.t[3] + (size_t)b * MF_R_W13 * MG_DIM;
@@ -598,8 +618,10 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
         mf_poll_rows<NU, MG_DIM, MG_DIM>(g_h, tag0 + 2u, xs, abort_flag_of, &s_abort, tid_o);
         __syncthreads();
         MF_ABORT_RETURN();
+        MF_STAMP(l, 10);
         mf_norm<R>(xs, nws + MG_DIM, a.eps, lane_o, wave_o);
         __syncthreads();
+        MF_STAMP(l, 11);
         {
             f32x4_t c0 = {0.f, 0.f, 0.f, 0.f}, l1 = c0, h1 = c0, c2 = c0, l3 = c0, h3 = c0;
 #pragma unroll
@@ -621,6 +643,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
             mf_put(red, wave_o, 3, lane_o, mf_half_tile(l3, h3, lane_o));
         }
         __syncthreads();
+        MF_STAMP(l, 12);
         if (tid_o < MF_R_W13 * NU) {
             const int i = pi, u = pu, n = MF_R_W13 * b + i;
             auto out = [&](int base, int j) { return i < 16 ? mf_get(red, base, i, j) : mf_get(red, base + 1, i - 16, j) + mf_get(red, base + 1, i - 8, j); };
@@ -629,6 +652,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
             gran_store(g_act + (size_t)u * MG_INTER + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 3u);
         }
         __builtin_amdgcn_sched_barrier(0);
+        MF_STAMP(l, 13);
         __syncthreads();   // published: the w2 rows may go out
         {   // w2 rows 8 b .. 8 b + 7, K = 5632 = 176 k-steps: 11 of each column half per wave, packed
             const bf16_t* slice = L.t[4] + (size_t)b * MF_R_W2 * MG_INTER;
@@ -645,6 +669,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
                 mf_poll_rows<NU, MG_INTER, MG_INTER>(g_act, tag0 + 3u, xs, abort_flag_of, &s_abort, tid_o);
                 __syncthreads();
                 MF_ABORT_RETURN();
+                MF_STAMP(l, 14);
 #pragma unroll
                 for (int i = 0; i < 11; ++i) {
                     lo = mf_mma(w2_r[i], mf_bfrag<R>(xs, 11 * wave_o + i, lane_o), lo);
@@ -662,12 +687,14 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
                 mf_poll_rows<NU, MG_INTER / 2, MG_INTER, MF_ACT8_UPP>(g_act + MG_INTER / 2, tag0 + 3u, xs, abort_flag_of, &s_abort, tid_o);
                 __syncthreads();
                 MF_ABORT_RETURN();
+                MF_STAMP(l, 14);
 #pragma unroll
                 for (int i = 0; i < 11; ++i) hi = mf_mma(w2_r[i], mf_bfrag<R>(xs, 11 * wave_o + i, lane_o), hi);
             }
             mf_put(red, wave_o, 0, lane_o, mf_half_tile(lo, hi, lane_o));
         }
         __syncthreads();
+        MF_STAMP(l, 15);
         if (tid_o < MF_R_W2 * NU) {
             const int i = pi, u = pu, n = MF_R_W2 * b + i;
             const bf16_t y0 = epi_resid((bf16_t)hres, mf_get(red, 0, i, 2 * u) + mf_get(red, 0, i + 8, 2 * u));
@@ -676,6 +703,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
             gran_store(g_x + (size_t)u * MG_DIM + n, xres, tag0 + 4u);
         }
         __builtin_amdgcn_sched_barrier(0);
+        MF_STAMP(l, 16);
         __syncthreads();   // published
         if (l + 1 < n_layer) request_wqkv(l + 1, lane_o, wave_o);
         else {   // LM-head rows 11 b .. 11 b + 10 (one row tile, 11 rows), and the final norm's weights

@@ -31,6 +31,20 @@ N.check(N.lib().mv_debug_stamps(e._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)),
 st = buf.reshape(2, L, S).astype(np.int64)
 TICK_US = 1 / 2340.0  # s_memtime ticks per us on this part (measured against HIP events)
 # coarse segments (slots 0..10) and, for the register-prefetch kernel, the fine order of slots inside a layer
+if NU >= 4 and e.decode_path()[0] == 3:   # the matrix-core instance (decode_mfma.hip): its own slot map
+    mf_names = ["x ready (poll)", "norm", "wqkv MFMAs + exchange", "reduce + q/k/v published", "q/k/v ready (V rows, wo requested; poll)", "key ranges scored",
+                "merge + partial / output published", "attention vector ready (w1 requested; combine + poll)", "wo MFMAs + reduce + h published", "h ready (w3 requested; poll)",
+                "norm", "w1|w3 MFMAs + exchange", "reduce + act published", "act ready (w2 requested; poll; 8 utterances: both halves)", "w2 MFMAs + exchange", "reduce + x published"]
+    for blk in range(2):
+        seq = st[blk][:, :17][2:-2]
+        dd = np.diff(seq, axis=1).mean(axis=0) * TICK_US
+        tot = (st[blk, 1:, 0] - st[blk, :-1, 0])[2:-2].mean() * TICK_US
+        nxt = tot - dd.sum()
+        print(f"decode_mfma_kernel<{NU}>, workgroup {'first' if blk == 0 else 'last'}: {tot:.1f} us per layer")
+        for nm, v in zip(mf_names, dd):
+            print(f"    {v:6.2f}  {nm}")
+        print(f"    {nxt:6.2f}  next layer top (next wqkv requested)")
+    sys.exit(0)
 names = ["wait x", "norm+qkv", "wait qkv", "attention", "wait attn", "wo -> P3", "wait h", "norm+w13 -> P4", "wait act", "w2+publish"]
 fine_order = [0, 1, 11, 12, 13, 2, 3, 14, 15, 4, 5, 16, 17, 6, 7, 18, 19, 20, 8, 9, 21, 10]
 fine_names = {0: "layer top", 1: "x ready", 11: "K/V requested", 12: "norm done", 13: "wqkv dots done", 2: "qkv published", 3: "q/k/v ready",
