@@ -153,7 +153,7 @@ __device__ __forceinline__ void mf_norm(bf16_t* xs, const bf16_t* nws, float eps
         for (int q = 0; q < 4; ++q) s += sumsq8(*(const u32x4*)(row + q * 512));
         const float rstd = rms_rstd(wave_sum(s), MG_DIM, eps);
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) *(u32x4*)(row + q * 512) = rms_apply8(*(const u32x4*)(row + q * 512), rstd, *(const u32x4*)(nws + q * 512 + lane * 8));
+        for (int q = 0; q < 4; ++q) *(u32x4*)(row + q * 512) = rms_apply8_unpacked(*(const u32x4*)(row + q * 512), rstd, *(const u32x4*)(nws + q * 512 + lane * 8));
     }
 }
 

@@ -29,6 +29,16 @@ __device__ __forceinline__ uint32_t rms_apply2(uint32_t x, float rstd, uint32_t 
     asm("" : "+v"(p));
     return pack_bf2(__uint_as_float(p << 16) * bf_lo(nw), __uint_as_float(p & 0xFFFF0000u) * bf_hi(nw));
 }
+// the form without the packed first rounding (one conversion per element): the same bits.  decode_mfma.hip keeps it -- with the packed form the
+// 8-utterance instance's register allocation spilled two K/V slots on arrival (tests/test_isa_regressions_cpu.py)
+__device__ __forceinline__ u32x4 rms_apply8_unpacked(const u32x4& x, float rstd, const u32x4& nw) {
+    u32x4 y;
+    y.x = pack_bf2(round_bf(bf_lo(x.x) * rstd) * bf_lo(nw.x), round_bf(bf_hi(x.x) * rstd) * bf_hi(nw.x));
+    y.y = pack_bf2(round_bf(bf_lo(x.y) * rstd) * bf_lo(nw.y), round_bf(bf_hi(x.y) * rstd) * bf_hi(nw.y));
+    y.z = pack_bf2(round_bf(bf_lo(x.z) * rstd) * bf_lo(nw.z), round_bf(bf_hi(x.z) * rstd) * bf_hi(nw.z));
+    y.w = pack_bf2(round_bf(bf_lo(x.w) * rstd) * bf_lo(nw.w), round_bf(bf_hi(x.w) * rstd) * bf_hi(nw.w));
+    return y;
+}
 __device__ __forceinline__ u32x4 rms_apply8(const u32x4& x, float rstd, const u32x4& nw) {
     u32x4 y;
     y.x = rms_apply2(x.x, rstd, nw.x);
