@@ -106,3 +106,22 @@ def test_fused_lstm_keeps_its_rows_in_registers(tmp_path):
     assert len(names) == 1 and usage[names[0]]["scratch"] == 0 and usage[names[0]]["vgpr"] >= 128   # 2 x 64 floats of gate rows per lane
     for name, body in kernel_bodies(asm, "lstm_seq"):
         assert "flat_load" not in body and "scratch_" not in body, name
+
+
+def test_round4_switch_patch_still_applies_and_compiles(tmp_path):
+    """tools/experiments/decode_mega_r04_switches.patch reinstates the compile-time switches that rounds 2-4 measured slower.  It
+    is the only place those experiments live now: it has to keep applying to the product source, and the patched kernel has to compile (all
+    switches at their defaults)."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    patch = os.path.join(ROOT, "tools", "experiments", "decode_mega_r04_switches.patch")
+    work = tmp_path / "tree"
+    shutil.copytree(os.path.join(ROOT, "metavoice-src_amd", "csrc"), work / "metavoice-src_amd" / "csrc")
+    shutil.copytree(os.path.join(ROOT, "include"), work / "include")
+    p = subprocess.run(["git", "apply", "--verbose", patch], cwd=work, capture_output=True, text=True)   # outside a repository: plain patch application
+    assert p.returncode == 0, p.stderr[-1500:]
+    src = (work / "metavoice-src_amd" / "csrc" / "decode_mega.hip").read_text()
+    assert "MEGA_POLL_NORM" in src and "MEGA_KV_UNCOND" in src and "MEGA_EARLY_QKV" in src
+    p = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-I" + str(work / "include"), "-S", "--cuda-device-only",
+                        "decode_mega.hip", "-o", str(tmp_path / "patched.s")], cwd=work / "metavoice-src_amd" / "csrc", capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-2000:]
