@@ -524,6 +524,8 @@ def main(argv=None):
     ap.add_argument("--quantisation_mode", choices=["int4", "int8"], default=None)
     ap.add_argument("--utterances_per_gpu", type=int, default=1, help="requests decoded together on one GPU (not in the reference)")
     a = ap.parse_args(argv)
+    if not 1 <= a.utterances_per_gpu <= 8 or (a.utterances_per_gpu > 4 and a.quantisation_mode is not None):
+        ap.error("--utterances_per_gpu: 1..8 (3 and 5..7 run on engines of 4 / 8 slots; more than 4 needs bf16 weights: the 8-slot engine runs on the matrix-core kernel)")
     logging.basicConfig(level=logging.INFO)
     import torch
 
