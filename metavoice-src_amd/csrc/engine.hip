@@ -195,20 +195,15 @@ int enqueue_step(mv_engine* e) {
         else HIP_TRY(launch_decode_mega(s, mega_args(e), c.weight_format));
         return enqueue_sampler(e);
     }
-    if (c.max_utterances == 8) return fail(MV_ERR_STATE, "an engine of 8 utterances decodes on the persistent matrix-core kernel only (mv_tune \"mega\" 0 / a timed-out launch leave it without a path)");
+    // Engines of 8 utterances (16 CFG rows): the per-layer kernels take up to 8 rows, so every launch is issued twice, once per half of the
+    // rows -- utterances 0..3 and 4..7 with their own slices of the activations, K/V caches, positions and split-attention scratch.  This is
+    // what mv_run falls back to when a hand-off of decode_mfma_kernel<8> times out, and what mv_tune("mega", 0) selects.
+    const int halves = R == 16 ? 2 : 1;
+    const int Rh = R / halves;
     for (int l = 0; l < c.n_layer; ++l) {
         const LayerW& w = e->layers[l];
-        bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
-        bf16_t* vc = e->vcache + (size_t)l * e->kv_layer_elems;
-        {   // RMSNorm + wqkv + KV-cache write            (fast_model.py:179,209,218)
-            GemvArgs a;
-            a.x = e->x; a.w = w.wqkv; a.norm_w = w.attn_norm; a.out = e->q; a.kcache = kc; a.vcache = vc;
-            a.pos = e->pos_arr; a.cache_len = c.block_size; a.n_head = c.n_head; a.dim = c.dim;
-            a.N = 3 * c.dim; a.K = c.dim; a.eps = c.norm_eps;
-            if (c.weight_format == MV_W_INT4_G128) HIP_TRY(launch_gemv_i4(s, R, to_i4(a, w.q[0], w.sz[0]), GEMV_QKV));
-            else if (c.weight_format == MV_W_INT8) HIP_TRY(launch_gemv_i8(s, R, to_i8(a, w.q8[0], w.s8[0]), GEMV_QKV));
-            else HIP_TRY(launch_gemv(s, R, a, GEMV_QKV));
-        }
+        bf16_t* kc_l = e->kcache + (size_t)l * e->kv_layer_elems;
+        bf16_t* vc_l = e->vcache + (size_t)l * e->kv_layer_elems;
         auto dbg_copy = [&](int which, const bf16_t* src, int cols) -> hipError_t {
             if (!e->dbg || R != 2) return hipSuccess;
             for (int r = 0; r < 2; ++r) {
@@ -218,44 +213,59 @@ int enqueue_step(mv_engine* e) {
             }
             return hipSuccess;
         };
+        for (int hf = 0; hf < halves; ++hf) {   // RMSNorm + wqkv + KV-cache write            (fast_model.py:179,209,218)
+            const size_t r0 = (size_t)hf * Rh;
+            GemvArgs a;
+            a.x = e->x + r0 * c.dim; a.w = w.wqkv; a.norm_w = w.attn_norm; a.out = e->q + r0 * c.dim;
+            a.kcache = kc_l + r0 * c.n_head * c.block_size * 128; a.vcache = vc_l + r0 * c.n_head * c.block_size * 128;
+            a.pos = e->pos_arr + r0 / 2; a.cache_len = c.block_size; a.n_head = c.n_head; a.dim = c.dim;
+            a.N = 3 * c.dim; a.K = c.dim; a.eps = c.norm_eps;
+            if (c.weight_format == MV_W_INT4_G128) HIP_TRY(launch_gemv_i4(s, Rh, to_i4(a, w.q[0], w.sz[0]), GEMV_QKV));
+            else if (c.weight_format == MV_W_INT8) HIP_TRY(launch_gemv_i8(s, Rh, to_i8(a, w.q8[0], w.s8[0]), GEMV_QKV));
+            else HIP_TRY(launch_gemv(s, Rh, a, GEMV_QKV));
+        }
         HIP_TRY(dbg_copy(0, e->q, c.dim));
-        {   // attention over keys [0, pos]                (fast_model.py:222)
+        for (int hf = 0; hf < halves; ++hf) {   // attention over keys [0, pos]                (fast_model.py:222)
+            const size_t r0 = (size_t)hf * Rh;
             AttnArgs a;
-            a.q = e->q; a.kcache = kc; a.vcache = vc; a.pos = e->pos_arr; a.partial = e->partial;
-            a.counters = e->counters; a.out = e->attn; a.n_head = c.n_head; a.cache_len = c.block_size;
-           
-            HIP_TRY(launch_attention_decode(s, R, a));
+            a.q = e->q + r0 * c.dim; a.kcache = kc_l + r0 * c.n_head * c.block_size * 128; a.vcache = vc_l + r0 * c.n_head * c.block_size * 128;
+            a.pos = e->pos_arr + r0 / 2; a.partial = e->partial + r0 * c.n_head * ATTN_NSPLIT * ATTN_PART_STRIDE;
+            a.counters = e->counters + r0 * c.n_head; a.out = e->attn + r0 * c.dim; a.n_head = c.n_head; a.cache_len = c.block_size;
+            HIP_TRY(launch_attention_decode(s, Rh, a));
         }
         HIP_TRY(dbg_copy(1, e->attn, c.dim));
-        {   // h = x + wo(attn)                            (fast_model.py:226,179)
+        for (int hf = 0; hf < halves; ++hf) {   // h = x + wo(attn)                            (fast_model.py:226,179)
+            const size_t r0 = (size_t)hf * Rh;
             GemvArgs a;
-            a.x = e->attn; a.w = w.wo; a.residual = e->x; a.out = e->h; a.N = c.dim; a.K = c.dim;
-            if (c.weight_format == MV_W_INT4_G128) HIP_TRY(launch_gemv_i4(s, R, to_i4(a, w.q[1], w.sz[1]), GEMV_RESID));
-            else if (c.weight_format == MV_W_INT8) HIP_TRY(launch_gemv_i8(s, R, to_i8(a, w.q8[1], w.s8[1]), GEMV_RESID));
-            else HIP_TRY(launch_gemv(s, R, a, GEMV_RESID));
+            a.x = e->attn + r0 * c.dim; a.w = w.wo; a.residual = e->x + r0 * c.dim; a.out = e->h + r0 * c.dim; a.N = c.dim; a.K = c.dim;
+            if (c.weight_format == MV_W_INT4_G128) HIP_TRY(launch_gemv_i4(s, Rh, to_i4(a, w.q[1], w.sz[1]), GEMV_RESID));
+            else if (c.weight_format == MV_W_INT8) HIP_TRY(launch_gemv_i8(s, Rh, to_i8(a, w.q8[1], w.s8[1]), GEMV_RESID));
+            else HIP_TRY(launch_gemv(s, Rh, a, GEMV_RESID));
         }
         HIP_TRY(dbg_copy(2, e->h, c.dim));
-        {   // act = silu(w1 n(h)) * w3 n(h)               (fast_model.py:180,237)
+        for (int hf = 0; hf < halves; ++hf) {   // act = silu(w1 n(h)) * w3 n(h)               (fast_model.py:180,237)
+            const size_t r0 = (size_t)hf * Rh;
             GemvArgs a;
-            a.x = e->h; a.w = w.w1; a.w2 = w.w3; a.norm_w = w.ffn_norm; a.out = e->act; a.N = c.intermediate;
+            a.x = e->h + r0 * c.dim; a.w = w.w1; a.w2 = w.w3; a.norm_w = w.ffn_norm; a.out = e->act + r0 * c.intermediate; a.N = c.intermediate;
             a.K = c.dim; a.eps = c.norm_eps;
             if (c.weight_format == MV_W_INT4_G128) {
                 GemvI4Args q = to_i4(a, w.q[2], w.sz[2]);
                 q.codes2 = w.q[3]; q.sz2 = w.sz[3];
-                HIP_TRY(launch_gemv_i4(s, R, q, GEMV_SWIGLU));
+                HIP_TRY(launch_gemv_i4(s, Rh, q, GEMV_SWIGLU));
             } else if (c.weight_format == MV_W_INT8) {
                 GemvI8Args q = to_i8(a, w.q8[2], w.s8[2]);
                 q.q2 = w.q8[3]; q.scales2 = w.s8[3];
-                HIP_TRY(launch_gemv_i8(s, R, q, GEMV_SWIGLU));
-            } else HIP_TRY(launch_gemv(s, R, a, GEMV_SWIGLU));
+                HIP_TRY(launch_gemv_i8(s, Rh, q, GEMV_SWIGLU));
+            } else HIP_TRY(launch_gemv(s, Rh, a, GEMV_SWIGLU));
         }
         HIP_TRY(dbg_copy(3, e->act, c.intermediate));
-        {   // x = h + w2(act)                             (fast_model.py:247,180)
+        for (int hf = 0; hf < halves; ++hf) {   // x = h + w2(act)                             (fast_model.py:247,180)
+            const size_t r0 = (size_t)hf * Rh;
             GemvArgs a;
-            a.x = e->act; a.w = w.w2; a.residual = e->h; a.out = e->x; a.N = c.dim; a.K = c.intermediate;
-            if (c.weight_format == MV_W_INT4_G128) HIP_TRY(launch_gemv_i4(s, R, to_i4(a, w.q[4], w.sz[4]), GEMV_RESID));
-            else if (c.weight_format == MV_W_INT8) HIP_TRY(launch_gemv_i8(s, R, to_i8(a, w.q8[4], w.s8[4]), GEMV_RESID));
-            else HIP_TRY(launch_gemv(s, R, a, GEMV_RESID));
+            a.x = e->act + r0 * c.intermediate; a.w = w.w2; a.residual = e->h + r0 * c.dim; a.out = e->x + r0 * c.dim; a.N = c.dim; a.K = c.intermediate;
+            if (c.weight_format == MV_W_INT4_G128) HIP_TRY(launch_gemv_i4(s, Rh, to_i4(a, w.q[4], w.sz[4]), GEMV_RESID));
+            else if (c.weight_format == MV_W_INT8) HIP_TRY(launch_gemv_i8(s, Rh, to_i8(a, w.q8[4], w.s8[4]), GEMV_RESID));
+            else HIP_TRY(launch_gemv(s, Rh, a, GEMV_RESID));
         }
         HIP_TRY(dbg_copy(4, e->x, c.dim));
     }
@@ -436,8 +446,8 @@ int mv_engine_create(const mv_config* cfg, mv_engine** out) {
     if (c.n_layer < 1 || c.n_head < 1 || c.dim < 128 || c.dim % c.n_head != 0 || c.dim / c.n_head != 128)
         return fail(MV_ERR_INVALID, "head_dim must be 128 (dim=%d n_head=%d)", c.dim, c.n_head);
     if (c.vocab < 2 || c.vocab > 4096) return fail(MV_ERR_INVALID, "vocab %d out of range [2,4096]", c.vocab);
-    // 8 utterances: only the matrix-core persistent kernel (decode_mfma.hip) decodes 16 rows -- bf16, MetaVoice-1B shape, checked at
-    // mv_finalize; there are no per-layer launches behind it (they stop at 8 rows), so a hand-off time-out is an error for such an engine
+    // 8 utterances: only the matrix-core persistent kernel (decode_mfma.hip) decodes 16 rows in one launch -- bf16, MetaVoice-1B shape, checked
+    // at mv_finalize; behind it the per-layer launches run once per half of the rows (enqueue_step), which is what a hand-off time-out falls back to
     const bool eight = c.max_utterances == 8 && c.weight_format == MV_W_BF16;
     if ((c.max_utterances < 1 || c.max_utterances > 4) && !eight) return fail(MV_ERR_INVALID, "max_utterances must be 1..4, or 8 with bf16 weights");
     if (!eight && (!gemv_supported(2 * c.max_utterances, c.dim) || !gemv_supported(2 * c.max_utterances, c.intermediate)))
@@ -896,18 +906,16 @@ int mv_run(mv_engine* e, int32_t max_steps, int32_t poll_every, int32_t* steps_r
         HIP_TRY(hipMemcpyAsync(e->host_flag, e->n_active, 4, hipMemcpyDeviceToHost, e->stream));
         if (mega_live) HIP_TRY(hipMemcpyAsync(e->host_flag + 1, e->abort_flag, 16, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
-        if (mega_live && e->host_flag[1] != 0 && U == 8) {
-            HIP_TRY(hipMemsetAsync(e->abort_flag, 0, 16, e->stream));
-            HIP_TRY(hipStreamSynchronize(e->stream));
-            ++e->mega_timeouts;
-            return fail(MV_ERR_HIP, "persistent decode kernel timed out waiting for a peer workgroup (grid not co-resident: is another kernel occupying the GPU?) "
-                                    "and an engine of 8 utterances has no per-layer launches to fall back to: run the batch again");
-        }
         if (mega_live && e->host_flag[1] != 0) {
             // A hand-off of the persistent kernel timed out (the 256 workgroups were not co-resident: another kernel held CUs).
             // A plain launch gives no residency guarantee, so this is a condition to survive, not an error: roll every utterance
             // back to the last poll, rebuild its input rows and redo the chunk -- and everything after it -- with per-layer launches
-            // (bit-identical arithmetic; the Philox noise is keyed by (seed, token, sequence index), so the redo draws the same tokens).
+            // (engines of 8 utterances: the same launches issued once per half of the rows, enqueue_step).  The Philox noise is keyed by
+            // (seed, token, sequence index), so the redo draws from the same noise.  Coming from decode_mega.hip the arithmetic is
+            // bit-identical and the redo draws the same tokens; coming from decode_mfma.hip (engines of 4 by default, of 8 always) the
+            // launches add every projection's fp32 terms in another order, so from the rolled-back position on the logits differ by
+            // the 1-2 bf16 ulps tests/test_fullsize_mfma_golden_gpu.py bounds and a sampled stream may leave the one the matrix-core
+            // kernel would have drawn: a valid draw of the same model, not the same draw (DESIGN.md "Reproducibility").
             HIP_TRY(hipMemsetAsync(e->abort_flag, 0, 16, e->stream));
             HIP_TRY(hipMemcpyAsync(e->utt, e->utt_shadow, (size_t)U * sizeof(UttState), hipMemcpyDeviceToDevice, e->stream));
             HIP_TRY(hipMemcpyAsync(e->pos_arr, e->pos_shadow, (size_t)U * 4, hipMemcpyDeviceToDevice, e->stream));

@@ -85,18 +85,37 @@ class EncodecDecoder(Decoder):
         """`decode_wav` for the utterances of a batch: the vocoder runs their diffusion bands on concurrent lanes where it can
         (`vocoder.MultiBandDiffusion.tokens_to_wav_many`; the same samples as one call per utterance).  With `return_exceptions` an
         utterance that fails ('wav predicted is shorter than 400ms!') leaves its exception in its slot."""
-        grids = [self._grid(t)[1] for t in token_lists]
-        many = getattr(self.vocoder, "tokens_to_wav_many", None)
-        wavs = many(grids) if many is not None and len(grids) > 1 else [self.vocoder(g) for g in grids]
-        out: list = []
-        for wav in wavs:
-            if wav.shape[-1] < 9600:
-                e = Exception("wav predicted is shorter than 400ms!")  # decoders.py:88-91
+        out: list = [None] * len(token_lists)
+        grids, idx = [], []
+        for i, t in enumerate(token_lists):   # the data adapter / grid of one utterance failing is that utterance's
+            try:
+                grids.append(self._grid(t)[1])
+                idx.append(i)
+            except Exception as e:
                 if not return_exceptions:
-                    raise e
-                out.append(e)
-            else:
-                out.append(wav)
+                    raise
+                out[i] = e
+        many = getattr(self.vocoder, "tokens_to_wav_many", None)
+        wavs: list
+        try:
+            wavs = many(grids) if many is not None and len(grids) > 1 else [self.vocoder(g) for g in grids]
+        except Exception:
+            if not return_exceptions:
+                raise
+            # a lane of the grouped call failed (a native error on one utterance's band): vocode one by one so that the failure stays
+            # with the utterance that caused it and the others of the group still come out
+            wavs = []
+            for g in grids:
+                try:
+                    wavs.append(self.vocoder(g))
+                except Exception as e:
+                    wavs.append(e)
+        for i, wav in zip(idx, wavs):
+            if not isinstance(wav, Exception) and wav.shape[-1] < 9600:
+                wav = Exception("wav predicted is shorter than 400ms!")  # decoders.py:88-91
+                if not return_exceptions:
+                    raise wav
+            out[i] = wav
         return out
 
     def wav_bytes(self, wav: torch.Tensor) -> bytes:

@@ -209,15 +209,17 @@ class TTS:
             for i, tokens in zip(good, streams):
                 try:
                     _, ids = self.first_stage_adapter.decode([tokens])
-                    (tl,) = list(self.llm_second_stage._second_stage_token_lists(
+                    tl = next(iter(self.llm_second_stage._second_stage_token_lists(
                         texts=[norm[i]], encodec_tokens=[torch.tensor(ids, dtype=torch.int32).unsqueeze(0)], speaker_embs=embs[i].unsqueeze(0),
-                        batch_size=1, top_k=200, temperature=1.0))
+                        batch_size=1, top_k=200, temperature=1.0)))
                     expanded.append((i, tl))
                 except Exception as e:
                     if not return_exceptions:
                         raise
                     out[i] = e
             if expanded:
+                # decode_wavs keeps a failure (the grid of one utterance, a native error on one vocoder lane, a too short waveform) in the
+                # slot of the utterance it belongs to when return_exceptions is set; without it the first failure propagates
                 wavs = self.llm_second_stage.decoder.decode_wavs([tl for _, tl in expanded], return_exceptions=return_exceptions)
                 for (i, _), w in zip(expanded, wavs):
                     out[i] = w

@@ -488,6 +488,109 @@ def test_matrix_core_persistent_kernel_for_eight_utterances():
     e6.close()
 
 
+def test_eight_utterance_engine_has_per_layer_launches_behind_the_matrix_core_kernel():
+    """An engine of 8 utterances with `mv_tune("mega", 0)`: the per-layer launches issued once per half of the 16 rows (csrc/engine.hip
+    enqueue_step).  Utterances 0..3 and 4..7 must decode exactly -- tokens and logits, bit for bit -- as they do four at a time on an engine
+    of 4 on the same launches (every row's arithmetic is its own), ragged prompts behind the MFMA prefill and teacher-forced."""
+    cfgk = dict(WIDE2, n_layer=2)
+    lens = [300, 12, 1030, 255, 40, 700, 17, 1500]
+    sd = o_s1.remap_checkpoint_keys(synthetic.stage1_state_dict(seed=23, **cfgk))
+    prompts = [synthetic.prompt_tokens(t, seed=210 + u) for u, t in enumerate(lens)]
+    spks = torch.cat([synthetic.speaker_embedding(220 + u) for u in range(8)])
+    sps = [mv.SamplingParams(guidance_scale=3.0, seed=230 + u, top_p=0.95) for u in range(8)]
+    n_new = 24
+    want_tok, want_lg = [], []
+    e4 = mv.Stage1Engine(mv.ModelArgs(**cfgk), max_utterances=4)
+    e4.load_state_dict(sd); e4.finalize()
+    e4.capture_logits(True)
+    e4.tune(mega=0)
+    for g0 in (0, 4):
+        e4.begin(prompts[g0:g0 + 4], spks[g0:g0 + 4], sps[g0:g0 + 4], max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
+        e4.run()
+        assert e4.decode_path() == (0, 0)
+        want_tok += [e4.tokens(k) for k in range(4)]
+        want_lg += [e4.captured_logits(lens[g0 + k], n_new - 1)[:, 2 * k:2 * k + 2].clone() for k in range(4)]
+    e4.tune(mega=1)
+    e4.close()
+    e8 = mv.Stage1Engine(mv.ModelArgs(**cfgk), max_utterances=8)
+    e8.load_state_dict(sd); e8.finalize()
+    e8.capture_logits(True)
+    try:
+        e8.tune(mega=0)
+        e8.begin(prompts, spks, sps, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
+        e8.run()
+        assert e8.decode_path() == (0, 0)
+        for u, t in enumerate(lens):
+            assert e8.tokens(u) == want_tok[u], f"utterance {u}: the halved launches of an engine of 8 draw other tokens than an engine of 4"
+            assert torch.equal(e8.captured_logits(t, n_new - 1)[:, 2 * u:2 * u + 2], want_lg[u])
+        # and the matrix-core kernel against these launches on the SAME engine (free-running greedy would fork at near-ties: teacher-forced)
+        short = [p[:200] for p in prompts]
+        forced = {}
+        for mega in (0, 1):
+            e8.tune(mega=mega)
+            e8.begin(short, spks, sps, max_new_tokens=2, end_of_audio_token=9999, prefill_mode=0)
+            e8.run()
+            assert e8.decode_path() == ((3, 0) if mega else (0, 0))
+            lg = e8.captured_logits(0, 200)
+            forced[mega] = [lg[:len(p), 2 * u:2 * u + 2].clone() for u, p in enumerate(short)]
+        worst = max(float((a - b).abs().max()) / float(b.std()) for a, b in zip(forced[1], forced[0]))
+        print(f"[engine of 8] decode_mfma_kernel<8> vs its own per-layer launches (two halves), teacher-forced: max |dlogit| / sigma {worst:.4f}")
+        assert worst <= 0.1
+    finally:
+        e8.tune(mega=1)
+    e8.close()
+
+
+@pytest.mark.parametrize("n_utt", [4, 8])
+def test_matrix_core_kernel_times_out_cleanly_and_the_batch_finishes_on_the_launches(n_utt):
+    """a hand-off time-out of `decode_mfma_kernel<4>` / `<8>` (grid not co-resident) must not fail the batch.  The
+    `mega_fault` hook makes one workgroup withhold one publish in every launch: the first chunk aborts, every utterance is rolled back to
+    the last poll and the batch -- that chunk and everything after it -- is decoded by the per-layer launches (engines of 8: once per half of
+    the rows).  `mv_run` returns success, `mv_decode_path` counts the abandoned launch, and since nothing of the aborted chunk counted the
+    tokens and logits are those of a run on the launches from the start, bit for bit.  Then the back-off / retry cycle of the one-utterance
+    test, and the kernel comes back once the obstacle is gone."""
+    cfgk = dict(WIDE2, n_layer=2)
+    lens = [40, 300, 17, 1030, 12, 700, 255, 90][:n_utt]
+    engine, sd, cfg = build(cfgk, 29, max_utterances=n_utt)
+    prompts = [synthetic.prompt_tokens(t, seed=310 + u) for u, t in enumerate(lens)]
+    spks = torch.cat([synthetic.speaker_embedding(320 + u) for u in range(n_utt)])
+    sps = [mv.SamplingParams(guidance_scale=3.0, seed=330 + u, top_p=0.9) for u in range(n_utt)]
+    n_new = 40
+    engine.capture_logits(True)
+
+    def run(poll_every=16):
+        engine.begin(prompts, spks, sps, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
+        steps = engine.run(poll_every=poll_every)
+        assert steps == n_new - 1
+        return [engine.tokens(u) for u in range(n_utt)], [engine.captured_logits(t, n_new - 1)[:, 2 * u:2 * u + 2].clone() for u, t in enumerate(lens)]
+
+    try:
+        engine.tune(mega=0)
+        want = run()
+        assert engine.decode_path() == (0, 0)
+        engine.tune(mega=1)
+        clean = run()
+        assert engine.decode_path() == (3, 0)
+        engine.tune(mega=1, mega_fault=8)
+        got = run()
+        assert engine.decode_path() == (0, 1), "one launch abandoned, the engine continues on the per-layer launches"
+        assert got[0] == want[0] and all(torch.equal(a, b) for a, b in zip(got[1], want[1]))
+        for _ in range(3):   # stays on the launches for the next three batches (no further time-out) ...
+            assert run()[0] == want[0] and engine.decode_path() == (0, 1)
+        assert run()[0] == want[0] and engine.decode_path() == (0, 2)   # ... tries again with the fourth: the fault is still there
+        engine.tune(mega_fault=0)
+        for _ in range(7):
+            run()
+            assert engine.decode_path() == (0, 2)
+        back = run()   # the obstacle is gone: the eighth batch after the second failure is the matrix-core kernel's again
+        assert engine.decode_path() == (3, 2)
+        assert back[0] == clean[0] and all(torch.equal(a, b) for a, b in zip(back[1], clean[1])), "the kernel came back with other bits than before the fault"
+    finally:
+        engine.tune(mega_fault=0)
+        engine.tune(mega=1)
+    engine.close()
+
+
 def test_persistent_kernel_times_out_cleanly_and_the_run_falls_back_to_launches():
     """A persistent kernel whose grid is not co-resident (or whose peer dies) must not hang and must not fail the run: every
     wait is bounded, the first workgroup to give up raises a device flag, the rest leave within a polling interval, and mv_run

@@ -284,3 +284,49 @@ def test_bpe_matches_independent_formulations_on_random_vocabularies():
     assert checked == 2400
     # the classic overlap case: "aaa" with the merge (a, a) fuses the LEFT pair
     assert tok_mod._bpe({b"a": 0, b"aa": 1}, b"aaa") == [1, 0]
+
+
+def test_grouped_vocoder_call_keeps_a_failure_with_its_utterance(tmp_path):
+    """`decode_wavs` vocodes a whole group in one call; with `return_exceptions` a failing utterance -- its token
+    grid, a native error on one vocoder lane, a waveform under 400 ms (fam/llm/decoders.py:88-91) -- must leave its exception in its own
+    slot and the rest of the group must still come out; without it the first failure propagates, as `decode()` of the reference does."""
+    import torch
+
+    decoders = load_pkg("decoders")
+
+    class Vocoder:
+        def __init__(self):
+            self.single_calls = 0
+
+        def __call__(self, grid):
+            self.single_calls += 1
+            if int(grid[0, 0, 0]) == 13:
+                raise RuntimeError("native lane error")
+            return torch.zeros(1, 1, 320 * grid.shape[-1])
+
+        def tokens_to_wav_many(self, grids):
+            if any(int(g[0, 0, 0]) == 13 for g in grids):
+                raise RuntimeError("native lane error")     # the grouped call fails as a whole ...
+            return [torch.zeros(1, 1, 320 * g.shape[-1]) for g in grids]
+
+    def adapter(tokens):
+        if tokens == "bad":
+            raise ValueError("adapter refused")
+        return [0], tokens
+
+    voc = Vocoder()
+    dec = decoders.EncodecDecoder(lambda ids: "t", adapter, str(tmp_path), vocoder=voc)
+    ok = [[7] * 40] * 8       # 40 frames = 12 800 samples
+    short = [[7] * 10] * 8    # 3 200 samples < 9 600
+    lane = [[13] * 40] * 8
+    out = dec.decode_wavs([ok, "bad", short, lane, ok], return_exceptions=True)
+    assert [type(o).__name__ for o in out] == ["Tensor", "ValueError", "Exception", "RuntimeError", "Tensor"]
+    assert "shorter than 400ms" in str(out[2]) and out[0].shape == (1, 1, 12800)
+    assert voc.single_calls == 4   # ... and the four utterances with a grid were vocoded one by one
+    with pytest.raises(ValueError):
+        dec.decode_wavs([ok, "bad"], return_exceptions=False)
+    with pytest.raises(Exception, match="shorter than 400ms"):
+        dec.decode_wavs([ok, short], return_exceptions=False)
+    with pytest.raises(RuntimeError):
+        dec.decode_wavs([ok, lane], return_exceptions=False)
+    assert [o.shape[-1] for o in dec.decode_wavs([ok, ok])] == [12800, 12800]
