@@ -46,10 +46,6 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #ifndef MF_KV_LDS
 #define MF_KV_LDS 0   // measured SLOWER (profiles/r05g: 1220 vs 1160 us/step): the loop still reloads spilled registers from scratch, and a scratch reload waits -- in order -- for the whole range in flight
 #endif
-// MF_ACT8_UPP: utterances per poll loop of the activation halves in the 8-utterance instance (4: 12 requests per lane and loop, 2: 6)
-#ifndef MF_ACT8_UPP
-#define MF_ACT8_UPP 2
-#endif
 // MF_NSPLIT: how many key ranges a (utterance, row, head) is cut into (see the geometry below): -1 = per instance -- 4 utterances: 1 | 4 | 8
 // (two workgroups share a (utterance, row, head): ceil(P / 256) ranges split 3 + 2 between them and measured no gain, r05j: 1164-1167 vs
 // 1169-1171 us/step), 8 utterances: ceil(P / 256) (one workgroup walks them all: 1859-1868 vs 1898 us/step)
@@ -157,36 +153,107 @@ __device__ __forceinline__ void mf_norm(bf16_t* xs, const bf16_t* nws, float eps
     }
 }
 
-// 64 lanes x 16 B of global memory -> 1 KB of LDS at `lds` (wave-uniform byte address), no registers: global_load_lds_dwordx4 (LDS
-// address = M0 + 16 x lane).  Completion is the wave's vmcnt like any load; the wave reads only slots it requested itself.
+// ---- hand-off of the activation vectors: TAG-FREE ROWS through LDS-DMA (round 6) ------------------------------------------------------
+// decode_mega.hip exchanges every vector as 8-byte granules {2 x bf16, 32-bit tag}: right for 2 rows, where a hand-off is a latency.  At 8 /
+// 16 rows it is a VOLUME: every workgroup polls every row of every vector -- 131 KB for each of x, h and the attention vector and 360 KB for
+// the activations at 16 rows, ~190 MB per layer chip-wide against 103 MB of weights -- and a poll keeps at most 12 x 16 B per lane in flight
+// (registers), so the activation vector came in four request -> land -> unpack rounds of ~3 us each (profiles/r05u: 12.4 of a layer's 72 us).
+// Here the four vectors are plain bf16 rows X | ATT | H | ACT [2 NU][columns] -- 2 bytes per value instead of 4 -- and a consumer pulls whole
+// rows straight into the operand rows `xs` with global_load_lds_dwordx4 (1 KB per wave instruction, no registers, no unpacking): all of a
+// wave's 4-12 requests are in flight at once, ONE round.
+//
+// Validity without tags: a slot holds either a value or the SENTINEL 0xFFFFFFFF per 32-bit word (two bf16 NaNs with every bit set; a
+// producer never stores that word: mf_word).  Producers publish with 4-byte (x, h, act) or 16-byte (attention output) agent-scope
+// write-through stores, consumers load agent-scope (sc1) and look for the sentinel in what landed; a request that still shows one is
+// repeated.  Every slot is put back to the sentinel by the thread that wrote it, once every reader is known to be done and before the
+// next poll of that wave (whose `s_waitcnt vmcnt(0)` also completes the wave's stores) -- i.e. before anything this workgroup publishes
+// later: a consumer that has seen those later publications can only find the sentinel or the NEW value (cdna_hip_programming.md Guideline
+// 16, "sc1 payload -> vmcnt(0) -> sc1 flag"; the flag here is the next vector).  Who is done when:
+//   H   (written P2 l, read P3 l)   every workgroup publishes act(l) behind its read     -> reset in front of the x poll of layer l + 1 (LM head: the last x poll)
+//   ACT (written P3 l, read P4 l)   every workgroup publishes x(l) behind its read       -> reset in front of the attention-vector poll of layer l + 1 (layer 23: behind the LM head's poll)
+//   X   (written P4 l, read P0 l+1) every workgroup publishes q/k/v(l+1) behind its read, and a complete attention vector needs every
+//                                   workgroup's q/k/v rows                                -> reset in front of the h poll of layer l + 1 (layer 23's stays: reset in front of the next launch's first poll)
+//   ATT (written P1 l, read P2 l)   every workgroup publishes h(l) behind its read       -> reset in front of the act poll of layer l
+// mv_begin fills all four with the sentinel (a fallback leaves them in any state).  q/k/v (3 KB per attention workgroup: a latency) and the
+// split-attention partials stay tagged granules.
+#define MF_SENTINEL 0xFFFFFFFFu
+__device__ __forceinline__ uint32_t mf_word(bf16_t lo, bf16_t hi) {   // two adjacent columns of one row as they are published
+    const uint32_t d = (uint32_t)lo | ((uint32_t)hi << 16);
+    return d == MF_SENTINEL ? 0x7FFF7FFFu : d;   // two NaNs stay two NaNs
+}
+__device__ __forceinline__ void mf_publish(bf16_t* p, uint32_t word) {
+    __hip_atomic_store((uint32_t*)p, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mf_publish16(bf16_t* p, u32x4 v) {
+    v.x = v.x == MF_SENTINEL ? 0x7FFF7FFFu : v.x; v.y = v.y == MF_SENTINEL ? 0x7FFF7FFFu : v.y;
+    v.z = v.z == MF_SENTINEL ? 0x7FFF7FFFu : v.z; v.w = v.w == MF_SENTINEL ? 0x7FFF7FFFu : v.w;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void mf_reset16(bf16_t* p) {
+    const u32x4 v = {MF_SENTINEL, MF_SENTINEL, MF_SENTINEL, MF_SENTINEL};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+// 64 lanes x 16 B of global memory -> 1 KB of LDS at `lds` (wave-uniform byte address), no registers: global_load_lds_dwordx4 (LDS address =
+// M0 + 16 x lane), agent scope.  Completion is the wave's vmcnt like any load; the wave reads only what it requested itself.
+template <bool AGENT>   // true: agent scope (sc1), a hand-off; false: nt, K/V rows that one workgroup reads once
 __device__ __forceinline__ void mf_row_to_lds(uint32_t lds, const void* g) {
     uint32_t m0_save;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(m0_save) : "s"(lds), "v"(g) : "memory");
+    if constexpr (AGENT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off sc1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_save) : "s"(lds), "v"(g) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_save) : "s"(lds), "v"(g) : "memory");
 }
 
-// 16-byte polls of NCOL columns of a row-paired vector of every utterance into the operand rows: `g` = the first polled column of
-// utterance 0, GSTRIDE granules from one utterance to the next; pair n = granules 2n, 2n + 1 = columns 2n, 2n + 1 of both rows of its
-// utterance.  UPP utterances per poll loop (poll16_loads has instances up to 12 requests).
-template <int NU, int NCOL, int GSTRIDE, int UPP_MAX = 4, typename AF>
-__device__ __forceinline__ void mf_poll_rows(const gran_t* g, uint32_t tag, bf16_t* xs, AF abort_flag, int* s_abort, int tid) {
-    constexpr int KP = mf_kp(NU);
-    constexpr int PPT = (NCOL / 2 + MG_THREADS - 1) / MG_THREADS;   // pairs per thread and utterance: 2 (2048 columns), 3 (2816) or 6 (5632)
-    constexpr int UPP = PPT <= 3 ? (UPP_MAX < 4 ? UPP_MAX : 4) : 2;
-    static_assert(NU % UPP == 0 && PPT * UPP <= 12, "utterances per poll loop");
+// NCOL columns (from `src`, row stride SRC_STRIDE elements) of the R rows of a vector into the operand rows: row r, columns 512 s .. 512 s + 511
+// = one request of one wave (wave w takes requests w, w + 8, ...: PER each), landing at xs[r][512 s ..].  Returns when nothing that landed
+// shows the sentinel (or the wait ran out: *s_abort set).
+template <int R, int NCOL, int SRC_STRIDE, typename AF>
+__device__ __forceinline__ void mf_fetch_rows(const bf16_t* src, bf16_t* xs, uint32_t xs_lds, uint32_t tag, AF abort_flag_of, int* s_abort, int lane, int wave_s) {
+    constexpr int KP = mf_kp(R / 2);
+    constexpr int NSEG = (NCOL + 511) / 512, NREQ = R * NSEG, PER = (NREQ + MG_WAVES - 1) / MG_WAVES;
+    static_assert(NCOL % 8 == 0 && PER <= 16, "request geometry");
+    uint32_t pending = (1u << PER) - 1u;   // wave-uniform
+    for (int tries = 0;; ++tries) {
 #pragma unroll
-    for (int u0 = 0; u0 < NU; u0 += UPP) {
-        wave_poll16<PPT * UPP>(g, tag, abort_flag, s_abort,
-                               [&](int k) {   // pair index relative to g, in granule PAIRS
-                                   const int n = tid + (k % PPT) * MG_THREADS;
-                                   return n < NCOL / 2 ? (u0 + k / PPT) * (GSTRIDE / 2) + n : -1;
-                               },
-                               [&](int n, uint32_t p0, uint32_t p1) {
-                                   bf16_t* row = xs + (size_t)(2 * (n / (GSTRIDE / 2))) * KP;
-                                   const int c = n % (GSTRIDE / 2);
-                                   *(uint32_t*)(row + 2 * c) = (p0 & 0xFFFFu) | (p1 << 16);
-                                   *(uint32_t*)(row + KP + 2 * c) = (p0 >> 16) | (p1 & 0xFFFF0000u);
-                               });
+        for (int i = 0; i < PER; ++i) {
+            const int q = wave_s + MG_WAVES * i;
+            if (q < NREQ && (pending >> i & 1u)) {
+                const int r = q / NSEG, sg = q % NSEG;
+                const int valid = NCOL - 512 * sg >= 512 ? 64 : (NCOL - 512 * sg) / 8;   // lanes of the row's last, partial request
+                if (lane < valid) mf_row_to_lds<true>(xs_lds + (uint32_t)(r * KP + 512 * sg) * 2u, src + (size_t)r * SRC_STRIDE + 512 * sg + lane * 8);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        mega_loads_have_landed();
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int q = wave_s + MG_WAVES * i;
+            if (q < NREQ && (pending >> i & 1u)) {
+                const int r = q / NSEG, sg = q % NSEG;
+                const int valid = NCOL - 512 * sg >= 512 ? 64 : (NCOL - 512 * sg) / 8;
+                bool bad = false;
+                if (lane < valid) {
+                    const u32x4 v = *(const u32x4*)(xs + (size_t)r * KP + 512 * sg + lane * 8);
+                    bad = v.x == MF_SENTINEL || v.y == MF_SENTINEL || v.z == MF_SENTINEL || v.w == MF_SENTINEL;
+                }
+                if (!__any(bad)) pending &= ~(1u << i);
+            }
+        }
+        pending = __builtin_amdgcn_readfirstlane(pending);
+        if (pending == 0u) return;
+        if ((tries & 1023) == 1023) {  // a peer is missing (grid not co-resident?) or already gave up
+            uint32_t* abort_flag = mega_abort_ptr(abort_flag_of);
+            const bool peer = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (peer || tries >= MG_SPIN_LIMIT) {
+                if (!peer) mega_report_timeout(abort_flag, tag);
+                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *(volatile int*)s_abort = 1;
+                return;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
     }
 }
 
@@ -261,19 +328,20 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
     const int at_s = (b % BPH) * rpw;                 // this workgroup's first range
     const bool any_att = at_s < geo[2][at_u];
 
-    // the six exchanged vectors of every utterance sit in ONE slab at compile-time offsets (engine.hip: mega_args)
-    gran_t* const g_x = a.g_x;
-    gran_t* const g_qkv = g_x + (size_t)NU * MG_DIM;
-    gran_t* const g_attn = g_qkv + (size_t)NU * 3 * MG_DIM;
-    gran_t* const g_h = g_attn + (size_t)NU * MG_DIM;
-    gran_t* const g_act = g_h + (size_t)NU * MG_DIM;
+    // the exchanged vectors sit in ONE slab at compile-time offsets (mfma_handoff_rows below; engine.hip arms the rows with the sentinel):
+    // q/k/v as tagged granules {columns 2 j | 2 j + 1 of ONE row, tag}, [R][3 x 1024]; then the tag-free rows X | ATT | H | ACT
+    gran_t* const g_qkv = a.g_x;
+    bf16_t* const r_x = (bf16_t*)(a.g_x + (size_t)NU * 3 * MG_DIM);
+    bf16_t* const r_attn = r_x + (size_t)R * MG_DIM;
+    bf16_t* const r_h = r_attn + (size_t)R * MG_DIM;
+    bf16_t* const r_act = r_h + (size_t)R * MG_DIM;
+    const uint32_t xs_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)mf_lds);
 
-    // reduce / publish thread t = (row slot i, utterance u): consecutive threads = the utterances of one weight row
-    uint32_t xres = 0u, hres = 0u;   // residual pair (row 0 | row 1 << 16) of column 8 b + pi of utterance pu: threads < 8 NU
-    if (tid < MF_R_WO * NU) {
-        const int pu = tid % NU, pi = tid / NU;
-        const bf16_t* xi = a.x_in + (size_t)pu * 2 * MG_DIM + 8 * b + pi;
-        xres = (uint32_t)xi[0] | ((uint32_t)xi[MG_DIM] << 16);
+    // reduce / publish thread t = (column pair j, row r): consecutive threads = the rows of one pair of weight rows
+    uint32_t xres = 0u, hres = 0u;   // residual of columns 8 b + 2 pj, + 1 of row pr: threads < 4 R
+    if (tid < MF_R_WO / 2 * R) {
+        const int pr = tid % R, pj = tid / R;
+        xres = *(const uint32_t*)(a.x_in + (size_t)pr * MG_DIM + 8 * b + 2 * pj);
     }
 
     u32x4 wq[12];      // wqkv fragments: rows 0..15 x 8 k-steps, rows 16..23 packed x 4 (head: 8 k-steps of one tile) -- requested at the end of a layer for the next
@@ -332,7 +400,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
         asm volatile("" : "+v"(lane_o), "+v"(wave_o));
         const int tid_o = wave_o * 64 + lane_o;
         const int wave_s = __builtin_amdgcn_readfirstlane(wave_o);   // wave-uniform: the k-step part of a fragment address stays in SGPRs
-        const int pu = tid_o % NU, pi = tid_o / NU;   // reduce / publish thread = (row slot pi, utterance pu): from the opaque id, see above
+        const int pr = tid_o % R, pj = tid_o / R;   // reduce / publish thread = (column pair pj, row pr): from the opaque id, see above
         // declared per layer: a register array that is assigned under a condition (the K/V rows of a workgroup that attends) and declared
         // outside the loop is live around the whole loop for the compiler
         u32x4 wo_r[4];     // wo: 8 rows packed, 4 fragments = 8 k-steps
@@ -353,7 +421,10 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
                 const int rho = it / (MG_DIM / 8), c = (it % (MG_DIM / 8)) * 8;
                 *(u32x4*)(xs + (size_t)rho * MF_KP + c) = load16(a.x_in + (size_t)rho * MG_DIM + c);
             }
-        } else mf_poll_rows<NU, MG_DIM, MG_DIM>(g_x, tag0 - 8u + 4u, xs, abort_flag_of, &s_abort, tid_o);
+        } else {
+            if (tid_o < MF_R_WO / 2 * R) mf_publish(r_h + (size_t)pr * MG_DIM + 8 * b + 2 * pj, MF_SENTINEL);   // h of layer l - 1: every reader is done (header)
+            mf_fetch_rows<R, MG_DIM, MG_DIM>(r_x, xs, xs_lds, tag0 - 8u + 4u, abort_flag_of, &s_abort, lane_o, wave_s);
+        }
         *(u32x4*)(nws + tid_o * 8) = nwp;   // this layer's norm weights (requested with its wqkv fragments; landed: the poll ended in vmcnt(0))
         __syncthreads();
         MF_ABORT_RETURN();
@@ -379,19 +450,18 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
         }
         __syncthreads();
         MF_STAMP(l, 3);
-        if (tid_o < MF_R_QKV * NU) {
-            const int i = pi, u = pu, n = MF_R_QKV * b + i;
+        if (tid_o < MF_R_QKV / 2 * R) {
+            const int r = pr, n = MF_R_QKV * b + 2 * pj;   // weight rows n, n + 1 (an even pair: never across the q | k | v boundaries)
             // rows 0..15: tile 0; rows 16..23: the packed half tile, k-range halves in row slots i - 16 and i - 8
-            const bf16_t y0 = f2bf(i < 16 ? mf_get(red, 0, i, 2 * u) : mf_get(red, 1, i - 16, 2 * u) + mf_get(red, 1, i - 8, 2 * u));
-            const bf16_t y1 = f2bf(i < 16 ? mf_get(red, 0, i, 2 * u + 1) : mf_get(red, 1, i - 16, 2 * u + 1) + mf_get(red, 1, i - 8, 2 * u + 1));
-            gran_store(g_qkv + (size_t)u * 3 * MG_DIM + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 0u);
+            auto out = [&](int i) { return f2bf(i < 16 ? mf_get(red, 0, i, r) : mf_get(red, 1, i - 16, r) + mf_get(red, 1, i - 8, r)); };
+            const uint32_t y = (uint32_t)out(2 * pj) | ((uint32_t)out(2 * pj + 1) << 16);
+            gran_store(g_qkv + (size_t)r * (3 * MG_DIM / 2) + n / 2, y, tag0 + 0u);
             if (n >= MG_DIM) {  // K / V rows also go to the cache for the FUTURE steps (this step reads them from the granules)
                 const int which = (n - MG_DIM) / MG_DIM, hd = (n - MG_DIM) % MG_DIM;
                 const size_t cache_len = (size_t)a.cache_len;
-                bf16_t* cache = (which ? a.vcache : a.kcache) + (size_t)l * a.kv_layer_elems + (size_t)2 * u * MG_HEADS * cache_len * 128;
-                const size_t off = ((size_t)(hd / 128) * cache_len + (geo[0][u] - 1)) * 128 + hd % 128;   // u differs per lane here: NOT MF_GEO (readfirstlane)
-                cache[off] = y0;
-                cache[(size_t)MG_HEADS * cache_len * 128 + off] = y1;
+                bf16_t* cache = (which ? a.vcache : a.kcache) + (size_t)l * a.kv_layer_elems + (size_t)r * MG_HEADS * cache_len * 128;
+                const size_t off = ((size_t)(hd / 128) * cache_len + (geo[0][r >> 1] - 1)) * 128 + hd % 128;   // the row differs per lane here: NOT MF_GEO (readfirstlane)
+                *(uint32_t*)(cache + off) = y;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -421,15 +491,15 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
         if (MF_W1_EARLY) { request_w1(); __builtin_amdgcn_sched_barrier(0); }
         if (!MF_W1_EARLY && !any_att) request_w1();
         if (any_att) {
-            {   // q, k_new, v_new of head at_h of this workgroup's utterance: 3 x 128 row-paired granules
-                const int sec = tid_o >> 7, c = tid_o & 127;
+            {   // q, k_new, v_new of head at_h of this workgroup's ROW: 3 x 64 column-paired granules
+                const int sec = tid_o >> 6, c = tid_o & 63;
                 wave_poll<1>(tag0 + 0u, abort_flag_of, &s_abort,
                              [&](int, u64& v) {
-                                 if (tid_o >= 384) return false;
-                                 v = gran_load(g_qkv + (size_t)at_u * 3 * MG_DIM + sec * MG_DIM + at_h * 128 + c);
+                                 if (tid_o >= 192) return false;
+                                 v = gran_load(g_qkv + (size_t)(2 * at_u + at_r) * (3 * MG_DIM / 2) + sec * (MG_DIM / 2) + at_h * 64 + c);
                                  return true;
                              },
-                             [&](int, uint32_t p) { qkv_s[(sec * 2 + 0) * 128 + c] = (bf16_t)p; qkv_s[(sec * 2 + 1) * 128 + c] = (bf16_t)(p >> 16); });
+                             [&](int, uint32_t p) { *(uint32_t*)(qkv_s + (sec * 2 + at_r) * 128 + 2 * c) = p; });
             }
             __syncthreads();
             MF_ABORT_RETURN();
@@ -485,10 +555,10 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
                 const size_t head_base = ((size_t)(2 * u + at_r) * MG_HEADS + at_h) * (size_t)a.cache_len * 128 + dl * 8;
 #pragma unroll
                 for (int q = 0; q < ATTN_U; ++q)
-                    if (q < nsl) mf_row_to_lds(pf_base + q * 1024, a.kcache + layer_off + head_base + (size_t)min(s0o + q * 4 + g, last_old) * 128);
+                    if (q < nsl) mf_row_to_lds<false>(pf_base + q * 1024, a.kcache + layer_off + head_base + (size_t)min(s0o + q * 4 + g, last_old) * 128);
 #pragma unroll
                 for (int q = 0; q < ATTN_U; ++q)
-                    if (q < nsl) mf_row_to_lds(pf_base + (nsl + q) * 1024, a.vcache + layer_off + head_base + (size_t)min(s0o + q * 4 + g, last_old) * 128);
+                    if (q < nsl) mf_row_to_lds<false>(pf_base + (nsl + q) * 1024, a.vcache + layer_off + head_base + (size_t)min(s0o + q * 4 + g, last_old) * 128);
             };
             if (pf_fits && n_my > 1) prefetch_range(at_s + 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -551,14 +621,8 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
                     *(volatile int*)&s_abort = 1;
                     last = false;
                 }
-                if (last && g == 0) {  // 8 dims per lane = 4 column-paired granules
-                    const u32x4 y = attn_normalise(bb);
-                    gran_t* gp = g_attn + (size_t)u * MG_DIM + at_r * (MG_DIM / 2) + (at_h * 128 + dl * 8) / 2;
-                    gran_store(gp + 0, y.x, tag0 + 1u);
-                    gran_store(gp + 1, y.y, tag0 + 1u);
-                    gran_store(gp + 2, y.z, tag0 + 1u);
-                    gran_store(gp + 3, y.w, tag0 + 1u);
-                }
+                if (last && g == 0)   // 8 dims per lane: one 16-byte store into the row
+                    mf_publish16(r_attn + (size_t)(2 * u + at_r) * MG_DIM + at_h * 128 + dl * 8, attn_normalise(bb));
             }
             __builtin_amdgcn_sched_barrier(0);
             MF_STAMP(l, 7);
@@ -569,16 +633,10 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
 
         // ================= P2: h = x + wo(attn)                         fast_model.py:224-226,179 =====================
         __syncthreads();
-        // granule i of utterance u = elements 2i, 2i+1 of its [2][2048] attention output (both rows back to back); 4 utterances per poll loop
-#pragma unroll
-        for (int u0 = 0; u0 < NU; u0 += 4) {
-            wave_poll16<8>(g_attn + (size_t)u0 * MG_DIM, tag0 + 1u, abort_flag_of, &s_abort, [&](int k) { return (k >> 1) * (MG_DIM / 2) + tid_o + (k & 1) * MG_THREADS; },
-                           [&](int n, uint32_t p0, uint32_t p1) {
-                               const int u = u0 + n / (MG_DIM / 2), e = (n % (MG_DIM / 2)) * 4;   // element index inside the utterance's [2][2048]
-                               bf16_t* dst = xs + (size_t)(2 * u + e / MG_DIM) * MF_KP + e % MG_DIM;
-                               *(uint2*)dst = make_uint2(p0, p1);
-                           });
-        }
+        if (l == 0) {   // x of the previous launch's last layer (the LM head read it; the launch boundary says every reader is done)
+            if (tid_o < MF_R_W2 / 2 * R) mf_publish(r_x + (size_t)pr * MG_DIM + 8 * b + 2 * pj, MF_SENTINEL);
+        } else if (tid_o < MF_R_W13 / 2 * R) mf_publish(r_act + (size_t)pr * MG_INTER + MF_R_W13 * b + 2 * pj, MF_SENTINEL);   // act of layer l - 1
+        mf_fetch_rows<R, MG_DIM, MG_DIM>(r_attn, xs, xs_lds, tag0 + 1u, abort_flag_of, &s_abort, lane_o, wave_s);
         __syncthreads();
         MF_ABORT_RETURN();
         MF_STAMP(l, 8);
@@ -592,14 +650,14 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
             mf_put(red, wave_o, 0, lane_o, mf_half_tile(lo, hi, lane_o));
         }
         __syncthreads();
-        if (tid_o < MF_R_WO * NU) {
-            const int i = pi, u = pu, n = MF_R_WO * b + i;
-            const bf16_t y0 = epi_resid((bf16_t)xres, mf_get(red, 0, i, 2 * u) + mf_get(red, 0, i + 8, 2 * u));
-            const bf16_t y1 = epi_resid((bf16_t)(xres >> 16), mf_get(red, 0, i, 2 * u + 1) + mf_get(red, 0, i + 8, 2 * u + 1));
+        if (tid_o < MF_R_WO / 2 * R) {
+            const int r = pr, i = 2 * pj, n = MF_R_WO * b + i;
+            const bf16_t y0 = epi_resid((bf16_t)xres, mf_get(red, 0, i, r) + mf_get(red, 0, i + 8, r));
+            const bf16_t y1 = epi_resid((bf16_t)(xres >> 16), mf_get(red, 0, i + 1, r) + mf_get(red, 0, i + 9, r));
             hres = (uint32_t)y0 | ((uint32_t)y1 << 16);
             bool withhold = false;   // test hook (mv_tune "mega_fault"): see decode_mega.hip
             if (l == 1) { const int fault = a.fault; withhold = fault != 0 && b == ((fault - 1) & 255); }
-            if (!withhold) gran_store(g_h + (size_t)u * MG_DIM + n, hres, tag0 + 2u);
+            if (!withhold) mf_publish(r_h + (size_t)r * MG_DIM + n, mf_word(y0, y1));
         }
         __builtin_amdgcn_sched_barrier(0);
         MF_STAMP(l, 9);
@@ -615,7 +673,8 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
         __builtin_amdgcn_sched_barrier(0);
 
         // ================= P3: act = silu(w1 n(h)) * w3 n(h)            fast_model.py:180,237 =========================
-        mf_poll_rows<NU, MG_DIM, MG_DIM>(g_h, tag0 + 2u, xs, abort_flag_of, &s_abort, tid_o);
+        if (l > 0 && tid_o < MF_R_W2 / 2 * R) mf_publish(r_x + (size_t)pr * MG_DIM + 8 * b + 2 * pj, MF_SENTINEL);   // x of layer l - 1 (layer 0: done in front of the attention-vector poll)
+        mf_fetch_rows<R, MG_DIM, MG_DIM>(r_h, xs, xs_lds, tag0 + 2u, abort_flag_of, &s_abort, lane_o, wave_s);
         __syncthreads();
         MF_ABORT_RETURN();
         MF_STAMP(l, 10);
@@ -644,12 +703,12 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
         }
         __syncthreads();
         MF_STAMP(l, 12);
-        if (tid_o < MF_R_W13 * NU) {
-            const int i = pi, u = pu, n = MF_R_W13 * b + i;
-            auto out = [&](int base, int j) { return i < 16 ? mf_get(red, base, i, j) : mf_get(red, base + 1, i - 16, j) + mf_get(red, base + 1, i - 8, j); };
-            const bf16_t y0 = epi_swiglu(out(0, 2 * u), out(2, 2 * u));
-            const bf16_t y1 = epi_swiglu(out(0, 2 * u + 1), out(2, 2 * u + 1));
-            gran_store(g_act + (size_t)u * MG_INTER + n, (uint32_t)y0 | ((uint32_t)y1 << 16), tag0 + 3u);
+        if (tid_o < MF_R_W13 / 2 * R) {
+            const int r = pr, n = MF_R_W13 * b + 2 * pj;
+            auto out = [&](int base, int i) { return i < 16 ? mf_get(red, base, i, r) : mf_get(red, base + 1, i - 16, r) + mf_get(red, base + 1, i - 8, r); };
+            const bf16_t y0 = epi_swiglu(out(0, 2 * pj), out(2, 2 * pj));
+            const bf16_t y1 = epi_swiglu(out(0, 2 * pj + 1), out(2, 2 * pj + 1));
+            mf_publish(r_act + (size_t)r * MG_INTER + n, mf_word(y0, y1));
         }
         __builtin_amdgcn_sched_barrier(0);
         MF_STAMP(l, 13);
@@ -665,8 +724,10 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
         // ================= P4: x = h + w2(act)                          fast_model.py:247,180 =========================
         {
             f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+            // the attention vector of this layer: every reader is done (they all published h behind it)
+            if (any_att && wave_o == 0 && at_s == 0 && lane_o < 16) mf_reset16(r_attn + (size_t)(2 * at_u + at_r) * MG_DIM + at_h * 128 + lane_o * 8);
             if constexpr (NU <= 4) {   // the whole activation vector in the operand rows: one pass
-                mf_poll_rows<NU, MG_INTER, MG_INTER>(g_act, tag0 + 3u, xs, abort_flag_of, &s_abort, tid_o);
+                mf_fetch_rows<R, MG_INTER, MG_INTER>(r_act, xs, xs_lds, tag0 + 3u, abort_flag_of, &s_abort, lane_o, wave_s);
                 __syncthreads();
                 MF_ABORT_RETURN();
                 MF_STAMP(l, 14);
@@ -677,14 +738,14 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
                     if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             } else {                   // 16 rows: the operand rows hold one column half at a time
-                mf_poll_rows<NU, MG_INTER / 2, MG_INTER, MF_ACT8_UPP>(g_act, tag0 + 3u, xs, abort_flag_of, &s_abort, tid_o);
+                mf_fetch_rows<R, MG_INTER / 2, MG_INTER>(r_act, xs, xs_lds, tag0 + 3u, abort_flag_of, &s_abort, lane_o, wave_s);
                 __syncthreads();
                 MF_ABORT_RETURN();
 #pragma unroll
                 for (int i = 0; i < 11; ++i) lo = mf_mma(w2_r[i], mf_bfrag<R>(xs, 11 * wave_o + i, lane_o), lo);
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();       // every wave has read the first half
-                mf_poll_rows<NU, MG_INTER / 2, MG_INTER, MF_ACT8_UPP>(g_act + MG_INTER / 2, tag0 + 3u, xs, abort_flag_of, &s_abort, tid_o);
+                mf_fetch_rows<R, MG_INTER / 2, MG_INTER>(r_act + MG_INTER / 2, xs, xs_lds, tag0 + 3u, abort_flag_of, &s_abort, lane_o, wave_s);
                 __syncthreads();
                 MF_ABORT_RETURN();
                 MF_STAMP(l, 14);
@@ -695,12 +756,12 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
         }
         __syncthreads();
         MF_STAMP(l, 15);
-        if (tid_o < MF_R_W2 * NU) {
-            const int i = pi, u = pu, n = MF_R_W2 * b + i;
-            const bf16_t y0 = epi_resid((bf16_t)hres, mf_get(red, 0, i, 2 * u) + mf_get(red, 0, i + 8, 2 * u));
-            const bf16_t y1 = epi_resid((bf16_t)(hres >> 16), mf_get(red, 0, i, 2 * u + 1) + mf_get(red, 0, i + 8, 2 * u + 1));
+        if (tid_o < MF_R_W2 / 2 * R) {
+            const int r = pr, i = 2 * pj, n = MF_R_W2 * b + i;
+            const bf16_t y0 = epi_resid((bf16_t)hres, mf_get(red, 0, i, r) + mf_get(red, 0, i + 8, r));
+            const bf16_t y1 = epi_resid((bf16_t)(hres >> 16), mf_get(red, 0, i + 1, r) + mf_get(red, 0, i + 9, r));
             xres = (uint32_t)y0 | ((uint32_t)y1 << 16);
-            gran_store(g_x + (size_t)u * MG_DIM + n, xres, tag0 + 4u);
+            mf_publish(r_x + (size_t)r * MG_DIM + n, mf_word(y0, y1));
         }
         __builtin_amdgcn_sched_barrier(0);
         MF_STAMP(l, 16);
@@ -720,8 +781,10 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
 
     // ================= LM head on the last position: logits = head(norm(x))     fast_model.py:161-162 =================
     __syncthreads();
-    mf_poll_rows<NU, MG_DIM, MG_DIM>(g_x, epoch + (uint32_t)(n_layer - 1) * 8u + 1u + 4u, xs, abort_flag_of, &s_abort, tid);
+    if (tid < MF_R_WO / 2 * R) mf_publish(r_h + (size_t)(tid % R) * MG_DIM + 8 * b + 2 * (tid / R), MF_SENTINEL);   // h of the last layer
+    mf_fetch_rows<R, MG_DIM, MG_DIM>(r_x, xs, xs_lds, epoch + (uint32_t)(n_layer - 1) * 8u + 1u + 4u, abort_flag_of, &s_abort, lane, __builtin_amdgcn_readfirstlane(wave));
     *(u32x4*)(nws + tid * 8) = nwp;   // the final norm's weights (both halves hold them)
+    if (tid < MF_R_W13 / 2 * R) mf_publish(r_act + (size_t)(tid % R) * MG_INTER + MF_R_W13 * b + 2 * (tid / R), MF_SENTINEL);   // act of the last layer (the launch's end completes the store)
     __syncthreads();
     MF_ABORT_RETURN();
     mf_norm<R>(xs, nws, a.eps, lane, wave);
@@ -740,6 +803,12 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
             a.logits[(size_t)(2 * u + 1) * vocab + n] = f2bf(mf_get(red, 0, i, 2 * u + 1));
         }
     }
+}
+
+// the tag-free rows X | ATT | H | ACT inside the engine's hand-off slab (behind the q/k/v granules): mv_begin fills them with the sentinel
+void mfma_handoff_rows(int n_utt, size_t* offset_bytes, size_t* bytes) {
+    *offset_bytes = (size_t)n_utt * 3 * MG_DIM * sizeof(gran_t);
+    *bytes = (size_t)2 * n_utt * (3 * MG_DIM + MG_INTER) * sizeof(bf16_t);
 }
 
 bool mfma_decode_supported(int weight_format, int n_utt) { return weight_format == MV_W_BF16 && (n_utt == 4 || n_utt == 8); }

@@ -839,6 +839,13 @@ int mv_begin(mv_engine* e, int32_t n_utt, const int32_t* prompts, const int32_t*
     // A fresh hand-off epoch for this utterance's first persistent launch: no sampler runs before it when the prompt is teacher-
     // forced, and the previous utterance's last launches left every granule tagged with the epoch they ran under.
     HIP_TRY(launch_bump_counter(e->stream, e->step_counter));
+    if (e->mfma_ok && (g_tune.mfma || U == 8)) {
+        // decode_mfma.hip exchanges x / attention / h / activations as tag-free rows: "not yet published" is the sentinel word 0xFFFFFFFF.
+        // In steady state the kernel puts every slot back itself; a fallback, a switch of paths or a probe may have left anything there.
+        size_t off = 0, bytes = 0;
+        mfma_handoff_rows(U, &off, &bytes);
+        HIP_TRY(hipMemsetAsync((unsigned char*)e->granules + off, 0xFF, bytes, e->stream));
+    }
     SampleArgs a;
     a.seq = e->seq; a.tok_emb = e->tok_emb; a.pos_emb = e->pos_emb; a.spk_proj = e->spk_proj; a.x_next = e->x;
     a.dim = c.dim; a.block_size = c.block_size; a.n_utt = U;
