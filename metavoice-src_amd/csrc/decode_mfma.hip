@@ -174,7 +174,9 @@ __device__ __forceinline__ void mf_norm(bf16_t* xs, const bf16_t* nws, float eps
 //   X   (written P4 l, read P0 l+1) every workgroup publishes q/k/v(l+1) behind its read, and a complete attention vector needs every
 //                                   workgroup's q/k/v rows                                -> reset in front of the h poll of layer l + 1 (layer 23's stays: reset in front of the next launch's first poll)
 //   ATT (written P1 l, read P2 l)   every workgroup publishes h(l) behind its read       -> reset in front of the act poll of layer l
-// mv_begin fills all four with the sentinel (a fallback leaves them in any state).  q/k/v (3 KB per attention workgroup: a latency) and the
+// There are TWO sets of the four vectors, used by even and odd layers: the thread that puts a slot back does so a whole layer (five hand-offs of
+// its own) before it writes the slot again, which takes the order in which a reset and the next value become visible out of the discussion.
+// mv_begin fills all of them with the sentinel (a fallback leaves them in any state).  q/k/v (3 KB per attention workgroup: a latency) and the
 // split-attention partials stay tagged granules.
 #define MF_SENTINEL 0xFFFFFFFFu
 __device__ __forceinline__ uint32_t mf_word(bf16_t lo, bf16_t hi) {   // two adjacent columns of one row as they are published
@@ -331,10 +333,9 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
     // the exchanged vectors sit in ONE slab at compile-time offsets (mfma_handoff_rows below; engine.hip arms the rows with the sentinel):
     // q/k/v as tagged granules {columns 2 j | 2 j + 1 of ONE row, tag}, [R][3 x 1024]; then the tag-free rows X | ATT | H | ACT
     gran_t* const g_qkv = a.g_x;
-    bf16_t* const r_x = (bf16_t*)(a.g_x + (size_t)NU * 3 * MG_DIM);
-    bf16_t* const r_attn = r_x + (size_t)R * MG_DIM;
-    bf16_t* const r_h = r_attn + (size_t)R * MG_DIM;
-    bf16_t* const r_act = r_h + (size_t)R * MG_DIM;
+    // (two sets, by layer parity: a slot is put back to the sentinel a whole layer before it is written again)
+    constexpr size_t ROWS_SET = (size_t)R * (3 * MG_DIM + MG_INTER);
+    bf16_t* const rows0 = (bf16_t*)(a.g_x + (size_t)NU * 3 * MG_DIM);
     const uint32_t xs_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)mf_lds);
 
     // reduce / publish thread t = (column pair j, row r): consecutive threads = the rows of one pair of weight rows
@@ -412,6 +413,14 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
 #endif
         const __attribute__((address_space(4))) MegaLayer& L = MF_LAYER(l);
         const uint32_t tag0 = epoch + (uint32_t)l * 8u + 1u;  // + phase index
+        // this layer's rows X | ATT | H | ACT, and the previous layer's (layer 0: the previous launch's last layer)
+        bf16_t* const r_x = rows0 + (size_t)(l & 1) * ROWS_SET;
+        bf16_t* const r_attn = r_x + (size_t)R * MG_DIM;
+        bf16_t* const r_h = r_attn + (size_t)R * MG_DIM;
+        bf16_t* const r_act = r_h + (size_t)R * MG_DIM;
+        bf16_t* const p_x = rows0 + (size_t)((l > 0 ? l - 1 : n_layer - 1) & 1) * ROWS_SET;
+        bf16_t* const p_h = p_x + (size_t)2 * R * MG_DIM;
+        bf16_t* const p_act = p_h + (size_t)R * MG_DIM;
 
         // ================= P0: RMSNorm + wqkv (+ KV-cache write)        fast_model.py:179,209,218 ====================
         __syncthreads();
@@ -422,8 +431,8 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
                 *(u32x4*)(xs + (size_t)rho * MF_KP + c) = load16(a.x_in + (size_t)rho * MG_DIM + c);
             }
         } else {
-            if (tid_o < MF_R_WO / 2 * R) mf_publish(r_h + (size_t)pr * MG_DIM + 8 * b + 2 * pj, MF_SENTINEL);   // h of layer l - 1: every reader is done (header)
-            mf_fetch_rows<R, MG_DIM, MG_DIM>(r_x, xs, xs_lds, tag0 - 8u + 4u, abort_flag_of, &s_abort, lane_o, wave_s);
+            if (tid_o < MF_R_WO / 2 * R) mf_publish(p_h + (size_t)pr * MG_DIM + 8 * b + 2 * pj, MF_SENTINEL);   // h of layer l - 1: every reader is done (header)
+            mf_fetch_rows<R, MG_DIM, MG_DIM>(p_x, xs, xs_lds, tag0 - 8u + 4u, abort_flag_of, &s_abort, lane_o, wave_s);
         }
         *(u32x4*)(nws + tid_o * 8) = nwp;   // this layer's norm weights (requested with its wqkv fragments; landed: the poll ended in vmcnt(0))
         __syncthreads();
@@ -606,23 +615,57 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
             MF_STAMP(l, 6);
             __builtin_amdgcn_sched_barrier(0);
             // wave j merges range j and publishes its partial; with a single range (<= 256 keys) the merged result is the output
-            u64* slots = (u64*)a.partial + ((size_t)(2 * u + at_r) * MG_HEADS + at_h) * ATTN_NSPLIT * ATTN_TPART_STRIDE;
             AttnAcc bb;
-            if (at_w < n_my) {
-                bb = attn_merge_waves<false>(sm + at_w * ATTN_WAVES, g, dl);
-                if (nactu > 1) attn_publish_tagged(bb, slots + (size_t)(at_s + at_w) * ATTN_TPART_STRIDE, tag0 + 5u, lane);
-            }
-            if (at_w == 0 && at_s == 0) {   // the workgroup of the first ranges combines (utterance, row, head) and publishes its output
-                bool last = true;
-                if (nactu > 1 && !attn_combine_tagged<false>(bb, slots, tag0 + 5u, nactu, lane, MG_SPIN_LIMIT)) {
-                    uint32_t* af = a.abort_flag;
-                    mega_report_timeout(af, tag0 + 5u);
-                    __hip_atomic_store(af, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    *(volatile int*)&s_abort = 1;
-                    last = false;
+            if constexpr (BPH == 1) {
+                // 8 utterances: ONE workgroup walks all ranges of its (utterance, row, head), so the merged partials meet in LDS (the operand rows
+                // are idle between the wqkv MFMAs and the attention-vector hand-off) instead of travelling through memory to wave 0 of the same
+                // workgroup -- a store, its visibility and a load round trip (~2-3 us of every layer) for a hand-off nobody else takes part in.
+                // Same values, same lane assignment, same attn_combine_math as attn_combine_tagged: same bits.
+                float (*pm)[16][12] = (float(*)[16][12])xs;   // [range][16 dim groups][m, l, o[8]]
+                if (at_w < n_my) {
+                    bb = attn_merge_waves<false>(sm + at_w * ATTN_WAVES, g, dl);
+                    if (nactu > 1 && g == 0) {
+                        pm[at_w][dl][0] = bb.m;
+                        pm[at_w][dl][1] = bb.l;
+#pragma unroll
+                        for (int d = 0; d < 8; ++d) pm[at_w][dl][2 + d] = bb.o[d];
+                    }
                 }
-                if (last && g == 0)   // 8 dims per lane: one 16-byte store into the row
-                    mf_publish16(r_attn + (size_t)(2 * u + at_r) * MG_DIM + at_h * 128 + dl * 8, attn_normalise(bb));
+                if (nactu > 1) __syncthreads();   // (uniform over the workgroup: the geometry of its utterance)
+                if (at_w == 0) {
+                    if (nactu > 1) {
+                        float ms[2], ls[2], t[2][8];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int sp = min(g + 4 * q, nactu - 1);   // clamped: weighted 0 below
+                            ms[q] = (g + 4 * q < nactu) ? pm[sp][dl][0] : -INFINITY;
+                            ls[q] = pm[sp][dl][1];
+#pragma unroll
+                            for (int d = 0; d < 8; ++d) t[q][d] = pm[sp][dl][2 + d];
+                        }
+                        attn_combine_math<false>(bb, ms, ls, t);
+                    }
+                    if (g == 0)   // 8 dims per lane: one 16-byte store into the row
+                        mf_publish16(r_attn + (size_t)(2 * u + at_r) * MG_DIM + at_h * 128 + dl * 8, attn_normalise(bb));
+                }
+            } else {
+                u64* slots = (u64*)a.partial + ((size_t)(2 * u + at_r) * MG_HEADS + at_h) * ATTN_NSPLIT * ATTN_TPART_STRIDE;
+                if (at_w < n_my) {
+                    bb = attn_merge_waves<false>(sm + at_w * ATTN_WAVES, g, dl);
+                    if (nactu > 1) attn_publish_tagged(bb, slots + (size_t)(at_s + at_w) * ATTN_TPART_STRIDE, tag0 + 5u, lane);
+                }
+                if (at_w == 0 && at_s == 0) {   // the workgroup of the first ranges combines (utterance, row, head) and publishes its output
+                    bool last = true;
+                    if (nactu > 1 && !attn_combine_tagged<false>(bb, slots, tag0 + 5u, nactu, lane, MG_SPIN_LIMIT)) {
+                        uint32_t* af = a.abort_flag;
+                        mega_report_timeout(af, tag0 + 5u);
+                        __hip_atomic_store(af, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *(volatile int*)&s_abort = 1;
+                        last = false;
+                    }
+                    if (last && g == 0)   // 8 dims per lane: one 16-byte store into the row
+                        mf_publish16(r_attn + (size_t)(2 * u + at_r) * MG_DIM + at_h * 128 + dl * 8, attn_normalise(bb));
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             MF_STAMP(l, 7);
@@ -634,8 +677,8 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
         // ================= P2: h = x + wo(attn)                         fast_model.py:224-226,179 =====================
         __syncthreads();
         if (l == 0) {   // x of the previous launch's last layer (the LM head read it; the launch boundary says every reader is done)
-            if (tid_o < MF_R_W2 / 2 * R) mf_publish(r_x + (size_t)pr * MG_DIM + 8 * b + 2 * pj, MF_SENTINEL);
-        } else if (tid_o < MF_R_W13 / 2 * R) mf_publish(r_act + (size_t)pr * MG_INTER + MF_R_W13 * b + 2 * pj, MF_SENTINEL);   // act of layer l - 1
+            if (tid_o < MF_R_W2 / 2 * R) mf_publish(p_x + (size_t)pr * MG_DIM + 8 * b + 2 * pj, MF_SENTINEL);
+        } else if (tid_o < MF_R_W13 / 2 * R) mf_publish(p_act + (size_t)pr * MG_INTER + MF_R_W13 * b + 2 * pj, MF_SENTINEL);   // act of layer l - 1
         mf_fetch_rows<R, MG_DIM, MG_DIM>(r_attn, xs, xs_lds, tag0 + 1u, abort_flag_of, &s_abort, lane_o, wave_s);
         __syncthreads();
         MF_ABORT_RETURN();
@@ -673,7 +716,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
         __builtin_amdgcn_sched_barrier(0);
 
         // ================= P3: act = silu(w1 n(h)) * w3 n(h)            fast_model.py:180,237 =========================
-        if (l > 0 && tid_o < MF_R_W2 / 2 * R) mf_publish(r_x + (size_t)pr * MG_DIM + 8 * b + 2 * pj, MF_SENTINEL);   // x of layer l - 1 (layer 0: done in front of the attention-vector poll)
+        if (l > 0 && tid_o < MF_R_W2 / 2 * R) mf_publish(p_x + (size_t)pr * MG_DIM + 8 * b + 2 * pj, MF_SENTINEL);   // x of layer l - 1 (layer 0: done in front of the attention-vector poll)
         mf_fetch_rows<R, MG_DIM, MG_DIM>(r_h, xs, xs_lds, tag0 + 2u, abort_flag_of, &s_abort, lane_o, wave_s);
         __syncthreads();
         MF_ABORT_RETURN();
@@ -781,6 +824,9 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
 
     // ================= LM head on the last position: logits = head(norm(x))     fast_model.py:161-162 =================
     __syncthreads();
+    bf16_t* const r_x = rows0 + (size_t)((n_layer - 1) & 1) * ROWS_SET;
+    bf16_t* const r_h = r_x + (size_t)2 * R * MG_DIM;
+    bf16_t* const r_act = r_h + (size_t)R * MG_DIM;
     if (tid < MF_R_WO / 2 * R) mf_publish(r_h + (size_t)(tid % R) * MG_DIM + 8 * b + 2 * (tid / R), MF_SENTINEL);   // h of the last layer
     mf_fetch_rows<R, MG_DIM, MG_DIM>(r_x, xs, xs_lds, epoch + (uint32_t)(n_layer - 1) * 8u + 1u + 4u, abort_flag_of, &s_abort, lane, __builtin_amdgcn_readfirstlane(wave));
     *(u32x4*)(nws + tid * 8) = nwp;   // the final norm's weights (both halves hold them)
@@ -808,7 +854,7 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
 // the tag-free rows X | ATT | H | ACT inside the engine's hand-off slab (behind the q/k/v granules): mv_begin fills them with the sentinel
 void mfma_handoff_rows(int n_utt, size_t* offset_bytes, size_t* bytes) {
     *offset_bytes = (size_t)n_utt * 3 * MG_DIM * sizeof(gran_t);
-    *bytes = (size_t)2 * n_utt * (3 * MG_DIM + MG_INTER) * sizeof(bf16_t);
+    *bytes = (size_t)2 * 2 * n_utt * (3 * MG_DIM + MG_INTER) * sizeof(bf16_t);   // two sets (layer parity)
 }
 
 bool mfma_decode_supported(int weight_format, int n_utt) { return weight_format == MV_W_BF16 && (n_utt == 4 || n_utt == 8); }
