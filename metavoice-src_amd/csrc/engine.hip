@@ -844,7 +844,7 @@ int mv_begin(mv_engine* e, int32_t n_utt, const int32_t* prompts, const int32_t*
         // In steady state the kernel puts every slot back itself; a fallback, a switch of paths or a probe may have left anything there.
         size_t off = 0, bytes = 0;
         mfma_handoff_rows(U, &off, &bytes);
-        HIP_TRY(hipMemsetAsync((unsigned char*)e->granules + off, 0xFF, bytes, e->stream));
+        if (bytes) HIP_TRY(hipMemsetAsync((unsigned char*)e->granules + off, 0xFF, bytes, e->stream));
     }
     SampleArgs a;
     a.seq = e->seq; a.tok_emb = e->tok_emb; a.pos_emb = e->pos_emb; a.spk_proj = e->spk_proj; a.x_next = e->x;

@@ -384,12 +384,12 @@ def test_matrix_core_persistent_kernel_for_four_utterances(n_layer, lens, n_new,
         engine.begin(prompts, spks, sps, max_new_tokens=2, end_of_audio_token=9999, prefill_mode=0)
         engine.run()
         lg = engine.captured_logits(0, L)   # (L, 8 rows, vocab): entry p = logits computed at input position p
+        if mfma:   # (first: a run that fell back to the launches half way would show as "not reproducible" below)
+            assert engine.decode_path() == (3, 0), "decode_mfma.hip did not run (or a hand-off timed out)"
         for u, t in enumerate(lens):        # only the positions an utterance really decoded: the rest of the capture buffer is never written
             if (mfma, mega) in forced:
                 assert torch.equal(lg[:t, 2 * u:2 * u + 2], forced[(mfma, mega)][:t, 2 * u:2 * u + 2]), "the matrix-core kernel is not reproducible run to run"
         forced[(mfma, mega)] = lg
-        if mfma:
-            assert engine.decode_path() == (3, 0), "decode_mfma.hip did not run (or a hand-off timed out)"
     worst = 0.0
     for u, t in enumerate(lens):
         a, b = forced[(1, 1)][:t, 2 * u:2 * u + 2], forced[(0, 0)][:t, 2 * u:2 * u + 2]   # the positions utterance u really decoded
@@ -588,6 +588,40 @@ def test_matrix_core_kernel_times_out_cleanly_and_the_batch_finishes_on_the_laun
     finally:
         engine.tune(mega_fault=0)
         engine.tune(mega=1)
+    engine.close()
+
+
+@pytest.mark.parametrize("n_utt", [4, 8])
+def test_matrix_core_hand_offs_survive_skewed_workgroups(n_utt):
+    """The hand-offs of `decode_mfma.hip` (tag-free rows pulled with LDS-DMA, a sentinel word for "not yet published") under UNEVEN arrival: the
+    `mega_fault = 1000` hook makes every workgroup write back its XCD's L2 behind the last layer's x publish, so that the workgroups reach the
+    following hand-offs microseconds apart, first looks come back incomplete and the repeated looks run.  Every run must stay on the kernel
+    (`decode_path() == (3, 0)`: no wait ran out) and give the bits of the first run.  History (profiles/r06m): the first version of the row hand-off
+    put the last layer's activation slots back to the sentinel as soon as ONE WAVE had seen its share of the x vector -- a fast workgroup then
+    reset slots a slow one was still reading, which looked at sentinels until its wait ran out: 5-7 time-outs per 10^6 launches, 14 runs of 30 under
+    this hook, none since the reset sits behind the workgroup's barrier.  `tools/mfma_repro.py` is the long form of this test."""
+    cfgk = dict(WIDE2, n_layer=2)
+    lens = [300, 12, 1000, 255, 40, 800, 17, 450][:n_utt]
+    engine, sd, cfg = build(cfgk, 17, max_utterances=n_utt)
+    prompts = [synthetic.prompt_tokens(t, seed=90 + u) for u, t in enumerate(lens)]
+    spks = torch.cat([synthetic.speaker_embedding(95 + u) for u in range(n_utt)])
+    sps = [mv.SamplingParams(guidance_scale=3.0, seed=70 + u, top_k=1) for u in range(n_utt)]
+    engine.capture_logits(True)
+    first = None
+    try:
+        engine.tune(mega=1, mega_fault=1000)
+        for rep in range(30):
+            engine.begin(prompts, spks, sps, max_new_tokens=2, end_of_audio_token=9999, prefill_mode=0)
+            engine.run()
+            assert engine.decode_path() == (3, 0), f"run {rep}: a hand-off wait ran out under skew"
+            lg = engine.captured_logits(0, max(lens))
+            cur = [lg[:t, 2 * u:2 * u + 2].clone() for u, t in enumerate(lens)]
+            if first is None:
+                first = cur
+            else:
+                assert all(torch.equal(a, b) for a, b in zip(cur, first)), f"run {rep}: other bits under skew (a stale value was taken for a published one)"
+    finally:
+        engine.tune(mega_fault=0)
     engine.close()
 
 

@@ -44,6 +44,9 @@ if NU >= 4 and e.decode_path()[0] == 3:   # the matrix-core instance (decode_mfm
         for nm, v in zip(mf_names, dd):
             print(f"    {v:6.2f}  {nm}")
         print(f"    {nxt:6.2f}  next layer top (next wqkv requested)")
+        tr = st[blk][2:-2, 17:22].astype(np.float64)
+        print("    attempts of each row fetch that came back with a sentinel (wave 0; mean over layers, max): " +
+              ", ".join(f"{h} {tr[:, k].mean():.2f} ({int(tr[:, k].max())})" for k, h in enumerate(["x", "attention vector", "h", "act", "act 2nd half"])))
     sys.exit(0)
 names = ["wait x", "norm+qkv", "wait qkv", "attention", "wait attn", "wo -> P3", "wait h", "norm+w13 -> P4", "wait act", "w2+publish"]
 fine_order = [0, 1, 11, 12, 13, 2, 3, 14, 15, 4, 5, 16, 17, 6, 7, 18, 19, 20, 8, 9, 21, 10]
