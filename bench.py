@@ -130,18 +130,24 @@ def reference_dir():
 def pick_cpu_threads(step_fn, trial_steps=3):
     """A decode step streams 5 GB of fp32 weights: memory-bound, and on a many-core host torch's default (one thread per logical core)
     can be several times SLOWER than a fraction of the cores (round 4: 128 threads -> 2 tok/s on the GPU box's EPYC, 8 threads -> 13 tok/s
-    on the build container).  Time `trial_steps` steps at all / half / quarter / eighth of the cores (>= 8) and keep the fastest setting,
-    so that the baseline is the host's best, not its default.  -> (threads, {threads: s/token})."""
+    on the build container).  Time `trial_steps` steps at all of the cores, then at half, a quarter, ... and go on halving UNTIL THE TIME PER
+    TOKEN TURNS (a setting slower than the one before it), down to one thread: the minimum then lies inside the scanned range, not on its
+    edge (round 5's scan stopped at an eighth of the cores while still improving).  -> (threads, {threads: s/token})."""
     n0 = torch.get_num_threads()
-    cands = sorted({n for n in (n0, n0 // 2, n0 // 4, n0 // 8) if n >= min(8, n0)}, reverse=True)
     seen = {}
-    for n in cands:
+    n = n0
+    while n >= 1:
         torch.set_num_threads(n)
         step_fn()   # warm the pool at this size
         t = time.perf_counter()
         for _ in range(trial_steps):
             step_fn()
         seen[n] = (time.perf_counter() - t) / trial_steps
+        if len(seen) >= 2 and seen[n] > 1.03 * min(v for k, v in seen.items() if k != n):
+            break   # turned: fewer threads are slower again
+        if n == 1:
+            break
+        n = max(1, n // 2)
     best = min(seen, key=seen.get)
     torch.set_num_threads(best)
     return best, {k: round(v, 4) for k, v in seen.items()}
@@ -729,9 +735,9 @@ def self_launch_argv(a, argv, port=None):
 EXTRA_CONFIGS = [
     ("configs[3] int4 first-stage decode", dict(quantisation_mode="int4", steps=3, warmup=1)),
     ("configs[3'] int8 first-stage decode", dict(quantisation_mode="int8", steps=3, warmup=1)),
-    ("configs[2] 4 utterances per GPU, full vocoder", dict(utterances_per_gpu=4, steps=2, warmup=1)),
-    ("configs[2'] 8 utterances per GPU (batch 64 over 8 GPUs), full vocoder", dict(utterances_per_gpu=8, steps=1, warmup=1)),
-    ("configs[4] long-form 10000 characters, full vocoder, 8 chunks per engine run", dict(long_form=True, long_form_chars=10000, utterances_per_gpu=8, steps=1, warmup=0)),
+    ("configs[2] 4 utterances per GPU, full vocoder", dict(utterances_per_gpu=4, steps=3, warmup=1)),
+    ("configs[2'] 8 utterances per GPU (batch 64 over 8 GPUs), full vocoder", dict(utterances_per_gpu=8, steps=3, warmup=1)),
+    ("configs[4] long-form 10000 characters, full vocoder, 8 chunks per engine run", dict(long_form=True, long_form_chars=10000, utterances_per_gpu=8, steps=3, warmup=1)),
 ]
 
 

@@ -282,6 +282,9 @@ int mv_spkenc_embed(mv_spkenc* e, const float* mels, int32_t n_partials, int32_t
  *                     n_frames = 1 + (n + 2 (frame_length / 2) - frame_length) / hop_length
  * mv_audio_mel      : librosa.feature.melspectrogram(power=2): centred frames of n_fft samples (zero padded), times `window`, |DFT|^2,
  *                     times filterbank [n_mels][n_fft / 2 + 1] -> mel_out [n_frames][n_mels], n_frames = 1 + n / hop_length */
+/* mv_audio_set_device: the HIP device the three calls below work on (-1, the default: the calling thread's current device).  Process-wide; a
+ *                     server whose request threads are new threads (current device 0) sets it once per rank. */
+int mv_audio_set_device(int32_t device);
 int mv_audio_resample(const float* x, int64_t n, const float* h, int32_t taps, int32_t up, int32_t down, int64_t n_pre_remove, int64_t n_out, float* y);
 int mv_audio_frame_rms(const float* x, int64_t n, int32_t frame_length, int32_t hop_length, double* rms_out, int64_t n_frames);
 int mv_audio_mel(const float* wav, int64_t n, const float* window, const float* filterbank, int32_t n_fft, int32_t hop_length, int32_t n_mels,

@@ -126,6 +126,7 @@ SYMBOLS = [
     ("mv_spkenc_load_weight", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_float), C.c_int64]),
     ("mv_spkenc_finalize", C.c_int, [_P]),
     ("mv_spkenc_embed", C.c_int, [_P, C.POINTER(C.c_float), C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
+    ("mv_audio_set_device", C.c_int, [C.c_int32]),
     ("mv_audio_resample", C.c_int, [C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_float)]),
     ("mv_audio_frame_rms", C.c_int, [C.POINTER(C.c_float), C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_int64]),
     ("mv_audio_mel", C.c_int, [C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_int32,

@@ -8,6 +8,7 @@
 //
 // Stateless entry points on a private stream; host buffers in, host buffers out (the callers are file loaders).
 #include <cstdint>
+#include <atomic>
 #include <vector>
 
 #include "common.h"
@@ -101,14 +102,26 @@ struct Scratch {
         return e;
     }
 };
+// The device the front end works on: a new host thread's current HIP device is 0, and a request thread of rank r > 0 calling in here would
+// otherwise build a context on GPU 0 and run next to rank 0's persistent decode kernel (which needs every CU).  -1: the caller's current device.
+std::atomic<int> g_audio_device{-1};
+#define AF_DEVICE() do { const int d_ = g_audio_device.load(); if (d_ >= 0) AF_TRY(hipSetDevice(d_)); } while (0)
 #define AF_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return mv_fail(MV_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
 
 }  // namespace
 
 extern "C" {
 
+int mv_audio_set_device(int32_t device) {
+    int n = 0;
+    if (device >= 0 && (hipGetDeviceCount(&n) != hipSuccess || device >= n)) return mv_fail(MV_ERR_INVALID, "mv_audio_set_device: no device %d", device);
+    g_audio_device.store(device < 0 ? -1 : device);
+    return MV_OK;
+}
+
 int mv_audio_resample(const float* x, int64_t n, const float* h, int32_t taps, int32_t up, int32_t down, int64_t n_pre_remove, int64_t n_out, float* y) {
     if (!x || !h || !y || n < 1 || taps < 1 || up < 1 || down < 1 || n_out < 1 || n_pre_remove < 0) return mv_fail(MV_ERR_INVALID, "mv_audio_resample: bad argument");
+    AF_DEVICE();
     Scratch sc;
     AF_TRY(hipStreamCreateWithFlags(&sc.s, hipStreamNonBlocking));
     float *dx = nullptr, *dh = nullptr, *dy = nullptr;
@@ -126,6 +139,7 @@ int mv_audio_resample(const float* x, int64_t n, const float* h, int32_t taps, i
 
 int mv_audio_frame_rms(const float* x, int64_t n, int32_t frame_length, int32_t hop_length, double* rms_out, int64_t n_frames) {
     if (!x || !rms_out || n < 1 || frame_length < 2 || hop_length < 1 || n_frames < 1) return mv_fail(MV_ERR_INVALID, "mv_audio_frame_rms: bad argument");
+    AF_DEVICE();
     if (n_frames != 1 + (n + 2 * (int64_t)(frame_length / 2) - frame_length) / hop_length) return mv_fail(MV_ERR_INVALID, "mv_audio_frame_rms: n_frames must be 1 + (n + 2 (frame / 2) - frame) / hop");
     Scratch sc;
     AF_TRY(hipStreamCreateWithFlags(&sc.s, hipStreamNonBlocking));
@@ -145,6 +159,7 @@ int mv_audio_mel(const float* wav, int64_t n, const float* window, const float* 
                  float* mel_out, int64_t n_frames) {
     if (!wav || !window || !filterbank || !mel_out || n < 1 || n_fft < 8 || n_fft > 4096 || (n_fft & 1) || hop_length < 1 || n_mels < 1 || n_mels > 256)
         return mv_fail(MV_ERR_INVALID, "mv_audio_mel: bad argument");
+    AF_DEVICE();
     if (n_frames != 1 + n / hop_length) return mv_fail(MV_ERR_INVALID, "mv_audio_mel: n_frames must be 1 + n / hop (centred frames)");
     Scratch sc;
     AF_TRY(hipStreamCreateWithFlags(&sc.s, hipStreamNonBlocking));

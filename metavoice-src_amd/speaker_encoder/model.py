@@ -30,6 +30,9 @@ class SpeakerEncoder:
             checkpoint = torch.load(weights_fpath, map_location="cpu", weights_only=False)
             state_dict = checkpoint["model_state"]  # model.py:48-49 (strict=False there: extra keys are ignored)
         self.device = torch.device(device) if isinstance(device, str) else device
+        if self.device is not None and self.device.type == "cuda" and self.device.index is not None:
+            # the audio front end (mv_audio_*) is called from request threads, whose current HIP device would be 0 on every rank
+            N.check(N.lib().mv_audio_set_device(int(self.device.index)))
         cfg = N.mv_spkenc_config(n_mels=mel_n_channels, hidden=model_hidden_size, n_layers=model_num_layers, emb=model_embedding_size)
         self._h = C.c_void_p()
         N.check(N.lib().mv_spkenc_create(C.byref(cfg), C.byref(self._h)))

@@ -92,3 +92,22 @@ def test_embedding_of_a_file_goes_through_the_gpu_front_end(tmp_path):
     print(f"[speaker embedding from a file] max |d| {d:.2e} (|e| = 1)")
     assert got.shape == (256,) and d <= 1e-4
     enc.close()
+
+
+def test_front_end_device_can_be_pinned():
+    """`mv_audio_*` used to run on the calling thread's current HIP device -- 0 for every new request thread, on every rank.
+    `mv_audio_set_device` pins the front end process-wide (SpeakerEncoder does it with its own device); a device that does not exist is an
+    error, -1 gives the old behaviour back, and a call from a fresh thread gives the same spectrogram as one from the main thread."""
+    import threading
+
+    N = load_pkg("_native")
+    with pytest.raises(ValueError):
+        N.check(N.lib().mv_audio_set_device(torch.cuda.device_count()))
+    N.check(N.lib().mv_audio_set_device(0))
+    wav = np.random.default_rng(0).standard_normal(16000).astype(np.float32) * 0.1
+    want = audio.wav_to_mel_spectrogram(wav)
+    got = {}
+    t = threading.Thread(target=lambda: got.setdefault("mel", audio.wav_to_mel_spectrogram(wav)))
+    t.start(); t.join()
+    assert np.array_equal(got["mel"], want)
+    N.check(N.lib().mv_audio_set_device(-1))
