@@ -138,6 +138,7 @@ struct mv_engine {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     bool graph_dirty = false;   // a tuning knob changed after capture
+    bool rows_armed = false;    // the tag-free hand-off rows of decode_mfma.hip hold the sentinel / a consistent inter-launch state (arm_handoff_rows)
 
 
     int n_utt = 0;
@@ -371,6 +372,18 @@ int enqueue_prefill(mv_engine* e, int u, int T) {
     for (int r = 0; r < 2; ++r)
         HIP_TRY(hipMemcpyAsync(e->x + (size_t)(2 * u + r) * c.dim, e->px + ((size_t)r * T + T - 1) * c.dim, (size_t)c.dim * 2,
                                hipMemcpyDeviceToDevice, s));
+    return MV_OK;
+}
+
+// decode_mfma.hip exchanges x / attention / h / activations as tag-free rows: "not yet published" is the sentinel word 0xFFFFFFFF.  In steady
+// state the kernel puts every slot back itself; a fallback (aborted launch) or a first use leaves anything there, so the rows are filled
+// with the sentinel at every mv_begin that selects the kernel -- and in mv_run when the kernel is selected later (mv_tune between begin and
+// run, a re-arm behind a fallback) and the rows have not been filled since.
+int arm_handoff_rows(mv_engine* e) {
+    size_t off = 0, bytes = 0;
+    mfma_handoff_rows(e->cfg.max_utterances, &off, &bytes);
+    if (bytes) HIP_TRY(hipMemsetAsync((unsigned char*)e->granules + off, 0xFF, bytes, e->stream));
+    e->rows_armed = true;
     return MV_OK;
 }
 
@@ -839,12 +852,10 @@ int mv_begin(mv_engine* e, int32_t n_utt, const int32_t* prompts, const int32_t*
     // A fresh hand-off epoch for this utterance's first persistent launch: no sampler runs before it when the prompt is teacher-
     // forced, and the previous utterance's last launches left every granule tagged with the epoch they ran under.
     HIP_TRY(launch_bump_counter(e->stream, e->step_counter));
+    e->rows_armed = false;
     if (e->mfma_ok && (g_tune.mfma || U == 8)) {
-        // decode_mfma.hip exchanges x / attention / h / activations as tag-free rows: "not yet published" is the sentinel word 0xFFFFFFFF.
-        // In steady state the kernel puts every slot back itself; a fallback, a switch of paths or a probe may have left anything there.
-        size_t off = 0, bytes = 0;
-        mfma_handoff_rows(U, &off, &bytes);
-        if (bytes) HIP_TRY(hipMemsetAsync((unsigned char*)e->granules + off, 0xFF, bytes, e->stream));
+        const int rc = arm_handoff_rows(e);
+        if (rc != MV_OK) return rc;
     }
     SampleArgs a;
     a.seq = e->seq; a.tok_emb = e->tok_emb; a.pos_emb = e->pos_emb; a.spk_proj = e->spk_proj; a.x_next = e->x;
@@ -874,6 +885,10 @@ int mv_run(mv_engine* e, int32_t max_steps, int32_t poll_every, int32_t* steps_r
     if (poll_every < 1) poll_every = 16;
     if (e->graph_dirty) {  // a tuning knob changed since the last capture
         const int rc = build_graph(e);
+        if (rc != MV_OK) return rc;
+    }
+    if (!e->rows_armed && e->mega_ok && g_tune.mega && !e->mega_failed && e->mfma_ok && (g_tune.mfma || e->cfg.max_utterances == 8)) {
+        const int rc = arm_handoff_rows(e);   // the matrix-core kernel was selected after mv_begin (or re-armed behind a fallback)
         if (rc != MV_OK) return rc;
     }
     int limit = e->steps_budget;
@@ -937,6 +952,7 @@ int mv_run(mv_engine* e, int32_t max_steps, int32_t poll_every, int32_t* steps_r
             a.dim = e->cfg.dim; a.block_size = e->cfg.block_size; a.n_utt = U;
             HIP_TRY(launch_embed_current(e->stream, a));
             e->mega_failed = true;
+            e->rows_armed = false;   // an aborted launch leaves the hand-off rows in any state
             e->mega_backoff = e->mega_backoff ? (e->mega_backoff < 128 ? 2 * e->mega_backoff : 256) : 4;
             e->mega_retry_in = e->mega_backoff;
             {

@@ -591,6 +591,33 @@ def test_matrix_core_kernel_times_out_cleanly_and_the_batch_finishes_on_the_laun
     engine.close()
 
 
+def test_matrix_core_kernel_selected_between_begin_and_run():
+    """`mv_tune` between `mv_begin` and `mv_run` (the graph is re-captured in `mv_run`): an engine of 4 that began on the per-layer launches and is
+    switched to the matrix-core kernel before it runs -- behind an EARLIER run of that kernel, whose last launch left real values in its x rows -- must
+    find its tag-free hand-off rows armed (sentinel), i.e. decode exactly as a run that began on the kernel."""
+    cfgk = dict(WIDE2, n_layer=2)
+    lens = [40, 300, 17, 260]
+    engine, sd, cfg = build(cfgk, 31, max_utterances=4)
+    prompts = [synthetic.prompt_tokens(t, seed=410 + u) for u, t in enumerate(lens)]
+    spks = torch.cat([synthetic.speaker_embedding(420 + u) for u in range(4)])
+    sps = [mv.SamplingParams(guidance_scale=3.0, seed=430 + u, top_p=0.9) for u in range(4)]
+    try:
+        engine.tune(mega=1, mfma=1)
+        engine.begin(prompts, spks, sps, max_new_tokens=24, end_of_audio_token=9999, prefill_mode=1)
+        engine.run()
+        assert engine.decode_path() == (3, 0)
+        want = [engine.tokens(u) for u in range(4)]
+        engine.tune(mega=0)
+        engine.begin(prompts, spks, sps, max_new_tokens=24, end_of_audio_token=9999, prefill_mode=1)
+        engine.tune(mega=1)          # selected after mv_begin
+        engine.run()
+        assert engine.decode_path() == (3, 0)
+        assert [engine.tokens(u) for u in range(4)] == want
+    finally:
+        engine.tune(mega=1, mfma=1)
+    engine.close()
+
+
 @pytest.mark.parametrize("n_utt", [4, 8])
 def test_matrix_core_hand_offs_survive_skewed_workgroups(n_utt):
     """The hand-offs of `decode_mfma.hip` (tag-free rows pulled with LDS-DMA, a sentinel word for "not yet published") under UNEVEN arrival: the
