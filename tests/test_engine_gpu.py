@@ -699,6 +699,47 @@ def test_persistent_kernel_times_out_cleanly_and_the_run_falls_back_to_launches(
     engine.close()
 
 
+def test_engine_of_eight_next_to_a_competing_kernel_finishes_the_batch():
+    """the competing-kernel situation for an engine of 8 utterances.  Large matmuls are queued on another stream right before the
+    decode steps; whatever the device does -- the grid of `decode_mfma_kernel<8>` becomes resident in time, or a hand-off wait runs out and the batch is
+    rolled back and finished on the per-layer launches (two halves of the rows) -- `mv_run` must return success with every utterance at its full
+    length.  Without an abandoned launch the streams are the clean run's, bit for bit; with one they are a valid draw from the launches' logits
+    (DESIGN.md 6 "Reproducibility") and only their shape is asserted.  The outcome of every attempt is printed."""
+    cfgk = dict(WIDE2, n_layer=3)
+    lens = [280, 40, 700, 17, 300, 12, 1030, 90]
+    engine, sd, cfg = build(cfgk, 37, max_utterances=8)
+    prompts = [synthetic.prompt_tokens(t, seed=510 + u) for u, t in enumerate(lens)]
+    spks = torch.cat([synthetic.speaker_embedding(520 + u) for u in range(8)])
+    sps = [mv.SamplingParams(guidance_scale=3.0, seed=530 + u, top_p=0.95) for u in range(8)]
+    n_new = 48
+    engine.begin(prompts, spks, sps, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
+    engine.run()
+    assert engine.decode_path() == (3, 0)
+    clean = [engine.tokens(u) for u in range(8)]
+    a = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+    side = torch.cuda.Stream()
+    outcomes = []
+    for attempt in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(12):
+                a = (a @ a).clamp_(-1, 1)
+        before = engine.decode_path()[1]
+        engine.begin(prompts, spks, sps, max_new_tokens=n_new, end_of_audio_token=9999, prefill_mode=1)
+        steps = engine.run(poll_every=8)
+        assert steps == n_new - 1
+        toks = [engine.tokens(u) for u in range(8)]
+        assert [len(t) for t in toks] == [t + n_new for t in lens]
+        assert all(t[:n] == p.tolist() for t, n, p in zip(toks, lens, prompts))
+        path = engine.decode_path()
+        outcomes.append(path)
+        if path[1] == before:
+            assert toks == clean, "no launch was abandoned, yet the streams differ from the clean run"
+        side.synchronize()
+        engine.tune(mega=1)
+    print(f"[competing kernel, engine of 8] (path, abandoned launches so far) per attempt: {outcomes}")
+    engine.close()
+
+
 def test_hand_off_epoch_advances_across_an_utterance_that_ended_mid_chunk():
     """Regression: the sampler used to return before bumping the hand-off epoch once the utterance was done, so
     the trailing graph replays of that mv_run chunk -- and the first launch of the NEXT utterance when its prompt is teacher-
