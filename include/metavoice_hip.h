@@ -252,7 +252,8 @@ int mv_mbd_unet_forward(mv_mbd* m, int32_t band, const float* x, int32_t samples
  * GEMM kernel a layer runs on).  x: host fp32 [n_models][samples]; out: host fp32 [samples] = sum over the bands of unet_b(x_b). */
 int mv_mbd_unet_forward_sum(mv_mbd* m, const float* x, int32_t samples, int32_t step, const float* latent, int32_t frames, float* out);
 /* launches per convolution-GEMM kernel since mv_mbd_create, out[8]: [0] mbd_gemm_t256_kernel, [1] mbd_gemm_glds3_kernel<64,192>,
- * [2] mbd_gemm_glds3_kernel<128,128>, [3] mbd_gemm_thin_kernel, [4] mbd_gemm_glds_kernel, [5] mbd_gemm_kernel<128>, [6] mbd_gemm_kernel<64> */
+ * [2] mbd_gemm_glds3_kernel<128,128>, [3] mbd_gemm_thin_kernel, [4] mbd_gemm_glds_kernel, [5] mbd_gemm_kernel<128>, [6] mbd_gemm_kernel<64>;
+ * [7] (not a kernel) how many of those launches were transposed convolutions whose epilogue also wrote the decoder's `z + skip` */
 int mv_mbd_kernel_counts(const mv_mbd* m, int64_t* out);
 
 /* ---- speaker encoder: replaces SpeakerEncoder.forward (fam/quantiser/audio/speaker_encoder/model.py:21-59): 3-layer LSTM over

@@ -77,6 +77,12 @@ struct MbdGemmArgs {   // the band models run the same shapes: grid.z = band
     // to gn_part[band][tile][group][2] (double), gn_final_kernel adds the tiles in index order -- the output is not read again.
     double* gn_part = nullptr;
     int gn_cg = 0, gn_G = 0;
+    int gn_period = 0;     // column n belongs to group (n % gn_period) / gn_cg: N for a convolution, Cout for a transposed one (N = stride x Cout)
+    // Only the elements whose flat index m * ldc + n lies in [valid_lo, valid_hi) are stored (and counted in the statistics): the
+    // transposed convolution writes the s output phases of step q as ONE row of s * Cout values, shifted by `pad` time steps against
+    // the tensor it lands in -- the first `pad` steps of row 0 and whatever lies beyond the skip tensor's length are dropped here,
+    // so `out` / `residual` may point `pad` steps in front of their buffers (round 6: z = up(x)[:, :, :T] + skip in the epilogue).
+    int64_t valid_lo = 0, valid_hi = INT64_MAX;
 };
 
 // C = A W^T on BM x 128 x 128 tiles (BM = 128 or 64), 256 threads = 4 waves (2 x 2), each wave (BM / 2) x 64 = MI x 4 MFMA 16x16x32
@@ -168,11 +174,99 @@ __global__ void __launch_bounds__(256, 3) mbd_gemm_kernel(const MbdGemmArgs a) {
             for (int reg = 0; reg < 4; ++reg) {
                 const int m = tile_m + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + reg;
                 if (m >= M) continue;
+                const int64_t f = (int64_t)m * a.ldc + n;
+                if (f < a.valid_lo || f >= a.valid_hi) continue;
                 float y = acc[i][j][reg] + add;
                 if (a.residual) y += a.residual[(size_t)band * a.res_band + (size_t)m * a.ldr + n];
-                a.out[(size_t)band * a.out_band + (size_t)m * a.ldc + n] = y;
+                a.out[(size_t)band * a.out_band + f] = y;
             }
         }
+}
+
+// (mean, rstd) of the G groups of one band from its n_rec partial records [n_rec][G][2] (one 256-thread block; red: 256 doubles of LDS):
+// thread t sums entry q = t % (2 G) of records t / (2 G), t / (2 G) + 256 / (2 G), ...; the 256 / (2 G) per-q partials are then added in
+// index order -- a fixed order.  Round 6: four records of a thread are in flight at once (added in the old order: same bits); with one load
+// per trip the 450 records of a normalise pass cost 14 dependent L2 round trips, most of this kernel's 5.8 us (480 launches per utterance).
+// Measured and dropped in round 6 (profiles/r06x): finishing the statistics inside the PRODUCING kernel -- records as write-through stores, a
+// ticket counter per band, the last block to arrive reduces -- is bit-identical and removes this launch, but the 240-3600 same-address
+// atomics of a launch serialise: the whole stage 124-125 ms against 121-123 with this kernel.
+__device__ __forceinline__ void gn_finalize(const double* __restrict__ part, int n_rec, int G, double count, float eps, float* __restrict__ stats, double* red) {
+    const int nq = 2 * G, lanes = 256 / nq, q = threadIdx.x % nq, j = threadIdx.x / nq;
+    double a = 0.0;
+    if (j < lanes) {
+        int c = j;
+        for (; c + 3 * lanes < n_rec; c += 4 * lanes) {
+            const double v0 = part[(size_t)c * nq + q], v1 = part[(size_t)(c + lanes) * nq + q], v2 = part[(size_t)(c + 2 * lanes) * nq + q],
+                         v3 = part[(size_t)(c + 3 * lanes) * nq + q];
+            a += v0; a += v1; a += v2; a += v3;
+        }
+        for (; c < n_rec; c += lanes) a += part[(size_t)c * nq + q];
+    }
+    red[threadIdx.x] = j < lanes ? a : 0.0;
+    __syncthreads();
+    if ((int)threadIdx.x < G) {
+        double sum = 0.0, sq = 0.0;
+        for (int k = 0; k < lanes; ++k) { sum += red[k * nq + 2 * threadIdx.x]; sq += red[k * nq + 2 * threadIdx.x + 1]; }
+        const double mean = sum / count;
+        stats[2 * threadIdx.x] = (float)mean;
+        stats[2 * threadIdx.x + 1] = (float)(1.0 / sqrt(fmax(sq / count - mean * mean, 0.0) + (double)eps));
+    }
+}
+
+// GroupNorm partial record of one 256-thread block (round 6: the statistics ride on whatever kernel PRODUCES the tensor -- the thin GEMM, the
+// first convolution, the normalise / activation pass, the GEMM epilogues below -- so that no pass reads a tensor only to sum it).
+// s[g] / s2[g]: this thread's fp32 sum and sum of squares per channel group (slots >= G stay zero; a thread has summed a few dozen
+// elements).  The 64 lanes of a wave are added in fp32 by the fixed DPP tree of wave_sum_n (2 GM values side by side: ~100 cycles, against
+// 24 GM ds_bpermute round trips for a double-precision shuffle tree: this runs at the end of every 4-16 KB block of an HBM-bound pass),
+// the four waves in double in index order: the same bits on every run.  rec: [G][2] doubles.
+template <int GM>
+__device__ __forceinline__ void gn_block_record(const float (&s)[GM], const float (&s2)[GM], int G, double* __restrict__ rec, double (*red)[GM][2]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float v[2 * GM];
+#pragma unroll
+    for (int g = 0; g < GM; ++g) { v[2 * g] = s[g]; v[2 * g + 1] = s2[g]; }
+    wave_sum_n<2 * GM>(v);
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g < GM; ++g) { red[wave][g][0] = (double)v[2 * g]; red[wave][g][1] = (double)v[2 * g + 1]; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * G) {
+        const int g = threadIdx.x >> 1, w = threadIdx.x & 1;
+        rec[threadIdx.x] = ((red[0][g][w] + red[1][g][w]) + red[2][g][w]) + red[3][g][w];
+    }
+}
+// group of channel ch when the groups are cg channels wide (G <= GM <= 8: a compare chain instead of a division)
+template <int GM>
+__device__ __forceinline__ int gn_group_of(int ch, int cg) {
+    int g = 0;
+#pragma unroll
+    for (int q = 1; q < GM; ++q) g += ch >= q * cg;
+    return g;
+}
+
+// Epilogue of the kernels that accumulate C^T (W fragment as the first MFMA operand): a lane holds row m and the four consecutive columns
+// n .. n + 3 of a 16 x 16 block -- bias + step-embedding row, residual, the [valid_lo, valid_hi) window and the store as 16-byte accesses (the
+// C layout gave 4-byte ones: a quarter of the bytes per store instruction, and these epilogues write 59 MB per launch); s / s2: the lane's running
+// GroupNorm sums of what it stored.  N, ldc, ldr, the band strides and the window bounds are multiples of 4.
+__device__ __forceinline__ float4 epilogue_col_add(const MbdGemmArgs& a, int band, int n) {
+    float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias.p[band]) add = *(const float4*)(a.bias.p[band] + n);
+    if (a.col_add.p[band]) { const float4 c = *(const float4*)(a.col_add.p[band] + n); add.x += c.x; add.y += c.y; add.z += c.z; add.w += c.w; }
+    return add;
+}
+__device__ __forceinline__ void epilogue_store4(const MbdGemmArgs& a, int band, int m, int n, const f32x4_t& acc, const float4& add, float& s, float& s2) {
+    if (m >= a.M) return;
+    const int64_t f = (int64_t)m * a.ldc + n;
+    if (f < a.valid_lo || f >= a.valid_hi) return;
+    float4 y = make_float4(acc[0] + add.x, acc[1] + add.y, acc[2] + add.z, acc[3] + add.w);
+    if (a.residual) {
+        const float4 r = *(const float4*)(a.residual + (size_t)band * a.res_band + (size_t)m * a.ldr + n);
+        y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+    }
+    *(float4*)(a.out + (size_t)band * a.out_band + f) = y;
+    s += (y.x + y.y) + (y.z + y.w);
+    s2 = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, fmaf(y.w, y.w, s2))));
 }
 
 // Thin layers (round 4): N <= 64 output channels, one contiguous K <= 160 window per term -- the 48-channel ResBlock convolutions of the
@@ -182,9 +276,15 @@ __global__ void __launch_bounds__(256, 3) mbd_gemm_kernel(const MbdGemmArgs a) {
 // global memory (16 B per lane; the windows of consecutive rows overlap by 2/3, so the 64-byte pieces hit in L1): no LDS, no barrier, no
 // padding columns; three MFMAs (a_hi w_hi + a_hi w_lo + a_lo w_hi) per fragment pair as in the fused three-term kernels.  K is walked in
 // steps of 32 with the tail zeroed on the A side (144 = 4 x 32 + 16).  Bound by its bytes: A hi | lo, the residual and the fp32 output.
-template <int NTN>
+// GM > 0 (round 6): the GroupNorm partials of the output from the epilogue, one record per block (a.gn_part[band][block][G][2]); a lane's
+// column j * 16 + col has its own group (groups of 12 channels at 48 / 4: not aligned to the 16-column fragments).
+template <int NTN, int GM>
 __global__ void __launch_bounds__(256) mbd_gemm_thin_kernel(const MbdGemmArgs a) {
     constexpr int KS = 5, MT = 4;   // K-steps of 32 (K <= 160); 16-row tiles per wave and loop trip
+    __shared__ double gn_red[4][GM ? GM : 1][2];
+    float gs[NTN], gs2[NTN];
+#pragma unroll
+    for (int j = 0; j < NTN; ++j) gs[j] = gs2[j] = 0.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, band = blockIdx.y;
     const int M = a.M, N = a.N, K = a.seg[0].K;
     const int col = lane & 15, kg = lane >> 4;
@@ -222,25 +322,29 @@ __global__ void __launch_bounds__(256) mbd_gemm_thin_kernel(const MbdGemmArgs a)
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int j = 0; j < NTN; ++j) {
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[ks], wh[j][ks], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[ks], wl[j][ks], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[ks], wh[j][ks], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j][ks], fh[ks], acc[j], 0, 0, 0);   // W first: C^T, see mbd_gemm_t256_kernel
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j][ks], fh[ks], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j][ks], fl[ks], acc[j], 0, 0, 0);
             }
-        // C fragment j: column lane & 15, rows (lane >> 4) * 4 + reg
+        // C^T fragment j: row lane & 15, columns j * 16 + (lane >> 4) * 4 + reg
 #pragma unroll
         for (int j = 0; j < NTN; ++j) {
-            const int n = j * 16 + col;
+            const int n = j * 16 + kg * 4;
             if (n >= N) continue;
-            const float add = (a.bias.p[band] ? a.bias.p[band][n] : 0.f) + (a.col_add.p[band] ? a.col_add.p[band][n] : 0.f);
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int m = m0 + kg * 4 + reg;
-                if (m >= M) continue;
-                float y = acc[j][reg] + add;
-                if (a.residual) y += a.residual[(size_t)band * a.res_band + (size_t)m * a.ldr + n];
-                a.out[(size_t)band * a.out_band + (size_t)m * a.ldc + n] = y;
-            }
+            epilogue_store4(a, band, m0 + col, n, acc[j], epilogue_col_add(a, band, n), gs[j], gs2[j]);
         }
+    }
+    if constexpr (GM > 0) {
+        float s[GM], s2[GM];
+#pragma unroll
+        for (int g = 0; g < GM; ++g) s[g] = s2[g] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) {
+            const int gj = gn_group_of<GM>((j * 16 + kg * 4) % a.gn_period, a.gn_cg);   // (group widths are multiples of 4: launch_gemm checks)
+#pragma unroll
+            for (int g = 0; g < GM; ++g) { s[g] += g == gj ? gs[j] : 0.f; s2[g] += g == gj ? gs2[j] : 0.f; }
+        }
+        gn_block_record<GM>(s, s2, a.gn_G, a.gn_part + ((size_t)band * gridDim.x + blockIdx.x) * a.gn_G * 2, gn_red);
     }
 }
 
@@ -318,38 +422,43 @@ __global__ void __launch_bounds__(256, 4) mbd_gemm_glds_kernel(const MbdGemmArgs
             for (int reg = 0; reg < 4; ++reg) {
                 const int m = tile_m + wm * 64 + i * 16 + (lane >> 4) * 4 + reg;
                 if (m >= M) continue;
+                const int64_t f = (int64_t)m * a.ldc + n;
+                if (f < a.valid_lo || f >= a.valid_hi) continue;
                 float y = acc[i][j][reg] + add;
                 if (a.residual) y += a.residual[(size_t)band * a.res_band + (size_t)m * a.ldr + n];
-                a.out[(size_t)band * a.out_band + (size_t)m * a.ldc + n] = y;
+                a.out[(size_t)band * a.out_band + f] = y;
             }
         }
 }
 
-// GroupNorm partials of one output tile (MbdGemmArgs::gn_part).  gs / gs2: this thread's sum and sum of squares (fp32, in the fixed
-// order of the epilogue loops) over its rows of the four 16-column blocks j of its wave; a block lies inside one group (gn_cg is a
-// multiple of 16).  Lanes are added in double in a fixed order, then thread (g, which) adds the (wave, j) entries of group g in
-// index order: the same bits on every run.
-template <int NW, int NJ = 4>   // NJ: 16-column tiles a wave holds (<= 4)
-__device__ __forceinline__ void gn_tile_partials(const MbdGemmArgs& a, const float (&gs)[4], const float (&gs2)[4], int wave_col0, int wave, int lane,
-                                                 int tid, double* dst, double (*red)[4][2], int* grp) {
+// GroupNorm partials of one output tile (MbdGemmArgs::gn_part).  gs / gs2[j]: this lane's sum and sum of squares (fp32, in the fixed order of
+// the epilogue loops) over its rows of the four columns wave_col0 + j * 16 + (lane >> 4) * 4 .. + 3 of column block j of its wave; the four
+// columns lie in one group (group widths are multiples of 4), so each lane files its sums under its own groups -- no condition on how the
+// groups meet the 16-column blocks (round 6: 48 / 4 = 12 channels per group on the 64 x 192 tiles).  Lanes are added by the DPP tree, the
+// waves in double in index order: the same bits on every run.  red: [NW][8][2] doubles of LDS.
+template <int NW, int NJ = 4>   // NJ: 16-column blocks a wave holds (<= 4)
+__device__ __forceinline__ void gn_tile_record(const MbdGemmArgs& a, const float (&gs)[4], const float (&gs2)[4], int wave_col0, int wave, int lane,
+                                               int tid, double* dst, double (*red)[8][2]) {
+    float v[16];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        double s = j < NJ ? gs[j] : 0.f, s2 = j < NJ ? gs2[j] : 0.f;
-        for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); s2 += __shfl_down(s2, off, 64); }
-        if (lane == 0) {
-            red[wave][j][0] = s;
-            red[wave][j][1] = s2;
-            grp[wave * 4 + j] = j < NJ && wave_col0 + j * 16 < a.N ? (wave_col0 + j * 16) / a.gn_cg : -1;
-        }
+    for (int q = 0; q < 16; ++q) v[q] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int gj = gn_group_of<8>((wave_col0 + j * 16 + (lane >> 4) * 4) % a.gn_period, a.gn_cg);   // (columns >= N carry zero sums)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { v[2 * g] += g == gj ? gs[j] : 0.f; v[2 * g + 1] += g == gj ? gs2[j] : 0.f; }
+    }
+    wave_sum_n<16>(v);
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { red[wave][g][0] = (double)v[2 * g]; red[wave][g][1] = (double)v[2 * g + 1]; }
     }
     __syncthreads();
     if (tid < 2 * a.gn_G) {
-        const int g = tid >> 1, which = tid & 1;
+        const int g = tid >> 1, w = tid & 1;
         double t = 0.0;
-        for (int w = 0; w < NW; ++w)
-            for (int j = 0; j < 4; ++j)
-                if (grp[w * 4 + j] == g) t += red[w][j][which];
-        dst[g * 2 + which] = t;
+        for (int wv = 0; wv < NW; ++wv) t += red[wv][g][w];
+        dst[tid] = t;
     }
 }
 
@@ -424,37 +533,26 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_glds3_kernel(const MbdGemmArg
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[i], bfh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[i], bfl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[i], bfh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfh[j], afh[i], acc[i][j], 0, 0, 0);   // W first: C^T, see mbd_gemm_t256_kernel
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfl[j], afh[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfh[j], afl[i], acc[i][j], 0, 0, 0);
                 }
         }
         __syncthreads();
     }
     float gs[4] = {0.f, 0.f, 0.f, 0.f}, gs2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < NI; ++j) {
+        const int n = tile_n + wn * (NI * 16) + j * 16 + (lane >> 4) * 4;
+        if (n >= N) continue;
+        const float4 add = epilogue_col_add(a, band, n);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int n = tile_n + wn * (NI * 16) + j * 16 + (lane & 15);
-            if (n >= N) continue;
-            const float add = (a.bias.p[band] ? a.bias.p[band][n] : 0.f) + (a.col_add.p[band] ? a.col_add.p[band][n] : 0.f);
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int m = tile_m + wm * 64 + i * 16 + (lane >> 4) * 4 + reg;
-                if (m >= M) continue;
-                float y = acc[i][j][reg] + add;
-                if (a.residual) y += a.residual[(size_t)band * a.res_band + (size_t)m * a.ldr + n];
-                a.out[(size_t)band * a.out_band + (size_t)m * a.ldc + n] = y;
-                gs[j] += y;
-                gs2[j] = fmaf(y, y, gs2[j]);
-            }
-        }
+        for (int i = 0; i < 4; ++i) epilogue_store4(a, band, tile_m + wm * 64 + i * 16 + (lane & 15), n, acc[i][j], add, gs[j], gs2[j]);
+    }
     if (a.gn_part) {   // the operand tiles are dead (the K loop ended with a barrier): their LDS carries the reduction
-        double (*gn_red)[4][2] = reinterpret_cast<double (*)[4][2]>(lds_wh);
-        int* gn_grp = reinterpret_cast<int*>(lds_wl);
         const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x, tiles = (size_t)gridDim.x * gridDim.y;
-        gn_tile_partials<4, NI>(a, gs, gs2, tile_n + wn * (NI * 16), wave, lane, tid, a.gn_part + ((size_t)band * tiles + tile) * a.gn_G * 2, gn_red, gn_grp);
+        gn_tile_record<4, NI>(a, gs, gs2, tile_n + wn * (NI * 16), wave, lane, tid, a.gn_part + ((size_t)band * tiles + tile) * a.gn_G * 2,
+                              reinterpret_cast<double (*)[8][2]>(lds_wh));
     }
 }
 
@@ -495,7 +593,12 @@ constexpr int T256_STAGE_BYTES = 4 * 16 * 1024;   // a_hi | a_lo | w_hi | w_lo, 
 #define T256_TERM_ORDER 0
 #endif
 constexpr int T256_LDS_BYTES = 2 * T256_STAGE_BYTES + 8 * 256;   // + a 256-byte scratch slot per wave for the prefetch requests
-__global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs a, int nt_m, int nt_n, int n_blocks) {
+// Round 6, tile_rows = 240: all tiles of a launch run in ONE round (240 workgroups of the 3072-channel layers on 256 CUs), so a launch lasts as
+// long as a full tile -- and M = 1200 rows are 4.7 tiles of 256, M = 4800 are 18.75: the last row tile computes mostly clamped duplicates while
+// every other CU waits for nothing.  1200 = 5 x 240 and 4800 = 20 x 240: with 240-row tiles (15 blocks of 16 rows; the waves of the lower half
+// skip their eighth block -- they share a SIMD with the upper half's waves, so the SIMD's MFMA count per K-step drops from 192 to 180) every
+// tile is full and each is 1/16 shorter.  launch_gemm picks the height that minimises rounds x rows.
+__global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs a, int nt_m, int nt_n, int n_blocks, int tile_rows) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char t256_lds[];   // [2 stages][4 halves][16 sub-tiles][1 KB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -506,7 +609,8 @@ __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
     }
     const int tm = id % nt_m, tn = (id / nt_m) % nt_n, band = id / (nt_m * nt_n);
-    const int tile_m = tm * 256, tile_n = tn * 256;
+    const int tile_m = tm * tile_rows, tile_n = tn * 256;
+    const int ni = __builtin_amdgcn_readfirstlane(min(8, (tile_rows - wm * 128) >> 4));   // 16-row blocks of this wave that lie inside the tile (8, or 7 below row 240)
     const int M = a.M, N = a.N, K = a.seg[0].K;
 
     // loads: this wave fills sub-tiles 2 wave, 2 wave + 1 of each operand half; lane -> (row lane >> 2, chunk (lane & 3) ^ 2 (lane >> 5))
@@ -522,7 +626,9 @@ __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs
         ow[i] = (uint32_t)((size_t)min(tile_n + (2 * wave + i) * 16 + lrow, N - 1) * a.ldw);
     }
     // piece p of a stage (8 per wave): sub-tile 2 wave + (p >> 2) of operand half p & 3
+    const bool skip_a15 = __builtin_amdgcn_readfirstlane(wave == 7 && tile_rows < 256);   // sub-tile 15 of A = the next tile's first rows: not read
     auto stage_piece = [&](int stage, int k0, int p) {
+        if (skip_a15 && (p >> 2) == 1 && (p & 3) < 2) return;
         unsigned char* dst = t256_lds + stage * T256_STAGE_BYTES + (p & 3) * 16384 + (2 * wave + (p >> 2)) * 1024;
         const bf16_t* src = (p & 3) == 0 ? ah + oa[p >> 2] : (p & 3) == 1 ? al + oa[p >> 2] : (p & 3) == 2 ? wh + ow[p >> 2] : wl + ow[p >> 2];
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + k0), (lds_ptr_t)dst, 16, 0, 0);
@@ -614,21 +720,24 @@ __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs
                     stage_piece((kt + 1) & 1, (kt + 1) * 32, half * 4 + i);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (half * 4 + i >= ni) continue;
 #if T256_TERM_ORDER == 1
                 // term-major: the four hi x hi products first (they need a_hi and w_hi only), then lo x hi, then hi x lo
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[i], bfh[j], acc[half * 4 + i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfh[j], afh[i], acc[half * 4 + i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[i], bfh[j], acc[half * 4 + i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfh[j], afl[i], acc[half * 4 + i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[i], bfl[j], acc[half * 4 + i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfl[j], afh[i], acc[half * 4 + i][j], 0, 0, 0);
 #else
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4_t c = acc[half * 4 + i][j];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[i], bfh[j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[i], bfl[j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[i], bfh[j], c, 0, 0, 0);
+                    // W fragment FIRST (round 6): the accumulator then holds C^T -- a lane has row lane & 15 and FOUR CONSECUTIVE columns
+                    // (lane >> 4) * 4 + reg, so the epilogue moves 16 bytes per lane and instruction instead of 4 (same products, same k order)
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfh[j], afh[i], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfl[j], afh[i], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfh[j], afl[i], c, 0, 0, 0);
                     acc[half * 4 + i][j] = c;
                 }
 #endif
@@ -637,28 +746,18 @@ __global__ void __launch_bounds__(512, 2) mbd_gemm_t256_kernel(const MbdGemmArgs
     }
     float gs[4] = {0.f, 0.f, 0.f, 0.f}, gs2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 4; ++j) {
+        const int n = tile_n + wn * 64 + j * 16 + (lane >> 4) * 4;   // this lane's four columns (N is a multiple of 4)
+        if (n >= N) continue;
+        const float4 add = epilogue_col_add(a, band, n);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = tile_n + wn * 64 + j * 16 + (lane & 15);
-            if (n >= N) continue;
-            const float add = (a.bias.p[band] ? a.bias.p[band][n] : 0.f) + (a.col_add.p[band] ? a.col_add.p[band][n] : 0.f);
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int m = tile_m + wm * 128 + i * 16 + (lane >> 4) * 4 + reg;
-                if (m >= M) continue;
-                float y = acc[i][j][reg] + add;
-                if (a.residual) y += a.residual[(size_t)band * a.res_band + (size_t)m * a.ldr + n];
-                a.out[(size_t)band * a.out_band + (size_t)m * a.ldc + n] = y;
-                gs[j] += y;
-                gs2[j] = fmaf(y, y, gs2[j]);
-            }
-        }
+        for (int i = 0; i < 8; ++i)
+            if (i < ni) epilogue_store4(a, band, tile_m + wm * 128 + i * 16 + (lane & 15), n, acc[i][j], add, gs[j], gs2[j]);
+    }
     if (a.gn_part) {
-        __shared__ double gn_red[8][4][2];
-        __shared__ int gn_grp[32];
+        __shared__ double gn_red[8][8][2];
         const size_t tile = (size_t)tm * nt_n + tn, tiles = (size_t)nt_m * nt_n;
-        gn_tile_partials<8>(a, gs, gs2, tile_n + wn * 64, wave, lane, tid, a.gn_part + ((size_t)band * tiles + tile) * a.gn_G * 2, gn_red, gn_grp);
+        gn_tile_record<8>(a, gs, gs2, tile_n + wn * 64, wave, lane, tid, a.gn_part + ((size_t)band * tiles + tile) * a.gn_G * 2, gn_red);
     }
 }
 
@@ -726,21 +825,7 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const float* __restrict
 // of chunks t / (2 G), t / (2 G) + 256 / (2 G), ...; the 256 / (2 G) per-q partials are then added in index order.
 __global__ void __launch_bounds__(256) gn_final_kernel(const double* __restrict__ part, int n_chunks, int G, double count, float eps, float* __restrict__ stats) {
     __shared__ double red[256];
-    part += (size_t)blockIdx.x * n_chunks * G * 2;   // one block per band
-    stats += (size_t)blockIdx.x * 2 * G;
-    const int nq = 2 * G, lanes = 256 / nq, q = threadIdx.x % nq, j = threadIdx.x / nq;
-    double a = 0.0;
-    if (j < lanes)
-        for (int c = j; c < n_chunks; c += lanes) a += part[(size_t)c * nq + q];
-    red[threadIdx.x] = j < lanes ? a : 0.0;
-    __syncthreads();
-    if (threadIdx.x < G) {
-        double sum = 0.0, sq = 0.0;
-        for (int k = 0; k < lanes; ++k) { sum += red[k * nq + 2 * threadIdx.x]; sq += red[k * nq + 2 * threadIdx.x + 1]; }
-        const double mean = sum / count;
-        stats[2 * threadIdx.x] = (float)mean;
-        stats[2 * threadIdx.x + 1] = (float)(1.0 / sqrt(fmax(sq / count - mean * mean, 0.0) + (double)eps));
-    }
+    gn_finalize(part + (size_t)blockIdx.x * n_chunks * G * 2, n_chunks, G, count, eps, stats + (size_t)blockIdx.x * 2 * G, red);   // one block per band
 }
 
 __device__ __forceinline__ float mb_act(float v, int act) {
@@ -751,14 +836,20 @@ __device__ __forceinline__ float mb_act(float v, int act) {
 
 // y = act(gn(x)) (stats == null: y = x), written as fp32 [T][C] (optional) and as the bf16 hi / lo operands of the next
 // convolution: rows [0, front) and [front + T, front + T + back) of the operand buffers are the convolution's zero padding and are
-// written here too (no separate memsets).  Four elements per thread (C is a multiple of 8).
+// written here too (no separate memsets).
+// Round 6: a thread moves EIGHT consecutive elements per step (two 16-byte loads; one 16-byte store per operand half instead of two
+// 8-byte ones) with two steps in flight, a block walks `upb` such units, and -- GM > 0 -- the pass also leaves the GroupNorm partials of
+// its OUTPUT (part[band][block][G][2]: the encoder's act(gn(conv(x))) is the first ResBlock's GroupNorm input; gn_partial_kernel read
+// it again for that).  C is a multiple of 8, so a unit stays inside a row; its two halves may lie in different groups.
+template <int GM>
 __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__ x, int64_t x_band, int T, int C, int G, const float* __restrict__ stats,
                                                        const PF gammas, const PF betas, int act, float* __restrict__ y32, int64_t y_band,
-                                                       bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int64_t op_band, int front, int back) {
-    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;   // element index inside the operand buffer
-    const size_t total = (size_t)(front + T + back) * C;
-    if (i >= total) return;
+                                                       bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int64_t op_band, int front, int back, int upb,
+                                                       double* __restrict__ part) {
+    __shared__ double gn_red[4][GM ? GM : 1][2];
     const int band = blockIdx.y;
+    const uint32_t units = (uint32_t)(((size_t)(front + T + back) * C) >> 3);
+    const uint32_t u0 = blockIdx.x * (uint32_t)upb, u1 = min(units, u0 + (uint32_t)upb);
     x += (size_t)band * x_band;
     if (y32) y32 += (size_t)band * y_band;
     if (hi) hi += (size_t)band * op_band;
@@ -766,38 +857,80 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__
     if (stats) stats += (size_t)band * 2 * G;
     const float* gamma = gammas.p[band];
     const float* beta = betas.p[band];
-    const size_t row = i / C;
-    if (row < (size_t)front || row >= (size_t)front + T) {
-        if (hi) *(uint2*)(hi + i) = make_uint2(0u, 0u);
-        if (lo) *(uint2*)(lo + i) = make_uint2(0u, 0u);
-        return;
-    }
-    const size_t j = i - (size_t)front * C;   // element index inside x
-    const float4 xv = *(const float4*)(x + j);
-    float v[4] = {xv.x, xv.y, xv.z, xv.w};
-    if (stats) {
-        const int ch = (int)(j - (row - front) * (size_t)C), cg = C / G;
-        const float4 gm = *(const float4*)(gamma + ch), bt = *(const float4*)(beta + ch);
-        const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
-        if ((cg & 3) == 0) {  // the four channels share a group
-            const int g = ch / cg;
-            const float mean = stats[2 * g], rstd = stats[2 * g + 1];
+    const int cg = C / G;
+    const uint32_t body0 = (uint32_t)front * C, body1 = body0 + (uint32_t)T * C;
+    float s[GM ? GM : 1], s2[GM ? GM : 1];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = mb_act((v[q] - mean) * rstd * gmv[q] + btv[q], act);
-        } else {
+    for (int g = 0; g < (GM ? GM : 1); ++g) s[g] = s2[g] = 0.f;
+    for (uint32_t ub = u0 + threadIdx.x; ub < u1; ub += 512) {
+        uint32_t e[2];
+        bool live[2], body[2];
+        float4 xv[2][2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int g = (ch + q) / cg;
-                v[q] = mb_act((v[q] - stats[2 * g]) * stats[2 * g + 1] * gmv[q] + btv[q], act);
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t u = ub + 256 * q;
+            live[q] = u < u1;
+            e[q] = u * 8;   // element index inside the operand buffer
+            body[q] = live[q] && e[q] >= body0 && e[q] < body1;
+            if (body[q]) {
+                xv[q][0] = *(const float4*)(x + (e[q] - body0));
+                xv[q][1] = *(const float4*)(x + (e[q] - body0) + 4);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (!live[q]) continue;
+            if (!body[q]) {
+                if (hi) *(uint4*)(hi + e[q]) = make_uint4(0u, 0u, 0u, 0u);
+                if (lo) *(uint4*)(lo + e[q]) = make_uint4(0u, 0u, 0u, 0u);
+                continue;
+            }
+            const uint32_t j = e[q] - body0;   // element index inside x
+            const int ch = (int)(j % (uint32_t)C);
+            float v[8] = {xv[q][0].x, xv[q][0].y, xv[q][0].z, xv[q][0].w, xv[q][1].x, xv[q][1].y, xv[q][1].z, xv[q][1].w};
+            if (stats) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 gm = *(const float4*)(gamma + ch + 4 * h), bt = *(const float4*)(beta + ch + 4 * h);
+                    const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+                    if ((cg & 3) == 0) {  // the four channels share a group
+                        const int g = (ch + 4 * h) / cg;
+                        const float mean = stats[2 * g], rstd = stats[2 * g + 1];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[4 * h + r] = mb_act((v[4 * h + r] - mean) * rstd * gmv[r] + btv[r], act);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int g = (ch + 4 * h + r) / cg;
+                            v[4 * h + r] = mb_act((v[4 * h + r] - stats[2 * g]) * stats[2 * g + 1] * gmv[r] + btv[r], act);
+                        }
+                    }
+                }
+            }
+            if constexpr (GM > 0) {   // (the host asks for this only when the groups are float4-aligned)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int gh = gn_group_of<GM>(ch + 4 * h, cg);
+                    const float ps = (v[4 * h] + v[4 * h + 1]) + (v[4 * h + 2] + v[4 * h + 3]);
+                    const float ps2 = fmaf(v[4 * h], v[4 * h], fmaf(v[4 * h + 1], v[4 * h + 1], fmaf(v[4 * h + 2], v[4 * h + 2], v[4 * h + 3] * v[4 * h + 3])));
+#pragma unroll
+                    for (int g = 0; g < GM; ++g) { s[g] += g == gh ? ps : 0.f; s2[g] += g == gh ? ps2 : 0.f; }
+                }
+            }
+            if (y32) {
+                *(float4*)(y32 + j) = make_float4(v[0], v[1], v[2], v[3]);
+                *(float4*)(y32 + j + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            if (hi) {
+                const uint32_t h0 = pack_bf2(v[0], v[1]), h1 = pack_bf2(v[2], v[3]), h2 = pack_bf2(v[4], v[5]), h3 = pack_bf2(v[6], v[7]);
+                *(uint4*)(hi + e[q]) = make_uint4(h0, h1, h2, h3);
+                if (lo)
+                    *(uint4*)(lo + e[q]) = make_uint4(pack_bf2(v[0] - bf_lo(h0), v[1] - bf_hi(h0)), pack_bf2(v[2] - bf_lo(h1), v[3] - bf_hi(h1)),
+                                                     pack_bf2(v[4] - bf_lo(h2), v[5] - bf_hi(h2)), pack_bf2(v[6] - bf_lo(h3), v[7] - bf_hi(h3)));
             }
         }
     }
-    if (y32) *(float4*)(y32 + j) = make_float4(v[0], v[1], v[2], v[3]);
-    if (hi) {
-        const uint32_t h0 = pack_bf2(v[0], v[1]), h1 = pack_bf2(v[2], v[3]);
-        *(uint2*)(hi + i) = make_uint2(h0, h1);
-        if (lo) *(uint2*)(lo + i) = make_uint2(pack_bf2(v[0] - bf_lo(h0), v[1] - bf_hi(h0)), pack_bf2(v[2] - bf_lo(h1), v[3] - bf_hi(h1)));
-    }
+    if constexpr (GM > 0) gn_block_record<GM>(s, s2, G, part + ((size_t)band * gridDim.x + blockIdx.x) * G * 2, gn_red);
 }
 
 // first encoder convolution, 1 -> C channels: out[m][c] = sum_k w[c][k] x[m s + k - pad]   (zero padding, no bias).  A thread
@@ -823,6 +956,66 @@ __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ 
         acc[0] = fmaf(wv.x, xv, acc[0]); acc[1] = fmaf(wv.y, xv, acc[1]); acc[2] = fmaf(wv.z, xv, acc[2]); acc[3] = fmaf(wv.w, xv, acc[3]);
     }
     *(float4*)(out + (size_t)blockIdx.y * out_band + (size_t)m * C + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+// Round 6: the same convolution for k = 8, s = 4, C <= 1024 with the block's input samples staged in LDS (one coalesced pass; a row's window
+// is two aligned 16-byte LDS reads shared by the C / 4 threads of the row instead of eight global loads per thread), a thread's 4 x 8
+// weights in registers (its channel quad is fixed: thread -> (row t / (C / 4), quad t % (C / 4)), rows advance by 256 / (C / 4) per pass) and
+// -- GM > 0 -- the GroupNorm partials of the OUTPUT from the same pass (part[band][block][G][2]; the quad lies in one group).  Same fmaf
+// order per output as conv_in_kernel: identical bits.
+constexpr int CONV_IN_PASSES = 8;
+template <int GM>
+__global__ void __launch_bounds__(256) conv_in_rows_kernel(const float* __restrict__ x, int T, const PF ws, int C, int pad, float* __restrict__ out,
+                                                           int64_t out_band, int M, int G, double* __restrict__ part) {
+    constexpr int K = 8, S = 4;
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [rows_per_block * S + K - S]
+    __shared__ double gn_red[4][GM ? GM : 1][2];
+    const int band = blockIdx.y, q4 = C >> 2, rp = 256 / q4, rows_per_block = rp * CONV_IN_PASSES;
+    const int m0 = blockIdx.x * rows_per_block, n_x = rows_per_block * S + K - S;
+    x += (size_t)band * T;
+    for (int i = threadIdx.x; i < n_x; i += 256) {
+        const int t = m0 * S - pad + i;
+        xs[i] = (t >= 0 && t < T) ? x[t] : 0.f;
+    }
+    const int c4 = threadIdx.x % q4, r = threadIdx.x / q4, c = c4 * 4;
+    const bool active = r < rp;
+    float w[4][K];
+    if (active) {
+        const float4* wp = (const float4*)(ws.p[band] + (size_t)c * K);   // [C][k]: 32 contiguous floats for the quad
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a = wp[2 * q], b = wp[2 * q + 1];
+            w[q][0] = a.x; w[q][1] = a.y; w[q][2] = a.z; w[q][3] = a.w; w[q][4] = b.x; w[q][5] = b.y; w[q][6] = b.z; w[q][7] = b.w;
+        }
+    }
+    __syncthreads();
+    float ps = 0.f, ps2 = 0.f;
+    if (active) {
+        out += (size_t)band * out_band;
+#pragma unroll 2
+        for (int it = 0; it < CONV_IN_PASSES; ++it) {
+            const int lr = r + it * rp, m = m0 + lr;
+            if (m >= M) break;
+            const float4 xa = *(const float4*)(xs + lr * S), xb = *(const float4*)(xs + lr * S + 4);
+            const float xw[K] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(w[q][j], xw[j], acc[q]);
+            *(float4*)(out + (size_t)m * C + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            if (GM) {
+                ps += (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                ps2 = fmaf(acc[0], acc[0], fmaf(acc[1], acc[1], fmaf(acc[2], acc[2], fmaf(acc[3], acc[3], ps2))));
+            }
+        }
+    }
+    if constexpr (GM > 0) {
+        float s[GM], s2[GM];
+        const int gc = gn_group_of<GM>(c, C / G);
+#pragma unroll
+        for (int g = 0; g < GM; ++g) { s[g] = active && g == gc ? ps : 0.f; s2[g] = active && g == gc ? ps2 : 0.f; }
+        gn_block_record<GM>(s, s2, G, part + ((size_t)band * gridDim.x + blockIdx.x) * G * 2, gn_red);
+    }
 }
 // last decoder transposed convolution, C -> 1 channel: out[t'] = sum_c sum_{(t, j): t s + j - pad = t'} x[t][c] w[c][j].  One thread
 // per output sample: it walks the <= k / s input rows that reach it (a row is C contiguous floats, shared through L1 by the s
@@ -1488,14 +1681,20 @@ struct GnFuse {
     int G = 0;
     double* part = nullptr;
     int tiles = 0;
+    int period = 0;   // 0: the groups run over the GEMM's N columns; Cout for a transposed convolution (N = stride x Cout, MbdGemmArgs::gn_period)
 };
+// MV_MBD_NO_GN_FUSE=1: the round-2 scheme -- gn_partial_kernel reads every tensor again (tests compare both ways in one process: read per call)
+inline bool gn_fuse_enabled() { return !getenv("MV_MBD_NO_GN_FUSE"); }
 template <typename CW>
 hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, const bf16_t* a_hi, const bf16_t* a_lo, CW cw, int taps, int64_t tap_stride,
                        int k_per_tap, GnFuse* gf = nullptr) {
-    const bool gn_fused = !getenv("MV_MBD_NO_GN_FUSE");   // read per call: the tests compare both ways in one process
-    const bool gn_ok = gf && gn_fused && gf->G > 0 && g.N % gf->G == 0 && (g.N / gf->G) % 16 == 0 && 2 * gf->G <= 256;
+    const bool gn_fused = gn_fuse_enabled();
+    const int gn_period = gf && gf->period ? gf->period : g.N;
+    const bool gn_any = gf && gn_fused && gf->G > 0 && gf->G <= 8 && g.N % gn_period == 0 && gn_period % gf->G == 0 && (gn_period / gf->G) % 4 == 0;
+    const bool gn_ok = gn_any;   // (until round 6 the tiled kernels needed group widths that are multiples of 16)
     g.gn_part = nullptr;
     if (gf) gf->tiles = 0;
+    auto arm_gn = [&](int tiles) { g.gn_part = gf->part; g.gn_G = gf->G; g.gn_period = gn_period; g.gn_cg = gn_period / gf->G; gf->tiles = tiles; };
     g.n_seg = 0;
     g.ldw = cw(0).Ktot;
     g.w_hi = ph_of(nb, [&](int b) { return (const bf16_t*)cw(b).hi; });
@@ -1516,7 +1715,11 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
     (void)hipGetDevice(&t256_dev);
     std::atomic<bool>& t256_raised = t256_raised_on[t256_dev & 63];
     // 256 x 256 tiles once such tiles fill at least ~3/4 of the CUs (the 768- and 3072-channel layers with all bands in one launch)
-    const int nt_m256 = (g.M + 255) / 256, nt_n256 = (g.N + 255) / 256;
+    // tile height 256 or 240: whichever needs less (rounds of 256 workgroups) x rows
+    const int nt_n256 = (g.N + 255) / 256;
+    auto t256_cost = [&](int rows) { const size_t blocks = (size_t)((g.M + rows - 1) / rows) * nt_n256 * nb; return (blocks + 255) / 256 * (size_t)rows; };
+    const int t256_rows = getenv("MV_MBD_T256_ROWS") ? atoi(getenv("MV_MBD_T256_ROWS")) : t256_cost(240) < t256_cost(256) ? 240 : 256;
+    const int nt_m256 = (g.M + t256_rows - 1) / t256_rows;
     const char* t256_min_env = getenv("MV_MBD_T256_MIN_BLOCKS");   // tests lower it so that small shapes (ragged tiles) take this kernel
     const size_t t256_min = t256_min_env ? (size_t)atoi(t256_min_env) : 192;
     if (k64 && prec == 3 && taps == 1 && g.N >= 256 && (size_t)nt_m256 * nt_n256 * nb >= t256_min) {
@@ -1526,18 +1729,18 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
             t256_raised = true;
         }
         const int n_blocks = nt_m256 * nt_n256 * nb;
-        if (gn_ok) { g.gn_part = gf->part; g.gn_G = gf->G; g.gn_cg = g.N / gf->G; gf->tiles = nt_m256 * nt_n256; }
+        if (gn_ok) arm_gn(nt_m256 * nt_n256);
         ++m->gemm_launches[0];
-        hipLaunchKernelGGL(mbd_gemm_t256_kernel, dim3(n_blocks), dim3(512), T256_LDS_BYTES, s, g, nt_m256, nt_n256, n_blocks);
+        hipLaunchKernelGGL(mbd_gemm_t256_kernel, dim3(n_blocks), dim3(512), T256_LDS_BYTES, s, g, nt_m256, nt_n256, n_blocks, t256_rows);
     } else if (k64 && prec == 3 && taps == 1 && g.N % 192 == 0 && g.N % 128 != 0 && !getenv("MV_MBD_NO_N192") &&
                (size_t)(g.N / 192) * ((g.M + 63) / 64) * nb >= (getenv("MV_MBD_N192_MIN_BLOCKS") ? (size_t)atoi(getenv("MV_MBD_N192_MIN_BLOCKS")) : 400)) {
         // 192-channel layers: 64 x 192 tiles, no padding columns (MV_MBD_N192_MIN_BLOCKS: tests lower the threshold for small shapes)
         const int nt192 = g.N / 192, mt64 = (g.M + 63) / 64;
-        if (gn_ok) { g.gn_part = gf->part; g.gn_G = gf->G; g.gn_cg = g.N / gf->G; gf->tiles = nt192 * mt64; }
+        if (gn_ok) arm_gn(nt192 * mt64);
         ++m->gemm_launches[1];
         hipLaunchKernelGGL((mbd_gemm_glds3_kernel<64, 192>), dim3(nt192, mt64, nb), dim3(256), 0, s, g);
     } else if (k64 && prec == 3 && taps == 1 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400) {
-        if (gn_ok) { g.gn_part = gf->part; g.gn_G = gf->G; g.gn_cg = g.N / gf->G; gf->tiles = nt * ((g.M + 127) / 128); }
+        if (gn_ok) arm_gn(nt * ((g.M + 127) / 128));
         ++m->gemm_launches[2];
         hipLaunchKernelGGL((mbd_gemm_glds3_kernel<128, 128>), dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
     }
@@ -1545,12 +1748,18 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
         // thin layers: the whole W in registers, A fragments straight from global memory (MV_MBD_NO_THIN=1: the 128-column tiles; tests, A/B)
         const dim3 grid((unsigned)((g.M + 255) / 256), nb);
         ++m->gemm_launches[3];
+        if (gn_any) arm_gn((int)grid.x);   // one record per block; any group width (a lane's column has its own group)
+        const int gm = !gn_any ? 0 : gf->G <= 4 ? 4 : 8;
+#define MBD_THIN(NTN) do { if (gm == 0) hipLaunchKernelGGL((mbd_gemm_thin_kernel<NTN, 0>), grid, dim3(256), 0, s, g); \
+                           else if (gm == 4) hipLaunchKernelGGL((mbd_gemm_thin_kernel<NTN, 4>), grid, dim3(256), 0, s, g); \
+                           else hipLaunchKernelGGL((mbd_gemm_thin_kernel<NTN, 8>), grid, dim3(256), 0, s, g); } while (0)
         switch (g.N / 16) {
-            case 1: hipLaunchKernelGGL(mbd_gemm_thin_kernel<1>, grid, dim3(256), 0, s, g); break;
-            case 2: hipLaunchKernelGGL(mbd_gemm_thin_kernel<2>, grid, dim3(256), 0, s, g); break;
-            case 3: hipLaunchKernelGGL(mbd_gemm_thin_kernel<3>, grid, dim3(256), 0, s, g); break;
-            default: hipLaunchKernelGGL(mbd_gemm_thin_kernel<4>, grid, dim3(256), 0, s, g); break;
+            case 1: MBD_THIN(1); break;
+            case 2: MBD_THIN(2); break;
+            case 3: MBD_THIN(3); break;
+            default: MBD_THIN(4); break;
         }
+#undef MBD_THIN
     }
     else if (k64 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400) {
         ++m->gemm_launches[4];
@@ -1565,11 +1774,15 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
     return hipGetLastError();
 }
 
+// 8-element units per block of norm_act_kernel (8 K elements: two trips of 256 threads x 2 units).  256 / 512 / 1024 / 2048 measured within
+// noise of each other on the whole stage (profiles/r06v/ab.txt); 1024 keeps the records of a pass with statistics at 450 per band
+constexpr int NORM_UPB = 1024;
 size_t gn_blocks(int T, int C, int G) {   // partial records x G of a [T][C] tensor: the two-pass kernels, or the tiles of a GEMM epilogue
     const int rows_per = std::max(1, (int)((size_t)16384 * G / C));
     const size_t two_pass = (size_t)((T + rows_per - 1) / rows_per), tiles = (size_t)((T + 127) / 128) * ((C + BN - 1) / BN),
                  tiles192 = (size_t)((T + 63) / 64) * ((C + 191) / 192);   // the 64 x 192 tiles of the 192-channel layers
-    return std::max(std::max(two_pass, tiles), tiles192) * G;
+    const size_t norm = ((size_t)T * C / 8 + NORM_UPB - 1) / NORM_UPB;   // norm_act_kernel with output statistics: one record per block
+    return std::max(std::max(std::max(two_pass, tiles), tiles192), norm) * G;
 }
 hipError_t group_stats(hipStream_t s, const float* x, int64_t x_band, int T, int C, int G, UnetBuffers& ub) {
     // ~16 K elements per block whatever the [T][C] aspect ratio: rows_per rows of one group
@@ -1580,8 +1793,7 @@ hipError_t group_stats(hipStream_t s, const float* x, int64_t x_band, int T, int
     return hipGetLastError();
 }
 
-// z = a + b written to `out`, and the GroupNorm statistics of z, in ONE pass (the decoder's skip addition in front of its first ResBlock);
-// falls back to the separate add + two passes when the channel groups are not float4-aligned
+// z = a + b written to `out`, and the GroupNorm statistics of z, in ONE pass (the decoder's skip addition behind a BiLSTM bottleneck)
 hipError_t add_and_group_stats(hipStream_t s, const float* a, int64_t a_band, const float* b, int64_t b_band, float* out, int64_t out_band, int T, int C, int G,
                                UnetBuffers& ub) {
     const int rows_per = std::max(1, (int)((size_t)16384 * G / C));
@@ -1591,18 +1803,31 @@ hipError_t add_and_group_stats(hipStream_t s, const float* a, int64_t a_band, co
     return hipGetLastError();
 }
 
-// the statistics of a GEMM's output: from the partials its epilogue left (gf.tiles records per band), or the two passes over the output
+// the statistics of a tensor some kernel has produced: from the partial records it left (gf.tiles per band), or by the two passes over the tensor
 hipError_t stats_of_gemm_output(hipStream_t s, const GnFuse& gf, const float* x, int64_t x_band, int T, int C, int G, UnetBuffers& ub) {
     if (gf.tiles == 0) return group_stats(s, x, x_band, T, C, G, ub);
     hipLaunchKernelGGL(gn_final_kernel, dim3(ub.NB), dim3(256), 0, s, ub.part, gf.tiles, G, (double)T * (C / G), 1e-5f, ub.stats);
     return hipGetLastError();
 }
 
+// out_gf (optional): also leave the GroupNorm partials of the OUTPUT y (tiles = 0 when the groups are not float4-aligned or the fusion is
+// switched off: the caller then runs the two-pass statistics on y32)
 void launch_norm_act(hipStream_t s, const UnetBuffers& ub, const float* x, int64_t x_band, int T, int C, int G, const float* stats, PF gamma, PF beta, int act,
-                     float* y32, int64_t y_band, bf16_t* hi, bf16_t* lo, int front, int back) {
-    const size_t vec = (size_t)(front + T + back) * C / 4;
-    hipLaunchKernelGGL(norm_act_kernel, dim3((unsigned)((vec + 255) / 256), ub.NB), dim3(256), 0, s, x, x_band, T, C, G, stats, gamma, beta, act, y32, y_band, hi, lo,
-                       (int64_t)ub.op_band, front, back);
+                     float* y32, int64_t y_band, bf16_t* hi, bf16_t* lo, int front, int back, GnFuse* out_gf = nullptr) {
+    const size_t units = (size_t)(front + T + back) * C / 8;
+    const dim3 grid((unsigned)((units + NORM_UPB - 1) / NORM_UPB), ub.NB);
+    const bool fuse = out_gf && gn_fuse_enabled() && ((C / G) & 3) == 0 && G <= 8 && front == 0 && back == 0;
+    if (out_gf) out_gf->tiles = fuse ? (int)grid.x : 0;
+    double* part = fuse ? out_gf->part : nullptr;
+    if (!fuse)
+        hipLaunchKernelGGL(norm_act_kernel<0>, grid, dim3(256), 0, s, x, x_band, T, C, G, stats, gamma, beta, act, y32, y_band, hi, lo, (int64_t)ub.op_band, front, back,
+                           NORM_UPB, part);
+    else if (G <= 4)
+        hipLaunchKernelGGL(norm_act_kernel<4>, grid, dim3(256), 0, s, x, x_band, T, C, G, stats, gamma, beta, act, y32, y_band, hi, lo, (int64_t)ub.op_band, front, back,
+                           NORM_UPB, part);
+    else
+        hipLaunchKernelGGL(norm_act_kernel<8>, grid, dim3(256), 0, s, x, x_band, T, C, G, stats, gamma, beta, act, y32, y_band, hi, lo, (int64_t)ub.op_band, front, back,
+                           NORM_UPB, part);
 }
 
 // x [band][T][C] fp32 -> ResBlock(x) into `out` (may alias x): x + conv2(act(gn2(conv1(act(gn1(x))))))  (+ col_add); rw(b) = band b's weights
@@ -1760,16 +1985,29 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
     hipLaunchKernelGGL(init_noise_kernel, dim3((T + 255) / 256, NB), dim3(256), 0, s, cur, noise ? d_noise : nullptr, T, coef(-1), seed);
     for (int ev = 0; ev < g.n_eval; ++ev) {
         // ---------------- encoder ---------------------------------------------------------------------------------------------
+        const bool add_fuse = !getenv("MV_MBD_NO_ADD_FUSE");   // read per call: a test compares both ways in one process
+        const bool skip_direct = add_fuse && !g.bilstm;         // z = 0: the first decoder ResBlock reads the innermost skip in place (no copy)
+        GnFuse skip_gf{G, ub.part, 0};
         const float* zin = cur;   // [band][Tin][Cin]
         int64_t zin_band = T;
         int Tin = T;
         for (int i = 0; i < D; ++i) {
             const int Cin = i == 0 ? 1 : m->ch[i - 1], Cout = m->ch[i], To = ub.T[i];
             auto E = [&](int b) -> const EncW& { return m->band[b].enc[i]; };
-            GnFuse enc_gf{G, ub.part, 0};   // stays at 0 tiles for the first level (no GEMM): two-pass statistics
+            GnFuse enc_gf{G, ub.part, 0};   // the partials of the strided convolution's output, from the kernel that writes it
             if (i == 0) {
-                hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)(((size_t)To * (Cout / 4) + 255) / 256), NB), dim3(256), (size_t)Cout * k * 4, s, zin, Tin,
-                                   pf_of(NB, [&](int b) { return (const float*)E(b).conv_in_w; }), Cout, k, st, pad, ub.a32, WB, To);
+                const PF w_in = pf_of(NB, [&](int b) { return (const float*)E(b).conv_in_w; });
+                if (k == 8 && st == 4 && Cout <= 1024 && gn_fuse_enabled()) {   // input samples through LDS, weights in registers, statistics from the same pass
+                    const int rows_per_block = 256 / (Cout / 4) * CONV_IN_PASSES, blocks = (To + rows_per_block - 1) / rows_per_block;
+                    const size_t lds = (size_t)(rows_per_block * st + k - st) * 4;
+                    const bool fuse = ((Cout / G) & 3) == 0;
+                    if (!fuse) hipLaunchKernelGGL(conv_in_rows_kernel<0>, dim3(blocks, NB), dim3(256), lds, s, zin, Tin, w_in, Cout, pad, ub.a32, WB, To, G, (double*)nullptr);
+                    else if (G <= 4) hipLaunchKernelGGL(conv_in_rows_kernel<4>, dim3(blocks, NB), dim3(256), lds, s, zin, Tin, w_in, Cout, pad, ub.a32, WB, To, G, ub.part);
+                    else hipLaunchKernelGGL(conv_in_rows_kernel<8>, dim3(blocks, NB), dim3(256), lds, s, zin, Tin, w_in, Cout, pad, ub.a32, WB, To, G, ub.part);
+                    if (fuse) enc_gf.tiles = blocks;
+                } else
+                    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)(((size_t)To * (Cout / 4) + 255) / 256), NB), dim3(256), (size_t)Cout * k * 4, s, zin, Tin, w_in,
+                                       Cout, k, st, pad, ub.a32, WB, To);
             } else {
                 // operand: zin with `pad` zero rows in front and (Tpad - Tin) + k behind
                 const int back = ub.Tpad[i] - Tin + k;
@@ -1783,15 +2021,17 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
             const bool has_emb = i == 0 || g.emb_all_layers;
             const PF emb = has_emb ? pf_of(NB, [&](int b) { return (const float*)(E(b).emb + (size_t)m->band[b].steps[ev] * Cout); }) : PF{};
             if (g.res_blocks == 0) return mv_fail(MV_ERR_INVALID, "res_blocks = 0 is not supported");
+            // ResBlock r's input statistics: the partials its producer left -- this pass for the first one (round 6), ResBlock r - 1's conv2 after that
+            GnFuse chain{G, ub.part, 0};
             launch_norm_act(s, ub, ub.a32, WB, To, Cout, G, ub.stats, pf_of(NB, [&](int b) { return (const float*)E(b).norm.g; }),
-                            pf_of(NB, [&](int b) { return (const float*)E(b).norm.b; }), g.act, ub.c32, WB, nullptr, nullptr, 0, 0);
-            GnFuse chain{G, ub.part, 0};   // ResBlock r's output partials = ResBlock r + 1's input statistics
+                            pf_of(NB, [&](int b) { return (const float*)E(b).norm.b; }), g.act, ub.c32, WB, nullptr, nullptr, 0, 0, &chain);
             for (int r = 0; r < g.res_blocks; ++r) {
                 const bool lastr = r == g.res_blocks - 1;
                 const GnFuse in_gf = chain;
+                // the innermost skip is the decoder's first ResBlock input when there is no BiLSTM: its statistics come from this epilogue too
+                GnFuse* out_gf = !lastr ? &chain : (i == D - 1 && skip_direct) ? &skip_gf : nullptr;
                 MG_TRY(res_block(s, m, [&](int b) -> const ResW& { return E(b).res[r]; }, ub.c32, WB, lastr ? ub.skip[i] : ub.c32,
-                                 lastr ? (int64_t)ub.skip_band[i] : WB, To, Cout, 1 << r, lastr ? emb : PF{}, ub, lastr ? nullptr : &chain,
-                                 r > 0 && in_gf.tiles > 0 ? &in_gf : nullptr));
+                                 lastr ? (int64_t)ub.skip_band[i] : WB, To, Cout, 1 << r, lastr ? emb : PF{}, ub, out_gf, in_gf.tiles > 0 ? &in_gf : nullptr));
             }
             zin = ub.skip[i];
             zin_band = (int64_t)ub.skip_band[i];
@@ -1835,21 +2075,35 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
         // ---------------- decoder ---------------------------------------------------------------------------------------------
         const float* z = zb;
         int64_t z_band = lstm_band;
+        // Round 6: from the second level on z + skip is written by the up-convolution's own epilogue (MbdGemmArgs::valid_lo / residual),
+        // together with the GroupNorm partials of the sum -- add_and_group_stats read both tensors again for that
+        bool sum_ready = false;           // c32 already holds z + skip of this level
+        GnFuse sum_gf{G, ub.part, 0};     // ... and these are its partials (tiles = 0: the kernel that ran leaves none)
         for (int i = 0; i < D; ++i) {
             const int lvl = D - 1 - i, C = m->ch[lvl], Cout = lvl == 0 ? 1 : m->ch[lvl - 1], Ts = ub.T[lvl];
             auto Dw = [&](int b) -> const DecW& { return m->band[b].dec[i]; };
             // z = z[:, :, :skip.T] + skip   (z rows beyond skip.T are dropped; z never is shorter)
             const size_t n = (size_t)Ts * C;
-            // the skip addition and the statistics of its result (the first ResBlock's GroupNorm input) in one pass when the groups are
-            // float4-aligned and there is something to add (z == nullptr: the bottleneck without a BiLSTM is zeros -- add_kernel copies)
-            const bool fused_add = z != nullptr && ((C / G) & 3) == 0 && !getenv("MV_MBD_NO_ADD_FUSE");
-            if (fused_add) MG_TRY(add_and_group_stats(s, ub.skip[lvl], (int64_t)ub.skip_band[lvl], z, z_band, ub.c32, WB, Ts, C, G, ub));
-            else hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256), NB), dim3(256), 0, s, ub.skip[lvl], (int64_t)ub.skip_band[lvl], z, z_band, ub.c32, WB, n);
+            const float* x0 = ub.c32;     // the first ResBlock's input
+            int64_t x0_band = WB;
+            const GnFuse* x0_gf = nullptr;
+            bool x0_stats_ready = false;
+            if (sum_ready) {
+                if (sum_gf.tiles > 0) x0_gf = &sum_gf;
+            } else if (z == nullptr && skip_direct) {
+                x0 = ub.skip[lvl]; x0_band = (int64_t)ub.skip_band[lvl];
+                if (skip_gf.tiles > 0) x0_gf = &skip_gf;
+            } else if (z != nullptr && ((C / G) & 3) == 0 && add_fuse) {
+                // the skip addition and the statistics of its result in one pass (behind the BiLSTM, whose output no GEMM epilogue of ours writes)
+                MG_TRY(add_and_group_stats(s, ub.skip[lvl], (int64_t)ub.skip_band[lvl], z, z_band, ub.c32, WB, Ts, C, G, ub));
+                x0_stats_ready = true;
+            } else
+                hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256), NB), dim3(256), 0, s, ub.skip[lvl], (int64_t)ub.skip_band[lvl], z, z_band, ub.c32, WB, n);
             GnFuse dec_gf{G, ub.part, 0};   // every ResBlock leaves its output partials: the next one's input statistics, then the decoder norm's
             for (int r = 0; r < g.res_blocks; ++r) {
                 const GnFuse in_gf = dec_gf;
-                MG_TRY(res_block(s, m, [&](int b) -> const ResW& { return Dw(b).res[r]; }, ub.c32, WB, ub.c32, WB, Ts, C, 1 << r, PF{}, ub,
-                                 &dec_gf, r > 0 && in_gf.tiles > 0 ? &in_gf : nullptr, r == 0 && fused_add));
+                MG_TRY(res_block(s, m, [&](int b) -> const ResW& { return Dw(b).res[r]; }, r == 0 ? x0 : ub.c32, r == 0 ? x0_band : WB, ub.c32, WB, Ts, C, 1 << r, PF{}, ub,
+                                 &dec_gf, r == 0 ? x0_gf : in_gf.tiles > 0 ? &in_gf : nullptr, r == 0 && x0_stats_ready));
             }
             MG_TRY(stats_of_gemm_output(s, dec_gf, ub.c32, WB, Ts, C, G, ub));
             const PF ng = pf_of(NB, [&](int b) { return (const float*)Dw(b).norm.g; }), nbias = pf_of(NB, [&](int b) { return (const float*)Dw(b).norm.b; });
@@ -1861,12 +2115,27 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
                 // operand rows: [zero row | z rows 0..Ts-1 | zero row]; GEMM row q = (x[q-1], x[q]), q = 0..Ts
                 launch_norm_act(s, ub, ub.c32, WB, Ts, C, G, ub.stats, ng, nbias, g.act, nullptr, 0, ub.hi, g.precision > 2 ? ub.lo : nullptr, 1, 1);
                 MbdGemmArgs ga;
-                ga.M = Ts + 1; ga.N = st * Cout; ga.lda = C; ga.a_band = OB; ga.out = ub.dec_out; ga.ldc = (int64_t)st * Cout; ga.out_band = OB;
+                ga.M = Ts + 1; ga.N = st * Cout; ga.lda = C; ga.a_band = OB; ga.ldc = (int64_t)st * Cout;
                 ga.bias = PF{}; ga.col_add = PF{};
-                MG_TRY(launch_gemm(s, m, NB, ga, ub.hi, ub.lo, [&](int b) -> const ConvW& { return Dw(b).convtr; }, 1, 0, 2 * C));
-                // row q holds output times q st - pad + p: the valid signal starts `pad` rows into the buffer
-                z = ub.dec_out + (size_t)pad * Cout;
-                z_band = OB;
+                // row q holds output times q st - pad + p: the valid signal starts `pad` rows into the row-major image
+                if (add_fuse) {
+                    // ... so with `out` and `residual` set `pad` time steps in front of c32 / the next skip, image element f is time step f / Cout - pad
+                    // of both: the epilogue adds the skip, drops what lies outside [0, skip.T) and sums the rest for the next GroupNorm (c32 is free:
+                    // the pass above was its last reader)
+                    const int Tn = ub.T[lvl - 1];
+                    ga.out = ub.c32 - (size_t)pad * Cout; ga.out_band = WB;
+                    ga.residual = ub.skip[lvl - 1] - (size_t)pad * Cout; ga.ldr = ga.ldc; ga.res_band = (int64_t)ub.skip_band[lvl - 1];
+                    ga.valid_lo = (int64_t)pad * Cout; ga.valid_hi = ga.valid_lo + (int64_t)Tn * Cout;
+                    sum_gf = GnFuse{G, ub.part, 0, Cout};
+                    MG_TRY(launch_gemm(s, m, NB, ga, ub.hi, ub.lo, [&](int b) -> const ConvW& { return Dw(b).convtr; }, 1, 0, 2 * C, &sum_gf));
+                    sum_ready = true;
+                    ++m->gemm_launches[7];
+                } else {
+                    ga.out = ub.dec_out; ga.out_band = OB;
+                    MG_TRY(launch_gemm(s, m, NB, ga, ub.hi, ub.lo, [&](int b) -> const ConvW& { return Dw(b).convtr; }, 1, 0, 2 * C));
+                    z = ub.dec_out + (size_t)pad * Cout;
+                    z_band = OB;
+                }
             }
         }
         MG_TRY(hipGetLastError());
@@ -1982,7 +2251,8 @@ int mv_mbd_unet_forward_sum(mv_mbd* m, const float* x, int32_t T, int32_t step, 
 }
 
 // Launches per GEMM kernel since mv_mbd_create: out[0] mbd_gemm_t256_kernel, [1] mbd_gemm_glds3_kernel<64, 192>, [2] <128, 128>,
-// [3] mbd_gemm_thin_kernel, [4] mbd_gemm_glds_kernel, [5] mbd_gemm_kernel<128>, [6] mbd_gemm_kernel<64>, [7] 0.
+// [3] mbd_gemm_thin_kernel, [4] mbd_gemm_glds_kernel, [5] mbd_gemm_kernel<128>, [6] mbd_gemm_kernel<64>; [7] (not a kernel) the up-convolutions among
+// them whose epilogue wrote z + skip (round 6).
 int mv_mbd_kernel_counts(const mv_mbd* m, int64_t* out) {
     if (!m || !out) return mv_fail(MV_ERR_INVALID, "mv_mbd_kernel_counts: null argument");
     for (int i = 0; i < 8; ++i) out[i] = m->gemm_launches[i];

@@ -266,3 +266,9 @@ class MultiBandDiffusionBands:
         out = (C.c_int64 * 8)()
         N.check(N.lib().mv_mbd_kernel_counts(self._h, out))
         return {k: int(out[i]) for i, k in enumerate(self.GEMM_KERNELS)}
+
+    def fused_skip_additions(self) -> int:
+        """Transposed convolutions since the engine was built whose epilogue wrote the decoder's `z + skip` (no pass of its own for the sum)."""
+        out = (C.c_int64 * 8)()
+        N.check(N.lib().mv_mbd_kernel_counts(self._h, out))
+        return int(out[7])

@@ -86,6 +86,35 @@ def test_unet_forward_on_the_256x256_tile_gemm(kw, T, monkeypatch):
 
 
 @pytest.mark.parametrize("kw,T", [
+    (dict(hidden=64, depth=2, growth=4.0, codec_dim=None), 20011),    # M = 5003 / 5004 rows: 21 tiles of 240 (the last one ragged) against 20 of 256
+    (dict(hidden=32, depth=3, growth=4.0, codec_dim=24), 15360),      # M = 960 = 4 x 240 exactly, two column tiles; M = 961 for the up-convolution
+])
+def test_240_row_tiles_of_the_256x256_gemm(kw, T, monkeypatch):
+    """Round 6: `mbd_gemm_t256_kernel` with 240-row tiles (the lower waves skip their eighth 16-row block): what launch_gemm picks when it
+    saves a sixteenth of a one-round launch (M = 1200 / 4800 rows of the bench).  Forced here (`MV_MBD_T256_ROWS`) on shapes with ragged and
+    exact tile counts, against the oracle and against 256-row tiles -- the same K order per output element, so only the GroupNorm statistics
+    (summed per tile) may differ in their last bits."""
+    pkg = synthetic.mbd_package(seed=17, n_bands=2, proc_bands=1, **kw)
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(T, generator=g)
+    lat = torch.randn(1, kw["codec_dim"], 11, generator=g) if kw.get("codec_dim") else None
+    band = oracle_bands(pkg)[1]
+    ref = o_mbd.unet_forward(band.sd, band.cfg, x.view(1, 1, -1), 333, lat).reshape(-1)
+    eng = mbd.MultiBandDiffusionBands.from_package(pkg, precision=3, eq_bands=1)
+    monkeypatch.setenv("MV_MBD_T256_MIN_BLOCKS", "1")
+    monkeypatch.setenv("MV_MBD_T256_ROWS", "240")
+    t240 = eng.unet_forward(1, x, 333, lat)
+    again = eng.unet_forward(1, x, 333, lat)
+    monkeypatch.setenv("MV_MBD_T256_ROWS", "256")
+    t256 = eng.unet_forward(1, x, 333, lat)
+    s_240, s_256, s_pair = snr_db(t240, ref), snr_db(t256, ref), snr_db(t240, t256)
+    print(f"[mbd t256 rows {kw} T={T}] SNR vs oracle: 240-row tiles {s_240:.1f} dB, 256-row tiles {s_256:.1f} dB; between the two {s_pair:.1f} dB")
+    assert torch.equal(t240, again)
+    assert s_240 >= 60.0 and s_256 >= 60.0 and s_pair >= 100.0
+    eng.close()
+
+
+@pytest.mark.parametrize("kw,T", [
     (dict(hidden=48, depth=2, growth=4.0, codec_dim=None), 40003),   # the bench's two outer levels: 48 channels (thin kernel) and 192 (64 x 192 tiles)
     (dict(hidden=16, depth=3, growth=2.0, codec_dim=32), 9001),      # 16 / 32 / 64 channels: every instance of the thin kernel, K = 48 / 96 (two K-steps and a tail)
 ])
@@ -112,22 +141,40 @@ def test_thin_and_192_column_gemm_tiles(kw, T, monkeypatch):
     eng.close()
 
 
-def test_skip_addition_fused_into_the_group_norm_statistics(monkeypatch):
-    """The decoder's `z + skip` is written by the statistics pass of the GroupNorm that reads it (`gn_partial_kernel` with a second input):
-    same sums in the same order as the separate `add_kernel` + two-pass statistics => identical bits."""
-    kw = dict(hidden=16, depth=3, growth=2.0, codec_dim=32)
+@pytest.mark.parametrize("kw,T,frames,t256", [
+    (dict(hidden=16, depth=3, growth=2.0, codec_dim=32), 7001, 9, False),     # ragged lengths: the up-convolution's overhang past skip.T is dropped
+    (dict(hidden=64, depth=2, growth=4.0, codec_dim=None), 20011, 0, True),   # the 256 x 256-tile kernel writes z + skip (groups repeat with period Cout)
+    (dict(hidden=48, depth=2, growth=4.0, codec_dim=None), 40003, 0, False),  # 64 x 192 tiles
+    (dict(hidden=16, depth=2, growth=2.0, codec_dim=24, bilstm=True), 3000, 6, False),   # behind a BiLSTM: the first level's sum comes from the statistics pass
+])
+def test_skip_addition_in_the_up_convolution_epilogue(kw, T, frames, t256, monkeypatch):
+    """Round 6: the decoder's `z[:, :, :skip.T] + skip` is written by the epilogue of the transposed convolution that produces z (the s output
+    phases of a step are one GEMM row: `MbdGemmArgs::valid_lo / valid_hi` drop the `pad` leading steps and the overhang, `residual` is the
+    skip) together with the GroupNorm partials of the sum; the innermost skip is read in place when there is no BiLSTM.  With
+    MV_MBD_NO_ADD_FUSE the sum is a pass of its own (`add_kernel`, then the two-pass statistics): the same values, statistics summed in another order."""
     pkg = synthetic.mbd_package(seed=21, n_bands=2, proc_bands=1, **kw)
     g = torch.Generator().manual_seed(5)
-    x = torch.randn(7001, generator=g)
-    lat = torch.randn(1, 32, 9, generator=g)
+    x = torch.randn(T, generator=g)
+    lat = torch.randn(1, kw["codec_dim"], frames, generator=g) if kw.get("codec_dim") else None
     band = oracle_bands(pkg)[0]
     ref = o_mbd.unet_forward(band.sd, band.cfg, x.view(1, 1, -1), 600, lat).reshape(-1)
     eng = mbd.MultiBandDiffusionBands.from_package(pkg, precision=3, eq_bands=1)
+    if t256:
+        monkeypatch.setenv("MV_MBD_T256_MIN_BLOCKS", "1")
+    monkeypatch.setenv("MV_MBD_N192_MIN_BLOCKS", "1")
+    n0 = eng.fused_skip_additions()
     fused = eng.unet_forward(0, x, 600, lat)
+    n1 = eng.fused_skip_additions()
+    again = eng.unet_forward(0, x, 600, lat)
     monkeypatch.setenv("MV_MBD_NO_ADD_FUSE", "1")
+    n2 = eng.fused_skip_additions()
     separate = eng.unet_forward(0, x, 600, lat)
-    assert snr_db(fused, ref) >= 60.0
-    assert torch.equal(fused, separate)
+    s_f, s_s, s_pair = snr_db(fused, ref), snr_db(separate, ref), snr_db(fused, separate)
+    print(f"[mbd skip add {kw} T={T}] SNR vs oracle: in the epilogue {s_f:.1f} dB, separate pass {s_s:.1f} dB; between the two {s_pair:.1f} dB "
+          f"(> 280 = identical bits: the statistics are rounded to fp32 from double sums)")
+    assert n1 - n0 == kw["depth"] - 1 and eng.fused_skip_additions() == n2   # every level but the outermost; none with the switch
+    assert torch.equal(fused, again)
+    assert s_f >= 60.0 and s_s >= 60.0 and s_pair >= 100.0
     eng.close()
 
 
