@@ -279,7 +279,7 @@ __device__ __forceinline__ void epilogue_store4(const MbdGemmArgs& a, int band, 
 // GM > 0 (round 6): the GroupNorm partials of the output from the epilogue, one record per block (a.gn_part[band][block][G][2]); a lane's
 // column j * 16 + col has its own group (groups of 12 channels at 48 / 4: not aligned to the 16-column fragments).
 template <int NTN, int GM>
-__global__ void __launch_bounds__(256) mbd_gemm_thin_kernel(const MbdGemmArgs a) {
+__global__ void __launch_bounds__(256, 2) mbd_gemm_thin_kernel(const MbdGemmArgs a) {
     constexpr int KS = 5, MT = 4;   // K-steps of 32 (K <= 160); 16-row tiles per wave and loop trip
     __shared__ double gn_red[4][GM ? GM : 1][2];
     float gs[NTN], gs2[NTN];
@@ -303,35 +303,58 @@ __global__ void __launch_bounds__(256) mbd_gemm_thin_kernel(const MbdGemmArgs a)
     const bf16_t* ah = a.seg[0].a + (size_t)band * a.a_band;   // segment 0: a_hi x w_hi, segment 2: a_lo x w_hi (launch_gemm's order)
     const bf16_t* al = a.seg[2].a + (size_t)band * a.a_band;
     const int tile0 = (blockIdx.x * 4 + wave) * (16 * MT);
-#pragma unroll 1
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m0 = tile0 + mt * 16;
-        if (m0 >= M) break;
+    // Round 6: software-pipelined over the wave's MT tiles -- the A fragments of tile mt + 1 and the residual of tile mt are requested in
+    // front of tile mt's MFMAs (two waves per SIMD at ~240 VGPRs hide nothing of a load round trip by themselves: with one tile at a time
+    // the kernel ran at 2.8 TB/s of its own bytes).  Rows past M are clamped on the load side and dropped in the epilogue.
+    constexpr int NBUF = NTN <= 3 ? 2 : 1;   // (64 channels: the second fragment set does not fit in 256 registers -- one tile at a time as before)
+    bf16x8_t fh[NBUF][KS], fl[NBUF][KS];
+    auto load_tile = [&](int buf, int m0) {
         const size_t arow = (size_t)min(m0 + col, M - 1) * a.lda;
-        f32x4_t acc[NTN];
-#pragma unroll
-        for (int j = 0; j < NTN; ++j) acc[j] = f32x4_t{0, 0, 0, 0};
-        bf16x8_t fh[KS], fl[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int k = ks * 32 + kg * 8;
-            fh[ks] = __builtin_bit_cast(bf16x8_t, k < K ? load16(ah + arow + k) : zero);
-            fl[ks] = __builtin_bit_cast(bf16x8_t, k < K ? load16(al + arow + k) : zero);
+            fh[buf][ks] = __builtin_bit_cast(bf16x8_t, k < K ? load16(ah + arow + k) : zero);
+            fl[buf][ks] = __builtin_bit_cast(bf16x8_t, k < K ? load16(al + arow + k) : zero);
         }
+    };
+    if (NBUF == 2) load_tile(0, tile0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m0 = tile0 + mt * 16, cur = NBUF == 2 ? mt & 1 : 0;
+        if (NBUF == 1) load_tile(0, m0);
+        else if (mt + 1 < MT) load_tile(cur ^ 1, m0 + 16);
+        const int m = m0 + col;
+        float4 res[NTN];
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) {
+            const int n = j * 16 + kg * 4;
+            const int64_t f = (int64_t)min(m, M - 1) * a.ldc + n;   // (outside the window `residual` may point in front of its buffer)
+            res[j] = a.residual && n < N && f >= a.valid_lo && f < a.valid_hi ? *(const float4*)(a.residual + (size_t)band * a.res_band + (size_t)min(m, M - 1) * a.ldr + n)
+                                                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        f32x4_t acc[NTN];
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) acc[j] = f32x4_t{0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int j = 0; j < NTN; ++j) {
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j][ks], fh[ks], acc[j], 0, 0, 0);   // W first: C^T, see mbd_gemm_t256_kernel
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j][ks], fh[ks], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j][ks], fl[ks], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j][ks], fh[cur][ks], acc[j], 0, 0, 0);   // W first: C^T, see mbd_gemm_t256_kernel
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j][ks], fh[cur][ks], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j][ks], fl[cur][ks], acc[j], 0, 0, 0);
             }
         // C^T fragment j: row lane & 15, columns j * 16 + (lane >> 4) * 4 + reg
 #pragma unroll
         for (int j = 0; j < NTN; ++j) {
             const int n = j * 16 + kg * 4;
-            if (n >= N) continue;
-            epilogue_store4(a, band, m0 + col, n, acc[j], epilogue_col_add(a, band, n), gs[j], gs2[j]);
+            if (n >= N || m >= M) continue;
+            const int64_t f = (int64_t)m * a.ldc + n;
+            if (f < a.valid_lo || f >= a.valid_hi) continue;
+            const float4 add = epilogue_col_add(a, band, n);
+            const float4 y = make_float4(acc[j][0] + add.x + res[j].x, acc[j][1] + add.y + res[j].y, acc[j][2] + add.z + res[j].z, acc[j][3] + add.w + res[j].w);
+            *(float4*)(a.out + (size_t)band * a.out_band + f) = y;
+            gs[j] += (y.x + y.y) + (y.z + y.w);
+            gs2[j] = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, fmaf(y.w, y.w, gs2[j]))));
         }
     }
     if constexpr (GM > 0) {
@@ -845,16 +868,24 @@ template <int GM>
 __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__ x, int64_t x_band, int T, int C, int G, const float* __restrict__ stats,
                                                        const PF gammas, const PF betas, int act, float* __restrict__ y32, int64_t y_band,
                                                        bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int64_t op_band, int front, int back, int upb,
-                                                       double* __restrict__ part) {
+                                                       double* __restrict__ part, const double* __restrict__ fin_part, int fin_rec, double fin_count) {
     __shared__ double gn_red[4][GM ? GM : 1][2];
+    __shared__ double fin_red[256];
+    __shared__ float st[16];   // (mean, rstd) of the G <= 8 groups of this band
     const int band = blockIdx.y;
+    // The statistics of x: finished by gn_final_kernel (stats), or -- fin_part: the producer left few records (the 57-60 tiles per band of a
+    // 256 x 256-tile GEMM) -- finished HERE by every block in the same fixed order (3.8 KB of L2 reads and ~1 us per block, all blocks of a CU at
+    // once) instead of a 4.8 us launch and two kernel boundaries in front of this pass (11 of the 24 normalisations of an evaluation).
+    if (fin_part) gn_finalize(fin_part + (size_t)band * fin_rec * G * 2, fin_rec, G, fin_count, 1e-5f, st, fin_red);
+    else if (stats && (int)threadIdx.x < 2 * G) st[threadIdx.x] = stats[(size_t)band * 2 * G + threadIdx.x];
+    __syncthreads();
+    const bool normed = stats != nullptr || fin_part != nullptr;
     const uint32_t units = (uint32_t)(((size_t)(front + T + back) * C) >> 3);
     const uint32_t u0 = blockIdx.x * (uint32_t)upb, u1 = min(units, u0 + (uint32_t)upb);
     x += (size_t)band * x_band;
     if (y32) y32 += (size_t)band * y_band;
     if (hi) hi += (size_t)band * op_band;
     if (lo) lo += (size_t)band * op_band;
-    if (stats) stats += (size_t)band * 2 * G;
     const float* gamma = gammas.p[band];
     const float* beta = betas.p[band];
     const int cg = C / G;
@@ -888,21 +919,21 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__
             const uint32_t j = e[q] - body0;   // element index inside x
             const int ch = (int)(j % (uint32_t)C);
             float v[8] = {xv[q][0].x, xv[q][0].y, xv[q][0].z, xv[q][0].w, xv[q][1].x, xv[q][1].y, xv[q][1].z, xv[q][1].w};
-            if (stats) {
+            if (normed) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const float4 gm = *(const float4*)(gamma + ch + 4 * h), bt = *(const float4*)(beta + ch + 4 * h);
                     const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
                     if ((cg & 3) == 0) {  // the four channels share a group
                         const int g = (ch + 4 * h) / cg;
-                        const float mean = stats[2 * g], rstd = stats[2 * g + 1];
+                        const float mean = st[2 * g], rstd = st[2 * g + 1];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[4 * h + r] = mb_act((v[4 * h + r] - mean) * rstd * gmv[r] + btv[r], act);
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int g = (ch + 4 * h + r) / cg;
-                            v[4 * h + r] = mb_act((v[4 * h + r] - stats[2 * g]) * stats[2 * g + 1] * gmv[r] + btv[r], act);
+                            v[4 * h + r] = mb_act((v[4 * h + r] - st[2 * g]) * st[2 * g + 1] * gmv[r] + btv[r], act);
                         }
                     }
                 }
@@ -1665,7 +1696,13 @@ struct UnetBuffers {
     float *a32 = nullptr, *b32 = nullptr, *c32 = nullptr;   // fp32 scratch [band][widest]
     bf16_t *hi = nullptr, *lo = nullptr;   // bf16 conv operand with zero margins [band][op_band]
     double* part = nullptr;                // [band][part_band]
+    double* part2 = nullptr;               // the records a normalise pass writes while it may still be finishing the ones in `part`
     float* stats = nullptr;                // [band][2 G]
+    // statistics that no gn_final_kernel has finished: the next norm_act_kernel does it from these records (stats_of_gemm_output leaves them
+    // when they are few); null: `stats` is current
+    const double* pending_part = nullptr;
+    int pending_rec = 0;
+    double pending_count = 0.0;
     float* dec_out = nullptr;              // transposed-conv output [band][op_band]
     size_t widest = 0, op_band = 0;
 };
@@ -1777,6 +1814,7 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
 // 8-element units per block of norm_act_kernel (8 K elements: two trips of 256 threads x 2 units).  256 / 512 / 1024 / 2048 measured within
 // noise of each other on the whole stage (profiles/r06v/ab.txt); 1024 keeps the records of a pass with statistics at 450 per band
 constexpr int NORM_UPB = 1024;
+constexpr int GN_DEFER_MAX_RECORDS = 64;   // (a record is 2 G doubles: 4 KB per block at G = 4)
 size_t gn_blocks(int T, int C, int G) {   // partial records x G of a [T][C] tensor: the two-pass kernels, or the tiles of a GEMM epilogue
     const int rows_per = std::max(1, (int)((size_t)16384 * G / C));
     const size_t two_pass = (size_t)((T + rows_per - 1) / rows_per), tiles = (size_t)((T + 127) / 128) * ((C + BN - 1) / BN),
@@ -1790,6 +1828,7 @@ hipError_t group_stats(hipStream_t s, const float* x, int64_t x_band, int T, int
     const int chunks = (T + rows_per - 1) / rows_per;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, G, ub.NB), dim3(256), 0, s, x, x_band, T, C, G, rows_per, ub.part);
     hipLaunchKernelGGL(gn_final_kernel, dim3(ub.NB), dim3(256), 0, s, ub.part, chunks, G, (double)T * (C / G), 1e-5f, ub.stats);
+    ub.pending_part = nullptr;
     return hipGetLastError();
 }
 
@@ -1800,34 +1839,46 @@ hipError_t add_and_group_stats(hipStream_t s, const float* a, int64_t a_band, co
     const int chunks = (T + rows_per - 1) / rows_per;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, G, ub.NB), dim3(256), 0, s, a, a_band, T, C, G, rows_per, ub.part, b, b_band, out, out_band);
     hipLaunchKernelGGL(gn_final_kernel, dim3(ub.NB), dim3(256), 0, s, ub.part, chunks, G, (double)T * (C / G), 1e-5f, ub.stats);
+    ub.pending_part = nullptr;
     return hipGetLastError();
 }
 
 // the statistics of a tensor some kernel has produced: from the partial records it left (gf.tiles per band), or by the two passes over the tensor
 hipError_t stats_of_gemm_output(hipStream_t s, const GnFuse& gf, const float* x, int64_t x_band, int T, int C, int G, UnetBuffers& ub) {
     if (gf.tiles == 0) return group_stats(s, x, x_band, T, C, G, ub);
-    hipLaunchKernelGGL(gn_final_kernel, dim3(ub.NB), dim3(256), 0, s, ub.part, gf.tiles, G, (double)T * (C / G), 1e-5f, ub.stats);
+    if (gf.tiles <= GN_DEFER_MAX_RECORDS && gn_fuse_enabled()) {   // few records: the normalise pass that needs them finishes them itself
+        ub.pending_part = gf.part; ub.pending_rec = gf.tiles; ub.pending_count = (double)T * (C / G);
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(gn_final_kernel, dim3(ub.NB), dim3(256), 0, s, gf.part, gf.tiles, G, (double)T * (C / G), 1e-5f, ub.stats);
+    ub.pending_part = nullptr;
     return hipGetLastError();
 }
 
 // out_gf (optional): also leave the GroupNorm partials of the OUTPUT y (tiles = 0 when the groups are not float4-aligned or the fusion is
 // switched off: the caller then runs the two-pass statistics on y32)
-void launch_norm_act(hipStream_t s, const UnetBuffers& ub, const float* x, int64_t x_band, int T, int C, int G, const float* stats, PF gamma, PF beta, int act,
+void launch_norm_act(hipStream_t s, UnetBuffers& ub, const float* x, int64_t x_band, int T, int C, int G, const float* stats, PF gamma, PF beta, int act,
                      float* y32, int64_t y_band, bf16_t* hi, bf16_t* lo, int front, int back, GnFuse* out_gf = nullptr) {
     const size_t units = (size_t)(front + T + back) * C / 8;
     const dim3 grid((unsigned)((units + NORM_UPB - 1) / NORM_UPB), ub.NB);
     const bool fuse = out_gf && gn_fuse_enabled() && ((C / G) & 3) == 0 && G <= 8 && front == 0 && back == 0;
     if (out_gf) out_gf->tiles = fuse ? (int)grid.x : 0;
     double* part = fuse ? out_gf->part : nullptr;
+    // the statistics of x: `stats`, or the records stats_of_gemm_output left pending (consumed here)
+    const double* fin_part = stats ? ub.pending_part : nullptr;
+    const int fin_rec = fin_part ? ub.pending_rec : 0;
+    const double fin_count = fin_part ? ub.pending_count : 0.0;
+    if (stats) ub.pending_part = nullptr;
+    if (fin_part && part == fin_part) { mv_fail(MV_ERR_STATE, "launch_norm_act: the output records would overwrite the pending ones"); return; }
     if (!fuse)
         hipLaunchKernelGGL(norm_act_kernel<0>, grid, dim3(256), 0, s, x, x_band, T, C, G, stats, gamma, beta, act, y32, y_band, hi, lo, (int64_t)ub.op_band, front, back,
-                           NORM_UPB, part);
+                           NORM_UPB, part, fin_part, fin_rec, fin_count);
     else if (G <= 4)
         hipLaunchKernelGGL(norm_act_kernel<4>, grid, dim3(256), 0, s, x, x_band, T, C, G, stats, gamma, beta, act, y32, y_band, hi, lo, (int64_t)ub.op_band, front, back,
-                           NORM_UPB, part);
+                           NORM_UPB, part, fin_part, fin_rec, fin_count);
     else
         hipLaunchKernelGGL(norm_act_kernel<8>, grid, dim3(256), 0, s, x, x_band, T, C, G, stats, gamma, beta, act, y32, y_band, hi, lo, (int64_t)ub.op_band, front, back,
-                           NORM_UPB, part);
+                           NORM_UPB, part, fin_part, fin_rec, fin_count);
 }
 
 // x [band][T][C] fp32 -> ResBlock(x) into `out` (may alias x): x + conv2(act(gn2(conv1(act(gn1(x))))))  (+ col_add); rw(b) = band b's weights
@@ -1920,6 +1971,7 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
     MG_TRY(wk.get(&ub.lo, ub.op_band * NB, true));
     MG_TRY(wk.get(&ub.dec_out, ub.op_band * NB, false));
     MG_TRY(wk.get(&ub.part, max_gn * 2 * NB, false));
+    MG_TRY(wk.get(&ub.part2, max_gn * 2 * NB, false));
     MG_TRY(wk.get(&ub.stats, (size_t)2 * G * NB, false));
     const int64_t WB = (int64_t)ub.widest, OB = (int64_t)ub.op_band;
     float *cur = nullptr, *est = nullptr, *total = nullptr, *d_lat = nullptr, *d_noise = nullptr, *d_ref = nullptr;
@@ -2022,7 +2074,7 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
             const PF emb = has_emb ? pf_of(NB, [&](int b) { return (const float*)(E(b).emb + (size_t)m->band[b].steps[ev] * Cout); }) : PF{};
             if (g.res_blocks == 0) return mv_fail(MV_ERR_INVALID, "res_blocks = 0 is not supported");
             // ResBlock r's input statistics: the partials its producer left -- this pass for the first one (round 6), ResBlock r - 1's conv2 after that
-            GnFuse chain{G, ub.part, 0};
+            GnFuse chain{G, ub.part2, 0};   // (its own records: this pass may still be finishing the strided convolution's in ub.part)
             launch_norm_act(s, ub, ub.a32, WB, To, Cout, G, ub.stats, pf_of(NB, [&](int b) { return (const float*)E(b).norm.g; }),
                             pf_of(NB, [&](int b) { return (const float*)E(b).norm.b; }), g.act, ub.c32, WB, nullptr, nullptr, 0, 0, &chain);
             for (int r = 0; r < g.res_blocks; ++r) {
