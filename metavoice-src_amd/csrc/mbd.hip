@@ -83,6 +83,12 @@ struct MbdGemmArgs {   // the band models run the same shapes: grid.z = band
     // the tensor it lands in -- the first `pad` steps of row 0 and whatever lies beyond the skip tensor's length are dropped here,
     // so `out` / `residual` may point `pad` steps in front of their buffers (round 6: z = up(x)[:, :, :T] + skip in the epilogue).
     int64_t valid_lo = 0, valid_hi = INT64_MAX;
+    // Round 6: the output ALSO as the bf16 hi / lo operand of the next convolution (element f of `out` -> element f + op_shift of the operand
+    // buffers: `pad` zero rows in front): the encoder's skip tensors fed a pass of their own that did nothing but this split.  Kernels with
+    // the C^T epilogue only (launch_gemm reports through OpOut::written).
+    bf16_t* op_hi = nullptr;
+    bf16_t* op_lo = nullptr;
+    int64_t op_band = 0, op_shift = 0;
 };
 
 // C = A W^T on BM x 128 x 128 tiles (BM = 128 or 64), 256 threads = 4 waves (2 x 2), each wave (BM / 2) x 64 = MI x 4 MFMA 16x16x32
@@ -255,6 +261,13 @@ __device__ __forceinline__ float4 epilogue_col_add(const MbdGemmArgs& a, int ban
     if (a.col_add.p[band]) { const float4 c = *(const float4*)(a.col_add.p[band] + n); add.x += c.x; add.y += c.y; add.z += c.z; add.w += c.w; }
     return add;
 }
+__device__ __forceinline__ void epilogue_operand4(const MbdGemmArgs& a, int band, int64_t f, const float4& y) {
+    if (!a.op_hi) return;
+    const uint32_t h0 = pack_bf2(y.x, y.y), h1 = pack_bf2(y.z, y.w);
+    const size_t o = (size_t)band * a.op_band + f + a.op_shift;
+    *(uint2*)(a.op_hi + o) = make_uint2(h0, h1);
+    if (a.op_lo) *(uint2*)(a.op_lo + o) = make_uint2(pack_bf2(y.x - bf_lo(h0), y.y - bf_hi(h0)), pack_bf2(y.z - bf_lo(h1), y.w - bf_hi(h1)));
+}
 __device__ __forceinline__ void epilogue_store4(const MbdGemmArgs& a, int band, int m, int n, const f32x4_t& acc, const float4& add, float& s, float& s2) {
     if (m >= a.M) return;
     const int64_t f = (int64_t)m * a.ldc + n;
@@ -265,6 +278,7 @@ __device__ __forceinline__ void epilogue_store4(const MbdGemmArgs& a, int band, 
         y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
     }
     *(float4*)(a.out + (size_t)band * a.out_band + f) = y;
+    epilogue_operand4(a, band, f, y);
     s += (y.x + y.y) + (y.z + y.w);
     s2 = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, fmaf(y.w, y.w, s2))));
 }
@@ -353,6 +367,7 @@ __global__ void __launch_bounds__(256, 2) mbd_gemm_thin_kernel(const MbdGemmArgs
             const float4 add = epilogue_col_add(a, band, n);
             const float4 y = make_float4(acc[j][0] + add.x + res[j].x, acc[j][1] + add.y + res[j].y, acc[j][2] + add.z + res[j].z, acc[j][3] + add.w + res[j].w);
             *(float4*)(a.out + (size_t)band * a.out_band + f) = y;
+            epilogue_operand4(a, band, f, y);
             gs[j] += (y.x + y.y) + (y.z + y.w);
             gs2[j] = fmaf(y.x, y.x, fmaf(y.y, y.y, fmaf(y.z, y.z, fmaf(y.w, y.w, gs2[j]))));
         }
@@ -1074,6 +1089,108 @@ __global__ void __launch_bounds__(256) convtr_out_kernel(const float* __restrict
     out[(size_t)blockIdx.y * out_band + tp] = acc;
 }
 
+// Round 6: the same transposed convolution for k = 8, s = 4, C <= 64, by input ROWS -- and with the decoder's last GroupNorm + activation
+// applied on the way in (stats != null), so that act(gn(x)) is never written to memory.  A block stages CTO_ROWS input rows (coalesced 16-byte
+// loads, normalised, into LDS rows of C + 4 floats: a thread reading its own row in 16-byte steps is conflict-free at that stride), thread r
+// forms the row's eight tap products p[r][j] = sum_c x[r][c] w[c][j] (weights: [C][8] in LDS, read at wave-uniform addresses), and output
+// sample t s + j - pad = p[t][j] + p[t - 1][j + s] is put together from LDS: every input byte is read once (conv_out_kernel: one thread per
+// output sample walking two rows from global memory, 0.33 of the HBM rate).  The first row of a block is the previous block's last (halo).
+constexpr int CTO_ROWS = 64;   // rows = threads per block: 17 KB of LDS at C = 48, nine one-wave blocks per CU in different phases (256 rows: two blocks
+                                // per CU marching in step, 40-43 us against the old kernel's 25 + a 24 us normalise pass)
+__global__ void __launch_bounds__(CTO_ROWS) convtr_out_rows_kernel(const float* __restrict__ x, int64_t x_band, int Tin, int C, const PF ws, int pad, float* __restrict__ out,
+                                                              int64_t out_band, int Tout, int G, const float* __restrict__ stats, const PF gammas, const PF betas, int act) {
+    constexpr int K = 8, S = 4;
+    extern __shared__ __attribute__((aligned(16))) float cto_lds[];   // x rows [CTO_ROWS][C + 4] | w [C][8] | p [CTO_ROWS][8]
+    const int band = blockIdx.y, ldx = C + 4, q4 = C >> 2;
+    float* xs = cto_lds;
+    float* wl = xs + CTO_ROWS * ldx;
+    float* pl = wl + C * K;
+    const int t0 = blockIdx.x * (CTO_ROWS - 1);   // primary rows t0 .. t0 + CTO_ROWS - 2; local row i <-> input row t0 - 1 + i
+    x += (size_t)band * x_band;
+    // the weights as two 16-byte loads per thread, requested together with the rows below (C * K / 4 <= 2 * CTO_ROWS; a scalar loop here was six
+    // dependent round trips per block: most of the 37-44 us the first versions took)
+    float4 wv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = threadIdx.x + CTO_ROWS * u;
+        wv[u] = i < C * K / 4 ? *(const float4*)(ws.p[band] + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float* gamma = gammas.p[band];
+    const float* beta = betas.p[band];
+    const int cg = C / G;
+    // Staging: thread -> (channel quad tid % q4, row tid / q4), rows advancing by rp = CTO_ROWS / q4 per step: the quad -- and with it gamma, beta
+    // and the group statistics -- is fixed per thread, so a step is four fused multiply-adds and the activation (a first version recomputed
+    // (row, quad) from a running index: two integer divisions per 16 bytes made the kernel VALU-bound at 40-44 us whatever the block shape).
+    // All <= 16 loads of a thread are in flight at once.
+    {
+        constexpr int NLD = 16;
+        const int c = (threadIdx.x % q4) * 4, r0 = threadIdx.x / q4, rp = CTO_ROWS / q4;
+        const bool active = r0 < rp;
+        float mean[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4] = {1.f, 1.f, 1.f, 1.f};
+        float4 gm = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (stats && active) {
+            gm = *(const float4*)(gamma + c); bt = *(const float4*)(beta + c);
+            const float* st = stats + (size_t)band * 2 * G;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const int g = (c + e) / cg; mean[e] = st[2 * g]; rstd[e] = st[2 * g + 1]; }
+        }
+        float4 v[NLD];
+        bool in[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int r = r0 + rp * u, t = t0 - 1 + r;
+            in[u] = active && r < CTO_ROWS && t >= 0 && t < Tin;
+            v[u] = in[u] ? *(const float4*)(x + (size_t)t * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int r = r0 + rp * u;
+            if (!active || r >= CTO_ROWS) continue;
+            if (in[u] && stats) {
+                // (the expression and rounding order of norm_act_kernel)
+                v[u].x = mb_act((v[u].x - mean[0]) * rstd[0] * gm.x + bt.x, act); v[u].y = mb_act((v[u].y - mean[1]) * rstd[1] * gm.y + bt.y, act);
+                v[u].z = mb_act((v[u].z - mean[2]) * rstd[2] * gm.z + bt.z, act); v[u].w = mb_act((v[u].w - mean[3]) * rstd[3] * gm.w + bt.w, act);
+            }
+            *(float4*)(xs + r * ldx + c) = v[u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = threadIdx.x + CTO_ROWS * u;
+        if (i < C * K / 4) *(float4*)(wl + 4 * i) = wv[u];
+    }
+    __syncthreads();
+    {
+        float p[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) p[j] = 0.f;
+        const float* xr = xs + threadIdx.x * ldx;
+        for (int c = 0; c < C; c += 4) {
+            const float4 xv = *(const float4*)(xr + c);
+            const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 wa = *(const float4*)(wl + (c + e) * K), wb = *(const float4*)(wl + (c + e) * K + 4);
+                p[0] = fmaf(xe[e], wa.x, p[0]); p[1] = fmaf(xe[e], wa.y, p[1]); p[2] = fmaf(xe[e], wa.z, p[2]); p[3] = fmaf(xe[e], wa.w, p[3]);
+                p[4] = fmaf(xe[e], wb.x, p[4]); p[5] = fmaf(xe[e], wb.y, p[5]); p[6] = fmaf(xe[e], wb.z, p[6]); p[7] = fmaf(xe[e], wb.w, p[7]);
+            }
+        }
+        *(float4*)(pl + threadIdx.x * K) = make_float4(p[0], p[1], p[2], p[3]);
+        *(float4*)(pl + threadIdx.x * K + 4) = make_float4(p[4], p[5], p[6], p[7]);
+    }
+    __syncthreads();
+    out += (size_t)band * out_band;
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+        const int o = q * CTO_ROWS + threadIdx.x;          // output o of the block: primary local row 1 + o / S, phase o % S
+        const int i = 1 + o / S, jj = o % S;
+        if (i >= CTO_ROWS) continue;
+        const int tp = (t0 - 1 + i) * S + jj - pad;   // sample index
+        if (tp < 0 || tp >= Tout) continue;
+        out[tp] = pl[i * K + jj] + pl[(i - 1) * K + jj + S];
+    }
+}
+
 // z[t][c] = skip[t][c] (+ add[t][c])                      (decoder: z = z[:, :, :skip.T] + skip; the first z is zero or the LSTM's)
 __global__ void add_kernel(const float* __restrict__ a, int64_t a_band, const float* __restrict__ b, int64_t b_band, float* __restrict__ out,
                            int64_t out_band, size_t n) {
@@ -1695,6 +1812,9 @@ struct UnetBuffers {
     std::vector<size_t> skip_band;
     float *a32 = nullptr, *b32 = nullptr, *c32 = nullptr;   // fp32 scratch [band][widest]
     bf16_t *hi = nullptr, *lo = nullptr;   // bf16 conv operand with zero margins [band][op_band]
+    // the strided convolution's operand of encoder level i >= 1, written by the epilogue that produces skip[i - 1]; zeroed once per call (only
+    // body rows are ever written: the margins stay zero)
+    std::vector<bf16_t*> hi_lvl, lo_lvl;
     double* part = nullptr;                // [band][part_band]
     double* part2 = nullptr;               // the records a normalise pass writes while it may still be finishing the ones in `part`
     float* stats = nullptr;                // [band][2 G]
@@ -1722,9 +1842,20 @@ struct GnFuse {
 };
 // MV_MBD_NO_GN_FUSE=1: the round-2 scheme -- gn_partial_kernel reads every tensor again (tests compare both ways in one process: read per call)
 inline bool gn_fuse_enabled() { return !getenv("MV_MBD_NO_GN_FUSE"); }
+// the GEMM's output wanted as the next convolution's operand too (MbdGemmArgs::op_hi): `written` comes back false when the kernel that ran has
+// no such epilogue (the caller then runs the split pass)
+struct OpOut {
+    bf16_t* hi = nullptr;
+    bf16_t* lo = nullptr;
+    int64_t band = 0, shift = 0;
+    bool written = false;
+};
 template <typename CW>
 hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, const bf16_t* a_hi, const bf16_t* a_lo, CW cw, int taps, int64_t tap_stride,
-                       int k_per_tap, GnFuse* gf = nullptr) {
+                       int k_per_tap, GnFuse* gf = nullptr, OpOut* op = nullptr) {
+    g.op_hi = g.op_lo = nullptr;
+    if (op) op->written = false;
+    auto arm_op = [&]() { if (op && op->hi) { g.op_hi = op->hi; g.op_lo = op->lo; g.op_band = op->band; g.op_shift = op->shift; op->written = true; } };
     const bool gn_fused = gn_fuse_enabled();
     const int gn_period = gf && gf->period ? gf->period : g.N;
     const bool gn_any = gf && gn_fused && gf->G > 0 && gf->G <= 8 && g.N % gn_period == 0 && gn_period % gf->G == 0 && (gn_period / gf->G) % 4 == 0;
@@ -1767,6 +1898,7 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
         }
         const int n_blocks = nt_m256 * nt_n256 * nb;
         if (gn_ok) arm_gn(nt_m256 * nt_n256);
+        arm_op();
         ++m->gemm_launches[0];
         hipLaunchKernelGGL(mbd_gemm_t256_kernel, dim3(n_blocks), dim3(512), T256_LDS_BYTES, s, g, nt_m256, nt_n256, n_blocks, t256_rows);
     } else if (k64 && prec == 3 && taps == 1 && g.N % 192 == 0 && g.N % 128 != 0 && !getenv("MV_MBD_NO_N192") &&
@@ -1774,10 +1906,12 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
         // 192-channel layers: 64 x 192 tiles, no padding columns (MV_MBD_N192_MIN_BLOCKS: tests lower the threshold for small shapes)
         const int nt192 = g.N / 192, mt64 = (g.M + 63) / 64;
         if (gn_ok) arm_gn(nt192 * mt64);
+        arm_op();
         ++m->gemm_launches[1];
         hipLaunchKernelGGL((mbd_gemm_glds3_kernel<64, 192>), dim3(nt192, mt64, nb), dim3(256), 0, s, g);
     } else if (k64 && prec == 3 && taps == 1 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400) {
         if (gn_ok) arm_gn(nt * ((g.M + 127) / 128));
+        arm_op();
         ++m->gemm_launches[2];
         hipLaunchKernelGGL((mbd_gemm_glds3_kernel<128, 128>), dim3(nt, (g.M + 127) / 128, nb), dim3(256), 0, s, g);
     }
@@ -1785,6 +1919,7 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
         // thin layers: the whole W in registers, A fragments straight from global memory (MV_MBD_NO_THIN=1: the 128-column tiles; tests, A/B)
         const dim3 grid((unsigned)((g.M + 255) / 256), nb);
         ++m->gemm_launches[3];
+        arm_op();
         if (gn_any) arm_gn((int)grid.x);   // one record per block; any group width (a lane's column has its own group)
         const int gm = !gn_any ? 0 : gf->G <= 4 ? 4 : 8;
 #define MBD_THIN(NTN) do { if (gm == 0) hipLaunchKernelGGL((mbd_gemm_thin_kernel<NTN, 0>), grid, dim3(256), 0, s, g); \
@@ -1855,6 +1990,14 @@ hipError_t stats_of_gemm_output(hipStream_t s, const GnFuse& gf, const float* x,
     return hipGetLastError();
 }
 
+// statistics left pending for a normalise pass (stats_of_gemm_output), wanted by something else: gn_final_kernel after all
+hipError_t finish_pending_stats(hipStream_t s, UnetBuffers& ub, int G) {
+    if (!ub.pending_part) return hipSuccess;
+    hipLaunchKernelGGL(gn_final_kernel, dim3(ub.NB), dim3(256), 0, s, ub.pending_part, ub.pending_rec, G, ub.pending_count, 1e-5f, ub.stats);
+    ub.pending_part = nullptr;
+    return hipGetLastError();
+}
+
 // out_gf (optional): also leave the GroupNorm partials of the OUTPUT y (tiles = 0 when the groups are not float4-aligned or the fusion is
 // switched off: the caller then runs the two-pass statistics on y32)
 void launch_norm_act(hipStream_t s, UnetBuffers& ub, const float* x, int64_t x_band, int T, int C, int G, const float* stats, PF gamma, PF beta, int act,
@@ -1887,7 +2030,7 @@ void launch_norm_act(hipStream_t s, UnetBuffers& ub, const float* x, int64_t x_b
 // two-pass statistics of that tensor -- one more read of 59 MB per ResBlock -- are gone)
 template <typename RW>
 hipError_t res_block(hipStream_t s, const mv_mbd* m, RW rw, const float* x, int64_t x_band, float* out, int64_t out_band, int T, int C, int dilation, PF col_add,
-                     UnetBuffers& ub, GnFuse* out_gf = nullptr, const GnFuse* in_gf = nullptr, bool in_stats_ready = false) {
+                     UnetBuffers& ub, GnFuse* out_gf = nullptr, const GnFuse* in_gf = nullptr, bool in_stats_ready = false, OpOut* out_op = nullptr) {
     const int G = m->cfg.norm_groups, act = m->cfg.act, nb = ub.NB;
     const int pad = dilation;  // kernel 3
     hipError_t e;
@@ -1909,8 +2052,9 @@ hipError_t res_block(hipStream_t s, const mv_mbd* m, RW rw, const float* x, int6
         auto cw = [&](int b) -> const ConvW& { return half == 0 ? rw(b).c1 : rw(b).c2; };
         // window of output row t: rows t - pad + j * dilation, j = 0..2; contiguous (one segment per term) when dilation == 1
         GnFuse* gf = half == 0 ? &mid : out_gf;
-        if (dilation == 1) e = launch_gemm(s, m, nb, g, ub.hi, ub.lo, cw, 1, 0, 3 * C, gf);
-        else e = launch_gemm(s, m, nb, g, ub.hi, ub.lo, cw, 3, (int64_t)dilation * C, C, gf);
+        OpOut* op = half == 1 ? out_op : nullptr;
+        if (dilation == 1) e = launch_gemm(s, m, nb, g, ub.hi, ub.lo, cw, 1, 0, 3 * C, gf, op);
+        else e = launch_gemm(s, m, nb, g, ub.hi, ub.lo, cw, 3, (int64_t)dilation * C, C, gf, op);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -1969,6 +2113,12 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
     MG_TRY(wk.get(&ub.c32, ub.widest * NB, false));
     MG_TRY(wk.get(&ub.hi, ub.op_band * NB, true));
     MG_TRY(wk.get(&ub.lo, ub.op_band * NB, true));
+    ub.hi_lvl.assign(D, nullptr); ub.lo_lvl.assign(D, nullptr);
+    if (gn_fuse_enabled())
+        for (int i = 1; i < D; ++i) {
+            MG_TRY(wk.get(&ub.hi_lvl[i], ub.op_band * NB, true));
+            if (g.precision > 2) MG_TRY(wk.get(&ub.lo_lvl[i], ub.op_band * NB, true));
+        }
     MG_TRY(wk.get(&ub.dec_out, ub.op_band * NB, false));
     MG_TRY(wk.get(&ub.part, max_gn * 2 * NB, false));
     MG_TRY(wk.get(&ub.part2, max_gn * 2 * NB, false));
@@ -2040,6 +2190,7 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
         const bool add_fuse = !getenv("MV_MBD_NO_ADD_FUSE");   // read per call: a test compares both ways in one process
         const bool skip_direct = add_fuse && !g.bilstm;         // z = 0: the first decoder ResBlock reads the innermost skip in place (no copy)
         GnFuse skip_gf{G, ub.part, 0};
+        OpOut next_op;   // the operand the current level's last epilogue writes for the next level's strided convolution
         const float* zin = cur;   // [band][Tin][Cin]
         int64_t zin_band = T;
         int Tin = T;
@@ -2063,11 +2214,13 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
             } else {
                 // operand: zin with `pad` zero rows in front and (Tpad - Tin) + k behind
                 const int back = ub.Tpad[i] - Tin + k;
-                launch_norm_act(s, ub, zin, zin_band, Tin, Cin, G, nullptr, PF{}, PF{}, 0, nullptr, 0, ub.hi, g.precision > 2 ? ub.lo : nullptr, pad, back);
+                const bool have_op = next_op.written;   // (the previous level's last epilogue wrote hi_lvl / lo_lvl[i])
+                if (!have_op) launch_norm_act(s, ub, zin, zin_band, Tin, Cin, G, nullptr, PF{}, PF{}, 0, nullptr, 0, ub.hi, g.precision > 2 ? ub.lo : nullptr, pad, back);
                 MbdGemmArgs ga;
                 ga.M = To; ga.N = Cout; ga.lda = (int64_t)st * Cin; ga.a_band = OB; ga.out = ub.a32; ga.ldc = Cout; ga.out_band = WB;
                 ga.bias = PF{}; ga.col_add = PF{};
-                MG_TRY(launch_gemm(s, m, NB, ga, ub.hi, ub.lo, [&](int b) -> const ConvW& { return E(b).conv; }, 1, 0, k * Cin, &enc_gf));
+                MG_TRY(launch_gemm(s, m, NB, ga, have_op ? ub.hi_lvl[i] : ub.hi, have_op ? ub.lo_lvl[i] : ub.lo, [&](int b) -> const ConvW& { return E(b).conv; }, 1, 0,
+                                   k * Cin, &enc_gf));
             }
             MG_TRY(stats_of_gemm_output(s, enc_gf, ub.a32, WB, To, Cout, G, ub));
             const bool has_emb = i == 0 || g.emb_all_layers;
@@ -2082,8 +2235,11 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
                 const GnFuse in_gf = chain;
                 // the innermost skip is the decoder's first ResBlock input when there is no BiLSTM: its statistics come from this epilogue too
                 GnFuse* out_gf = !lastr ? &chain : (i == D - 1 && skip_direct) ? &skip_gf : nullptr;
+                next_op = OpOut{};
+                if (lastr && i + 1 < D && ub.hi_lvl[i + 1]) next_op = OpOut{ub.hi_lvl[i + 1], ub.lo_lvl[i + 1], OB, (int64_t)pad * Cout, false};
                 MG_TRY(res_block(s, m, [&](int b) -> const ResW& { return E(b).res[r]; }, ub.c32, WB, lastr ? ub.skip[i] : ub.c32,
-                                 lastr ? (int64_t)ub.skip_band[i] : WB, To, Cout, 1 << r, lastr ? emb : PF{}, ub, out_gf, in_gf.tiles > 0 ? &in_gf : nullptr));
+                                 lastr ? (int64_t)ub.skip_band[i] : WB, To, Cout, 1 << r, lastr ? emb : PF{}, ub, out_gf, in_gf.tiles > 0 ? &in_gf : nullptr, false,
+                                 lastr ? &next_op : nullptr));
             }
             zin = ub.skip[i];
             zin_band = (int64_t)ub.skip_band[i];
@@ -2160,9 +2316,16 @@ static int mbd_generate_impl(mv_mbd* m, const float* latent, int32_t frames, con
             MG_TRY(stats_of_gemm_output(s, dec_gf, ub.c32, WB, Ts, C, G, ub));
             const PF ng = pf_of(NB, [&](int b) { return (const float*)Dw(b).norm.g; }), nbias = pf_of(NB, [&](int b) { return (const float*)Dw(b).norm.b; });
             if (lvl == 0) {
-                launch_norm_act(s, ub, ub.c32, WB, Ts, C, G, ub.stats, ng, nbias, g.act, ub.a32, WB, nullptr, nullptr, 0, 0);
-                hipLaunchKernelGGL(convtr_out_kernel, dim3((T + 255) / 256, NB), dim3(256), (size_t)k * C * 4, s, ub.a32, WB, Ts, C,
-                                   pf_of(NB, [&](int b) { return (const float*)Dw(b).convtr_out_w; }), k, st, pad, est, est_band, T);
+                const PF w_out = pf_of(NB, [&](int b) { return (const float*)Dw(b).convtr_out_w; });
+                if (k == 8 && st == 4 && C <= 56 && gn_fuse_enabled()) {   // by rows, the decoder norm + activation applied on the way in: no act(gn(x)) tensor
+                    MG_TRY(finish_pending_stats(s, ub, G));
+                    const size_t lds = ((size_t)CTO_ROWS * (C + 4) + (size_t)C * k + (size_t)CTO_ROWS * k) * 4;
+                    hipLaunchKernelGGL(convtr_out_rows_kernel, dim3((unsigned)((Ts + 1 + CTO_ROWS - 2) / (CTO_ROWS - 1)), NB), dim3(CTO_ROWS), lds, s, ub.c32, WB, Ts, C, w_out, pad,
+                                       est, est_band, T, G, ub.stats, ng, nbias, g.act);
+                } else {
+                    launch_norm_act(s, ub, ub.c32, WB, Ts, C, G, ub.stats, ng, nbias, g.act, ub.a32, WB, nullptr, nullptr, 0, 0);
+                    hipLaunchKernelGGL(convtr_out_kernel, dim3((T + 255) / 256, NB), dim3(256), (size_t)k * C * 4, s, ub.a32, WB, Ts, C, w_out, k, st, pad, est, est_band, T);
+                }
             } else {
                 // operand rows: [zero row | z rows 0..Ts-1 | zero row]; GEMM row q = (x[q-1], x[q]), q = 0..Ts
                 launch_norm_act(s, ub, ub.c32, WB, Ts, C, G, ub.stats, ng, nbias, g.act, nullptr, 0, ub.hi, g.precision > 2 ? ub.lo : nullptr, 1, 1);
