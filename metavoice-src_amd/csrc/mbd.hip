@@ -292,9 +292,12 @@ __device__ __forceinline__ void epilogue_store4(const MbdGemmArgs& a, int band, 
 // steps of 32 with the tail zeroed on the A side (144 = 4 x 32 + 16).  Bound by its bytes: A hi | lo, the residual and the fp32 output.
 // GM > 0 (round 6): the GroupNorm partials of the output from the epilogue, one record per block (a.gn_part[band][block][G][2]); a lane's
 // column j * 16 + col has its own group (groups of 12 channels at 48 / 4: not aligned to the 16-column fragments).
-template <int NTN, int GM>
-__global__ void __launch_bounds__(256, 2) mbd_gemm_thin_kernel(const MbdGemmArgs a) {
-    constexpr int KS = 5, MT = 4;   // K-steps of 32 (K <= 160); 16-row tiles per wave and loop trip
+// MT: 16-row tiles per wave (4, or -- round 6 -- 10: a wave fetches the band's whole W, 27.6 KB at 48 channels, for MT x 9 KB of activations it
+// reads and writes; at 4 tiles the weights were as many bytes as the data (132 MB of L2 reads per launch), and 1200 blocks were 2.3 rounds of the
+// 512 that are resident: launch_gemm picks the MT with fewer rounds x (MT + 1))
+template <int NTN, int GM, int MT>
+__global__ void __launch_bounds__(256, NTN <= 3 ? 2 : 1) mbd_gemm_thin_kernel(const MbdGemmArgs a) {
+    constexpr int KS = 5;   // K-steps of 32 (K <= 160)
     __shared__ double gn_red[4][GM ? GM : 1][2];
     float gs[NTN], gs2[NTN];
 #pragma unroll
@@ -888,9 +891,9 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__
     __shared__ double fin_red[256];
     __shared__ float st[16];   // (mean, rstd) of the G <= 8 groups of this band
     const int band = blockIdx.y;
-    // The statistics of x: finished by gn_final_kernel (stats), or -- fin_part: the producer left few records (the 57-60 tiles per band of a
-    // 256 x 256-tile GEMM) -- finished HERE by every block in the same fixed order (3.8 KB of L2 reads and ~1 us per block, all blocks of a CU at
-    // once) instead of a 4.8 us launch and two kernel boundaries in front of this pass (11 of the 24 normalisations of an evaluation).
+    // The statistics of x: finished by gn_final_kernel (stats), or -- fin_part: the producer's records, up to GN_DEFER_MAX_RECORDS of them --
+    // finished HERE by every block in the same fixed order (4-32 KB of L2 reads and 1-2 us per block, all blocks of a CU at once) instead of a
+    // 4.8 us launch and two kernel boundaries in front of this pass (23 of the 24 normalisations of an evaluation at the benched shape).
     if (fin_part) gn_finalize(fin_part + (size_t)band * fin_rec * G * 2, fin_rec, G, fin_count, 1e-5f, st, fin_red);
     else if (stats && (int)threadIdx.x < 2 * G) st[threadIdx.x] = stats[(size_t)band * 2 * G + threadIdx.x];
     __syncthreads();
@@ -904,17 +907,24 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__
     const float* gamma = gammas.p[band];
     const float* beta = betas.p[band];
     const int cg = C / G;
+    // channel of a unit's first element: (8 u) mod C (the margins are whole rows) -- one integer modulo per thread, then a running sum: the
+    // thread's units are 256 apart (with this and the group look-ups as divisions, index arithmetic was half of the kernel's instructions)
+    const int d256 = 2048 % C;
+    int ch_run = (int)((8ull * (u0 + threadIdx.x)) % (uint32_t)C);
     const uint32_t body0 = (uint32_t)front * C, body1 = body0 + (uint32_t)T * C;
     float s[GM ? GM : 1], s2[GM ? GM : 1];
 #pragma unroll
     for (int g = 0; g < (GM ? GM : 1); ++g) s[g] = s2[g] = 0.f;
     for (uint32_t ub = u0 + threadIdx.x; ub < u1; ub += 512) {
         uint32_t e[2];
+        int chq[2];
         bool live[2], body[2];
         float4 xv[2][2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const uint32_t u = ub + 256 * q;
+            chq[q] = ch_run;
+            ch_run += d256; ch_run -= ch_run >= C ? C : 0;
             live[q] = u < u1;
             e[q] = u * 8;   // element index inside the operand buffer
             body[q] = live[q] && e[q] >= body0 && e[q] < body1;
@@ -932,7 +942,7 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__
                 continue;
             }
             const uint32_t j = e[q] - body0;   // element index inside x
-            const int ch = (int)(j % (uint32_t)C);
+            const int ch = chq[q];
             float v[8] = {xv[q][0].x, xv[q][0].y, xv[q][0].z, xv[q][0].w, xv[q][1].x, xv[q][1].y, xv[q][1].z, xv[q][1].w};
             if (normed) {
 #pragma unroll
@@ -940,7 +950,7 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__
                     const float4 gm = *(const float4*)(gamma + ch + 4 * h), bt = *(const float4*)(beta + ch + 4 * h);
                     const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
                     if ((cg & 3) == 0) {  // the four channels share a group
-                        const int g = (ch + 4 * h) / cg;
+                        const int g = gn_group_of<8>(ch + 4 * h, cg);
                         const float mean = st[2 * g], rstd = st[2 * g + 1];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[4 * h + r] = mb_act((v[4 * h + r] - mean) * rstd * gmv[r] + btv[r], act);
@@ -1917,14 +1927,17 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
     }
     else if (prec == 3 && taps == 1 && g.N <= 64 && g.N % 16 == 0 && g.seg[0].K <= 160 && g.seg[0].K % 8 == 0 && !getenv("MV_MBD_NO_THIN")) {
         // thin layers: the whole W in registers, A fragments straight from global memory (MV_MBD_NO_THIN=1: the 128-column tiles; tests, A/B)
-        const dim3 grid((unsigned)((g.M + 255) / 256), nb);
+        auto thin_cost = [&](int mt) { const size_t blocks = (size_t)((g.M + 64 * mt - 1) / (64 * mt)) * nb; return (blocks + 511) / 512 * (size_t)(mt + 1); };
+        const int mt = getenv("MV_MBD_THIN_MT") ? atoi(getenv("MV_MBD_THIN_MT")) : thin_cost(10) < thin_cost(4) ? 10 : 4;
+        const dim3 grid((unsigned)((g.M + 64 * mt - 1) / (64 * mt)), nb);
         ++m->gemm_launches[3];
         arm_op();
         if (gn_any) arm_gn((int)grid.x);   // one record per block; any group width (a lane's column has its own group)
         const int gm = !gn_any ? 0 : gf->G <= 4 ? 4 : 8;
-#define MBD_THIN(NTN) do { if (gm == 0) hipLaunchKernelGGL((mbd_gemm_thin_kernel<NTN, 0>), grid, dim3(256), 0, s, g); \
-                           else if (gm == 4) hipLaunchKernelGGL((mbd_gemm_thin_kernel<NTN, 4>), grid, dim3(256), 0, s, g); \
-                           else hipLaunchKernelGGL((mbd_gemm_thin_kernel<NTN, 8>), grid, dim3(256), 0, s, g); } while (0)
+#define MBD_THIN_MT(NTN, MT) do { if (gm == 0) hipLaunchKernelGGL((mbd_gemm_thin_kernel<NTN, 0, MT>), grid, dim3(256), 0, s, g); \
+                                  else if (gm == 4) hipLaunchKernelGGL((mbd_gemm_thin_kernel<NTN, 4, MT>), grid, dim3(256), 0, s, g); \
+                                  else hipLaunchKernelGGL((mbd_gemm_thin_kernel<NTN, 8, MT>), grid, dim3(256), 0, s, g); } while (0)
+#define MBD_THIN(NTN) do { if (mt == 10) MBD_THIN_MT(NTN, 10); else MBD_THIN_MT(NTN, 4); } while (0)
         switch (g.N / 16) {
             case 1: MBD_THIN(1); break;
             case 2: MBD_THIN(2); break;
@@ -1932,6 +1945,7 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
             default: MBD_THIN(4); break;
         }
 #undef MBD_THIN
+#undef MBD_THIN_MT
     }
     else if (k64 && (size_t)nt * ((g.M + 127) / 128) * nb >= 400) {
         ++m->gemm_launches[4];
@@ -1949,7 +1963,10 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
 // 8-element units per block of norm_act_kernel (8 K elements: two trips of 256 threads x 2 units).  256 / 512 / 1024 / 2048 measured within
 // noise of each other on the whole stage (profiles/r06v/ab.txt); 1024 keeps the records of a pass with statistics at 450 per band
 constexpr int NORM_UPB = 1024;
-constexpr int GN_DEFER_MAX_RECORDS = 64;   // (a record is 2 G doubles: 4 KB per block at G = 4)
+// records up to which the consuming normalise pass finishes the statistics itself (a record is 2 G doubles: 32 KB of L2 reads per block at
+// G = 4).  64 (the 256 x 256-tile GEMMs only) and 512 (every producer of the bench: 300 tiles of the 64 x 192 and thin GEMMs, 450 blocks of a
+// normalise pass) measured 116.7 and 116.4 ms for the stage (profiles/r06z8): the pass gets 1.7 us longer, a 4.8 us launch goes away
+constexpr int GN_DEFER_MAX_RECORDS = 512;
 size_t gn_blocks(int T, int C, int G) {   // partial records x G of a [T][C] tensor: the two-pass kernels, or the tiles of a GEMM epilogue
     const int rows_per = std::max(1, (int)((size_t)16384 * G / C));
     const size_t two_pass = (size_t)((T + rows_per - 1) / rows_per), tiles = (size_t)((T + 127) / 128) * ((C + BN - 1) / BN),

@@ -131,6 +131,12 @@ def test_thin_and_192_column_gemm_tiles(kw, T, monkeypatch):
     eng = mbd.MultiBandDiffusionBands.from_package(pkg, precision=3, eq_bands=1)
     monkeypatch.setenv("MV_MBD_N192_MIN_BLOCKS", "1")
     new = eng.unet_forward(1, x, 250, lat)
+    # ten 16-row tiles per wave instead of four (what launch_gemm picks at the bench's 76 800 rows): the same tiles, the same bits -- only the
+    # GroupNorm records are cut differently
+    monkeypatch.setenv("MV_MBD_THIN_MT", "10")
+    mt10 = eng.unet_forward(1, x, 250, lat)
+    monkeypatch.delenv("MV_MBD_THIN_MT")
+    assert snr_db(mt10, new) >= 100.0
     monkeypatch.setenv("MV_MBD_NO_THIN", "1")
     monkeypatch.setenv("MV_MBD_NO_N192", "1")
     old = eng.unet_forward(1, x, 250, lat)
