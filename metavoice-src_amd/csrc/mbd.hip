@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256, 3) mbd_gemm_kernel(const MbdGemmArgs a) {
 
 // (mean, rstd) of the G groups of one band from its n_rec partial records [n_rec][G][2] (one 256-thread block; red: 256 doubles of LDS):
 // thread t sums entry q = t % (2 G) of records t / (2 G), t / (2 G) + 256 / (2 G), ...; the 256 / (2 G) per-q partials are then added in
-// index order -- a fixed order.  Round 6: four records of a thread are in flight at once (added in the old order: same bits); with one load
+// index order -- a fixed order.  Round 6: eight records of a thread are in flight at once (added in the old order: same bits); with one load
 // per trip the 450 records of a normalise pass cost 14 dependent L2 round trips, most of this kernel's 5.8 us (480 launches per utterance).
 // Measured and dropped in round 6 (profiles/r06x): finishing the statistics inside the PRODUCING kernel -- records as write-through stores, a
 // ticket counter per band, the last block to arrive reduces -- is bit-identical and removes this launch, but the 240-3600 same-address
@@ -201,10 +201,12 @@ __device__ __forceinline__ void gn_finalize(const double* __restrict__ part, int
     double a = 0.0;
     if (j < lanes) {
         int c = j;
-        for (; c + 3 * lanes < n_rec; c += 4 * lanes) {
-            const double v0 = part[(size_t)c * nq + q], v1 = part[(size_t)(c + lanes) * nq + q], v2 = part[(size_t)(c + 2 * lanes) * nq + q],
-                         v3 = part[(size_t)(c + 3 * lanes) * nq + q];
-            a += v0; a += v1; a += v2; a += v3;
+        for (; c + 7 * lanes < n_rec; c += 8 * lanes) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(c + u * lanes) * nq + q];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
         }
         for (; c < n_rec; c += lanes) a += part[(size_t)c * nq + q];
     }
@@ -1960,8 +1962,9 @@ hipError_t launch_gemm(hipStream_t s, const mv_mbd* m, int nb, MbdGemmArgs& g, c
     return hipGetLastError();
 }
 
-// 8-element units per block of norm_act_kernel (8 K elements: two trips of 256 threads x 2 units).  256 / 512 / 1024 / 2048 measured within
-// noise of each other on the whole stage (profiles/r06v/ab.txt); 1024 keeps the records of a pass with statistics at 450 per band
+// 8-element units per block of norm_act_kernel (8 K elements: two trips of 256 threads x 2 units).  Per launch under rocprofv3 on one box
+// (profiles/r06z8/norm_upb_sweep.txt): 256: 28.7 us, 512: 26.0, 1024: 27.0, 2048: 28.5, 4096: 35.7; 1024 keeps the records of a pass with
+// statistics at 450 per band, under GN_DEFER_MAX_RECORDS (at 512 units a gn_final_kernel launch comes back: the stage 120.4 against 119.8 ms)
 constexpr int NORM_UPB = 1024;
 // records up to which the consuming normalise pass finishes the statistics itself (a record is 2 G doubles: 32 KB of L2 reads per block at
 // G = 4).  64 (the 256 x 256-tile GEMMs only) and 512 (every producer of the bench: 300 tiles of the 64 x 192 and thin GEMMs, 450 blocks of a
