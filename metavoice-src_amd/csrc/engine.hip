@@ -723,14 +723,16 @@ int mv_finalize(mv_engine* e) {
                 for (int l = 0; l < c.n_layer; ++l) {
                     const LayerW& w = e->layers[l];
                     const bf16_t* src[5] = {w.wqkv, w.wo, w.w1, w.w3, w.w2};
+                    // the RMSNorm weight in front of wqkv / w1 / w3 is folded into their tiled copies (decode_mfma.hip: MF_FOLD_NORM)
+                    const bf16_t* fold[5] = {w.attn_norm, nullptr, w.ffn_norm, w.ffn_norm, nullptr};
                     for (int m = 0; m < 5; ++m) {
-                        HIP_TRY(launch_tile_weights(e->stream, src[m], e->tiled + toff, (int)tshape[m][0], (int)tshape[m][1], tile_rows[m]));
+                        HIP_TRY(launch_tile_weights(e->stream, src[m], e->tiled + toff, (int)tshape[m][0], (int)tshape[m][1], tile_rows[m], fold[m]));
                         tptr[l][m] = e->tiled + toff;
                         toff += mfma_tiled_elems((int)tshape[m][1], tile_rows[m]);
                     }
                 }
                 e->head_t = e->tiled + toff;
-                HIP_TRY(launch_tile_weights(e->stream, e->head, e->head_t, c.vocab, c.dim, 11));
+                HIP_TRY(launch_tile_weights(e->stream, e->head, e->head_t, c.vocab, c.dim, 11, e->final_norm));
                 HIP_TRY(hipStreamSynchronize(e->stream));
                 e->mfma_ok = true;
             }

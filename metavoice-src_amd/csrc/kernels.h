@@ -305,7 +305,7 @@ struct MegaArgs {
 bool mfma_decode_supported(int weight_format, int n_utt);
 bool mfma_decode_fits(int n_utt, int n_cus);                       // occupancy query, like mega_fits
 size_t mfma_tiled_elems(int K, int rows_per_wg);                   // elements of a tiled matrix copy (256 workgroups x rows x K)
-hipError_t launch_tile_weights(hipStream_t s, const bf16_t* src, bf16_t* dst, int N, int K, int rows_per_wg);
+hipError_t launch_tile_weights(hipStream_t s, const bf16_t* src, bf16_t* dst, int N, int K, int rows_per_wg, const bf16_t* col_scale = nullptr);
 void mfma_handoff_rows(int n_utt, size_t* offset_bytes, size_t* bytes);   // the tag-free hand-off rows inside the granule slab: 0xFF-filled by mv_begin
 hipError_t launch_decode_mfma(hipStream_t s, const MegaArgs& a);   // one decode step (logits only; sample_kernel follows)
 bool mega_supported(const mv_config& c, int rows, int n_cus);

@@ -366,7 +366,8 @@ def test_persistent_kernel_with_several_utterances_is_bit_identical_to_launches(
 ])
 def test_matrix_core_persistent_kernel_for_four_utterances(n_layer, lens, n_new, combo):
     """decode_mfma.hip: the persistent step of 4-utterance engines on v_mfma_f32_16x16x32_bf16 (tiled weight copy, K split over the 8 waves
-    of a workgroup, packed half tiles).  Same rounding points as the launches, another ORDER of the fp32 additions inside every projection:
+    of a workgroup, packed half tiles).  Another ORDER of the fp32 additions inside every projection and (round 6) the RMSNorm weights folded
+    into the tiled matrices (one more bf16 rounding of a weight, two fewer of every normalised activation):
     not bit-identical, so (i) every position of every utterance TEACHER-FORCED through both paths (`prefill_mode=0`: the prompt goes through
     the decode kernels token by token) must give logits within 0.1 sigma of each other (engine vs oracle in this file: 0.06 sigma at 2 layers), (ii) the
     free-running streams agree with the launches' wherever the launches' own top-2 gap of the CFG mix exceeds that noise, and (iii) the
@@ -424,7 +425,11 @@ def test_matrix_core_persistent_kernel_for_four_utterances(n_layer, lens, n_new,
             assert float(top2[0] - top2[1]) <= 0.25, f"utterance {u} forks at {fork} although the launches' top-2 gap is {float(top2[0] - top2[1]):.3f}"
     print(f"[mfma x 4, {n_layer} layers, prompts {lens}] teacher-forced max |dlogit| / sigma {worst:.4f}; free-running agreement with the launches {agree} of {n_new}")
     if "top_k" in combo:
-        assert min(agree) >= 2   # greedy: a fork is margin-gated above; sampled streams (top-p) may fork at the first near-tie of the race
+        # greedy: a fork is margin-gated above (the launches' top-2 gap at the fork is inside the noise); sampled streams (top-p) may fork at the
+        # first near-tie of the race.  (Until round 6 this also asked for two common tokens; with the norm weight folded into the tiled matrices
+        # -- decode_mfma.hip MF_FOLD_NORM: other rounding points, not only another order -- one of these random-weight streams meets its first
+        # near-tie one token earlier.  The 24-layer reference goldens are the criterion: tests/test_fullsize_mfma_golden_gpu.py.)
+        assert min(agree) >= 1
     engine.close()
 
 
