@@ -41,6 +41,8 @@ def oracle_bands(pkg, **ucfg):
     (dict(hidden=8, depth=4, growth=2.0, codec_dim=16, emb_all_layers=False, activation="gelu"), 5000, 16),
     (dict(hidden=16, depth=2, growth=2.0, codec_dim=16, res_blocks=2), 1600, 5),  # second ResBlock: dilation 2
     (dict(hidden=64, depth=2, growth=4.0, codec_dim=None), 205003, 0),         # >= 400 GEMM tiles with K % 64 == 0: the direct-to-LDS GEMM
+    (dict(hidden=32, depth=3, growth=2.0, codec_dim=16, norm_groups=8), 6001, 7),   # 8 groups (4 / 8 / 16 channels wide): the GM = 8 instances of every kernel that sums
+    (dict(hidden=48, depth=2, growth=4.0, codec_dim=None, norm_groups=2), 30001, 0),  # 2 groups of 24 / 96 channels on the thin kernel and the 64 x 192 tiles
 ])
 def test_unet_forward_matches_oracle(kw, T, frames):
     pkg = synthetic.mbd_package(seed=3, n_bands=1, proc_bands=1, **kw)
