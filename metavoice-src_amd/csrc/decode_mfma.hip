@@ -53,6 +53,10 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #ifndef MF_FOLD_NORM
 #define MF_FOLD_NORM 1
 #endif
+// which instance this translation unit holds (4: decode_mfma.hip, with the host-side helpers; 8: decode_mfma8.hip -- see the end of the file)
+#ifndef MF_INSTANCE
+#define MF_INSTANCE 4
+#endif
 // operand row stride in LDS (elements).  4 utterances: 8 rows of a whole 5632-column activation vector (11 280 B = 2820 words = 4 banks
 // mod 32); 8 utterances: 16 rows of HALF of it (the w2 phase runs in two passes over the column halves: 16 whole rows would be 180 KB)
 __host__ __device__ constexpr int mf_kp(int nu) { return (nu <= 4 ? MG_INTER : MG_INTER / 2) + 8; }
@@ -65,6 +69,7 @@ __host__ __device__ constexpr int mf_kp(int nu) { return (nu <= 4 ? MG_INTER : M
 #define MF_R_W2 8
 #define MF_R_HEAD 11
 
+#if MF_INSTANCE == 4
 // ---- tiled weight copy ---------------------------------------------------------------------------------------------------------------
 // dst[((b * (K / 32) + s) * rows + r) * 32 + c] = src[min(b * rows + r, N - 1)][32 s + c]   (b < 256 workgroups, r < rows per workgroup)
 // col_scale (MF_FOLD_NORM): the norm weight g[k] of the RMSNorm in front of this matrix, multiplied into column k (fp32 product, one bf16 rounding)
@@ -94,6 +99,7 @@ hipError_t launch_tile_weights(hipStream_t s, const bf16_t* src, bf16_t* dst, in
     return hipGetLastError();
 }
 size_t mfma_tiled_elems(int K, int rows_per_wg) { return (size_t)256 * rows_per_wg * K; }
+#endif
 
 namespace {
 
@@ -809,6 +815,11 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
     }
 }
 
+// The two instances are compiled as two translation units (round 6): decode_mfma.hip = the 4-utterance instance, decode_mfma8.hip (`#define
+// MF_INSTANCE 8` + this file) = the 8-utterance one under `-mllvm -amdgpu-sched-strategy=max-memory-clause` -- hipcc's other scheduling strategy
+// is 1.5 % faster for the 16-row instance (1518 / 1505 -> 1496 / 1481 us per step, A B A B) and 1-2 % slower for the 8-row one (1045-1060 -> 1066;
+// profiles/r06flags2/ab.txt; same instructions in another order: same bits).
+#if MF_INSTANCE == 4
 // the tag-free rows X | ATT | H | ACT inside the engine's hand-off slab (behind the q/k/v granules): mv_begin fills them with the sentinel
 void mfma_handoff_rows(int n_utt, size_t* offset_bytes, size_t* bytes) {
     *offset_bytes = (size_t)n_utt * 3 * MG_DIM * sizeof(gran_t);
@@ -816,6 +827,7 @@ void mfma_handoff_rows(int n_utt, size_t* offset_bytes, size_t* bytes) {
 }
 
 bool mfma_decode_supported(int weight_format, int n_utt) { return weight_format == MV_W_BF16 && (n_utt == 4 || n_utt == 8); }
+#endif
 
 template <int NU>
 static bool mfma_instance_fits(int n_cus) {
@@ -825,7 +837,12 @@ static bool mfma_instance_fits(int n_cus) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)decode_mfma_kernel<NU>, MG_THREADS, lds) != hipSuccess) return false;
     return per_cu >= 1 && (long)per_cu * n_cus >= 256;
 }
-bool mfma_decode_fits(int n_utt, int n_cus) { return n_utt == 4 ? mfma_instance_fits<4>(n_cus) : n_utt == 8 ? mfma_instance_fits<8>(n_cus) : false; }
+#if MF_INSTANCE == 8
+bool mfma_decode_fits8(int n_cus) { return mfma_instance_fits<8>(n_cus); }
+#else
+bool mfma_decode_fits8(int n_cus);
+bool mfma_decode_fits(int n_utt, int n_cus) { return n_utt == 4 ? mfma_instance_fits<4>(n_cus) : n_utt == 8 ? mfma_decode_fits8(n_cus) : false; }
+#endif
 
 template <int NU>
 static hipError_t launch_mfma_instance(hipStream_t s, const MegaArgs& a) {
@@ -842,7 +859,12 @@ static hipError_t launch_mfma_instance(hipStream_t s, const MegaArgs& a) {
     hipLaunchKernelGGL((decode_mfma_kernel<NU>), dim3(256), dim3(MG_THREADS), lds, s, a);
     return hipGetLastError();
 }
+#if MF_INSTANCE == 8
+hipError_t launch_decode_mfma8(hipStream_t s, const MegaArgs& a) { return launch_mfma_instance<8>(s, a); }
+#else
+hipError_t launch_decode_mfma8(hipStream_t s, const MegaArgs& a);
 hipError_t launch_decode_mfma(hipStream_t s, const MegaArgs& a) {
     if (a.head_t == nullptr) return hipErrorInvalidValue;
-    return a.n_utt == 4 ? launch_mfma_instance<4>(s, a) : a.n_utt == 8 ? launch_mfma_instance<8>(s, a) : hipErrorInvalidValue;
+    return a.n_utt == 4 ? launch_mfma_instance<4>(s, a) : a.n_utt == 8 ? launch_decode_mfma8(s, a) : hipErrorInvalidValue;
 }
+#endif

@@ -14,11 +14,11 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 CSRC = os.path.join(ROOT, "metavoice-src_amd", "csrc")
 
 
-def compile_to_asm(source: str, tmp_path):
+def compile_to_asm(source: str, tmp_path, extra_flags=()):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
     out = tmp_path / (source + ".s")
-    p = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+    p = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), *extra_flags,
                         "-S", "--cuda-device-only", source + ".hip", "-o", str(out), "-Rpass-analysis=kernel-resource-usage"],
                        cwd=CSRC, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -87,16 +87,19 @@ def test_matrix_core_decode_kernel_keeps_its_fragments_in_registers(tmp_path):
     load, behind a full `s_waitcnt vmcnt(0)` -- until the register arrays were scoped per layer, the half tiles packed and the norm weights moved
     to LDS.  Guard: both instances exist, run on v_mfma_f32_16x16x32_bf16, stay under a spill bound, and no streaming load is followed
     directly by a full wait (the signature of a fragment spilled on arrival)."""
-    asm, usage = compile_to_asm("decode_mfma", tmp_path)
+    # two translation units since round 6 (the Makefile's flags): the 4-utterance instance, and the 8-utterance one under hipcc's other scheduling strategy
     seen = {}
-    for name, body in kernel_bodies(asm, "decode_mfma_kernel"):
-        nu = re.search(r"ILi(\d)E", name).group(1)
-        seen[nu] = usage[name]
-        assert body.count("v_mfma_f32_16x16x32_bf16") >= 60, name
-        assert usage[name]["spill"] <= (64 if nu == "4" else 128), f"{name}: {usage[name]}"
-        assert not re.search(r"global_load_dwordx4 [^\n]* nt\n(?:\s*[sv]_[^\n]*\n){0,3}?\s*s_waitcnt vmcnt\(0\)\n\s*scratch_store", body), \
-            f"{name}: a fragment is spilled right behind its load (r05: the 8-utterance instance did that to 6 of its 11 w2 fragments with 12-request act polls)"
-        assert "flat_load_dwordx4" not in body, name
+    for source, flags in (("decode_mfma", ()), ("decode_mfma8", ("-mllvm", "-amdgpu-sched-strategy=max-memory-clause"))):
+        asm, usage = compile_to_asm(source, tmp_path, flags)
+        for name, body in kernel_bodies(asm, "decode_mfma_kernel"):
+            nu = re.search(r"ILi(\d)E", name).group(1)
+            assert nu not in seen, f"{name} in two translation units"
+            seen[nu] = usage[name]
+            assert body.count("v_mfma_f32_16x16x32_bf16") >= 60, name
+            assert usage[name]["spill"] <= (64 if nu == "4" else 128), f"{name}: {usage[name]}"
+            assert not re.search(r"global_load_dwordx4 [^\n]* nt\n(?:\s*[sv]_[^\n]*\n){0,3}?\s*s_waitcnt vmcnt\(0\)\n\s*scratch_store", body), \
+                f"{name}: a fragment is spilled right behind its load (r05: the 8-utterance instance did that to 6 of its 11 w2 fragments with 12-request act polls)"
+            assert "flat_load_dwordx4" not in body, name
     assert set(seen) == {"4", "8"}, seen
 
 

@@ -11,6 +11,7 @@ one() {  # name, extra flags, source
   echo "$1 $(grep -v "^\s*;\|^\s*\.file\|^\s*\.loc\|\.ident\|^\s*\.section\s*\.debug\|__hip_cuid" "$t/$1.s" | sed 's/;.*$//' | md5sum | cut -d' ' -f1)"
 }
 for f in attention decode_mega decode_mfma engine lstm; do one $f "" $f & done
+one decode_mfma8 "-mllvm -amdgpu-sched-strategy=max-memory-clause" decode_mfma8 &
 one decode_mega_instr "-DMEGA_INSTR=1" decode_mega &
 wait
 rm -rf "$t"
