@@ -2027,12 +2027,13 @@ void launch_norm_act(hipStream_t s, UnetBuffers& ub, const float* x, int64_t x_b
     const bool fuse = out_gf && gn_fuse_enabled() && ((C / G) & 3) == 0 && G <= 8 && front == 0 && back == 0;
     if (out_gf) out_gf->tiles = fuse ? (int)grid.x : 0;
     double* part = fuse ? out_gf->part : nullptr;
-    // the statistics of x: `stats`, or the records stats_of_gemm_output left pending (consumed here)
+    // the statistics of x: `stats`, or the records stats_of_gemm_output left pending (consumed here).  A pass that writes its own records into
+    // the buffer the pending ones live in cannot finish them itself (early blocks would overwrite what late ones still read): gn_final_kernel then
+    if (stats && ub.pending_part && part == ub.pending_part) (void)finish_pending_stats(s, ub, G);
     const double* fin_part = stats ? ub.pending_part : nullptr;
     const int fin_rec = fin_part ? ub.pending_rec : 0;
     const double fin_count = fin_part ? ub.pending_count : 0.0;
     if (stats) ub.pending_part = nullptr;
-    if (fin_part && part == fin_part) { mv_fail(MV_ERR_STATE, "launch_norm_act: the output records would overwrite the pending ones"); return; }
     if (!fuse)
         hipLaunchKernelGGL(norm_act_kernel<0>, grid, dim3(256), 0, s, x, x_band, T, C, G, stats, gamma, beta, act, y32, y_band, hi, lo, (int64_t)ub.op_band, front, back,
                            NORM_UPB, part, fin_part, fin_rec, fin_count);
