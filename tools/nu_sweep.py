@@ -2,7 +2,7 @@
 """Decode-step time of the full-size engine with the token drawn inside the persistent launch (mega_fold 1) vs one step per launch +
 sample_kernel (mega_fold 0), for engines of 1 / 2 / 4 utterances and the three weight formats; token streams must be identical.
 usage: nu_sweep.py [n_new]   env NU_CASES="bf16:2,bf16:4,int8:1,int4:1" """
-import importlib, os, sys
+import hashlib, importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
@@ -31,5 +31,5 @@ for case in os.environ.get("NU_CASES", "bf16:2,bf16:4,int8:1,int4:1").split(",")
         toks = [e.tokens(u) for u in range(nu)]
         ref = ref or toks
         print(f"{fmt} x {nu} utterance(s), mega_fold={fold}: path {e.decode_path()}, {steps} steps, {e.last_run_ms / max(steps, 1) * 1e3:7.1f} us/step, "
-              f"{nu * steps / e.last_run_ms * 1e3:7.0f} tok/s, tokens {'identical' if toks == ref else 'DIFFER'}", flush=True)
+              f"{nu * steps / e.last_run_ms * 1e3:7.0f} tok/s, tokens {'identical' if toks == ref else 'DIFFER'} sha1 {hashlib.sha1(repr(toks).encode()).hexdigest()[:12]}", flush=True)
     e.close()
