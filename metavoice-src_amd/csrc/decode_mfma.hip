@@ -36,6 +36,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // us/step against 952-981 | 1320-1323 (370-430 spilled registers); MF_KV_LDS -- the next key range into LDS through global_load_lds while the current
 // one is scored -- 983-992 | 1330-1334; MF_W1_EARLY -- w1 with wo under the q/k/v hand-off -- 1233 | 1586; MF_W3_EARLY -- w3 with w1 behind the
 // attention -- 1098 | 1527 (profiles/r06e); the unpacked RMSNorm apply (one conversion per element) 986 | 1336-1357.
+// Re-measured at -O2 (3 | 0 spilled registers, see the end of this file; profiles/r06sw, 1896 steps): MF_KV_LDS 967-968 | 1376-1380 against
+// 954-955 | 1367-1368 -- it loses without scratch reloads too (the LDS -> register copy and its waits are on the range loop's path); MF_W1_EARLY
+// 1019 | 1414-1416; MF_KV_DB still spills 96 | 104 registers at -O2 and was not timed.
 // MF_NSPLIT: how many key ranges a (utterance, row, head) is cut into (see the geometry below): -1 = per instance -- 4 utterances: 1 | 4 | 8
 // (two workgroups share a (utterance, row, head): ceil(P / 256) ranges split 3 + 2 between them and measured no gain, r05j: 1164-1167 vs
 // 1169-1171 us/step), 8 utterances: ceil(P / 256) (one workgroup walks them all: 1859-1868 vs 1898 us/step)
@@ -816,9 +819,14 @@ __global__ void __launch_bounds__(MG_THREADS, 1) decode_mfma_kernel(const MegaAr
 }
 
 // The two instances are compiled as two translation units (round 6): decode_mfma.hip = the 4-utterance instance, decode_mfma8.hip (`#define
-// MF_INSTANCE 8` + this file) = the 8-utterance one under `-mllvm -amdgpu-sched-strategy=max-memory-clause` -- hipcc's other scheduling strategy
-// is 1.5 % faster for the 16-row instance (1518 / 1505 -> 1496 / 1481 us per step, A B A B) and 1-2 % slower for the 8-row one (1045-1060 -> 1066;
-// profiles/r06flags2/ab.txt; same instructions in another order: same bits).
+// MF_INSTANCE 8` + this file) = the 8-utterance one, each with its own flags (Makefile: MFMA4_FLAGS / MFMA8_FLAGS).
+// * -O2 instead of -O3 for both: at -O3 hipcc's register allocation spills 40 | 59 VGPRs (112 | 140 B of scratch per lane), and a scratch reload
+//   waits -- in order -- behind every weight request in flight; at -O2 3 | 7, and the 8-utterance instance with `-mllvm -disable-machine-licm`
+//   none at all (for the 4-utterance one that flag also gives 0 but is 1 % slower than the 3 it removes).  Same instructions' results, same tokens:
+//   4 utterances 1065 -> 958 us per step, 8 utterances 1545 -> 1370 (A B A B on one box, profiles/r06flags5; -O1, -Os and -O3 without the
+//   vectorisers lie in between).
+// * `-mllvm -amdgpu-sched-strategy=max-memory-clause` (hipcc's other scheduling strategy): at -O3 1.5 % faster for the 16-row instance and 1-2 %
+//   slower for the 8-row one (profiles/r06flags2/ab.txt); at -O2 a tie for the 8-row one (957.8-958.4 against 958.7-959.8), so both files use it.
 #if MF_INSTANCE == 4
 // the tag-free rows X | ATT | H | ACT inside the engine's hand-off slab (behind the q/k/v granules): mv_begin fills them with the sentinel
 void mfma_handoff_rows(int n_utt, size_t* offset_bytes, size_t* bytes) {
