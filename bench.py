@@ -645,6 +645,9 @@ def boundary_leg(rank: int, composed: dict, steps: int = 3):
     tts.first_stage_adapter.decode = folded_decode
     spk = mv.synthetic.speaker_embedding(rank)
     walls, decode_ms, begin_ms, audio_s, paths = [], [], [], [], []
+    import gc
+    gc.collect()   # this leg runs behind the other legs of the line: their garbage (engines, full-size state dicts) is collected here, not in a timed call
+    gc.freeze()    # ... and what survives is not walked again by a full collection that happens to fall into one (r06_final5 / 6: one call of three +426 / +85 ms on the host)
     for it in range(steps + 1):   # one warm-up call
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -678,6 +681,7 @@ def boundary_leg(rank: int, composed: dict, steps: int = 3):
                         "(normalise + tokenise -> first stage -> adapters -> second stage -> EnCodec + multi-band diffusion -> loudness -> .wav on disk); "
                         f"{n_prompt} prompt tokens (synthetic 512-rank BPE), generation to the context limit; rest_ms = wall - first-stage decode "
                         "(HIP events); host_overhead_ms = rest_ms - the composed line's non-decode time (prefill, second stage, codec, diffusion)")}
+    gc.unfreeze()
     tts.first_stage_adapter.decode = real_decode
     engine.begin = real_begin
     for closer in (getattr(tts.vocoder, "close", None), getattr(engine, "close", None)):
